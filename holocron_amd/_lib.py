@@ -1,0 +1,150 @@
+"""ctypes binding of libholocron_hip.so (C ABI declared in include/holocron_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, we raise.  The
+product path is the HIP path; the CPU restatement under oracle/ is test infrastructure only.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libholocron_hip.so")
+
+HC_MAX_TAPS = 12
+HC_MT_CHUNK = 65536
+
+c_void_p, c_int32, c_int64, c_float, c_double = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+
+class ConvClass(C.Structure):
+    _fields_ = [("OHg", c_int32), ("OWg", c_int32), ("oy0", c_int32), ("ox0", c_int32), ("ostep", c_int32),
+                ("istep", c_int32), ("ntaps", c_int32), ("tap", c_int32 * HC_MAX_TAPS)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("src0", c_void_p), ("src1", c_void_p), ("wpk", c_void_p), ("dst", c_void_p), ("resid", c_void_p),
+                ("stats", c_void_p), ("bias", c_void_p), ("act", c_int32),
+                ("N", c_int32), ("IH", c_int32), ("IW", c_int32), ("srcC", c_int32),
+                ("OH", c_int32), ("OW", c_int32), ("Cout", c_int32), ("T", c_int32), ("nclass", c_int32),
+                ("cls", ConvClass * 4)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("ws", c_void_p),
+                ("N", c_int32), ("IH", c_int32), ("IW", c_int32), ("Cin", c_int32), ("OH", c_int32), ("OW", c_int32),
+                ("Cout", c_int32), ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
+                ("beta", c_int32)]
+
+
+class RepBnDesc(C.Structure):
+    _fields_ = [("stats", c_void_p * 3), ("gamma", c_void_p * 3), ("beta", c_void_p * 3),
+                ("running_mean", c_void_p * 3), ("running_var", c_void_p * 3), ("num_batches_tracked", c_void_p * 3),
+                ("coef", c_void_p), ("save", c_void_p), ("C", c_int32), ("count", c_int64),
+                ("eps", c_float), ("momentum", c_float), ("training", c_int32)]
+
+
+class RepBnBwdDesc(C.Structure):
+    _fields_ = [("red", c_void_p), ("save", c_void_p), ("gamma", c_void_p * 3), ("dgamma", c_void_p * 3),
+                ("dbeta", c_void_p * 3), ("bcoef", c_void_p), ("C", c_int32), ("count", c_int64),
+                ("has_identity", c_int32), ("accumulate", c_int32)]
+
+
+class MtChunk(C.Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("s", c_void_p), ("smax", c_void_p),
+                ("n", c_int32), ("group", c_int32), ("tensor", c_int32), ("flags", c_int32)]
+
+
+class AdaBeliefGroup(C.Structure):
+    _fields_ = [("lr", c_double), ("beta1", c_double), ("beta2", c_double), ("eps", c_double),
+                ("weight_decay", c_double), ("step", c_int32), ("amsgrad", c_int32)]
+
+
+class LarsGroup(C.Structure):
+    _fields_ = [("lr", c_double), ("momentum", c_double), ("dampening", c_double), ("weight_decay", c_double),
+                ("nesterov", c_int32), ("pad_", c_int32)]
+
+
+def tap(dy, dx, src, wt):
+    """HC_TAP of the header."""
+    u = (dy & 0xff) | ((dx & 0xff) << 8) | ((src & 0xff) << 16) | ((wt & 0xff) << 24)
+    return u - (1 << 32) if u >= (1 << 31) else u
+
+
+# name -> (restype, argtypes); every symbol include/holocron_hip.h declares
+SIGNATURES = {
+    "hc_conv_gather": (c_int32, [C.POINTER(ConvDesc), c_void_p]),
+    "hc_conv_wgrad_ws_bytes": (c_int64, [C.POINTER(WgradDesc)]),
+    "hc_conv_wgrad": (c_int32, [C.POINTER(WgradDesc), c_void_p]),
+    "hc_pack_conv_weight": (c_int32, [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
+    "hc_nchw_to_nhwc_bf16": (c_int32, [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
+    "hc_nhwc_bf16_to_nchw": (c_int32, [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
+    "hc_im2col_small": (c_int32, [c_void_p, c_void_p] + [c_int32] * 11 + [c_void_p]),
+    "hc_unpack_im2col_grad": (c_int32, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p]),
+    "hc_rep_bn_finalize": (c_int32, [C.POINTER(RepBnDesc), c_void_p]),
+    "hc_rep_apply": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_int32, c_void_p]),
+    "hc_channel_stats": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "hc_rep_bwd_reduce": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_void_p]),
+    "hc_rep_bn_bwd_finalize": (c_int32, [C.POINTER(RepBnBwdDesc), c_void_p]),
+    "hc_rep_bwd_apply": (c_int32, [c_void_p] * 9 + [c_int64, c_int32, c_void_p]),
+    "hc_gap_fwd": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "hc_gap_bwd": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "hc_adabelief_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p]),
+    "hc_lars_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+    "hc_hard_mish_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "hc_hard_mish_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "hc_box_pairwise": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "hc_nms_ws_bytes": (c_int64, [c_int32]),
+    "hc_nms_sorted": (c_int32, [c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hc_focal_loss_fwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int64, c_int32, c_float, c_void_p]),
+    "hc_focal_loss_bwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int64, c_float, c_void_p]),
+    "hc_ce_fwd_bwd": (c_int32, [c_void_p] * 4 + [c_int32, c_int32, c_float, c_void_p]),
+    "hc_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m holocron_amd.build` "
+            "(there is no CPU fallback for the HIP path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library diverge
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_ERR = {1: "bad argument", 2: "kernel launch failure"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HipError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipError("holocron_amd kernels need CUDA(HIP) tensors; got a CPU tensor "
+                           "(the CPU restatement lives under oracle/ and is test-only)")

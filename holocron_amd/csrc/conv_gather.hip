@@ -1,0 +1,312 @@
+// Implicit-GEMM gather convolution on CDNA4 MFMA (v_mfma_f32_32x32x16_bf16).
+//
+// One kernel serves the forward conv and the data gradient of Holocron's conv stacks
+// (reference: nn.Conv2d built by conv_sequence, holocron/models/utils.py:73; RepBlock,
+// holocron/models/classification/repvgg.py:71-73).  GEMM view, per parity class:
+//     D[co][pix] = sum_{tap, k} Wpk[co][wt(tap)][k] * SRC_{src(tap)}[pix shifted by tap][k]
+// A operand = packed weights (rows = output channels), B operand = gathered NHWC pixels
+// (cols = output pixels), so every lane ends up with 4 consecutive output channels of one
+// pixel per accumulator quad -> 8-byte NHWC stores.  Zero padding and ragged tiles come from
+// buffer-descriptor range checks (out-of-range voffset reads 0), not from branches.
+#include "common.h"
+#include "../../include/holocron_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case 1: return v > 0.f ? v : 0.f;
+        case 2: { float t = fminf(fmaxf(v + 2.f, 0.f), 2.f); return 0.5f * v * t; }
+        case 3: return v > 0.f ? v : 0.1f * v;
+        case 4: { float sp = v > 20.f ? v : log1pf(__expf(v)); return v * tanhf(sp); }
+        case 5: return v / (1.f + __expf(-v));
+        case 6: return fminf(fmaxf(v, 0.f), 6.f);
+        default: return v;
+    }
+}
+
+template <int MR, int NR, int WM, int WN, int BK>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_conv_desc d) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BC = 32 * MR * WM;  // output-channel tile (A rows)
+    constexpr int BP = 32 * NR * WN;  // output-pixel tile (B cols)
+    constexpr int NC = BK / 8;        // 16-byte chunks per tile row
+    constexpr int RPP = NT / NC;      // tile rows covered by one pass of the block
+    constexpr int WI = (BC + RPP - 1) / RPP;
+    constexpr int XI = (BP + RPP - 1) / RPP;
+    constexpr int WBYTES = BC * BK * 2;
+    constexpr int STAGE = (BC + BP) * BK * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const hc_conv_class& cl = d.cls[blockIdx.z];
+    const int OHg = cl.OHg, OWg = cl.OWg;
+    const int M = d.N * OHg * OWg;
+    const int pbase = blockIdx.x * BP;
+    if (pbase >= M) return;
+    const int cbase = blockIdx.y * BC;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int IH = d.IH, IW = d.IW, srcC = d.srcC, T = d.T, Cout = d.Cout;
+
+    const unsigned src_bytes = (unsigned)d.N * IH * IW * srcC * 2u;
+    const __amdgpu_buffer_rsrc_t rsw = make_rsrc(d.wpk, (unsigned)Cout * T * srcC * 2u);
+
+    // ---- per-thread staging assignment: chunk column xc, rows r0 + i*RPP -------------------
+    const int xc = tid % NC;
+    const int r0 = tid / NC;
+    int x_nb[XI], x_iy0[XI], x_ix0[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int row = r0 + i * RPP;
+        const int m = pbase + row;
+        const bool ok = (row < BP) && (m < M);
+        const int mm = ok ? m : 0;
+        const int n = mm / (OHg * OWg);
+        const int rem = mm - n * (OHg * OWg);
+        const int oi = rem / OWg, oj = rem - oi * OWg;
+        x_nb[i] = n * IH * IW;
+        x_iy0[i] = ok ? oi * cl.istep : -(1 << 20);
+        x_ix0[i] = oj * cl.istep;
+    }
+    unsigned w_off[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = r0 + i * RPP;
+        const int co = cbase + row;
+        w_off[i] = (row < BC && co < Cout) ? (unsigned)co * T * srcC * 2u + xc * 16u : HC_OOB;
+    }
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int a = 0; a < MR; ++a)
+#pragma unroll
+        for (int b = 0; b < NR; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    u32x4 wreg[WI], xreg[XI];
+    const int kcb = srcC / BK;
+    const int S = cl.ntaps * kcb;
+
+    auto load_tiles = [&](int tap, int ck) {
+        const int tp = cl.tap[tap];
+        const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
+        const int sidx = (tp >> 16) & 0xff, wt = (tp >> 24) & 0xff;
+        const __amdgpu_buffer_rsrc_t rsx = make_rsrc(sidx ? d.src1 : d.src0, src_bytes);
+        const unsigned kofs = (unsigned)(ck * BK + xc * 8) * 2u;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int iy = x_iy0[i] + dy, ix = x_ix0[i] + dx;
+            const bool ok = ((unsigned)iy < (unsigned)IH) && ((unsigned)ix < (unsigned)IW);
+            const unsigned voff = ok ? (unsigned)(x_nb[i] + iy * IW + ix) * (unsigned)srcC * 2u + kofs : HC_OOB;
+            xreg[i] = buf_load16(rsx, voff);
+        }
+        const unsigned wk = (unsigned)(wt * srcC + ck * BK) * 2u;
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const unsigned voff = (w_off[i] == HC_OOB) ? HC_OOB : w_off[i] + wk;
+            wreg[i] = buf_load16(rsw, voff);
+        }
+    };
+    auto store_tiles = [&](int stage) {
+        char* sw = smem + stage * STAGE;
+        char* sx = sw + WBYTES;
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int row = r0 + i * RPP;
+            if (WI * RPP == BC || row < BC) *reinterpret_cast<u32x4*>(sw + lds_off<BK>(row, xc)) = wreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int row = r0 + i * RPP;
+            if (XI * RPP == BP || row < BP) *reinterpret_cast<u32x4*>(sx + lds_off<BK>(row, xc)) = xreg[i];
+        }
+    };
+    auto compute = [&](int stage) {
+        const char* sw = smem + stage * STAGE;
+        const char* sx = sw + WBYTES;
+        const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 a[MR], b[NR];
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+                a[mr] = *reinterpret_cast<const bf16x8*>(sw + lds_off<BK>((wm * MR + mr) * 32 + lr, kk * 2 + lh));
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+                b[nr] = *reinterpret_cast<const bf16x8*>(sx + lds_off<BK>((wn * NR + nr) * 32 + lr, kk * 2 + lh));
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mr], b[nr], acc[mr][nr], 0, 0, 0);
+        }
+    };
+
+    // ---- main loop: global->reg prefetch of step s+1 overlaps the MFMAs of step s ----------
+    if (S > 0) {  // a parity class may have no taps (e.g. 1x1 stride-2 dgrad): result is just resid
+        load_tiles(0, 0);
+        store_tiles(0);
+    }
+    __syncthreads();
+    int tap = 0, ck = 0;
+    for (int s = 0; s < S; ++s) {
+        const bool more = (s + 1 < S);
+        if (more) {
+            if (++ck == kcb) { ck = 0; ++tap; }
+            load_tiles(tap, ck);
+        }
+        compute(s & 1);
+        if (more) store_tiles((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue --------------------------------------------------------------------------
+    const int lr = lane & 31, lh = lane >> 5;
+    // per-channel batch statistics of the fp32 result (training-mode BatchNorm), before rounding
+    if (d.stats != nullptr) {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            float s1[16], s2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) {
+                    const float v = acc[mr][nr][r];
+                    a1 += v;
+                    a2 += v * v;
+                }
+                s1[r] = a1;
+                s2[r] = a2;
+            }
+            // butterfly over the 32 pixel-lanes of each half wave; 16 values -> 1 per lane pair
+#pragma unroll
+            for (int w = 8, o = 16; w >= 1; w >>= 1, o >>= 1) {
+                const bool up = (lane & o) != 0;
+#pragma unroll
+                for (int i = 0; i < w; ++i) {
+                    const float k1 = up ? s1[i + w] : s1[i], g1 = up ? s1[i] : s1[i + w];
+                    const float k2 = up ? s2[i + w] : s2[i], g2 = up ? s2[i] : s2[i + w];
+                    s1[i] = k1 + __shfl_xor(g1, o);
+                    s2[i] = k2 + __shfl_xor(g2, o);
+                }
+            }
+            s1[0] += __shfl_xor(s1[0], 1);
+            s2[0] += __shfl_xor(s2[0], 1);
+            if ((lane & 1) == 0) {
+                const int r = 8 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 1) & 1);
+                const int co = cbase + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < Cout) {
+                    atomicAdd(d.stats + co, s1[0]);
+                    atomicAdd(d.stats + Cout + co, s2[0]);
+                }
+            }
+        }
+    }
+
+    bf16_t* dst = reinterpret_cast<bf16_t*>(d.dst);
+    const bf16_t* resid = reinterpret_cast<const bf16_t*>(d.resid);
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int m = pbase + (wn * NR + nr) * 32 + lr;
+        if (m >= M) continue;
+        const int n = m / (OHg * OWg);
+        const int rem = m - n * (OHg * OWg);
+        const int oi = rem / OWg, oj = rem - oi * OWg;
+        const long pix = ((long)n * d.OH + (oi * cl.ostep + cl.oy0)) * d.OW + (oj * cl.ostep + cl.ox0);
+        const long pofs = pix * Cout;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = cbase + (wm * MR + mr) * 32 + 8 * q + 4 * lh;
+                if (co >= Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mr][nr][4 * q + e];
+                if (d.bias != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < Cout) v[e] += d.bias[co + e];
+                }
+                if ((Cout & 3) == 0) {
+                    if (resid != nullptr) {
+                        const u32x2 rv = *reinterpret_cast<const u32x2*>(resid + pofs + co);
+                        v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]);
+                        v[2] += bf16lo(rv[1]); v[3] += bf16hi(rv[1]);
+                    }
+                    if (d.act != 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], d.act);
+                    }
+                    u32x2 o;
+                    o[0] = pack_bf16x2(v[0], v[1]);
+                    o[1] = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(dst + pofs + co) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e >= Cout) continue;
+                        float t = v[e];
+                        if (resid != nullptr) t += bf16_to_f32(resid[pofs + co + e]);
+                        if (d.act != 0) t = apply_act(t, d.act);
+                        dst[pofs + co + e] = f32_to_bf16(t);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int MR, int NR, int WM, int WN, int BK>
+int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
+    constexpr int BC = 32 * MR * WM, BP = 32 * NR * WN;
+    constexpr int smem = 2 * (BC + BP) * BK * 2;
+    int maxM = 0;
+    for (int c = 0; c < d.nclass; ++c) {
+        const int m = d.N * d.cls[c].OHg * d.cls[c].OWg;
+        if (m > maxM) maxM = m;
+    }
+    if (maxM == 0) return HC_OK;
+    dim3 grid((maxM + BP - 1) / BP, (d.Cout + BC - 1) / BC, d.nclass);
+    auto kern = conv_gather_kernel<MR, NR, WM, WN, BK>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, st, d);
+    return hc_launch_status();
+}
+
+template <int BK>
+int launch_bk(const hc_conv_desc& d, hipStream_t st) {
+    const int C = d.Cout;
+    // channel tile: smallest padding waste, prefer the widest tile on ties
+    if (C <= 64) return launch_cfg<1, 2, 2, 2, BK>(d, st);
+    if (C <= 96) return launch_cfg<3, 1, 1, 4, BK>(d, st);
+    const int w128 = ((C + 127) / 128) * 128 - C, w192 = ((C + 191) / 192) * 192 - C;
+    if (w192 <= w128) return launch_cfg<3, 2, 2, 2, BK>(d, st);
+    return launch_cfg<2, 2, 2, 2, BK>(d, st);
+}
+
+}  // namespace
+
+extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
+    if (dp == nullptr) return HC_ERR_ARG;
+    const hc_conv_desc& d = *dp;
+    if (d.src0 == nullptr || d.wpk == nullptr || d.dst == nullptr) return HC_ERR_ARG;
+    if (d.nclass < 1 || d.nclass > 4 || d.srcC <= 0 || (d.srcC % 16) != 0 || d.Cout <= 0) return HC_ERR_ARG;
+    if ((double)d.N * d.IH * d.IW * d.srcC * 2.0 >= 4294967280.0) return HC_ERR_ARG;
+    if ((double)d.Cout * d.T * d.srcC * 2.0 >= 4294967280.0) return HC_ERR_ARG;
+    for (int c = 0; c < d.nclass; ++c) {
+        if (d.cls[c].ntaps < 0 || d.cls[c].ntaps > HC_MAX_TAPS) return HC_ERR_ARG;
+        for (int t = 0; t < d.cls[c].ntaps; ++t)
+            if (((d.cls[c].tap[t] >> 16) & 0xff) != 0 && d.src1 == nullptr) return HC_ERR_ARG;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d.srcC % 64 == 0) return launch_bk<64>(d, st);
+    if (d.srcC % 32 == 0) return launch_bk<32>(d, st);
+    return launch_bk<16>(d, st);
+}

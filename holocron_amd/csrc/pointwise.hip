@@ -1,0 +1,324 @@
+// Pointwise / small-reduction kernels of the path: HardMish, pairwise box ops, greedy NMS,
+// focal loss, label-smoothed cross entropy.  Compiled with -ffp-contract=off so that the fp32
+// expression trees round exactly like the reference's separate torch kernels (needed for the
+// bit-exact NMS / box-index contract, SURVEY.md §7 hard part 5).
+#include "common.h"
+#include "../../include/holocron_hip.h"
+
+namespace {
+
+inline int grid_for(long total, int threads = 256, int cap = 8192) {
+    long b = (total + threads - 1) / threads;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------- hard_mish (functional.py:30-41)
+__global__ void hard_mish_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const float t = fminf(fmaxf(v + 2.f, 0.f), 2.f);
+        y[i] = 0.5f * v * t;  // (0.5 * x) * clamp(x + 2, 0, 2)
+    }
+}
+__global__ void hard_mish_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        // d/dx [0.5 x clamp(x+2,0,2)]: 0 for x<-2 ; x+1 for -2<=x<=0 ; 1 for x>0 (torch clamp passes grad on bounds)
+        const float t = v + 2.f;
+        float d = 0.5f * fminf(fmaxf(t, 0.f), 2.f);
+        if (t >= 0.f && t <= 2.f) d += 0.5f * v;
+        dx[i] = dy[i] * d;
+    }
+}
+
+// ---------------------------------------------------------------- pairwise boxes (ops/boxes.py)
+struct Box { float x1, y1, x2, y2; };
+__device__ __forceinline__ float box_area(const Box b) { return (b.x2 - b.x1) * (b.y2 - b.y1); }
+__device__ __forceinline__ float pair_iou(const Box a, const Box b, float* union_out) {
+    const float area1 = box_area(a), area2 = box_area(b);
+    const float ltx = fmaxf(a.x1, b.x1), lty = fmaxf(a.y1, b.y1);
+    const float rbx = fminf(a.x2, b.x2), rby = fminf(a.y2, b.y2);
+    const float w = fmaxf(rbx - ltx, 0.f), h = fmaxf(rby - lty, 0.f);
+    const float inter = w * h;
+    const float uni = (area1 + area2) - inter;
+    if (union_out) *union_out = uni;
+    return inter / uni;
+}
+__device__ __forceinline__ float pair_penalty(const Box a, const Box b) {
+    // ops/boxes.py:79-103
+    float cx = fmaxf(a.x2, b.x2) - fminf(a.x1, b.x1);
+    float cy = fmaxf(a.y2, b.y2) - fminf(a.y1, b.y1);
+    const float c2 = cx * cx + cy * cy;
+    float dx = (a.x1 + a.x2) - (b.x1 + b.x2);
+    float dy = (a.y1 + a.y2) - (b.y1 + b.y2);
+    const float cd2 = (dx * dx + dy * dy) / 4.f;
+    return cd2 / c2;
+}
+__global__ void box_pairwise_kernel(const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out, int M,
+                                    int N, int kind) {
+    const long total = (long)M * N;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(t / N), j = (int)(t % N);
+        const Box a = {b1[4 * i], b1[4 * i + 1], b1[4 * i + 2], b1[4 * i + 3]};
+        const Box b = {b2[4 * j], b2[4 * j + 1], b2[4 * j + 2], b2[4 * j + 3]};
+        float r;
+        if (kind == 0) {
+            r = pair_iou(a, b, nullptr);
+        } else if (kind == 1) {
+            float uni;
+            const float iou = pair_iou(a, b, &uni);
+            const float w = fmaxf(fmaxf(a.x2, b.x2) - fminf(a.x1, b.x1), 0.f);
+            const float h = fmaxf(fmaxf(a.y2, b.y2) - fminf(a.y1, b.y1), 0.f);
+            const float area = w * h;
+            r = iou - (area - uni) / area;
+        } else if (kind == 2 || kind == 3) {
+            // ciou_loss == diou_loss numerically: the alpha*v term is added to a temporary copy
+            // in the reference (ops/boxes.py:208-209)
+            r = (1.f - pair_iou(a, b, nullptr)) + pair_penalty(a, b);
+        } else if (kind == 4) {
+            r = pair_penalty(a, b);
+        } else {
+            const float v = atanf((a.x2 - a.x1) / (a.y2 - a.y1)) - atanf((b.x2 - b.x1) / (b.y2 - b.y1));
+            r = (v * v) * (float)(4.0 / (3.141592653589793 * 3.141592653589793));
+        }
+        out[t] = r;
+    }
+}
+
+// ---------------------------------------------------------------- NMS (torchvision.ops.nms semantics)
+// pass 1: mask[i][w] bit b set  <=>  j = 64*w + b > i  and  IoU(i, j) > thr
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr,
+                                                       unsigned long long* __restrict__ mask, int nw) {
+    const int rb = blockIdx.y, cb = blockIdx.x;
+    if (cb < rb) return;  // only j > i matters
+    const int lane = threadIdx.x;
+    __shared__ float sb[64 * 4];
+    const int jn = min(64, n - cb * 64);
+    if (lane < jn) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sb[lane * 4 + e] = boxes[(long)(cb * 64 + lane) * 4 + e];
+    }
+    __syncthreads();
+    const int i = rb * 64 + lane;
+    if (i >= n) return;
+    const float x1 = boxes[(long)i * 4], y1 = boxes[(long)i * 4 + 1], x2 = boxes[(long)i * 4 + 2], y2 = boxes[(long)i * 4 + 3];
+    const float iarea = (x2 - x1) * (y2 - y1);
+    unsigned long long bits = 0;
+    const int start = (rb == cb) ? lane + 1 : 0;
+    for (int b = start; b < jn; ++b) {
+        const float bx1 = sb[b * 4], by1 = sb[b * 4 + 1], bx2 = sb[b * 4 + 2], by2 = sb[b * 4 + 3];
+        const float xx1 = fmaxf(x1, bx1), yy1 = fmaxf(y1, by1);
+        const float xx2 = fminf(x2, bx2), yy2 = fminf(y2, by2);
+        const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+        const float inter = w * h;
+        const float barea = (bx2 - bx1) * (by2 - by1);
+        const float ovr = inter / ((iarea + barea) - inter);
+        if (ovr > thr) bits |= 1ull << b;
+    }
+    mask[(long)i * nw + cb] = bits;
+}
+// pass 2: one workgroup walks the sorted boxes 64 at a time.  Wave 0 resolves the intra-block
+// dependency chain on the diagonal word with scalar code; then all threads OR the rows of the
+// kept boxes into the running "removed" bitmap held in LDS.
+__global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int nw,
+                                                         int* __restrict__ keep, int* __restrict__ nkeep) {
+    extern __shared__ unsigned long long removed[];  // nw words
+    __shared__ unsigned long long kept_sh;
+    __shared__ int count_sh;
+    const int tid = threadIdx.x;
+    for (int w = tid; w < nw; w += 1024) removed[w] = 0ull;
+    if (tid == 0) count_sh = 0;
+    __syncthreads();
+    for (int blk = 0; blk < nw; ++blk) {
+        const int base = blk * 64;
+        const int cnt = min(64, n - base);
+        if (tid < 64) {
+            const unsigned long long diag = (tid < cnt) ? mask[(long)(base + tid) * nw + blk] : 0ull;
+            unsigned long long rem = removed[blk];
+            unsigned long long kept = 0ull;
+            for (int b = 0; b < cnt; ++b) {
+                const unsigned long long row = __shfl(diag, b);
+                if (!((rem >> b) & 1ull)) {
+                    kept |= 1ull << b;
+                    rem |= row;
+                }
+            }
+            if (tid == 0) {
+                kept_sh = kept;
+                int c = count_sh;
+                unsigned long long k = kept;
+                while (k) {
+                    const int b = __ffsll((long long)k) - 1;
+                    keep[c++] = base + b;
+                    k &= k - 1;
+                }
+                count_sh = c;
+            }
+        }
+        __syncthreads();
+        const unsigned long long kept = kept_sh;
+        if (kept != 0ull) {
+            for (int w = blk + 1 + tid; w < nw; w += 1024) {
+                unsigned long long acc = 0ull;
+                unsigned long long k = kept;
+                while (k) {
+                    const int b = __ffsll((long long)k) - 1;
+                    acc |= mask[(long)(base + b) * nw + w];
+                    k &= k - 1;
+                }
+                removed[w] |= acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) nkeep[0] = count_sh;
+}
+
+// ---------------------------------------------------------------- focal loss (functional.py:59-113)
+__global__ void focal_fwd_kernel(const float* __restrict__ x, const long* __restrict__ target, const float* __restrict__ weight,
+                                 float* __restrict__ loss_el, uint8_t* __restrict__ valid, int N, int K, long S, int ignore_index,
+                                 float gamma) {
+    const long total = (long)N * S;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long n = t / S, s = t % S;
+        const float* px = x + n * K * S + s;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, px[(long)k * S]);
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += expf(px[(long)k * S] - mx);
+        const long tg = target[t];
+        float logpt = (px[tg * S] - mx) - logf(se);
+        const float pt = expf(logpt);
+        if (weight != nullptr) logpt = weight[tg] * logpt;
+        loss_el[t] = -1.f * powf(1.f - pt, gamma) * logpt;
+        valid[t] = !(ignore_index >= 0 && ignore_index < K && tg == ignore_index);
+    }
+}
+__global__ void focal_bwd_kernel(const float* __restrict__ x, const long* __restrict__ target, const float* __restrict__ weight,
+                                 const float* __restrict__ dloss, float* __restrict__ dx, int N, int K, long S, float gamma) {
+    const long total = (long)N * S;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long n = t / S, s = t % S;
+        const float* px = x + n * K * S + s;
+        float* pdx = dx + n * K * S + s;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, px[(long)k * S]);
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += expf(px[(long)k * S] - mx);
+        const long tg = target[t];
+        const float lse = logf(se);
+        const float logpt = (px[tg * S] - mx) - lse;
+        const float pt = expf(logpt);
+        const float w = weight != nullptr ? weight[tg] : 1.f;
+        const float om = 1.f - pt;
+        // loss = -(1-pt)^g * w * logpt ; d/dlogpt = -w [ (1-pt)^g - g (1-pt)^(g-1) pt logpt ]
+        float dl;
+        if (gamma == 0.f) dl = -w;
+        else dl = -w * (powf(om, gamma) - gamma * powf(om, gamma - 1.f) * pt * logpt);
+        const float gup = dloss[t] * dl;
+        for (int k = 0; k < K; ++k) {
+            const float pk = expf((px[(long)k * S] - mx) - lse);
+            pdx[(long)k * S] = gup * ((k == tg ? 1.f : 0.f) - pk);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- label-smoothed cross entropy
+__global__ void ce_fwd_bwd_kernel(const float* __restrict__ logits, const long* __restrict__ target, float* __restrict__ loss_el,
+                                  float* __restrict__ dlogits, int N, int K, float ls) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* px = logits + (long)n * K;
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, px[k]);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(px[k] - mx);
+    const float lse = logf(se) + mx;
+    const long tg = target[n];
+    float sum_logp = 0.f;
+    for (int k = 0; k < K; ++k) sum_logp += px[k] - lse;
+    const float nll = -(px[tg] - lse);
+    const float smooth = -sum_logp / (float)K;
+    loss_el[n] = (1.f - ls) * nll + ls * smooth;
+    if (dlogits != nullptr) {
+        const float invN = 1.f / (float)N;
+        for (int k = 0; k < K; ++k) {
+            const float p = expf(px[k] - lse);
+            dlogits[(long)n * K + k] = (p - (1.f - ls) * (k == tg ? 1.f : 0.f) - ls / (float)K) * invN;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hc_hard_mish_fwd(const float* x, float* y, int64_t n, hc_stream_t stream) {
+    if (x == nullptr || y == nullptr || n < 0) return HC_ERR_ARG;
+    if (n == 0) return HC_OK;
+    hipLaunchKernelGGL(hard_mish_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n);
+    return hc_launch_status();
+}
+int hc_hard_mish_bwd(const float* x, const float* dy, float* dx, int64_t n, hc_stream_t stream) {
+    if (x == nullptr || dy == nullptr || dx == nullptr || n < 0) return HC_ERR_ARG;
+    if (n == 0) return HC_OK;
+    hipLaunchKernelGGL(hard_mish_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (long)n);
+    return hc_launch_status();
+}
+
+int hc_box_pairwise(const float* b1, const float* b2, float* out, int32_t M, int32_t N, int32_t kind, hc_stream_t stream) {
+    if (M < 0 || N < 0 || kind < 0 || kind > 5) return HC_ERR_ARG;
+    if (M == 0 || N == 0) return HC_OK;
+    if (b1 == nullptr || b2 == nullptr || out == nullptr) return HC_ERR_ARG;
+    hipLaunchKernelGGL(box_pairwise_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, (hipStream_t)stream, b1, b2, out, M, N, kind);
+    return hc_launch_status();
+}
+
+int64_t hc_nms_ws_bytes(int32_t n) {
+    if (n <= 0) return 0;
+    const int64_t nw = (n + 63) / 64;
+    return (int64_t)n * nw * 8;
+}
+int hc_nms_sorted(const float* boxes, int32_t n, float iou_thr, void* ws, int32_t* keep, int32_t* nkeep, hc_stream_t stream) {
+    if (n < 0 || nkeep == nullptr) return HC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        if (hipMemsetAsync(nkeep, 0, sizeof(int32_t), st) != hipSuccess) return HC_ERR_LAUNCH;
+        return HC_OK;
+    }
+    if (boxes == nullptr || ws == nullptr || keep == nullptr) return HC_ERR_ARG;
+    const int nw = (n + 63) / 64;
+    if ((size_t)nw * 8 > 60000) return HC_ERR_ARG;  // bitmap must fit LDS (n <= 480000)
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nw, nw), dim3(64), 0, st, boxes, n, iou_thr, (unsigned long long*)ws, nw);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), nw * 8, st, (const unsigned long long*)ws, n, nw, keep, nkeep);
+    return hc_launch_status();
+}
+
+int hc_focal_loss_fwd(const float* x, const int64_t* target, const float* weight, float* loss_el, uint8_t* valid, int32_t N,
+                      int32_t K, int64_t S, int32_t ignore_index, float gamma, hc_stream_t stream) {
+    if (x == nullptr || target == nullptr || loss_el == nullptr || valid == nullptr || K <= 0) return HC_ERR_ARG;
+    if ((long)N * S == 0) return HC_OK;
+    hipLaunchKernelGGL(focal_fwd_kernel, dim3(grid_for((long)N * S)), dim3(256), 0, (hipStream_t)stream, x, (const long*)target,
+                       weight, loss_el, valid, N, K, (long)S, ignore_index, gamma);
+    return hc_launch_status();
+}
+int hc_focal_loss_bwd(const float* x, const int64_t* target, const float* weight, const float* dloss_el, float* dx, int32_t N,
+                      int32_t K, int64_t S, float gamma, hc_stream_t stream) {
+    if (x == nullptr || target == nullptr || dloss_el == nullptr || dx == nullptr || K <= 0) return HC_ERR_ARG;
+    if ((long)N * S == 0) return HC_OK;
+    hipLaunchKernelGGL(focal_bwd_kernel, dim3(grid_for((long)N * S)), dim3(256), 0, (hipStream_t)stream, x, (const long*)target,
+                       weight, dloss_el, dx, N, K, (long)S, gamma);
+    return hc_launch_status();
+}
+
+int hc_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss_el, float* dlogits, int32_t N, int32_t K,
+                  float label_smoothing, hc_stream_t stream) {
+    if (logits == nullptr || target == nullptr || loss_el == nullptr || N <= 0 || K <= 0) return HC_ERR_ARG;
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, logits, (const long*)target,
+                       loss_el, dlogits, N, K, label_smoothing);
+    return hc_launch_status();
+}
+
+}  // extern "C"

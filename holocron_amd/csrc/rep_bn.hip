@@ -1,0 +1,540 @@
+// HBM-bound passes around the MFMA convs: RepBlock training-mode BatchNorm fusion
+// (reference: holocron/models/classification/repvgg.py:71-73 -> three nn.BatchNorm2d, a python
+// sum() and one shared ReLU), global average pool, layout changes and weight packing.
+//
+// All activation tensors are NHWC bf16; a thread owns one 16-byte chunk (8 channels) per
+// iteration and the launch is sized so that a thread's channel group never changes, which
+// keeps the per-channel coefficients in registers.
+#include "common.h"
+#include "../../include/holocron_hip.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+struct EwGrid {
+    int blocks;
+};
+// number of blocks such that (blocks*256) % (C/8) == 0 and every thread gets >= ~8 chunks
+inline int ew_blocks(long nchunks, int cg) {
+    int a = cg, b = EW_THREADS;
+    while (b) { int t = a % b; a = b; b = t; }
+    const int unit = cg / a;  // blocks must be a multiple of this
+    long want = nchunks / (EW_THREADS * 8);
+    if (want > 2048) want = 2048;
+    if (want < 1) want = 1;
+    long k = (want + unit - 1) / unit;
+    return (int)(k * unit);
+}
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf16lo(v[i]); f[2 * i + 1] = bf16hi(v[i]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+}
+
+// ---------------------------------------------------------------- forward BN finalize
+__global__ void rep_bn_finalize_kernel(const hc_rep_bn_desc d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.C) return;
+    const float cnt = (float)d.count;
+    float shift = 0.f;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        float a = 0.f, mean = 0.f, invstd = 0.f;
+        if (d.gamma[b] != nullptr) {
+            if (d.training) {
+                const float s1 = d.stats[b][c], s2 = d.stats[b][d.C + c];
+                mean = s1 / cnt;
+                float var = s2 / cnt - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                invstd = rsqrtf(var + d.eps);
+                if (d.running_mean[b] != nullptr) {
+                    const float unb = d.count > 1 ? var * (cnt / (cnt - 1.f)) : var;
+                    d.running_mean[b][c] = (1.f - d.momentum) * d.running_mean[b][c] + d.momentum * mean;
+                    d.running_var[b][c] = (1.f - d.momentum) * d.running_var[b][c] + d.momentum * unb;
+                }
+                if (c == 0 && d.num_batches_tracked[b] != nullptr) d.num_batches_tracked[b][0] += 1;
+            } else {
+                mean = d.running_mean[b][c];
+                invstd = rsqrtf(d.running_var[b][c] + d.eps);
+            }
+            a = d.gamma[b][c] * invstd;
+            shift += d.beta[b][c] - a * mean;
+        }
+        d.coef[b * d.C + c] = a;
+        if (d.save != nullptr) {
+            d.save[(2 * b) * d.C + c] = mean;
+            d.save[(2 * b + 1) * d.C + c] = invstd;
+        }
+    }
+    d.coef[3 * d.C + c] = shift;
+}
+
+// ---------------------------------------------------------------- forward apply
+template <bool HAS_ID, bool STATS>
+__global__ __launch_bounds__(EW_THREADS) void rep_apply_kernel(const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
+                                                               const u32x4* __restrict__ x, const float* __restrict__ coef,
+                                                               u32x4* __restrict__ out, float* __restrict__ out_stats,
+                                                               long nchunks, int C, int act) {
+    extern __shared__ float sred[];  // [2][C] when STATS
+    const int cg = C / 8;
+    const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
+    const long stride = (long)gridDim.x * EW_THREADS;
+    const int c0 = (int)(gtid % cg) * 8;
+    float a3[8], a1[8], a0[8], sh[8];
+    load8f(coef + c0, a3);
+    load8f(coef + C + c0, a1);
+    if (HAS_ID) load8f(coef + 2 * C + c0, a0);
+    load8f(coef + 3 * C + c0, sh);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+    if (STATS) {
+        for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) sred[i] = 0.f;
+        __syncthreads();
+    }
+    for (long q = gtid; q < nchunks; q += stride) {
+        float f3[8], f1[8], f0[8], o[8];
+        unpack8(y3[q], f3);
+        unpack8(y1[q], f1);
+        if (HAS_ID) unpack8(x[q], f0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float z = a3[i] * f3[i] + a1[i] * f1[i] + sh[i];
+            if (HAS_ID) z += a0[i] * f0[i];
+            if (act == 1) z = z > 0.f ? z : 0.f;
+            o[i] = z;
+        }
+        const u32x4 pk = pack8(o);
+        out[q] = pk;
+        if (STATS) {  // statistics of what the next block will actually read (bf16-rounded)
+            float r[8];
+            unpack8(pk, r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s1[i] += r[i]; s2[i] += r[i] * r[i]; }
+        }
+    }
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            atomicAdd(&sred[c0 + i], s1[i]);
+            atomicAdd(&sred[C + c0 + i], s2[i]);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) atomicAdd(out_stats + i, sred[i]);
+    }
+}
+
+// per-channel sum / sum of squares of an NHWC bf16 tensor (identity-branch BN statistics when the
+// producer did not emit them)
+__global__ __launch_bounds__(EW_THREADS) void channel_stats_kernel(const u32x4* __restrict__ x, float* __restrict__ stats,
+                                                                   long nchunks, int C) {
+    extern __shared__ float sred[];  // [2][C]
+    const int cg = C / 8;
+    const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
+    const long stride = (long)gridDim.x * EW_THREADS;
+    const int c0 = (int)(gtid % cg) * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) sred[i] = 0.f;
+    __syncthreads();
+    for (long q = gtid; q < nchunks; q += stride) {
+        float f[8];
+        unpack8(x[q], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        atomicAdd(&sred[c0 + i], s1[i]);
+        atomicAdd(&sred[C + c0 + i], s2[i]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) atomicAdd(stats + i, sred[i]);
+}
+
+// ---------------------------------------------------------------- backward reduce
+template <bool HAS_ID>
+__global__ __launch_bounds__(EW_THREADS) void rep_bwd_reduce_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ out,
+                                                                    const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
+                                                                    const u32x4* __restrict__ x, float* __restrict__ red,
+                                                                    long nchunks, int C) {
+    extern __shared__ float sred[];  // [4][C]
+    const int cg = C / 8;
+    const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
+    const long stride = (long)gridDim.x * EW_THREADS;
+    const int c0 = (int)(gtid % cg) * 8;
+    float sz[8], s3[8], s1[8], s0[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sz[i] = s3[i] = s1[i] = s0[i] = 0.f;
+    for (int i = threadIdx.x; i < 4 * C; i += EW_THREADS) sred[i] = 0.f;
+    __syncthreads();
+    for (long q = gtid; q < nchunks; q += stride) {
+        float fg[8], fo[8], f3[8], f1[8], f0[8];
+        unpack8(g[q], fg);
+        unpack8(out[q], fo);
+        unpack8(y3[q], f3);
+        unpack8(y1[q], f1);
+        if (HAS_ID) unpack8(x[q], f0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float dz = fo[i] > 0.f ? fg[i] : 0.f;
+            sz[i] += dz;
+            s3[i] += dz * f3[i];
+            s1[i] += dz * f1[i];
+            if (HAS_ID) s0[i] += dz * f0[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        atomicAdd(&sred[c0 + i], sz[i]);
+        atomicAdd(&sred[C + c0 + i], s3[i]);
+        atomicAdd(&sred[2 * C + c0 + i], s1[i]);
+        if (HAS_ID) atomicAdd(&sred[3 * C + c0 + i], s0[i]);
+    }
+    __syncthreads();
+    const int lim = HAS_ID ? 4 * C : 3 * C;
+    for (int i = threadIdx.x; i < lim; i += EW_THREADS) atomicAdd(red + i, sred[i]);
+}
+
+__global__ void rep_bn_bwd_finalize_kernel(const hc_rep_bn_bwd_desc d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.C) return;
+    const float cnt = (float)d.count;
+    const float sdz = d.red[c];
+    const int nb = d.has_identity ? 3 : 2;
+    for (int b = 0; b < 3; ++b) {
+        float A = 0.f, B = 0.f, Cc = 0.f;
+        if (b < nb) {
+            const float mean = d.save[(2 * b) * d.C + c], invstd = d.save[(2 * b + 1) * d.C + c];
+            const float sdzy = d.red[(b + 1) * d.C + c];
+            const float dgamma = invstd * (sdzy - mean * sdz);
+            const float a = d.gamma[b][c] * invstd;
+            A = a;
+            B = -a * invstd * dgamma / cnt;
+            Cc = -a * sdz / cnt - B * mean;
+            if (d.dgamma[b] != nullptr) d.dgamma[b][c] = d.accumulate ? d.dgamma[b][c] + dgamma : dgamma;
+            if (d.dbeta[b] != nullptr) d.dbeta[b][c] = d.accumulate ? d.dbeta[b][c] + sdz : sdz;
+        }
+        d.bcoef[(3 * b) * d.C + c] = A;
+        d.bcoef[(3 * b + 1) * d.C + c] = B;
+        d.bcoef[(3 * b + 2) * d.C + c] = Cc;
+    }
+}
+
+template <bool HAS_ID>
+__global__ __launch_bounds__(EW_THREADS) void rep_bwd_apply_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ out,
+                                                                   const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
+                                                                   const u32x4* __restrict__ x, const float* __restrict__ bc,
+                                                                   u32x4* __restrict__ dy3, u32x4* __restrict__ dy1,
+                                                                   u32x4* __restrict__ dxid, long nchunks, int C) {
+    const int cg = C / 8;
+    const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
+    const long stride = (long)gridDim.x * EW_THREADS;
+    const int c0 = (int)(gtid % cg) * 8;
+    float A3[8], B3[8], C3[8], A1[8], B1[8], C1[8], A0[8], B0[8], C0[8];
+    load8f(bc + 0 * C + c0, A3); load8f(bc + 1 * C + c0, B3); load8f(bc + 2 * C + c0, C3);
+    load8f(bc + 3 * C + c0, A1); load8f(bc + 4 * C + c0, B1); load8f(bc + 5 * C + c0, C1);
+    if (HAS_ID) { load8f(bc + 6 * C + c0, A0); load8f(bc + 7 * C + c0, B0); load8f(bc + 8 * C + c0, C0); }
+    for (long q = gtid; q < nchunks; q += stride) {
+        float fg[8], fo[8], f3[8], f1[8], f0[8], o3[8], o1[8], o0[8];
+        unpack8(g[q], fg);
+        unpack8(out[q], fo);
+        unpack8(y3[q], f3);
+        unpack8(y1[q], f1);
+        if (HAS_ID) unpack8(x[q], f0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float dz = fo[i] > 0.f ? fg[i] : 0.f;
+            o3[i] = A3[i] * dz + B3[i] * f3[i] + C3[i];
+            o1[i] = A1[i] * dz + B1[i] * f1[i] + C1[i];
+            if (HAS_ID) o0[i] = A0[i] * dz + B0[i] * f0[i] + C0[i];
+        }
+        dy3[q] = pack8(o3);
+        dy1[q] = pack8(o1);
+        if (HAS_ID) dxid[q] = pack8(o0);
+    }
+}
+
+// ---------------------------------------------------------------- global average pool
+__global__ void gap_fwd_kernel(const u32x4* __restrict__ x, float* __restrict__ y, int N, int HW, int C) {
+    const int cg = C / 8;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)N * cg) return;
+    const int n = (int)(t / cg), g = (int)(t % cg);
+    float s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = 0.f;
+    const u32x4* p = x + (long)n * HW * cg + g;
+    for (int h = 0; h < HW; ++h) {
+        float f[8];
+        unpack8(p[(long)h * cg], f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] += f[i];
+    }
+    const float inv = 1.f / (float)HW;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[(long)n * C + g * 8 + i] = s[i] * inv;
+}
+__global__ void gap_bwd_kernel(const float* __restrict__ dy, u32x4* __restrict__ dx, int N, int HW, int C) {
+    const int cg = C / 8;
+    const long total = (long)N * HW * cg;
+    const float inv = 1.f / (float)HW;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(q % cg);
+        const int n = (int)(q / ((long)HW * cg));
+        float f[8];
+        load8f(dy + (long)n * C + g * 8, f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] *= inv;
+        dx[q] = pack8(f);
+    }
+}
+
+// ---------------------------------------------------------------- layout / packing
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int N, int C, int H, int W, int Cpad) {
+    const long total = (long)N * H * W * Cpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        const long p = i / Cpad;
+        const int w = (int)(p % W);
+        const long r = p / W;
+        const int h = (int)(r % H);
+        const int n = (int)(r / H);
+        y[i] = c < C ? f32_to_bf16(x[(((long)n * C + c) * H + h) * W + w]) : (bf16_t)0;
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W, int Cpad) {
+    const long total = (long)N * C * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W);
+        long r = i / W;
+        const int h = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % C);
+        const int n = (int)(r / C);
+        y[i] = bf16_to_f32(x[(((long)n * H + h) * W + w) * Cpad + c]);
+    }
+}
+// mode 0: wpk[co][tap0 + kh*KW+kw][ci]            (forward)
+// mode 1: wpk[ci][tap0 + flipped(kh,kw)][co]      (data gradient)
+// mode 2: wpk[co][0][(kh*KW+kw)*Cin + ci], K padded to T*? (im2col order; T = padded K)
+__global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wpk, int Cout, int Cin, int KH, int KW,
+                                   int mode, int tap0, int T) {
+    const long total = (long)Cout * Cin * KH * KW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int kw = (int)(i % KW);
+        long r = i / KW;
+        const int kh = (int)(r % KH);
+        r /= KH;
+        const int ci = (int)(r % Cin);
+        const int co = (int)(r / Cin);
+        const bf16_t v = f32_to_bf16(w[i]);
+        if (mode == 0) {
+            wpk[((long)co * T + tap0 + kh * KW + kw) * Cin + ci] = v;
+        } else if (mode == 1) {
+            const int t = (KH - 1 - kh) * KW + (KW - 1 - kw);
+            wpk[((long)ci * T + tap0 + t) * Cout + co] = v;
+        } else {
+            wpk[(long)co * T + (kh * KW + kw) * Cin + ci] = v;
+        }
+    }
+}
+// im2col for tiny Cin (stem): x NCHW fp32 -> col [N][OH][OW][Kpad] bf16, k = (kh*KW+kw)*Cin+ci
+__global__ void im2col_small_kernel(const float* __restrict__ x, bf16_t* __restrict__ col, int N, int Cin, int H, int W, int OH,
+                                    int OW, int KH, int KW, int stride, int pad, int Kpad) {
+    const long total = (long)N * OH * OW * (Kpad / 8);
+    const int K = Cin * KH * KW;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+        const int kc = (int)(q % (Kpad / 8));
+        const long p = q / (Kpad / 8);
+        const int ox = (int)(p % OW);
+        const long r = p / OW;
+        const int oy = (int)(r % OH);
+        const int n = (int)(r / OH);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kc * 8 + e;
+            float v = 0.f;
+            if (k < K) {
+                const int ci = k % Cin, t = k / Cin;
+                const int kh = t / KW, kw = t % KW;
+                const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[(((long)n * Cin + ci) * H + iy) * W + ix];
+            }
+            f[e] = v;
+        }
+        reinterpret_cast<u32x4*>(col)[q] = pack8(f);
+    }
+}
+// dwcol fp32 [Cout][Kpad] (k = (kh*KW+kw)*Cin+ci) -> dw OIHW
+__global__ void unpack_im2col_grad_kernel(const float* __restrict__ dwcol, float* __restrict__ dw, int Cout, int Cin, int KH, int KW,
+                                          int Kpad, int beta) {
+    const int total = Cout * Cin * KH * KW;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int kw = i % KW;
+    int r = i / KW;
+    const int kh = r % KH;
+    r /= KH;
+    const int ci = r % Cin;
+    const int co = r / Cin;
+    const float v = dwcol[(long)co * Kpad + (kh * KW + kw) * Cin + ci];
+    dw[i] = beta ? dw[i] + v : v;
+}
+
+inline int grid_for(long total, int threads = 256, int cap = 4096) {
+    long b = (total + threads - 1) / threads;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hc_rep_bn_finalize(const hc_rep_bn_desc* d, hc_stream_t stream) {
+    if (d == nullptr || d->coef == nullptr || d->C <= 0) return HC_ERR_ARG;
+    hipLaunchKernelGGL(rep_bn_finalize_kernel, dim3((d->C + 127) / 128), dim3(128), 0, (hipStream_t)stream, *d);
+    return hc_launch_status();
+}
+
+int hc_rep_apply(const void* y3, const void* y1, const void* x, const float* coef, void* out, float* out_stats, int64_t npix,
+                 int32_t C, int32_t act, hc_stream_t stream) {
+    if (y3 == nullptr || y1 == nullptr || coef == nullptr || out == nullptr || (C % 8) != 0) return HC_ERR_ARG;
+    const long nchunks = (long)npix * (C / 8);
+    const int blocks = ew_blocks(nchunks, C / 8);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sm = out_stats ? 2 * C * sizeof(float) : 0;
+#define HC_LAUNCH_APPLY(ID, ST)                                                                                          \
+    hipLaunchKernelGGL((rep_apply_kernel<ID, ST>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)y3,             \
+                       (const u32x4*)y1, (const u32x4*)x, coef, (u32x4*)out, out_stats, nchunks, C, act)
+    if (x != nullptr) {
+        if (out_stats) HC_LAUNCH_APPLY(true, true); else HC_LAUNCH_APPLY(true, false);
+    } else {
+        if (out_stats) HC_LAUNCH_APPLY(false, true); else HC_LAUNCH_APPLY(false, false);
+    }
+#undef HC_LAUNCH_APPLY
+    return hc_launch_status();
+}
+
+int hc_channel_stats(const void* x, float* stats, int64_t npix, int32_t C, hc_stream_t stream) {
+    if (x == nullptr || stats == nullptr || (C % 8) != 0) return HC_ERR_ARG;
+    const long nchunks = (long)npix * (C / 8);
+    const int blocks = ew_blocks(nchunks, C / 8);
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(blocks), dim3(EW_THREADS), 2 * C * sizeof(float), (hipStream_t)stream,
+                       (const u32x4*)x, stats, nchunks, C);
+    return hc_launch_status();
+}
+
+int hc_rep_bwd_reduce(const void* g, const void* out, const void* y3, const void* y1, const void* x, float* red, int64_t npix,
+                      int32_t C, hc_stream_t stream) {
+    if (g == nullptr || out == nullptr || y3 == nullptr || y1 == nullptr || red == nullptr || (C % 8) != 0) return HC_ERR_ARG;
+    const long nchunks = (long)npix * (C / 8);
+    const int blocks = ew_blocks(nchunks, C / 8);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sm = 4 * C * sizeof(float);
+    if (x != nullptr)
+        hipLaunchKernelGGL((rep_bwd_reduce_kernel<true>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)g,
+                           (const u32x4*)out, (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, red, nchunks, C);
+    else
+        hipLaunchKernelGGL((rep_bwd_reduce_kernel<false>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)g,
+                           (const u32x4*)out, (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, red, nchunks, C);
+    return hc_launch_status();
+}
+
+int hc_rep_bn_bwd_finalize(const hc_rep_bn_bwd_desc* d, hc_stream_t stream) {
+    if (d == nullptr || d->red == nullptr || d->save == nullptr || d->bcoef == nullptr) return HC_ERR_ARG;
+    hipLaunchKernelGGL(rep_bn_bwd_finalize_kernel, dim3((d->C + 127) / 128), dim3(128), 0, (hipStream_t)stream, *d);
+    return hc_launch_status();
+}
+
+int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void* y1, const void* x, const float* bcoef, void* dy3,
+                     void* dy1, void* dxid, int64_t npix, int32_t C, hc_stream_t stream) {
+    if (g == nullptr || out == nullptr || y3 == nullptr || y1 == nullptr || bcoef == nullptr || dy3 == nullptr || dy1 == nullptr ||
+        (C % 8) != 0)
+        return HC_ERR_ARG;
+    if ((x == nullptr) != (dxid == nullptr)) return HC_ERR_ARG;
+    const long nchunks = (long)npix * (C / 8);
+    const int blocks = ew_blocks(nchunks, C / 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (x != nullptr)
+        hipLaunchKernelGGL((rep_bwd_apply_kernel<true>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)g, (const u32x4*)out,
+                           (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, bcoef, (u32x4*)dy3, (u32x4*)dy1, (u32x4*)dxid,
+                           nchunks, C);
+    else
+        hipLaunchKernelGGL((rep_bwd_apply_kernel<false>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)g, (const u32x4*)out,
+                           (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, bcoef, (u32x4*)dy3, (u32x4*)dy1, (u32x4*)dxid,
+                           nchunks, C);
+    return hc_launch_status();
+}
+
+int hc_gap_fwd(const void* x, float* y, int32_t N, int32_t HW, int32_t C, hc_stream_t stream) {
+    if (x == nullptr || y == nullptr || (C % 8) != 0) return HC_ERR_ARG;
+    const long t = (long)N * (C / 8);
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3((t + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, y, N, HW, C);
+    return hc_launch_status();
+}
+int hc_gap_bwd(const float* dy, void* dx, int32_t N, int32_t HW, int32_t C, hc_stream_t stream) {
+    if (dy == nullptr || dx == nullptr || (C % 8) != 0) return HC_ERR_ARG;
+    const long total = (long)N * HW * (C / 8);
+    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, (u32x4*)dx, N, HW, C);
+    return hc_launch_status();
+}
+
+int hc_nchw_to_nhwc_bf16(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cpad, hc_stream_t stream) {
+    if (x == nullptr || y == nullptr || Cpad < C) return HC_ERR_ARG;
+    const long total = (long)N * H * W * Cpad;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, N,
+                       C, H, W, Cpad);
+    return hc_launch_status();
+}
+int hc_nhwc_bf16_to_nchw(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cpad, hc_stream_t stream) {
+    if (x == nullptr || y == nullptr || Cpad < C) return HC_ERR_ARG;
+    const long total = (long)N * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       y, N, C, H, W, Cpad);
+    return hc_launch_status();
+}
+int hc_pack_conv_weight(const float* w, void* wpk, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t mode, int32_t tap0,
+                        int32_t T, hc_stream_t stream) {
+    if (w == nullptr || wpk == nullptr || mode < 0 || mode > 2) return HC_ERR_ARG;
+    const long total = (long)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wpk, Cout, Cin, KH,
+                       KW, mode, tap0, T);
+    return hc_launch_status();
+}
+int hc_im2col_small(const float* x, void* col, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t KH,
+                    int32_t KW, int32_t stride, int32_t pad, int32_t Kpad, hc_stream_t stream) {
+    if (x == nullptr || col == nullptr || (Kpad % 8) != 0 || Cin * KH * KW > Kpad) return HC_ERR_ARG;
+    const long total = (long)N * OH * OW * (Kpad / 8);
+    hipLaunchKernelGGL(im2col_small_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)col, N,
+                       Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad);
+    return hc_launch_status();
+}
+int hc_unpack_im2col_grad(const float* dwcol, float* dw, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t Kpad,
+                          int32_t beta, hc_stream_t stream) {
+    if (dwcol == nullptr || dw == nullptr) return HC_ERR_ARG;
+    const int total = Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(unpack_im2col_grad_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, dwcol, dw, Cout, Cin,
+                       KH, KW, Kpad, beta);
+    return hc_launch_status();
+}
+
+const char* hc_version(void) { return "holocron_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,3 @@
+from . import detection, utils  # noqa: F401
+from .classification import *  # noqa: F401,F403
+from . import classification  # noqa: F401

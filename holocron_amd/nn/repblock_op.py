@@ -1,0 +1,208 @@
+"""Fused training/inference step of a RepVGG block on the HIP kernels.
+
+Reference semantics (holocron/models/classification/repvgg.py:71-73):
+    out = act( BN3(conv3x3(x)) + BN1(conv1x1(x)) [+ BN0(x)] )
+with torch ``nn.BatchNorm2d`` in training mode (biased batch variance for normalisation,
+unbiased for ``running_var``, momentum 0.1, ``num_batches_tracked += 1``).
+
+Kernel sequence (DESIGN.md "RepBlock step"):
+  forward : conv3x3 -> y3 (+ sum/sumsq epilogue) ; conv1x1 -> y1 (+ stats) ; bn_finalize ;
+            rep_apply (3 x BN-apply + add + ReLU in one pass, optional stats of `out`)
+  backward: rep_bwd_reduce (sum dz, dz*y3, dz*y1, dz*x) ; bn_bwd_finalize ; rep_bwd_apply
+            (dy3, dy1, dx_identity) ; dual-source dgrad (3x3 + 1x1 in one accumulator, + dx_id) ;
+            wgrad 3x3 ; wgrad 1x1
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from .._lib import RepBnBwdDesc, RepBnDesc, check, ptr, stream
+from ..ops import conv as cv
+
+STEM_KPAD = 32
+
+
+class RepState:
+    """Per-module host state: packed-weight caches, geometry descriptors, BN buffers."""
+
+    def __init__(self, stride, identity):
+        self.stride = stride
+        self.identity = identity
+        self.emit_stats = False     # set by the model builder when the consumer has an identity BN
+        self.fwd_cache = cv.PackCache()
+        self.bwd_cache = cv.PackCache()
+        self.desc = {}
+        self.bn = None              # list of (running_mean, running_var, num_batches_tracked)
+        self.eps = 1e-5
+        self.momentum = 0.1
+        self.training = True
+        self.last_out_stats = None
+
+    def descs(self, N, Cin, H, W, Cout):
+        key = (N, Cin, H, W, Cout)
+        if key not in self.desc:
+            s = self.stride
+            if Cin % 16 == 0:
+                f3 = cv.fwd_desc(N, Cin, H, W, Cout, 3, 3, s, 1)
+                f1 = cv.fwd_desc(N, Cin, H, W, Cout, 1, 1, s, 0)
+                dg = cv.dgrad_desc(N, Cin, H, W, Cout, [(3, 3, 1, 0, 0), (1, 1, 0, 1, 9)], s)
+            else:  # stem: explicit im2col, both branches are 1x1 convs over the column tensor
+                OH, OW = cv.conv_out_size(H, 3, s, 1), cv.conv_out_size(W, 3, s, 1)
+                f3 = cv.fwd_desc(N, STEM_KPAD, OH, OW, Cout, 1, 1, 1, 0)
+                f1 = cv.fwd_desc(N, STEM_KPAD, OH, OW, Cout, 1, 1, 1, 0)
+                dg = None
+            self.desc[key] = (f3, f1, dg)
+        return self.desc[key]
+
+
+def _stats_of(x):
+    st = getattr(x, "_hc_stats", None)
+    if st is not None:
+        return st
+    N, Cc, H, W = x.shape
+    st = torch.zeros((2, Cc), dtype=torch.float32, device=x.device)
+    check(_lib.load().hc_channel_stats(ptr(x), ptr(st), N * H * W, Cc, stream()), "hc_channel_stats")
+    return st
+
+
+class RepBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w3, w1, g3, b3, g1, b1, g0, b0, st, relu):
+        lib = _lib.load()
+        Cout, Cin = w3.shape[0], w3.shape[1]
+        N, _, H, W = x.shape
+        dev = x.device
+        stem = (Cin % 16) != 0
+        f3, f1, _ = st.descs(N, Cin, H, W, Cout)
+        OH, OW = (f3.OH, f3.OW)
+        x_stats = None
+        if stem:
+            if st.identity:
+                raise NotImplementedError("identity branch with Cin % 16 != 0")
+            src = cv.im2col_small(x, 3, 3, st.stride, 1, STEM_KPAD)
+            wp3, wp1 = st.fwd_cache.get((w3, w1), lambda: (
+                cv.pack_weight_im2col(w3, STEM_KPAD), cv.pack_weight_im2col(w1, STEM_KPAD, k0=4 * Cin)))
+        else:
+            src = cv.to_cl_bf16(x)
+            if st.identity and st.training:
+                x_stats = _stats_of(src if src is not x else x)
+            wp3, wp1 = st.fwd_cache.get((w3, w1), lambda: (cv.pack_weight(w3, 0), cv.pack_weight(w1, 0)))
+        y3 = cv.empty_cl(N, Cout, OH, OW, dev)
+        y1 = cv.empty_cl(N, Cout, OH, OW, dev)
+        stats = torch.zeros((2, 2, Cout), dtype=torch.float32, device=dev) if st.training else None
+        cv.launch_conv(f3, src, wp3, y3, stats=None if stats is None else stats[0])
+        cv.launch_conv(f1, src, wp1, y1, stats=None if stats is None else stats[1])
+
+        coef = torch.empty((4, Cout), dtype=torch.float32, device=dev)
+        save = torch.empty((6, Cout), dtype=torch.float32, device=dev)
+        d = RepBnDesc()
+        gammas, betas = (g3, g1, g0), (b3, b1, b0)
+        nb = 3 if st.identity else 2
+        for b in range(3):
+            live = b < nb
+            d.gamma[b] = ptr(gammas[b]) if live else None
+            d.beta[b] = ptr(betas[b]) if live else None
+            rm, rv, nbt = st.bn[b] if live else (None, None, None)
+            d.running_mean[b], d.running_var[b], d.num_batches_tracked[b] = ptr(rm), ptr(rv), ptr(nbt)
+            d.stats[b] = None
+        if st.training:
+            d.stats[0], d.stats[1] = ptr(stats[0]), ptr(stats[1])
+            if st.identity:
+                d.stats[2] = ptr(x_stats)
+        d.coef, d.save, d.C, d.count = ptr(coef), ptr(save), Cout, N * OH * OW
+        d.eps, d.momentum, d.training = st.eps, st.momentum, 1 if st.training else 0
+        check(lib.hc_rep_bn_finalize(C.byref(d), stream()), "hc_rep_bn_finalize")
+
+        out = cv.empty_cl(N, Cout, OH, OW, dev)
+        out_stats = torch.zeros((2, Cout), dtype=torch.float32, device=dev) if (st.emit_stats and st.training) else None
+        check(lib.hc_rep_apply(ptr(y3), ptr(y1), ptr(src) if st.identity else None, ptr(coef), ptr(out), ptr(out_stats),
+                               N * OH * OW, Cout, 1 if relu else 0, stream()), "hc_rep_apply")
+        ctx.st, ctx.relu, ctx.stem = st, relu, stem
+        ctx.geom = (N, Cin, H, W, Cout, OH, OW)
+        ctx.was_training = st.training
+        ctx.save_for_backward(src, y3, y1, out, save, g3, g1, g0 if st.identity else None, w3, w1)
+        st.last_out_stats = out_stats
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.was_training:
+            raise NotImplementedError("RepBlock backward in eval mode (running statistics) is not implemented")
+        lib = _lib.load()
+        st = ctx.st
+        src, y3, y1, out, save, g3, g1, g0, w3, w1 = ctx.saved_tensors
+        N, Cin, H, W, Cout, OH, OW = ctx.geom
+        dev = g.device
+        g = cv.to_cl_bf16(g)
+        npix = N * OH * OW
+        mask_src = out if ctx.relu else torch.ones_like(out)
+        xid = src if st.identity else None
+
+        red = torch.zeros((4, Cout), dtype=torch.float32, device=dev)
+        check(lib.hc_rep_bwd_reduce(ptr(g), ptr(mask_src), ptr(y3), ptr(y1), ptr(xid), ptr(red), npix, Cout, stream()),
+              "hc_rep_bwd_reduce")
+        nb = 3 if st.identity else 2
+        dgam = torch.empty((3, Cout), dtype=torch.float32, device=dev)
+        dbet = torch.empty((3, Cout), dtype=torch.float32, device=dev)
+        bcoef = torch.empty((9, Cout), dtype=torch.float32, device=dev)
+        d = RepBnBwdDesc()
+        d.red, d.save, d.bcoef = ptr(red), ptr(save), ptr(bcoef)
+        gam = (g3, g1, g0)
+        for b in range(3):
+            live = b < nb
+            d.gamma[b] = ptr(gam[b]) if live else None
+            d.dgamma[b] = ptr(dgam[b]) if live else None
+            d.dbeta[b] = ptr(dbet[b]) if live else None
+        d.C, d.count, d.has_identity, d.accumulate = Cout, npix, 1 if st.identity else 0, 0
+        check(lib.hc_rep_bn_bwd_finalize(C.byref(d), stream()), "hc_rep_bn_bwd_finalize")
+
+        dy3 = torch.empty_like(y3)
+        dy1 = torch.empty_like(y1)
+        dxid = torch.empty_like(src) if st.identity else None
+        check(lib.hc_rep_bwd_apply(ptr(g), ptr(mask_src), ptr(y3), ptr(y1), ptr(xid), ptr(bcoef), ptr(dy3), ptr(dy1),
+                                   ptr(dxid), npix, Cout, stream()), "hc_rep_bwd_apply")
+
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.stem:
+                raise NotImplementedError("input gradient of the im2col stem path")
+            _, _, dg = st.descs(N, Cin, H, W, Cout)
+
+            def build():
+                wp = torch.empty((Cin, 10, Cout), dtype=torch.bfloat16, device=dev)
+                cv.pack_weight(w3, 1, out=wp, tap0=0, T=10)
+                cv.pack_weight(w1, 1, out=wp, tap0=9, T=10)
+                return wp
+            wpd = st.bwd_cache.get((w3, w1), build)
+            dx = cv.empty_cl(N, Cin, H, W, dev)
+            cv.launch_conv(dg, dy3, wpd, dx, src1=dy1, resid=dxid)
+
+        if ctx.stem:
+            K = STEM_KPAD
+            dwc3 = cv.conv_wgrad(src, dy3, K, Cout, 1, 1, 1, 0)
+            dwc1 = cv.conv_wgrad(src, dy1, K, Cout, 1, 1, 1, 0)
+            dw3 = torch.empty_like(w3, dtype=torch.float32)
+            check(lib.hc_unpack_im2col_grad(ptr(dwc3), ptr(dw3), Cout, Cin, 3, 3, K, 0, stream()), "hc_unpack_im2col_grad")
+            dw1 = dwc1.view(Cout, K)[:, 4 * Cin:5 * Cin].reshape(Cout, Cin, 1, 1).contiguous()
+        else:
+            dw3 = cv.conv_wgrad(src, dy3, Cin, Cout, 3, 3, st.stride, 1)
+            dw1 = cv.conv_wgrad(src, dy1, Cin, Cout, 1, 1, st.stride, 0)
+        return (dx, dw3, dw1, dgam[0], dbet[0], dgam[1], dbet[1],
+                dgam[2] if st.identity else None, dbet[2] if st.identity else None, None, None)
+
+
+def rep_block_forward(x, w3, w1, bn3, bn1, bn0, st, relu=True):
+    """x: logical NCHW tensor.  bnX: nn.BatchNorm2d modules (bn0 may be None)."""
+    st.bn = [(bn3.running_mean, bn3.running_var, bn3.num_batches_tracked),
+             (bn1.running_mean, bn1.running_var, bn1.num_batches_tracked),
+             (bn0.running_mean, bn0.running_var, bn0.num_batches_tracked) if bn0 is not None else (None, None, None)]
+    st.eps = bn3.eps
+    st.momentum = 0.1 if bn3.momentum is None else bn3.momentum
+    st.training = bn3.training
+    out = RepBlockFn.apply(x, w3, w1, bn3.weight, bn3.bias, bn1.weight, bn1.bias,
+                           bn0.weight if bn0 is not None else None, bn0.bias if bn0 is not None else None, st, relu)
+    if st.last_out_stats is not None:
+        out._hc_stats = st.last_out_stats  # consumed by the next block's identity BatchNorm
+        st.last_out_stats = None
+    return out

@@ -1,0 +1,81 @@
+"""Pairwise box operators (reference: holocron/ops/boxes.py:16-211) on the HIP kernels.
+
+``ciou_loss`` reproduces the reference numerically, including its quirk that the aspect-ratio
+term is added to a temporary copy and therefore never reaches the result.
+"""
+import torch
+from torch import Tensor
+
+from .. import _lib
+from .._lib import check, ptr, stream
+
+__all__ = ["box_iou", "box_giou", "diou_loss", "ciou_loss", "iou_penalty", "aspect_ratio", "aspect_ratio_consistency",
+           "nms"]
+
+_KINDS = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3, "penalty": 4, "arc": 5}
+
+
+def _pairwise(boxes1: Tensor, boxes2: Tensor, kind: str) -> Tensor:
+    _lib.require_gpu(boxes1, boxes2)
+    b1 = boxes1.detach().float().contiguous()
+    b2 = boxes2.detach().float().contiguous()
+    M, N = b1.shape[0], b2.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=b1.device)
+    check(_lib.load().hc_box_pairwise(ptr(b1), ptr(b2), ptr(out), M, N, _KINDS[kind], stream()), "hc_box_pairwise")
+    return out
+
+
+def box_iou(boxes1: Tensor, boxes2: Tensor) -> Tensor:
+    """IoU matrix [M, N] (torchvision.ops.box_iou as used at holocron/ops/boxes.py:130,202)."""
+    return _pairwise(boxes1, boxes2, "iou")
+
+
+def box_giou(boxes1: Tensor, boxes2: Tensor) -> Tensor:
+    """Generalized IoU (holocron/ops/boxes.py:33-66); degenerate boxes raise AssertionError."""
+    if torch.any(boxes1[:, 2:] < boxes1[:, :2]) or torch.any(boxes2[:, 2:] < boxes2[:, :2]):
+        raise AssertionError("Incorrect coordinate format")
+    return _pairwise(boxes1, boxes2, "giou")
+
+
+def iou_penalty(boxes1: Tensor, boxes2: Tensor) -> Tensor:
+    """Centre-distance penalty of the DIoU loss (holocron/ops/boxes.py:69-103)."""
+    return _pairwise(boxes1, boxes2, "penalty")
+
+
+def diou_loss(boxes1: Tensor, boxes2: Tensor) -> Tensor:
+    """Distance-IoU loss ``1 - IoU + penalty`` (holocron/ops/boxes.py:106-131)."""
+    return _pairwise(boxes1, boxes2, "diou")
+
+
+def aspect_ratio(boxes: Tensor) -> Tensor:
+    """atan(w / h) (holocron/ops/boxes.py:134-143)."""
+    return torch.atan((boxes[:, 2] - boxes[:, 0]) / (boxes[:, 3] - boxes[:, 1]))
+
+
+def aspect_ratio_consistency(boxes1: Tensor, boxes2: Tensor) -> Tensor:
+    """4/pi^2 (atan(w1/h1) - atan(w2/h2))^2 (holocron/ops/boxes.py:146-160)."""
+    return _pairwise(boxes1, boxes2, "arc")
+
+
+def ciou_loss(boxes1: Tensor, boxes2: Tensor) -> Tensor:
+    """Complete-IoU loss as the reference computes it (holocron/ops/boxes.py:163-211)."""
+    return _pairwise(boxes1, boxes2, "ciou")
+
+
+def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
+    """Greedy NMS with torchvision.ops.nms semantics (call site holocron/models/detection/yolov4.py:329):
+    stable descending sort of the scores, suppress j when IoU(i, j) > threshold (strict), returns
+    the kept indices (int64) in score order."""
+    _lib.require_gpu(boxes, scores)
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    order = torch.sort(scores, descending=True, stable=True).indices
+    b = boxes.detach().float()[order].contiguous()
+    lib = _lib.load()
+    ws = torch.empty((max(int(lib.hc_nms_ws_bytes(n)), 8),), dtype=torch.uint8, device=boxes.device)
+    keep = torch.empty((n,), dtype=torch.int32, device=boxes.device)
+    nkeep = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
+    check(lib.hc_nms_sorted(ptr(b), n, float(iou_threshold), ptr(ws), ptr(keep), ptr(nkeep), stream()), "hc_nms_sorted")
+    k = int(nkeep.item())
+    return order[keep[:k].long()]

@@ -1,0 +1,214 @@
+"""Host side of the MFMA convolution kernels: descriptor construction and thin launch wrappers.
+
+Activations are logically NCHW ``torch.Tensor``s in bf16 with ``torch.channels_last`` strides,
+i.e. NHWC in HBM — the layout the kernels are written for.  Weights stay fp32 OIHW at the API
+surface (reference ``state_dict`` layout, SURVEY.md §5 checkpoint row) and are re-packed to the
+kernel layout lazily (cached on parameter version + optimizer epoch).
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from .._lib import ConvDesc, WgradDesc, check, ptr, stream, tap
+
+_WEIGHTS_EPOCH = [0]  # bumped by holocron_amd.optim after every raw-pointer parameter update
+
+
+def bump_weights_epoch():
+    _WEIGHTS_EPOCH[0] += 1
+
+
+def weights_epoch():
+    return _WEIGHTS_EPOCH[0]
+
+
+def is_cl_bf16(x):
+    return (x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_cuda
+            and x.is_contiguous(memory_format=torch.channels_last)
+            and (x.stride(1) == 1 or x.shape[1] == 1))
+
+
+def to_cl_bf16(x):
+    """Logical NCHW tensor -> bf16, NHWC in memory."""
+    _lib.require_gpu(x)
+    if is_cl_bf16(x):
+        return x
+    N, Cc, H, W = x.shape
+    if x.dtype == torch.float32 and x.is_contiguous():
+        out = torch.empty((N, Cc, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        check(_lib.load().hc_nchw_to_nhwc_bf16(ptr(x), ptr(out), N, Cc, H, W, Cc, stream()), "hc_nchw_to_nhwc_bf16")
+        return out
+    out = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    if out.stride(1) != 1:  # C == 1 or degenerate: force dense NHWC
+        out = out.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return out
+
+
+def empty_cl(N, Cc, H, W, device):
+    return torch.empty((N, Cc, H, W), dtype=torch.bfloat16, device=device, memory_format=torch.channels_last)
+
+
+def conv_out_size(H, k, s, p):
+    return (H + 2 * p - k) // s + 1
+
+
+# ------------------------------------------------------------------ descriptors
+def _fill_fwd_class(cl, OH, OW, KH, KW, stride, pad, tap0=0):
+    cl.OHg, cl.OWg, cl.oy0, cl.ox0, cl.ostep, cl.istep = OH, OW, 0, 0, 1, stride
+    n = 0
+    for kh in range(KH):
+        for kw in range(KW):
+            cl.tap[n] = tap(kh - pad, kw - pad, 0, tap0 + kh * KW + kw)
+            n += 1
+    cl.ntaps = n
+
+
+def fwd_desc(N, Cin, H, W, Cout, KH, KW, stride, pad, T=None, tap0=0):
+    """Descriptor of a forward conv (pointers left NULL)."""
+    if KH * KW > _lib.HC_MAX_TAPS:
+        raise ValueError("kernel too large for the gather-conv tap table")
+    d = ConvDesc()
+    OH, OW = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
+    d.N, d.IH, d.IW, d.srcC = N, H, W, Cin
+    d.OH, d.OW, d.Cout = OH, OW, Cout
+    d.T = KH * KW if T is None else T
+    d.nclass = 1
+    _fill_fwd_class(d.cls[0], OH, OW, KH, KW, stride, pad, tap0)
+    return d
+
+
+def dgrad_desc(N, Cin, H, W, Cout, branches, stride):
+    """Descriptor of the data gradient dx[N,H,W,Cin] of one or two convs that share input/stride.
+
+    ``branches``: list of (KH, KW, pad, src_index, tap0) — the weights of all branches are packed
+    (mode 1) into one tensor [Cin][T][Cout], branch b at taps [tap0, tap0+KH*KW)."""
+    if stride not in (1, 2):
+        raise NotImplementedError("gather-conv data gradient supports stride 1 and 2")
+    d = ConvDesc()
+    KH0, KW0, pad0 = branches[0][0], branches[0][1], branches[0][2]
+    OH, OW = conv_out_size(H, KH0, stride, pad0), conv_out_size(W, KW0, stride, pad0)
+    d.N, d.IH, d.IW, d.srcC = N, OH, OW, Cout      # source = dy
+    d.OH, d.OW, d.Cout = H, W, Cin                  # destination = dx
+    d.T = sum(b[0] * b[1] for b in branches)
+    d.nclass = stride * stride
+    for py in range(stride):
+        for px in range(stride):
+            cl = d.cls[py * stride + px]
+            cl.OHg = (H - py + stride - 1) // stride
+            cl.OWg = (W - px + stride - 1) // stride
+            cl.oy0, cl.ox0, cl.ostep, cl.istep = py, px, stride, 1
+            n = 0
+            for (KH, KW, pad, src, tap0) in branches:
+                for kh in range(KH):
+                    if (py + pad - kh) % stride:
+                        continue
+                    for kw in range(KW):
+                        if (px + pad - kw) % stride:
+                            continue
+                        wt = tap0 + (KH - 1 - kh) * KW + (KW - 1 - kw)
+                        cl.tap[n] = tap((py + pad - kh) // stride, (px + pad - kw) // stride, src, wt)
+                        n += 1
+            cl.ntaps = n
+    return d
+
+
+def launch_conv(d, src0, wpk, dst, src1=None, resid=None, stats=None, bias=None, act=0):
+    d.src0, d.src1, d.wpk, d.dst = ptr(src0), ptr(src1), ptr(wpk), ptr(dst)
+    d.resid, d.stats, d.bias, d.act = ptr(resid), ptr(stats), ptr(bias), act
+    check(_lib.load().hc_conv_gather(C.byref(d), stream()), "hc_conv_gather")
+
+
+# ------------------------------------------------------------------ weight packing
+def pack_weight(w, mode, out=None, tap0=0, T=None):
+    """fp32 OIHW -> packed bf16 (mode 0 fwd [Cout][T][Cin], mode 1 dgrad [Cin][T][Cout])."""
+    Cout, Cin, KH, KW = w.shape
+    T = KH * KW if T is None else T
+    if out is None:
+        shape = (Cout, T, Cin) if mode == 0 else (Cin, T, Cout)
+        out = torch.empty(shape, dtype=torch.bfloat16, device=w.device)
+    wc = w.detach()
+    if wc.dtype != torch.float32 or not wc.is_contiguous():
+        wc = wc.float().contiguous()
+    check(_lib.load().hc_pack_conv_weight(ptr(wc), ptr(out), Cout, Cin, KH, KW, mode, tap0, T, stream()),
+          "hc_pack_conv_weight")
+    return out
+
+
+def pack_weight_im2col(w, Kpad, k0=0):
+    """fp32 OIHW (tiny Cin) -> bf16 [Cout][1][Kpad] with k = k0 + (kh*KW+kw)*Cin + ci."""
+    Cout, Cin, KH, KW = w.shape
+    flat = w.detach().float().permute(0, 2, 3, 1).reshape(Cout, KH * KW * Cin)
+    out = torch.zeros((Cout, 1, Kpad), dtype=torch.bfloat16, device=w.device)
+    out[:, 0, k0:k0 + flat.shape[1]] = flat.to(torch.bfloat16)
+    return out
+
+
+class PackCache:
+    """Caches packed weights of one module; invalidated by in-place updates of the parameters
+    (torch version counter) or by our raw-pointer optimizers (weights epoch)."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, params, builder):
+        key = tuple((p.data_ptr(), p._version) for p in params) + (weights_epoch(),)
+        if key != self._key:
+            self._val = builder()
+            self._key = key
+        return self._val
+
+
+# ------------------------------------------------------------------ weight gradient
+def conv_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, out=None, accumulate=False):
+    """dW (fp32 OIHW) of a conv from NHWC-bf16 ``x`` [N,Cin,H,W] and ``dy`` [N,Cout,OH,OW]."""
+    N, _, H, W = x.shape
+    _, _, OH, OW = dy.shape
+    d = WgradDesc()
+    d.N, d.IH, d.IW, d.Cin, d.OH, d.OW, d.Cout = N, H, W, Cin, OH, OW, Cout
+    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    d.beta = 1 if (accumulate and out is not None) else 0
+    lib = _lib.load()
+    nbytes = lib.hc_conv_wgrad_ws_bytes(C.byref(d))
+    ws = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=x.device)
+    if out is None:
+        out = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=x.device)
+    d.x, d.dy, d.dw, d.ws = ptr(x), ptr(dy), ptr(out), ptr(ws)
+    check(lib.hc_conv_wgrad(C.byref(d), stream()), "hc_conv_wgrad")
+    return out
+
+
+def im2col_small(x, KH, KW, stride, pad, Kpad):
+    """NCHW fp32 (tiny Cin) -> NHWC bf16 column tensor, logical shape [N, Kpad, OH, OW]."""
+    N, Cin, H, W = x.shape
+    OH, OW = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
+    xc = x.detach()
+    if xc.dtype != torch.float32 or not xc.is_contiguous():
+        xc = xc.float().contiguous()
+    col = empty_cl(N, Kpad, OH, OW, x.device)
+    check(_lib.load().hc_im2col_small(ptr(xc), ptr(col), N, Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad, stream()),
+          "hc_im2col_small")
+    return col
+
+
+# ------------------------------------------------------------------ plain conv2d (inference / tests)
+def conv2d(x, weight, bias=None, stride=1, padding=0, act=0, stats=None):
+    """Forward convolution on the MFMA kernel (no autograd).  x: logical NCHW; returns bf16 NHWC."""
+    Cout, Cin, KH, KW = weight.shape
+    N, _, H, W = x.shape
+    if Cin % 16 != 0:
+        K = Cin * KH * KW
+        Kpad = ((K + 15) // 16) * 16
+        col = im2col_small(x, KH, KW, stride, padding, Kpad)
+        wpk = pack_weight_im2col(weight, Kpad)
+        d = fwd_desc(N, Kpad, col.shape[2], col.shape[3], Cout, 1, 1, 1, 0)
+        src = col
+    else:
+        src = to_cl_bf16(x)
+        wpk = pack_weight(weight, 0)
+        d = fwd_desc(N, Cin, H, W, Cout, KH, KW, stride, padding)
+    out = empty_cl(N, Cout, d.OH, d.OW, x.device)
+    b = None if bias is None else bias.detach().float().contiguous()
+    launch_conv(d, src, wpk, out, stats=stats, bias=b, act=act)
+    return out

@@ -1,0 +1,2 @@
+from .adabelief import *  # noqa: F401,F403
+from .lars import *  # noqa: F401,F403

@@ -1,0 +1,215 @@
+/* holocron_hip.h — C ABI of libholocron_hip.so (MI355X / gfx950).
+ *
+ * The reference (frgfm/Holocron) is pure Python on top of torch ops; it has no FFI of its
+ * own.  These entry points are what a binding for its hot path would call:
+ * each one replaces the aten / torchvision kernels that the cited reference lines launch.
+ * All pointers are DEVICE pointers unless said otherwise; no torch types cross this
+ * boundary.  Every function enqueues work on `stream` and returns immediately:
+ * 0 = ok, 1 = bad argument, 2 = launch failure.  Buffers are owned by the caller.
+ *
+ * Tensor layout: activations are NHWC bf16 ("channels-last" in HBM), weights are packed
+ * bf16 [rows][taps][k] by hc_pack_conv_weight, parameters/gradients/optimizer state are fp32
+ * in the reference's own layouts (OIHW for conv weights).
+ */
+#ifndef HOLOCRON_HIP_H
+#define HOLOCRON_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hc_stream_t; /* hipStream_t */
+
+#define HC_MAX_TAPS 12
+
+/* One "parity class" of a gather-conv: output sub-grid (i,j) -> output pixel
+ * (i*ostep+oy0, j*ostep+ox0); tap t reads source pixel (i*istep+dy[t], j*istep+dx[t]) of
+ * source tensor src[t] and multiplies with weight tap wt[t]. */
+typedef struct {
+    int32_t OHg, OWg, oy0, ox0, ostep, istep, ntaps;
+    int32_t tap[HC_MAX_TAPS]; /* packed: (dy & 0xff) | (dx & 0xff) << 8 | src << 16 | wt << 24 */
+} hc_conv_class;
+#define HC_TAP(dy, dx, src, wt) \
+    ((int32_t)(((uint32_t)(dy) & 0xffu) | (((uint32_t)(dx) & 0xffu) << 8) | ((uint32_t)(src) << 16) | ((uint32_t)(wt) << 24)))
+
+/* Implicit-GEMM convolution on MFMA: forward conv (1 class) and data-gradient
+ * (1 class for stride 1, 4 parity classes for stride 2; two sources fuse the 3x3 and 1x1
+ * branches of a RepBlock).  Replaces aten::convolution / convolution_backward(input) as
+ * launched by nn.Conv2d in holocron/models/utils.py:73 (conv_sequence) and
+ * holocron/models/classification/repvgg.py:71-73 (RepBlock.forward). */
+typedef struct {
+    const void* src0;   /* NHWC bf16 [N][IH][IW][srcC] */
+    const void* src1;   /* second source (same geometry) or NULL */
+    const void* wpk;    /* packed bf16 weights [Cout][T][srcC] */
+    void* dst;          /* NHWC bf16 [N][OH][OW][Cout] */
+    const void* resid;  /* optional NHWC bf16 added to the result (same shape as dst) */
+    float* stats;       /* optional fp32 [2][Cout]: += sum(y), += sum(y*y) (atomics) */
+    const float* bias;  /* optional fp32 [Cout] */
+    int32_t act;        /* 0 none, 1 relu, 2 hard_mish, 3 leaky(0.1), 4 mish, 5 silu */
+    int32_t N, IH, IW, srcC;
+    int32_t OH, OW, Cout;
+    int32_t T;          /* taps stored in wpk */
+    int32_t nclass;
+    hc_conv_class cls[4];
+} hc_conv_desc;
+int hc_conv_gather(const hc_conv_desc* d, hc_stream_t stream);
+
+/* Weight gradient dW[co][ci][kh][kw] = sum_m dy[m][co] * x[m + tap][ci].
+ * Replaces aten::convolution_backward(weight).  Split-K over output pixels: partial fp32
+ * slabs go to `ws` (at least hc_conv_wgrad_ws_bytes bytes), then a reduce kernel writes
+ * (beta=0) or accumulates (beta=1) the OIHW fp32 gradient. */
+typedef struct {
+    const void* x;      /* NHWC bf16 [N][IH][IW][Cin] */
+    const void* dy;     /* NHWC bf16 [N][OH][OW][Cout] */
+    float* dw;          /* fp32 [Cout][Cin][KH][KW] */
+    void* ws;
+    int32_t N, IH, IW, Cin, OH, OW, Cout;
+    int32_t KH, KW, stride, pad;
+    int32_t beta;
+} hc_wgrad_desc;
+int64_t hc_conv_wgrad_ws_bytes(const hc_wgrad_desc* d);
+int hc_conv_wgrad(const hc_wgrad_desc* d, hc_stream_t stream);
+
+/* fp32 OIHW master weights -> packed bf16.  mode 0: forward  [Cout][KH*KW][Cin];
+ * mode 1: data-gradient [Cin][KH*KW (spatially flipped)][Cout].  `tap0`/`T` let several
+ * kernels (3x3 + 1x1) share one packed tensor: taps are written at [tap0, tap0+KH*KW). */
+int hc_pack_conv_weight(const float* w, void* wpk, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
+                        int32_t mode, int32_t tap0, int32_t T, hc_stream_t stream);
+
+/* NCHW fp32 -> NHWC bf16 with channel padding to Cpad (zero filled) and back. */
+int hc_nchw_to_nhwc_bf16(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cpad,
+                         hc_stream_t stream);
+int hc_nhwc_bf16_to_nchw(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cpad,
+                         hc_stream_t stream);
+
+/* ---- RepBlock training-mode BatchNorm fusion (repvgg.py:71-73 + torch BatchNorm2d) ---- */
+/* From the conv-epilogue statistics compute the per-channel affine of every branch and update
+ * running_mean/var (momentum, unbiased var) and num_batches_tracked like nn.BatchNorm2d.
+ * coef out: fp32 [4][C] = a3, a1, a0, b ; save out: fp32 [6][C] = mean/invstd per branch. */
+typedef struct {
+    const float* stats[3];     /* [2][C] sums per branch (3x3, 1x1, identity); identity may be NULL */
+    const float* gamma[3];
+    const float* beta[3];
+    float* running_mean[3];
+    float* running_var[3];
+    int64_t* num_batches_tracked[3];
+    float* coef;
+    float* save;
+    int32_t C;
+    int64_t count;             /* N*H*W */
+    float eps, momentum;
+    int32_t training;          /* 0: use running stats (eval) */
+} hc_rep_bn_desc;
+int hc_rep_bn_finalize(const hc_rep_bn_desc* d, hc_stream_t stream);
+
+/* out = act(a3*y3 + a1*y1 + a0*x + b); optionally accumulates sum/sumsq of `out` into
+ * out_stats (the next block's identity-BN statistics). */
+int hc_rep_apply(const void* y3, const void* y1, const void* x, const float* coef, void* out, float* out_stats,
+                 int64_t npix, int32_t C, int32_t act, hc_stream_t stream);
+
+/* stats[2][C] += per-channel sum / sum of squares of an NHWC bf16 tensor. */
+int hc_channel_stats(const void* x, float* stats, int64_t npix, int32_t C, hc_stream_t stream);
+
+/* Backward of the fused BN+sum+ReLU.  Pass 1: per-channel sums of dz = g*(out>0), dz*y3,
+ * dz*y1, dz*x into red[4][C].  Pass 2 (after hc_rep_bn_bwd_finalize): dy3, dy1, dx_id. */
+int hc_rep_bwd_reduce(const void* g, const void* out, const void* y3, const void* y1, const void* x, float* red,
+                      int64_t npix, int32_t C, hc_stream_t stream);
+typedef struct {
+    const float* red;          /* [4][C] */
+    const float* save;         /* [6][C] from forward */
+    const float* gamma[3];
+    float* dgamma[3];
+    float* dbeta[3];
+    float* bcoef;              /* out fp32 [9][C]: A,B,Cc per branch */
+    int32_t C;
+    int64_t count;
+    int32_t has_identity;
+    int32_t accumulate;        /* 1: dgamma/dbeta += */
+} hc_rep_bn_bwd_desc;
+int hc_rep_bn_bwd_finalize(const hc_rep_bn_bwd_desc* d, hc_stream_t stream);
+int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void* y1, const void* x,
+                     const float* bcoef, void* dy3, void* dy1, void* dxid, int64_t npix, int32_t C,
+                     hc_stream_t stream);
+
+/* Global average pool over H*W (holocron/nn/modules/downsample.py:70-74) on NHWC bf16. */
+int hc_gap_fwd(const void* x, float* y, int32_t N, int32_t HW, int32_t C, hc_stream_t stream);
+int hc_gap_bwd(const float* dy, void* dx, int32_t N, int32_t HW, int32_t C, hc_stream_t stream);
+
+/* Stem / tiny-Cin convs go through an explicit im2col: x NCHW fp32 -> col NHWC bf16
+ * [N][OH][OW][Kpad] with k = (kh*KW+kw)*Cin+ci (zero padded to Kpad, Kpad % 16 == 0); the conv is
+ * then a 1x1 hc_conv_gather on `col` with weights packed in mode 2, and its weight gradient a 1x1
+ * hc_conv_wgrad unpacked by hc_unpack_im2col_grad. */
+int hc_im2col_small(const float* x, void* col, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                    int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t Kpad, hc_stream_t stream);
+int hc_unpack_im2col_grad(const float* dwcol, float* dw, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t Kpad,
+                          int32_t beta, hc_stream_t stream);
+
+/* ---- optimizers (multi-tensor; holocron/optim/adabelief.py:121-167, lars.py:90-135) ---- */
+/* One entry per CHUNK of a parameter tensor (the host splits tensors into chunks of at most
+ * HC_MT_CHUNK elements so that one workgroup handles one entry). */
+#define HC_MT_CHUNK 65536
+typedef struct {
+    float* p;
+    float* g;          /* LARS adds weight decay into g in place (lars.py:113-114) */
+    float* m;          /* exp_avg / momentum_buffer (may be NULL for LARS with momentum 0) */
+    float* s;          /* exp_avg_sq (AdaBelief) */
+    float* smax;       /* max_exp_avg_sq (amsgrad) or NULL */
+    int32_t n;         /* elements in this chunk */
+    int32_t group;     /* index into the group array */
+    int32_t tensor;    /* index of the owning tensor (LARS norms) */
+    int32_t flags;     /* bit0: LARS momentum buffer is initialised from the gradient */
+} hc_mt_chunk;
+typedef struct {
+    double lr, beta1, beta2, eps, weight_decay;
+    int32_t step;      /* step count AFTER increment (>=1) */
+    int32_t amsgrad;
+} hc_adabelief_group;
+/* `chunks` and `groups` are DEVICE arrays (the caller keeps them alive). */
+int hc_adabelief_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_adabelief_group* groups, hc_stream_t stream);
+
+typedef struct {
+    double lr, momentum, dampening, weight_decay;
+    int32_t nesterov;
+    int32_t pad_;
+} hc_lars_group;
+/* norms: fp32 [ntensors][2] scratch (sum of squares of p and g), zeroed by the callee. */
+int hc_lars_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_lars_group* groups, float* norms,
+                 int32_t ntensors, hc_stream_t stream);
+
+/* ---- pointwise / losses / boxes ---- */
+/* hard_mish: 0.5*x*clamp(x+2,0,2) (holocron/nn/functional.py:30-41), fp32, y may alias x. */
+int hc_hard_mish_fwd(const float* x, float* y, int64_t n, hc_stream_t stream);
+int hc_hard_mish_bwd(const float* x, const float* dy, float* dx, int64_t n, hc_stream_t stream);
+
+/* pairwise box ops (holocron/ops/boxes.py:16-211), boxes fp32 xyxy; out [M][N].
+ * kind: 0 iou, 1 giou, 2 diou_loss, 3 ciou_loss (== diou_loss), 4 iou_penalty,
+ * 5 aspect_ratio_consistency */
+int hc_box_pairwise(const float* b1, const float* b2, float* out, int32_t M, int32_t N, int32_t kind,
+                    hc_stream_t stream);
+
+/* Greedy NMS with torchvision.ops.nms semantics (yolov4.py:329): boxes [n][4] fp32 already
+ * sorted by descending score (stable); ws scratch of hc_nms_ws_bytes(n); keep out: int32 [n]
+ * indices into the sorted order (ascending), nkeep out: int32[1]. */
+int64_t hc_nms_ws_bytes(int32_t n);
+int hc_nms_sorted(const float* boxes, int32_t n, float iou_thr, void* ws, int32_t* keep, int32_t* nkeep,
+                  hc_stream_t stream);
+
+/* focal loss forward/backward (holocron/nn/functional.py:59-113); x [N][K][S] fp32 (S = product
+ * of trailing dims), target int64 [N][S]; loss_el out [N*S] (unreduced), valid out uint8 [N*S]
+ * (0 where target == ignore_index and 0 <= ignore_index < K). */
+int hc_focal_loss_fwd(const float* x, const int64_t* target, const float* weight, float* loss_el, uint8_t* valid,
+                      int32_t N, int32_t K, int64_t S, int32_t ignore_index, float gamma, hc_stream_t stream);
+int hc_focal_loss_bwd(const float* x, const int64_t* target, const float* weight, const float* dloss_el, float* dx,
+                      int32_t N, int32_t K, int64_t S, float gamma, hc_stream_t stream);
+
+/* softmax cross-entropy with label smoothing on [N][K] fp32 logits (criterion of
+ * references/classification/train.py:194); per-sample loss and dlogits of the MEAN loss. */
+int hc_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss_el, float* dlogits, int32_t N, int32_t K,
+                  float label_smoothing, hc_stream_t stream);
+
+const char* hc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,147 @@
+"""Functional restatement of the reference RepVGG (holocron/models/classification/repvgg.py,
+holocron/models/utils.py, holocron/nn/init.py, holocron/nn/modules/downsample.py) on torch-CPU fp32.
+
+The model is a plain ``dict`` of tensors with the reference's ``state_dict`` keys; forward is a chain
+of ``F.conv2d`` / ``F.batch_norm`` calls in the reference's order.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1   # torch nn.BatchNorm2d defaults used by the reference
+
+ARCH = {  # repvgg.py:232,280,328,376,424,472,498
+    "repvgg_a0": ([1, 2, 4, 14, 1], 0.75, 2.5),
+    "repvgg_a1": ([1, 2, 4, 14, 1], 1, 2.5),
+    "repvgg_a2": ([1, 2, 4, 14, 1], 1.5, 2.75),
+    "repvgg_b0": ([1, 4, 6, 16, 1], 1, 2.5),
+}
+PLANES = [64, 64, 128, 256, 512]  # repvgg.py:183
+
+
+def widths(planes, a, b, in_channels=3):  # repvgg.py:146-148
+    ch = [in_channels, int(min(1, a) * planes[0])]
+    ch.extend(int(a * c) for c in planes[1:-1])
+    ch.append(int(b * planes[-1]))
+    return ch
+
+
+def layout(num_blocks, chans):
+    """[(key prefix, cin, cout, stride, identity)] in execution order (repvgg.py:151-154)."""
+    out = []
+    for si, (nb, cin, cout) in enumerate(zip(num_blocks, chans[:-1], chans[1:])):
+        out.append((f"features.{si}.0", cin, cout, 2, False))
+        for bi in range(nb):
+            out.append((f"features.{si}.{bi + 1}", cout, cout, 1, True))
+    return out
+
+
+def init_state(num_blocks, chans, num_classes=10, seed=0):
+    """Random state with the reference's init rules (nn/init.py:17-24: kaiming-normal fan_out for
+    convs, BN weight 1 / bias 0; nn.Linear default init).  RNG order differs from the reference's
+    module construction, so parity tests load a *shared* state_dict instead of relying on seeds."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(key, cout, cin, k):
+        std = math.sqrt(2.0) / math.sqrt(cout * k * k)
+        sd[key] = torch.randn((cout, cin, k, k), generator=g) * std
+
+    def bn(prefix, c):
+        sd[prefix + ".weight"] = torch.ones(c)
+        sd[prefix + ".bias"] = torch.zeros(c)
+        sd[prefix + ".running_mean"] = torch.zeros(c)
+        sd[prefix + ".running_var"] = torch.ones(c)
+        sd[prefix + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+
+    for prefix, cin, cout, _, identity in layout(num_blocks, chans):
+        conv(prefix + ".branches.0.0.weight", cout, cin, 3)
+        bn(prefix + ".branches.0.1", cout)
+        conv(prefix + ".branches.1.0.weight", cout, cin, 1)
+        bn(prefix + ".branches.1.1", cout)
+        if identity:
+            bn(prefix + ".branches.2", cout)
+    bound = 1 / math.sqrt(chans[-1])
+    sd["head.weight"] = (torch.rand((num_classes, chans[-1]), generator=g) * 2 - 1) * bound
+    sd["head.bias"] = (torch.rand((num_classes,), generator=g) * 2 - 1) * bound
+    return sd
+
+
+def _bn(x, sd, prefix, training):
+    # nn.BatchNorm2d.forward: num_batches_tracked += 1, then F.batch_norm with momentum 0.1
+    if training:
+        sd[prefix + ".num_batches_tracked"] += 1
+    return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
+                        sd[prefix + ".bias"], training, BN_MOMENTUM, BN_EPS)
+
+
+def rep_block(x, sd, prefix, stride, identity, training):
+    """repvgg.py:71-73: python ``sum()`` over the branches (starts from int 0), then ReLU."""
+    if prefix + ".branches.weight" in sd:  # re-parametrised block: single conv with bias
+        return F.relu(F.conv2d(x, sd[prefix + ".branches.weight"], sd[prefix + ".branches.bias"], stride, 1))
+    out = 0 + _bn(F.conv2d(x, sd[prefix + ".branches.0.0.weight"], None, stride, 1), sd, prefix + ".branches.0.1", training)
+    out = out + _bn(F.conv2d(x, sd[prefix + ".branches.1.0.weight"], None, stride, 0), sd, prefix + ".branches.1.1", training)
+    if identity:
+        out = out + _bn(x, sd, prefix + ".branches.2", training)
+    return F.relu(out)
+
+
+def forward(sd, x, num_blocks, chans, training=False, taps=None):
+    """RepVGG.forward (nn.Sequential: features -> pool -> head).  ``taps`` (dict) collects block outputs."""
+    for prefix, _, _, stride, identity in layout(num_blocks, chans):
+        x = rep_block(x, sd, prefix, stride, identity, training)
+        if taps is not None:
+            taps[prefix] = x
+    x = x.view(x.shape[0], x.shape[1], -1).mean(2)      # GlobalAvgPool2d(flatten=True), downsample.py:70-73
+    return F.linear(x, sd["head.weight"], sd["head.bias"])
+
+
+def fuse_conv_bn(w, sd, bn_prefix):
+    """models/utils.py:116-143."""
+    scale = sd[bn_prefix + ".weight"] / torch.sqrt(sd[bn_prefix + ".running_var"] + BN_EPS)
+    return scale.view(-1, 1, 1, 1) * w, sd[bn_prefix + ".bias"] - scale * sd[bn_prefix + ".running_mean"]
+
+
+def reparametrize(sd, num_blocks, chans):
+    """RepBlock.reparametrize for every block (repvgg.py:75-107); returns a new state dict."""
+    out = {"head.weight": sd["head.weight"], "head.bias": sd["head.bias"]}
+    for prefix, cin, cout, _, identity in layout(num_blocks, chans):
+        k3, b3 = fuse_conv_bn(sd[prefix + ".branches.0.0.weight"], sd, prefix + ".branches.0.1")
+        k1, b1 = fuse_conv_bn(sd[prefix + ".branches.1.0.weight"], sd, prefix + ".branches.1.1")
+        k = k3.clone()
+        k[..., 1:2, 1:2] += k1
+        b = b3 + b1
+        if identity:
+            p = prefix + ".branches.2"
+            scale = sd[p + ".weight"] / (sd[p + ".running_var"] + BN_EPS).sqrt()
+            k[range(cout), range(cin), 1, 1] += scale
+            b = b + sd[p + ".bias"] - scale * sd[p + ".running_mean"]
+        out[prefix + ".branches.weight"] = k
+        out[prefix + ".branches.bias"] = b
+    return out
+
+
+def trainable_keys(sd):
+    return [k for k in sd if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))]
+
+
+def train_step(sd, opt_state, x, target, num_blocks, chans, lr=1e-3, betas=(0.95, 0.99), eps=1e-6, weight_decay=0.0,
+               label_smoothing=0.1):
+    """One reference training step: forward (train mode), CrossEntropyLoss(label_smoothing)
+    (references/classification/train.py:194), backward, AdaBelief (train.py:208-209).  In place."""
+    from .optim import adabelief_step
+    keys = trainable_keys(sd)
+    params = {k: sd[k].detach().requires_grad_(True) for k in keys}
+    work = dict(sd)
+    work.update(params)
+    logits = forward(work, x, num_blocks, chans, training=True)
+    loss = F.cross_entropy(logits, target, label_smoothing=label_smoothing)
+    grads = torch.autograd.grad(loss, [params[k] for k in keys])
+    opt_state["step"] = opt_state.get("step", 0) + 1
+    with torch.no_grad():
+        for k, g in zip(keys, grads):
+            m = opt_state.setdefault("m." + k, torch.zeros_like(sd[k]))
+            s = opt_state.setdefault("s." + k, torch.zeros_like(sd[k]))
+            adabelief_step(sd[k], g, m, s, opt_state["step"], lr, betas[0], betas[1], eps, weight_decay)
+    return loss.detach(), logits.detach(), dict(zip(keys, grads))

@@ -1,0 +1,149 @@
+"""CPU: pin the oracle (oracle/) against golden vectors produced by the reference itself."""
+import torch
+
+from oracle import boxes as ob
+from oracle import functional as of
+from oracle import optim as oo
+from oracle import repvgg as orv
+from oracle import tv_ops
+
+
+def test_boxes_match_reference(golden):
+    g = golden("boxes.pt")
+    for tag, (x, y) in {"rand": (g["b1"], g["b2"]), "kat": (g["kat_boxes"], g["kat_boxes"])}.items():
+        ref = g[tag]
+        assert torch.equal(tv_ops.box_iou(x, y), ref["iou"])
+        assert torch.equal(ob.box_giou(x, y), ref["giou"])
+        assert torch.equal(ob.iou_penalty(x, y), ref["penalty"])
+        assert torch.equal(ob.diou_loss(x, y), ref["diou"])
+        assert torch.equal(ob.ciou_loss(x, y), ref["ciou"])
+        assert torch.allclose(ob.aspect_ratio_consistency(x, y), ref["arc"], rtol=0, atol=0)
+    # reference KATs (tests/test_ops.py:26-34): diou of a box with itself is 0; known values
+    kat = g["kat_boxes"]
+    d = ob.diou_loss(kat, kat)
+    assert d[0, 0] == 0
+    assert d[0, 1] == 1 - 0.25 + 25 ** 2 / 100 ** 2
+    assert d[0, 3] == 1 + 100 ** 2 / 200 ** 2
+    # Q1: the reference's ciou == diou
+    assert torch.equal(g["rand"]["ciou"], g["rand"]["diou"])
+
+
+def test_functional_match_reference(golden):
+    g = golden("functional.pt")
+    hm = g["hard_mish"]
+    x = hm["x"].clone().requires_grad_(True)
+    y = of.hard_mish(x)
+    assert torch.equal(y, hm["y"])
+    (dx,) = torch.autograd.grad((y * hm["r"]).sum(), x)
+    assert torch.equal(dx, hm["dx"])
+    for c in g["focal"]:
+        x = c["x"].clone().requires_grad_(True)
+        loss = of.focal_loss(x, c["target"], c["weight"], c["ignore_index"], c["reduction"], c["gamma"])
+        assert torch.allclose(loss, c["loss"], rtol=1e-6, atol=1e-7)
+        (dx,) = torch.autograd.grad((loss * c["r"]).sum(), x)
+        assert torch.allclose(dx, c["dx"], rtol=1e-5, atol=1e-7)
+
+
+def test_optim_match_reference(golden):
+    g = golden("optim.pt")
+    for c in g["adabelief"]:
+        kw = c["kw"]
+        p = c["p0"].clone()
+        m, s = torch.zeros_like(p), torch.zeros_like(p)
+        smax = torch.zeros_like(p) if kw["amsgrad"] else None
+        for i, gr in enumerate(c["grads"]):
+            oo.adabelief_step(p, gr.clone(), m, s, i + 1, kw["lr"], kw["betas"][0], kw["betas"][1], kw["eps"],
+                              kw["weight_decay"], smax)
+            assert torch.equal(p, c["traj"][i])
+        assert torch.equal(m, c["exp_avg"]) and torch.equal(s, c["exp_avg_sq"])
+    for c in g["lars"]:
+        kw = dict(c["kw"])
+        lr = kw.pop("lr")
+        p = c["p0"].clone()
+        buf = None
+        for i, gr in enumerate(c["grads"]):
+            gg = gr.clone()
+            buf = oo.lars_step(p, gg, buf, lr, **kw)
+            assert torch.allclose(p, c["traj"][i], rtol=1e-6, atol=1e-7)
+            assert torch.equal(gg, c["grad_after"][i])
+
+
+def _block_sd(state, prefix="blk"):
+    return {prefix + "." + k: v.clone() for k, v in state.items()}
+
+
+def test_repblock_match_reference(golden):
+    for c in golden("repblock.pt"):
+        cin, cout, stride, ident = c["cfg"]
+        sd = _block_sd(c["state"])
+        keys = [k for k in orv.trainable_keys(sd)]
+        for k in keys:
+            sd[k].requires_grad_(True)
+        x = c["x"].clone().requires_grad_(True)
+        out = orv.rep_block(x, sd, "blk", stride, ident, training=True)
+        assert torch.equal(out, c["out"])
+        grads = torch.autograd.grad((out * c["r"]).sum(), [x] + [sd[k] for k in keys])
+        # conv-backward reduction order depends on the CPU thread count: tight tolerance, not bits
+        assert torch.allclose(grads[0], c["dx"], rtol=1e-4, atol=1e-5)
+        for k, gr in zip(keys, grads[1:]):
+            assert torch.allclose(gr, c["dparams"][k[len("blk."):]], rtol=1e-4, atol=1e-4), k
+        for k, v in c["state_after"].items():
+            assert torch.equal(sd["blk." + k].detach(), v), k
+        # eval + reparametrisation (repvgg.py:75-107)
+        sd_eval = {k: v.detach().clone() for k, v in sd.items()}
+        with torch.no_grad():
+            out_eval = orv.rep_block(c["x"], sd_eval, "blk", stride, ident, training=False)
+        assert torch.equal(out_eval, c["out_eval"])
+        k3, b3 = orv.fuse_conv_bn(sd_eval["blk.branches.0.0.weight"], sd_eval, "blk.branches.0.1")
+        k1, b1 = orv.fuse_conv_bn(sd_eval["blk.branches.1.0.weight"], sd_eval, "blk.branches.1.1")
+        k = k3.clone()
+        k[..., 1:2, 1:2] += k1
+        b = b3 + b1
+        if ident:
+            scale = sd_eval["blk.branches.2.weight"] / (sd_eval["blk.branches.2.running_var"] + 1e-5).sqrt()
+            k[range(cout), range(cin), 1, 1] += scale
+            b = b + sd_eval["blk.branches.2.bias"] - scale * sd_eval["blk.branches.2.running_mean"]
+        assert torch.allclose(k, c["rep_weight"], rtol=1e-6, atol=1e-7)
+        assert torch.allclose(b, c["rep_bias"], rtol=1e-5, atol=1e-6)
+
+
+def test_repvgg_small_train_steps_match_reference(golden):
+    g = golden("repvgg_small.pt")
+    cfg = g["cfg"]
+    nb = cfg["num_blocks"]
+    ch = orv.widths(cfg["planes"], cfg["width_multiplier"], cfg["final_width_multiplier"])
+    sd = {k: v.clone() for k, v in g["state"].items()}
+    opt = {}
+    for step in g["steps"]:
+        loss, logits, grads = orv.train_step(sd, opt, g["x"], g["target"], nb, ch)
+        assert torch.allclose(logits, step["logits"], rtol=1e-4, atol=1e-4)
+        assert torch.allclose(loss, step["loss"], rtol=1e-5, atol=1e-6)
+        for k, gr in grads.items():
+            assert torch.allclose(gr, step["grads"][k], rtol=1e-3, atol=1e-4), k
+        for k, v in step["state_after"].items():
+            assert torch.allclose(sd[k].float(), v.float(), rtol=1e-3, atol=2e-4), k
+    with torch.no_grad():
+        ev = orv.forward(sd, g["x"], nb, ch, training=False)
+        assert torch.allclose(ev, g["eval_logits"], rtol=1e-3, atol=1e-3)
+        rep = orv.reparametrize(sd, nb, ch)
+        ev_rep = orv.forward(rep, g["x"], nb, ch, training=False)
+    assert torch.allclose(ev_rep, g["eval_logits_rep"], rtol=1e-3, atol=1e-3)
+
+
+def test_arch_tables_match_reference_param_counts():
+    # published metadata: repvgg_a0 has 24 741 642 parameters (repvgg.py:195)
+    nb, a, b = orv.ARCH["repvgg_a0"]
+    ch = orv.widths(orv.PLANES, a, b)
+    assert ch == [3, 48, 48, 96, 192, 1280]
+    sd = orv.init_state(nb, ch)
+    assert sum(sd[k].numel() for k in orv.trainable_keys(sd)) == 24741642
+
+
+def test_nms_restatement_cases(golden):
+    for c in golden("nms.pt"):
+        keep = tv_ops.nms(c["boxes"], c["scores"], c["thr"])
+        assert torch.equal(keep, c["keep"])
+        if c["pinned_by"].startswith("reference test (disjoint)"):
+            assert keep.numel() == 49 and torch.equal(keep, torch.sort(c["scores"], descending=True, stable=True).indices)
+        if c["pinned_by"].startswith("reference test (identical)"):
+            assert keep.tolist() == [0]
