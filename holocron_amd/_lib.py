@@ -89,7 +89,7 @@ SIGNATURES = {
     "hc_rep_bwd_apply": (c_int32, [c_void_p] * 9 + [c_int64, c_int32, c_void_p]),
     "hc_gap_fwd": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "hc_gap_bwd": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
-    "hc_adabelief_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p]),
+    "hc_adabelief_step": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "hc_lars_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     "hc_hard_mish_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "hc_hard_mish_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

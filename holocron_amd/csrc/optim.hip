@@ -62,6 +62,11 @@ __global__ __launch_bounds__(256) void adabelief_kernel(const hc_mt_chunk* __res
     }
 }
 
+__global__ void adabelief_advance_kernel(hc_adabelief_group* __restrict__ groups, int ngroups) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < ngroups) groups[g].step += 1;
+}
+
 __global__ __launch_bounds__(256) void lars_norm_kernel(const hc_mt_chunk* __restrict__ chunks, float* __restrict__ norms) {
     const hc_mt_chunk ck = chunks[blockIdx.x];
     float sp = 0.f, sg = 0.f;
@@ -113,10 +118,14 @@ __global__ __launch_bounds__(256) void lars_update_kernel(const hc_mt_chunk* __r
 
 extern "C" {
 
-int hc_adabelief_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_adabelief_group* groups, hc_stream_t stream) {
-    if (chunks == nullptr || groups == nullptr || nchunks < 0) return HC_ERR_ARG;
-    if (nchunks == 0) return HC_OK;
-    hipLaunchKernelGGL(adabelief_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, chunks, groups);
+int hc_adabelief_step(const hc_mt_chunk* chunks, int32_t nchunks, hc_adabelief_group* groups, int32_t ngroups,
+                      int32_t advance, hc_stream_t stream) {
+    if (chunks == nullptr || groups == nullptr || nchunks < 0 || ngroups < 1) return HC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    // the step counters live on the device so that a step replayed from a captured hipGraph keeps
+    // counting without any host write (a host-updated counter would race with queued replays)
+    if (advance) hipLaunchKernelGGL(adabelief_advance_kernel, dim3((ngroups + 63) / 64), dim3(64), 0, st, groups, ngroups);
+    if (nchunks > 0) hipLaunchKernelGGL(adabelief_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups);
     return hc_launch_status();
 }
 

@@ -91,8 +91,11 @@ class RepBlockFn(torch.autograd.Function):
         y3 = cv.empty_cl(N, Cout, OH, OW, dev)
         y1 = cv.empty_cl(N, Cout, OH, OW, dev)
         stats = torch.zeros((2, 2, Cout), dtype=torch.float32, device=dev) if st.training else None
-        cv.launch_conv(f3, src, wp3, y3, stats=None if stats is None else stats[0])
-        cv.launch_conv(f1, src, wp1, y1, stats=None if stats is None else stats[1])
+        fl3 = fl1 = None
+        if stem:  # algorithmic flops of the real 3x3 / 1x1 convs, not of the padded im2col GEMM
+            fl3, fl1 = 2.0 * N * OH * OW * Cout * 9 * Cin, 2.0 * N * OH * OW * Cout * Cin
+        cv.launch_conv(f3, src, wp3, y3, stats=None if stats is None else stats[0], flops=fl3)
+        cv.launch_conv(f1, src, wp1, y1, stats=None if stats is None else stats[1], flops=fl1)
 
         coef = torch.empty((4, Cout), dtype=torch.float32, device=dev)
         save = torch.empty((6, Cout), dtype=torch.float32, device=dev)
@@ -180,8 +183,8 @@ class RepBlockFn(torch.autograd.Function):
 
         if ctx.stem:
             K = STEM_KPAD
-            dwc3 = cv.conv_wgrad(src, dy3, K, Cout, 1, 1, 1, 0)
-            dwc1 = cv.conv_wgrad(src, dy1, K, Cout, 1, 1, 1, 0)
+            dwc3 = cv.conv_wgrad(src, dy3, K, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * 9 * Cin)
+            dwc1 = cv.conv_wgrad(src, dy1, K, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * Cin)
             dw3 = torch.empty_like(w3, dtype=torch.float32)
             check(lib.hc_unpack_im2col_grad(ptr(dwc3), ptr(dw3), Cout, Cin, 3, 3, K, 0, stream()), "hc_unpack_im2col_grad")
             dw1 = dwc1.view(Cout, K)[:, 4 * Cin:5 * Cin].reshape(Cout, Cin, 1, 1).contiguous()

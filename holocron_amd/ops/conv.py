@@ -113,9 +113,27 @@ def dgrad_desc(N, Cin, H, W, Cout, branches, stride):
     return d
 
 
-def launch_conv(d, src0, wpk, dst, src1=None, resid=None, stats=None, bias=None, act=0):
+PROFILE = None  # bench.py sets this to a list: (family, algorithmic flops, start event, end event)
+
+
+def _desc_flops(d):
+    macs = 0
+    for c in range(d.nclass):
+        cl = d.cls[c]
+        macs += d.N * cl.OHg * cl.OWg * cl.ntaps
+    return 2.0 * macs * d.srcC * d.Cout
+
+
+def launch_conv(d, src0, wpk, dst, src1=None, resid=None, stats=None, bias=None, act=0, flops=None):
     d.src0, d.src1, d.wpk, d.dst = ptr(src0), ptr(src1), ptr(wpk), ptr(dst)
     d.resid, d.stats, d.bias, d.act = ptr(resid), ptr(stats), ptr(bias), act
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().hc_conv_gather(C.byref(d), stream()), "hc_conv_gather")
+        e1.record()
+        PROFILE.append(("conv_gather", _desc_flops(d) if flops is None else flops, e0, e1))
+        return
     check(_lib.load().hc_conv_gather(C.byref(d), stream()), "hc_conv_gather")
 
 
@@ -161,7 +179,7 @@ class PackCache:
 
 
 # ------------------------------------------------------------------ weight gradient
-def conv_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, out=None, accumulate=False):
+def conv_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, out=None, accumulate=False, flops=None):
     """dW (fp32 OIHW) of a conv from NHWC-bf16 ``x`` [N,Cin,H,W] and ``dy`` [N,Cout,OH,OW]."""
     N, _, H, W = x.shape
     _, _, OH, OW = dy.shape
@@ -175,6 +193,13 @@ def conv_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, out=None, accumulate=False
     if out is None:
         out = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=x.device)
     d.x, d.dy, d.dw, d.ws = ptr(x), ptr(dy), ptr(out), ptr(ws)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.hc_conv_wgrad(C.byref(d), stream()), "hc_conv_wgrad")
+        e1.record()
+        PROFILE.append(("conv_wgrad", 2.0 * N * OH * OW * Cout * KH * KW * Cin if flops is None else flops, e0, e1))
+        return out
     check(lib.hc_conv_wgrad(C.byref(d), stream()), "hc_conv_wgrad")
     return out
 

@@ -1,4 +1,5 @@
-"""Chunk tables for the multi-tensor optimizer kernels (hc_mt_chunk in include/holocron_hip.h)."""
+"""Chunk tables for the multi-tensor optimizer kernels (hc_mt_chunk in include/holocron_hip.h) and
+stream-ordered host->device staging that is safe when the host runs ahead of the GPU."""
 import ctypes as C
 
 import numpy as np
@@ -11,9 +12,9 @@ _CHUNK_DT = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("s", "<u8"), ("
 assert _CHUNK_DT.itemsize == C.sizeof(MtChunk)
 
 
-def build_chunks(entries):
+def chunk_rows(entries):
     """entries: list of dict(p, g, m, s, smax, group, tensor, flags) of fp32 tensors (m/s/smax optional).
-    Returns a uint8 CPU tensor holding the hc_mt_chunk array and the chunk count."""
+    Returns the hc_mt_chunk array as raw uint8 numpy bytes and the chunk count."""
     rows = []
     for e in entries:
         n = e["p"].numel()
@@ -22,4 +23,45 @@ def build_chunks(entries):
             cnt = min(HC_MT_CHUNK, n - off)
             rows.append(tuple((q + 4 * off) if q else 0 for q in ptrs) + (cnt, e["group"], e["tensor"], e.get("flags", 0)))
     arr = np.array(rows, dtype=_CHUNK_DT) if rows else np.zeros((0,), dtype=_CHUNK_DT)
-    return torch.from_numpy(arr.view(np.uint8).copy()), len(rows)
+    return arr.view(np.uint8).copy(), len(rows)
+
+
+def build_chunks(entries):
+    raw, n = chunk_rows(entries)
+    return torch.from_numpy(raw), n
+
+
+class Staging:
+    """A device buffer fed from a small ring of pinned host buffers with async copies.  Every slot
+    carries an event so that the host never rewrites a slot whose copy the GPU has not executed
+    yet.  Nothing is allocated after construction, so ``upload`` may run inside a hipGraph capture
+    (the captured copy node keeps reading its slot; the ring is not reused by the host afterwards
+    unless ``upload`` is called again, which then picks another slot)."""
+
+    def __init__(self, nbytes, device, slots=4):
+        self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.host = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.locked = [False] * slots   # slots a captured graph keeps reading on every replay
+        self.cur = 0
+
+    def upload(self, raw):
+        capturing = torch.cuda.is_current_stream_capturing()
+        for _ in range(len(self.host)):
+            i = self.cur
+            self.cur = (self.cur + 1) % len(self.host)
+            if not self.locked[i]:
+                break
+        else:
+            raise RuntimeError("all staging slots are owned by captured graphs")
+        if capturing:
+            self.locked[i] = True
+        if self.events[i] is not None and not capturing:
+            self.events[i].synchronize()
+        self.host[i].numpy()[:raw.size] = raw
+        self.dev.copy_(self.host[i], non_blocking=True)
+        if not capturing:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.events[i] = ev
+        return self.dev

@@ -161,11 +161,14 @@ typedef struct {
 } hc_mt_chunk;
 typedef struct {
     double lr, beta1, beta2, eps, weight_decay;
-    int32_t step;      /* step count AFTER increment (>=1) */
+    int32_t step;      /* step count used by the update (>=1 when the update runs) */
     int32_t amsgrad;
 } hc_adabelief_group;
-/* `chunks` and `groups` are DEVICE arrays (the caller keeps them alive). */
-int hc_adabelief_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_adabelief_group* groups, hc_stream_t stream);
+/* `chunks` and `groups` are DEVICE arrays (the caller keeps them alive).  advance != 0 first
+ * increments every group's `step` ON THE DEVICE (so a step captured in a hipGraph keeps counting
+ * across replays), then applies the update. */
+int hc_adabelief_step(const hc_mt_chunk* chunks, int32_t nchunks, hc_adabelief_group* groups, int32_t ngroups,
+                      int32_t advance, hc_stream_t stream);
 
 typedef struct {
     double lr, momentum, dampening, weight_decay;

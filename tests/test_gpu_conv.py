@@ -1,0 +1,124 @@
+"""GPU: the MFMA conv kernels against torch-CPU fp32 on bf16-representable operands.
+
+Tolerances: results stored as bf16 carry a rounding of 2^-9 relative per element (RMS ~1.1e-3),
+so bf16 outputs are checked to rel-L2 <= 3e-3; fp32 outputs (statistics, weight gradients) to 2e-4.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _to_nchw_f32(y):
+    return y.float().cpu().contiguous()
+
+
+CONV_CASES = [
+    # N, Cin, Cout, H, W, k, stride
+    (2, 16, 48, 13, 13, 3, 1),     # BK=16, 64-wide channel tile with padding
+    (2, 48, 48, 14, 9, 3, 2),
+    (3, 32, 96, 9, 9, 3, 1),       # BK=32, 96 tile
+    (2, 64, 192, 14, 14, 3, 1),    # BK=64, 192 tile
+    (2, 192, 192, 7, 7, 1, 1),
+    (2, 64, 128, 10, 10, 3, 2),    # 128 tile
+    (1, 128, 320, 7, 7, 3, 1),     # two channel tiles + ragged
+    (2, 96, 40, 5, 5, 1, 2),       # Cout % 32 != 0
+    (5, 16, 255, 6, 6, 1, 1),      # Cout % 4 != 0 (YOLO head width): scalar store path
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,stride", CONV_CASES)
+def test_conv_forward_matches_cpu(N, Cin, Cout, H, W, k, stride):
+    from holocron_amd.ops import conv as cv
+    torch.manual_seed(N * 1000 + Cin + Cout)
+    x = bf16r(torch.randn(N, Cin, H, W))
+    w = bf16r(torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5)
+    b = torch.randn(Cout)
+    ref = F.conv2d(x, w, b, stride, k // 2)
+    stats = torch.zeros(2, Cout, device="cuda")
+    out = cv.conv2d(x.cuda(), w.cuda(), b.cuda(), stride, k // 2, stats=stats)
+    assert out.shape == ref.shape
+    assert rel_l2(_to_nchw_f32(out), ref) < 3e-3
+    # the statistics epilogue sees the fp32 accumulators BEFORE bias/rounding
+    nob = F.conv2d(x, w, None, stride, k // 2).double()
+    s = stats.cpu().double()
+    assert rel_l2(s[0], nob.sum((0, 2, 3))) < 2e-4 or (s[0] - nob.sum((0, 2, 3))).abs().max() < 1e-2
+    assert rel_l2(s[1], (nob * nob).sum((0, 2, 3))) < 2e-4
+    relu = cv.conv2d(x.cuda(), w.cuda(), b.cuda(), stride, k // 2, act=1)
+    assert rel_l2(_to_nchw_f32(relu), F.relu(ref)) < 3e-3
+
+
+def test_conv_forward_stem_im2col():
+    from holocron_amd.ops import conv as cv
+    torch.manual_seed(3)
+    x = bf16r(torch.rand(3, 3, 33, 31))
+    w = bf16r(torch.randn(48, 3, 3, 3) * 0.2)
+    out = cv.conv2d(x.cuda(), w.cuda(), None, 2, 1)
+    assert rel_l2(_to_nchw_f32(out), F.conv2d(x, w, None, 2, 1)) < 3e-3
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,stride", [(2, 16, 48, 12, 12, 1), (2, 48, 96, 13, 10, 2), (2, 64, 192, 9, 9, 1),
+                                                     (1, 192, 128, 8, 8, 2), (2, 32, 64, 7, 7, 2)])
+def test_dual_branch_dgrad_matches_autograd(N, Cin, Cout, H, W, stride):
+    from holocron_amd.ops import conv as cv
+    torch.manual_seed(Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, requires_grad=True)
+    w3 = bf16r(torch.randn(Cout, Cin, 3, 3) / (Cout * 9) ** 0.5)
+    w1 = bf16r(torch.randn(Cout, Cin, 1, 1) / Cout ** 0.5)
+    y3, y1 = F.conv2d(x, w3, None, stride, 1), F.conv2d(x, w1, None, stride, 0)
+    g3, g1 = bf16r(torch.randn_like(y3)), bf16r(torch.randn_like(y1))
+    res = bf16r(torch.randn(N, Cin, H, W))
+    (dx,) = torch.autograd.grad((y3 * g3).sum() + (y1 * g1).sum(), x)
+    d = cv.dgrad_desc(N, Cin, H, W, Cout, [(3, 3, 1, 0, 0), (1, 1, 0, 1, 9)], stride)
+    wp = torch.empty((Cin, 10, Cout), dtype=torch.bfloat16, device="cuda")
+    cv.pack_weight(w3.cuda(), 1, out=wp, tap0=0, T=10)
+    cv.pack_weight(w1.cuda(), 1, out=wp, tap0=9, T=10)
+    out = cv.empty_cl(N, Cin, H, W, "cuda")
+    cv.launch_conv(d, cv.to_cl_bf16(g3.cuda()), wp, out, src1=cv.to_cl_bf16(g1.cuda()), resid=cv.to_cl_bf16(res.cuda()))
+    assert rel_l2(_to_nchw_f32(out), dx + res) < 3e-3
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,k,stride", [(2, 16, 48, 12, 12, 3, 1), (3, 48, 48, 11, 9, 3, 2), (2, 64, 192, 9, 9, 3, 1),
+                                                       (2, 192, 64, 8, 8, 1, 1), (4, 32, 96, 7, 7, 1, 2), (2, 136, 200, 6, 6, 3, 1)])
+def test_wgrad_matches_autograd(N, Cin, Cout, H, W, k, stride):
+    from holocron_amd.ops import conv as cv
+    torch.manual_seed(Cin * 3 + Cout)
+    x = bf16r(torch.randn(N, Cin, H, W))
+    w = torch.randn(Cout, Cin, k, k, requires_grad=True)
+    y = F.conv2d(x, w, None, stride, k // 2)
+    g = bf16r(torch.randn_like(y))
+    (dw,) = torch.autograd.grad((y * g).sum(), w)
+    out = cv.conv_wgrad(cv.to_cl_bf16(x.cuda()), cv.to_cl_bf16(g.cuda()), Cin, Cout, k, k, stride, k // 2)
+    assert out.shape == dw.shape
+    assert rel_l2(out.cpu(), dw) < 2e-4
+    acc = cv.conv_wgrad(cv.to_cl_bf16(x.cuda()), cv.to_cl_bf16(g.cuda()), Cin, Cout, k, k, stride, k // 2,
+                        out=out.clone(), accumulate=True)
+    assert rel_l2(acc.cpu(), 2 * dw) < 2e-4
+
+
+def test_wgrad_large_reduction_split_k():
+    """many output pixels -> several K splits (slab reduce path)"""
+    from holocron_amd.ops import conv as cv
+    torch.manual_seed(0)
+    N, Cin, Cout, H = 8, 48, 48, 56
+    x = bf16r(torch.randn(N, Cin, H, H))
+    w = torch.randn(Cout, Cin, 3, 3, requires_grad=True)
+    y = F.conv2d(x, w, None, 1, 1)
+    g = bf16r(torch.randn_like(y))
+    (dw,) = torch.autograd.grad((y * g).sum(), w)
+    out = cv.conv_wgrad(cv.to_cl_bf16(x.cuda()), cv.to_cl_bf16(g.cuda()), Cin, Cout, 3, 3, 1, 1)
+    assert rel_l2(out.cpu(), dw) < 2e-4
+
+
+def test_layout_roundtrip():
+    from holocron_amd.ops import conv as cv
+    x = bf16r(torch.randn(2, 24, 5, 7))
+    y = cv.to_cl_bf16(x.cuda())
+    assert y.is_contiguous(memory_format=torch.channels_last) and torch.equal(y.float().cpu(), x)

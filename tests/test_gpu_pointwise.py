@@ -1,0 +1,137 @@
+"""GPU: pointwise / box / NMS / loss / optimizer kernels against golden vectors and the oracle.
+Box indices and NMS results are integer work: bit-exact.  Box arithmetic (fp32, no contraction) is
+bit-exact too except the atan-based aspect term."""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def test_boxes_bit_exact_vs_reference(golden):
+    from holocron_amd.ops import boxes as hb
+    g = golden("boxes.pt")
+    for tag, (x, y) in {"rand": (g["b1"], g["b2"]), "kat": (g["kat_boxes"], g["kat_boxes"])}.items():
+        ref = g[tag]
+        xc, yc = x.cuda(), y.cuda()
+        assert torch.equal(hb.box_iou(xc, yc).cpu(), ref["iou"])
+        assert torch.equal(hb.box_giou(xc, yc).cpu(), ref["giou"])
+        assert torch.equal(hb.iou_penalty(xc, yc).cpu(), ref["penalty"])
+        assert torch.equal(hb.diou_loss(xc, yc).cpu(), ref["diou"])
+        assert torch.equal(hb.ciou_loss(xc, yc).cpu(), ref["ciou"])
+        assert torch.allclose(hb.aspect_ratio_consistency(xc, yc).cpu(), ref["arc"], rtol=1e-5, atol=1e-7)
+    with pytest.raises(AssertionError):
+        hb.box_giou(torch.tensor([[1.0, 1.0, 0.0, 2.0]]).cuda(), g["b2"].cuda())
+
+
+def test_boxes_large_vs_oracle():
+    from holocron_amd.ops import boxes as hb
+    from oracle import boxes as ob, tv_ops
+    g = torch.Generator().manual_seed(1)
+    xy = torch.rand((3000, 2), generator=g)
+    b1 = torch.cat([xy, xy + torch.rand((3000, 2), generator=g) * 0.3 + 1e-3], 1)
+    xy = torch.rand((257, 2), generator=g)
+    b2 = torch.cat([xy, xy + torch.rand((257, 2), generator=g) * 0.3 + 1e-3], 1)
+    assert torch.equal(hb.box_iou(b1.cuda(), b2.cuda()).cpu(), tv_ops.box_iou(b1, b2))
+    assert torch.equal(hb.diou_loss(b1.cuda(), b2.cuda()).cpu(), ob.diou_loss(b1, b2))
+    assert torch.equal(hb.box_giou(b1.cuda(), b2.cuda()).cpu(), ob.box_giou(b1, b2))
+    assert hb.box_iou(b1[:0].cuda(), b2.cuda()).shape == (0, 257)
+
+
+def test_nms_bit_exact(golden):
+    from holocron_amd.ops import boxes as hb
+    for c in golden("nms.pt"):
+        keep = hb.nms(c["boxes"].cuda(), c["scores"].cuda(), c["thr"])
+        assert keep.dtype == torch.int64
+        assert torch.equal(keep.cpu(), c["keep"]), c["pinned_by"]
+    assert hb.nms(torch.zeros((0, 4)).cuda(), torch.zeros((0,)).cuda(), 0.5).numel() == 0
+
+
+def test_nms_yolov4_scale_all_equal_scores():
+    """a zero-initialised YOLOv4 head hands NMS thousands of boxes with identical scores;
+    the stable sort order decides the result.  4332 boxes (one 38x38x3 scale) vs the oracle."""
+    from holocron_amd.ops import boxes as hb
+    from oracle import tv_ops
+    g = torch.Generator().manual_seed(2)
+    n = 4332
+    c = torch.rand((n, 2), generator=g)
+    wh = torch.rand((n, 2), generator=g) * 0.2 + 0.01
+    b = torch.cat([c - wh / 2, c + wh / 2], 1).clamp(0, 1)
+    s = torch.full((n,), 0.25)
+    assert torch.equal(hb.nms(b.cuda(), s.cuda(), 0.7).cpu(), tv_ops.nms(b, s, 0.7))
+
+
+def test_hard_mish_and_focal(golden):
+    import holocron_amd as h
+    g = golden("functional.pt")
+    hm = g["hard_mish"]
+    x = hm["x"].cuda().requires_grad_(True)
+    y = h.nn.functional.hard_mish(x)
+    assert torch.equal(y.detach().cpu(), hm["y"])
+    (y * hm["r"].cuda()).sum().backward()
+    assert torch.allclose(x.grad.cpu(), hm["dx"], rtol=1e-6, atol=1e-7)
+    z = hm["x"].cuda().clone()
+    z2 = h.nn.functional.hard_mish(z, inplace=True)
+    assert z2.data_ptr() == z.data_ptr() and torch.equal(z.cpu(), hm["y"])      # tests/test_nn_activation.py:24-27
+    for c in g["focal"]:
+        x = c["x"].cuda().requires_grad_(True)
+        w = None if c["weight"] is None else c["weight"].cuda()
+        loss = h.nn.functional.focal_loss(x, c["target"].cuda(), w, c["ignore_index"], c["reduction"], c["gamma"])
+        assert torch.allclose(loss.detach().cpu(), c["loss"], rtol=2e-5, atol=1e-6)
+        (loss * c["r"].cuda()).sum().backward()
+        assert torch.allclose(x.grad.cpu(), c["dx"], rtol=2e-4, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        h.nn.FocalLoss(reduction="bogus")
+
+
+def test_adabelief_matches_reference(golden):
+    import holocron_amd as h
+    for c in golden("optim.pt")["adabelief"]:
+        p = torch.nn.Parameter(c["p0"].clone().cuda())
+        opt = h.optim.AdaBelief([p], **c["kw"])
+        for i, gr in enumerate(c["grads"]):
+            p.grad = gr.clone().cuda()
+            opt.step()
+            assert torch.allclose(p.detach().cpu(), c["traj"][i], rtol=1e-6, atol=1e-7), (c["kw"], i)
+        st = opt.state[p]
+        assert st["step"] == len(c["grads"])
+        assert torch.allclose(st["exp_avg"].cpu(), c["exp_avg"], rtol=1e-6, atol=1e-8)
+        assert torch.allclose(st["exp_avg_sq"].cpu(), c["exp_avg_sq"], rtol=1e-5, atol=1e-10)
+
+
+def test_adabelief_multi_tensor_large_vs_oracle():
+    import holocron_amd as h
+    from oracle import optim as oo
+    torch.manual_seed(0)
+    shapes = [(1280, 640, 3, 3), (48, 3, 3, 3), (1280,), (10, 1280), (7,)]
+    ps = [torch.nn.Parameter(torch.randn(s).cuda()) for s in shapes]
+    ref = [p.detach().cpu().clone() for p in ps]
+    ms, ss = [torch.zeros_like(r) for r in ref], [torch.zeros_like(r) for r in ref]
+    opt = h.optim.AdaBelief([{"params": ps[:2], "lr": 1e-3}, {"params": ps[2:], "lr": 5e-3, "weight_decay": 1e-2}],
+                            betas=(0.95, 0.99), eps=1e-6)
+    for step in range(1, 3):
+        gs = [torch.randn(s) for s in shapes]
+        for p, g_ in zip(ps, gs):
+            p.grad = g_.cuda()
+        opt.step()
+        for i in range(len(ps)):
+            lr, wd = (1e-3, 0.0) if i < 2 else (5e-3, 1e-2)
+            oo.adabelief_step(ref[i], gs[i], ms[i], ss[i], step, lr, 0.95, 0.99, 1e-6, wd)
+            assert torch.allclose(ps[i].detach().cpu(), ref[i], rtol=1e-5, atol=1e-6), (step, i)
+
+
+def test_lars_matches_reference(golden):
+    import holocron_amd as h
+    for c in golden("optim.pt")["lars"]:
+        p = torch.nn.Parameter(c["p0"].clone().cuda())
+        opt = h.optim.LARS([p], **c["kw"])
+        for i, gr in enumerate(c["grads"]):
+            p.grad = gr.clone().cuda()
+            opt.step()
+            assert torch.allclose(p.detach().cpu(), c["traj"][i], rtol=2e-5, atol=1e-6), (c["kw"], i)
+            assert torch.allclose(p.grad.cpu(), c["grad_after"][i], rtol=1e-6, atol=1e-7)   # weight decay lands in .grad (Q4)
+    with pytest.raises(ValueError):
+        h.optim.LARS([torch.nn.Parameter(torch.zeros(1))], lr=-1.0)
+    with pytest.raises(ValueError):
+        h.optim.LARS([torch.nn.Parameter(torch.zeros(1))], lr=1e-3, nesterov=True)

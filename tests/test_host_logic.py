@@ -1,0 +1,133 @@
+"""CPU: host-side logic that does not need a GPU — gather-conv descriptors (interpreted by a tiny
+torch emulator and compared with F.conv2d / autograd), chunk tables, C-ABI surface."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from holocron_amd import _lib
+from holocron_amd.ops import conv as cv
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _s8(v):
+    return v - 256 if v >= 128 else v
+
+
+def emulate(d, src0, src1, wpk):
+    """Interpret an hc_conv_desc on CPU.  src*: [N, IH, IW, srcC] fp32; wpk: [Cout, T, srcC] fp32."""
+    dst = torch.zeros((d.N, d.OH, d.OW, d.Cout))
+    written = torch.zeros((d.OH, d.OW), dtype=torch.int32)
+    for c in range(d.nclass):
+        cl = d.cls[c]
+        ii = torch.arange(cl.OHg)
+        jj = torch.arange(cl.OWg)
+        oy, ox = ii * cl.ostep + cl.oy0, jj * cl.ostep + cl.ox0
+        assert (oy < d.OH).all() and (ox < d.OW).all()
+        written[oy[:, None], ox[None, :]] += 1
+        for t in range(cl.ntaps):
+            tp = cl.tap[t] & 0xffffffff
+            dy, dx, s, wt = _s8(tp & 0xff), _s8((tp >> 8) & 0xff), (tp >> 16) & 0xff, (tp >> 24) & 0xff
+            src = src1 if s else src0
+            iy, ix = ii * cl.istep + dy, jj * cl.istep + dx
+            vy, vx = (iy >= 0) & (iy < d.IH), (ix >= 0) & (ix < d.IW)
+            if not vy.any() or not vx.any():
+                continue
+            g = src[:, iy[vy]][:, :, ix[vx]]                       # [N, a, b, srcC]
+            contrib = g @ wpk[:, wt, :].T                          # [N, a, b, Cout]
+            yy, xx = oy[vy], ox[vx]
+            dst[:, yy[:, None], xx[None, :], :] += contrib
+    assert (written == 1).all(), "every output pixel must belong to exactly one class"
+    return dst
+
+
+def _pack_fwd(w):      # mode 0 of hc_pack_conv_weight
+    Cout, Cin, KH, KW = w.shape
+    return w.permute(0, 2, 3, 1).reshape(Cout, KH * KW, Cin)
+
+
+def _pack_dgrad(w, T, tap0, out=None):   # mode 1
+    Cout, Cin, KH, KW = w.shape
+    if out is None:
+        out = torch.zeros((Cin, T, Cout))
+    flipped = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, KH * KW, Cout)
+    out[:, tap0:tap0 + KH * KW] = flipped
+    return out
+
+
+@pytest.mark.parametrize("H,W,stride,k,pad", [(9, 9, 1, 3, 1), (10, 7, 2, 3, 1), (8, 8, 2, 1, 0), (7, 11, 1, 1, 0), (11, 11, 2, 3, 1)])
+def test_forward_descriptor(H, W, stride, k, pad):
+    torch.manual_seed(0)
+    N, Cin, Cout = 2, 16, 8
+    x = torch.randn(N, Cin, H, W)
+    w = torch.randn(Cout, Cin, k, k)
+    d = cv.fwd_desc(N, Cin, H, W, Cout, k, k, stride, pad)
+    out = emulate(d, x.permute(0, 2, 3, 1), None, _pack_fwd(w)).permute(0, 3, 1, 2)
+    assert torch.allclose(out, F.conv2d(x, w, None, stride, pad), atol=1e-4)
+
+
+@pytest.mark.parametrize("H,W,stride", [(9, 9, 1), (10, 7, 2), (11, 11, 2), (8, 8, 2), (6, 6, 1)])
+def test_dual_branch_dgrad_descriptor(H, W, stride):
+    """dx of conv3x3(x) + conv1x1(x) (RepBlock) from one two-source gather-conv."""
+    torch.manual_seed(1)
+    N, Cin, Cout = 2, 16, 32
+    x = torch.randn(N, Cin, H, W, requires_grad=True)
+    w3, w1 = torch.randn(Cout, Cin, 3, 3), torch.randn(Cout, Cin, 1, 1)
+    y3, y1 = F.conv2d(x, w3, None, stride, 1), F.conv2d(x, w1, None, stride, 0)
+    g3, g1 = torch.randn_like(y3), torch.randn_like(y1)
+    (dx,) = torch.autograd.grad((y3 * g3).sum() + (y1 * g1).sum(), x)
+    d = cv.dgrad_desc(N, Cin, H, W, Cout, [(3, 3, 1, 0, 0), (1, 1, 0, 1, 9)], stride)
+    wp = _pack_dgrad(w3, 10, 0)
+    _pack_dgrad(w1, 10, 9, out=wp)
+    out = emulate(d, g3.permute(0, 2, 3, 1), g1.permute(0, 2, 3, 1), wp).permute(0, 3, 1, 2)
+    assert torch.allclose(out, dx, atol=1e-3)
+
+
+def test_tap_packing_roundtrip():
+    for dy, dx, s, wt in [(-1, -1, 0, 0), (1, 0, 1, 9), (0, 1, 0, 8), (-1, 1, 1, 11)]:
+        tp = _lib.tap(dy, dx, s, wt) & 0xffffffff
+        assert (_s8(tp & 0xff), _s8((tp >> 8) & 0xff), (tp >> 16) & 0xff, (tp >> 24) & 0xff) == (dy, dx, s, wt)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "holocron_hip.h")).read()
+    declared = set(re.findall(r"\b(hc_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/holocron_hip.h but missing from the library"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.load().hc_version().startswith(b"holocron_hip")
+
+
+def test_struct_sizes_match_header_layout():
+    # natural alignment, no packing pragmas: ctypes and hipcc agree when field order/types agree
+    assert ctypes.sizeof(_lib.ConvClass) == 7 * 4 + 12 * 4
+    assert ctypes.sizeof(_lib.ConvDesc) == 7 * 8 + 4 + 9 * 4 + 4 * ctypes.sizeof(_lib.ConvClass) + 0
+    assert ctypes.sizeof(_lib.MtChunk) == 5 * 8 + 4 * 4
+    assert ctypes.sizeof(_lib.AdaBeliefGroup) == 5 * 8 + 2 * 4
+    assert ctypes.sizeof(_lib.LarsGroup) == 4 * 8 + 2 * 4
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    import holocron_amd as h
+    with pytest.raises(_lib.HipError):
+        h.nn.functional.hard_mish(torch.zeros(4))
+    with pytest.raises(_lib.HipError):
+        h.ops.boxes.box_iou(torch.zeros(1, 4), torch.zeros(1, 4))
+
+
+def test_chunk_table():
+    from holocron_amd.optim._multi_tensor import build_chunks
+    p = torch.zeros(3 * _lib.HC_MT_CHUNK + 5)
+    g = torch.zeros_like(p)
+    tab, n = build_chunks([{"p": p, "g": g, "m": p, "s": p, "smax": None, "group": 2, "tensor": 7}])
+    assert n == 4 and tab.numel() == 4 * ctypes.sizeof(_lib.MtChunk)
+    arr = (_lib.MtChunk * 4).from_buffer_copy(tab.numpy().tobytes())
+    assert [c.n for c in arr] == [_lib.HC_MT_CHUNK] * 3 + [5]
+    assert arr[1].p == p.data_ptr() + 4 * _lib.HC_MT_CHUNK and arr[3].group == 2 and arr[3].tensor == 7
+    assert arr[0].smax is None
