@@ -31,5 +31,12 @@ def golden():
 
 
 def rel_l2(a, b):
-    a, b = a.double().flatten(), b.double().flatten()
+    a, b = a.detach().double().flatten(), b.detach().double().flatten()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def close_frac(a, b, rtol, atol):
+    """fraction of elements with |a-b| <= atol + rtol*|b| — robust to the few elements that sit on a
+    ReLU kink, where a bf16 rounding flips the mask and changes a gradient by O(1)"""
+    a, b = a.detach().double().flatten(), b.detach().double().flatten()
+    return float(((a - b).abs() <= atol + rtol * b.abs()).double().mean())
