@@ -18,6 +18,7 @@ ARCH = "gfx950"
 SOURCES = {
     "conv_gather.hip": [],
     "conv_wgrad.hip": [],
+    "conv_wgrad_tr.hip": [],
     "rep_bn.hip": [],
     "optim.hip": [],
     # separate torch kernels in the reference round after every op: no fused multiply-add here

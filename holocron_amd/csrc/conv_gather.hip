@@ -163,8 +163,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
 
     // ---- epilogue --------------------------------------------------------------------------
     const int lr = lane & 31, lh = lane >> 5;
-    // per-channel batch statistics of the fp32 result (training-mode BatchNorm), before rounding
+    // per-channel batch statistics of the fp32 result (training-mode BatchNorm), before rounding.
+    // Contention matters more than instruction count here: a 112x112 layer has 25k workgroups and
+    // only 2*Cout distinct addresses, so (1) the waves of a workgroup are combined in LDS first and
+    // (2) the global atomics are spread over HC_STAT_REPLICAS copies that bn_finalize sums.
     if (d.stats != nullptr) {
+        float* sred = reinterpret_cast<float*>(smem);  // [2][BC], the staging tiles are dead now
+        for (int i = tid; i < 2 * BC; i += NT) sred[i] = 0.f;
+        __syncthreads();
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
             float s1[16], s2[16];
@@ -196,12 +202,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
             s2[0] += __shfl_xor(s2[0], 1);
             if ((lane & 1) == 0) {
                 const int r = 8 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 1) & 1);
-                const int co = cbase + (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co < Cout) {
-                    atomicAdd(d.stats + co, s1[0]);
-                    atomicAdd(d.stats + Cout + co, s2[0]);
+                const int cl_ = (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (WN > 1) {
+                    atomicAdd(&sred[cl_], s1[0]);
+                    atomicAdd(&sred[BC + cl_], s2[0]);
+                } else {
+                    sred[cl_] = s1[0];
+                    sred[BC + cl_] = s2[0];
                 }
             }
+        }
+        __syncthreads();
+        float* rep = d.stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * Cout;
+        for (int i = tid; i < 2 * BC; i += NT) {
+            const int which = i / BC, c = i - which * BC;
+            if (cbase + c < Cout) atomicAdd(rep + which * Cout + cbase + c, sred[i]);
         }
     }
 

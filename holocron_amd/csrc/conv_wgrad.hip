@@ -12,6 +12,10 @@
 #include "common.h"
 #include "../../include/holocron_hip.h"
 
+// small-channel specialisation (conv_wgrad_tr.hip)
+int wgrad_tr_nsplit(const hc_wgrad_desc& d);
+int wgrad_tr_launch(const hc_wgrad_desc& d, hipStream_t st, int* nsplit_out);
+
 namespace {
 
 constexpr int BKP = 64;  // pixels per k-step
@@ -199,31 +203,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// dw[co][ci][t] = beta*dw + sum_split ws[split][co][t][ci]; one block per co, LDS transpose
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                           int nsplit, int Cout, int T, int Cin, int beta) {
-    extern __shared__ float sm[];
-    const int co = blockIdx.x;
-    const int row = T * Cin;
-    const long slab = (long)Cout * row;
-    for (int base = 0; base < row; base += 4096) {
-        const int cnt = min(4096, row - base);
-        // cnt is a multiple of ... not necessarily of T; handle generic (t,ci) index math
-        for (int i = threadIdx.x; i < cnt; i += 256) {
-            float s = 0.f;
-            const float* p = ws + (long)co * row + base + i;
-            for (int k = 0; k < nsplit; ++k) s += p[(long)k * slab];
-            sm[i] = s;
+// dw[co][ci][t] = beta*dw + sum_split ws[split][co][t][ci].  One workgroup per (co, 64-wide ci tile):
+// thread (t, c) sums its element over the splits with reads coalesced along ci, the tile is turned
+// through LDS and written as one contiguous run of 64*T floats of the OIHW gradient.
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int Cout, int T, int Cin,
+                                    int beta) {
+    extern __shared__ float sm[];  // [T][64]
+    const int co = blockIdx.x, ci0 = blockIdx.y * 64;
+    const int t = threadIdx.x / 64, c = threadIdx.x % 64;
+    const long slab = (long)Cout * T * Cin;
+    float s = 0.f;
+    if (ci0 + c < Cin) {
+        const float* p = ws + ((long)co * T + t) * Cin + ci0 + c;
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8) {   // 8 independent loads in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)(k + u) * slab];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
         }
-        __syncthreads();
-        // elements base..base+cnt of the [t][ci] row; scatter to [ci][t]
-        for (int i = threadIdx.x; i < cnt; i += 256) {
-            const int idx = base + i;
-            const int t = idx / Cin, ci = idx - t * Cin;
-            float* o = dw + (long)co * row + (long)ci * T + t;
-            *o = beta ? *o + sm[i] : sm[i];
-        }
-        __syncthreads();
+        for (; k < nsplit; ++k) s += p[(long)k * slab];
+    }
+    sm[t * 64 + c] = s;
+    __syncthreads();
+    const int j = threadIdx.x;          // element j of the [64][T] output run
+    const int cl = j / T, tt = j - cl * T;
+    if (ci0 + cl < Cin) {
+        float* o = dw + ((long)co * Cin + ci0 + cl) * T + tt;
+        const float v = sm[tt * 64 + cl];
+        *o = beta ? *o + v : v;
     }
 }
 
@@ -253,7 +262,7 @@ int launch_wgrad(const hc_wgrad_desc& d, hipStream_t st) {
     }
     dim3 grid(a.n_ci_tiles * T, n_co_tiles, nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d.Cout), dim3(256), 4096 * sizeof(float), st,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d.Cout, (d.Cin + 63) / 64), dim3(64 * T), 64 * T * sizeof(float), st,
                        reinterpret_cast<const float*>(d.ws), d.dw, nsplit, d.Cout, T, d.Cin, d.beta);
     return hc_launch_status();
 }
@@ -276,8 +285,11 @@ bool small_tiles(const hc_wgrad_desc& d) { return d.Cin <= 64 && d.Cout <= 64; }
 
 extern "C" int64_t hc_conv_wgrad_ws_bytes(const hc_wgrad_desc* d) {
     if (d == nullptr) return -1;
-    const int t = small_tiles(*d) ? 64 : 128;
-    const int ns = wgrad_nsplit(*d, t, t);
+    int ns = wgrad_tr_nsplit(*d);
+    if (ns == 0) {
+        const int t = small_tiles(*d) ? 64 : 128;
+        ns = wgrad_nsplit(*d, t, t);
+    }
     return (int64_t)ns * d->Cout * d->KH * d->KW * d->Cin * 4;
 }
 
@@ -285,10 +297,19 @@ extern "C" int hc_conv_wgrad(const hc_wgrad_desc* dp, hc_stream_t stream) {
     if (dp == nullptr) return HC_ERR_ARG;
     const hc_wgrad_desc& d = *dp;
     if (d.x == nullptr || d.dy == nullptr || d.dw == nullptr || d.ws == nullptr) return HC_ERR_ARG;
-    if ((d.Cin % 8) != 0 || (d.Cout % 8) != 0 || d.stride < 1) return HC_ERR_ARG;
+    if ((d.Cin % 8) != 0 || (d.Cout % 8) != 0 || d.stride < 1 || d.KH * d.KW > 16) return HC_ERR_ARG;
     if ((double)d.N * d.IH * d.IW * d.Cin * 2.0 >= 4294967280.0) return HC_ERR_ARG;
     if ((double)d.N * d.OH * d.OW * d.Cout * 2.0 >= 4294967280.0) return HC_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int ns = 0;
+    const int rc = wgrad_tr_launch(d, st, &ns);
+    if (rc >= 0) {
+        if (rc != HC_OK) return rc;
+        const int T = d.KH * d.KW;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d.Cout, (d.Cin + 63) / 64), dim3(64 * T), 64 * T * sizeof(float), st,
+                           reinterpret_cast<const float*>(d.ws), d.dw, ns, d.Cout, T, d.Cin, d.beta);
+        return hc_launch_status();
+    }
     if (small_tiles(d)) return launch_wgrad<1, 1>(d, st);
     return launch_wgrad<2, 2>(d, st);
 }

@@ -54,7 +54,11 @@ __global__ void rep_bn_finalize_kernel(const hc_rep_bn_desc d) {
         float a = 0.f, mean = 0.f, invstd = 0.f;
         if (d.gamma[b] != nullptr) {
             if (d.training) {
-                const float s1 = d.stats[b][c], s2 = d.stats[b][d.C + c];
+                float s1 = 0.f, s2 = 0.f;
+                for (int r = 0; r < HC_STAT_REPLICAS; ++r) {
+                    s1 += d.stats[b][(2 * r) * d.C + c];
+                    s2 += d.stats[b][(2 * r + 1) * d.C + c];
+                }
                 mean = s1 / cnt;
                 float var = s2 / cnt - mean * mean;
                 var = var > 0.f ? var : 0.f;
@@ -132,7 +136,8 @@ __global__ __launch_bounds__(EW_THREADS) void rep_apply_kernel(const u32x4* __re
             atomicAdd(&sred[C + c0 + i], s2[i]);
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) atomicAdd(out_stats + i, sred[i]);
+        float* rep = out_stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * C;
+        for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) atomicAdd(rep + i, sred[i]);
     }
 }
 
@@ -162,7 +167,8 @@ __global__ __launch_bounds__(EW_THREADS) void channel_stats_kernel(const u32x4* 
         atomicAdd(&sred[C + c0 + i], s2[i]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) atomicAdd(stats + i, sred[i]);
+    float* rep = stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) atomicAdd(rep + i, sred[i]);
 }
 
 // ---------------------------------------------------------------- backward reduce

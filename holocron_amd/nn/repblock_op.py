@@ -61,7 +61,7 @@ def _stats_of(x):
     if st is not None:
         return st
     N, Cc, H, W = x.shape
-    st = torch.zeros((2, Cc), dtype=torch.float32, device=x.device)
+    st = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Cc), dtype=torch.float32, device=x.device)
     check(_lib.load().hc_channel_stats(ptr(x), ptr(st), N * H * W, Cc, stream()), "hc_channel_stats")
     return st
 
@@ -90,7 +90,8 @@ class RepBlockFn(torch.autograd.Function):
             wp3, wp1 = st.fwd_cache.get((w3, w1), lambda: (cv.pack_weight(w3, 0), cv.pack_weight(w1, 0)))
         y3 = cv.empty_cl(N, Cout, OH, OW, dev)
         y1 = cv.empty_cl(N, Cout, OH, OW, dev)
-        stats = torch.zeros((2, 2, Cout), dtype=torch.float32, device=dev) if st.training else None
+        R = _lib.HC_STAT_REPLICAS
+        stats = torch.zeros((2, R, 2, Cout), dtype=torch.float32, device=dev) if st.training else None
         fl3 = fl1 = None
         if stem:  # algorithmic flops of the real 3x3 / 1x1 convs, not of the padded im2col GEMM
             fl3, fl1 = 2.0 * N * OH * OW * Cout * 9 * Cin, 2.0 * N * OH * OW * Cout * Cin
@@ -118,7 +119,8 @@ class RepBlockFn(torch.autograd.Function):
         check(lib.hc_rep_bn_finalize(C.byref(d), stream()), "hc_rep_bn_finalize")
 
         out = cv.empty_cl(N, Cout, OH, OW, dev)
-        out_stats = torch.zeros((2, Cout), dtype=torch.float32, device=dev) if (st.emit_stats and st.training) else None
+        out_stats = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Cout), dtype=torch.float32, device=dev) \
+            if (st.emit_stats and st.training) else None
         check(lib.hc_rep_apply(ptr(y3), ptr(y1), ptr(src) if st.identity else None, ptr(coef), ptr(out), ptr(out_stats),
                                N * OH * OW, Cout, 1 if relu else 0, stream()), "hc_rep_apply")
         ctx.st, ctx.relu, ctx.stem = st, relu, stem

@@ -21,6 +21,7 @@ extern "C" {
 typedef void* hc_stream_t; /* hipStream_t */
 
 #define HC_MAX_TAPS 12
+#define HC_STAT_REPLICAS 32
 
 /* One "parity class" of a gather-conv: output sub-grid (i,j) -> output pixel
  * (i*ostep+oy0, j*ostep+ox0); tap t reads source pixel (i*istep+dy[t], j*istep+dx[t]) of
@@ -43,7 +44,8 @@ typedef struct {
     const void* wpk;    /* packed bf16 weights [Cout][T][srcC] */
     void* dst;          /* NHWC bf16 [N][OH][OW][Cout] */
     const void* resid;  /* optional NHWC bf16 added to the result (same shape as dst) */
-    float* stats;       /* optional fp32 [2][Cout]: += sum(y), += sum(y*y) (atomics) */
+    float* stats;       /* optional fp32 [HC_STAT_REPLICAS][2][Cout]: += sum(y), += sum(y*y); the
+                           replicas spread atomic contention, hc_rep_bn_finalize sums them */
     const float* bias;  /* optional fp32 [Cout] */
     int32_t act;        /* 0 none, 1 relu, 2 hard_mish, 3 leaky(0.1), 4 mish, 5 silu */
     int32_t N, IH, IW, srcC;
@@ -87,7 +89,7 @@ int hc_nhwc_bf16_to_nchw(const void* x, float* y, int32_t N, int32_t C, int32_t 
  * running_mean/var (momentum, unbiased var) and num_batches_tracked like nn.BatchNorm2d.
  * coef out: fp32 [4][C] = a3, a1, a0, b ; save out: fp32 [6][C] = mean/invstd per branch. */
 typedef struct {
-    const float* stats[3];     /* [2][C] sums per branch (3x3, 1x1, identity); identity may be NULL */
+    const float* stats[3];     /* [HC_STAT_REPLICAS][2][C] sums per branch (3x3, 1x1, identity) */
     const float* gamma[3];
     const float* beta[3];
     float* running_mean[3];
@@ -103,11 +105,11 @@ typedef struct {
 int hc_rep_bn_finalize(const hc_rep_bn_desc* d, hc_stream_t stream);
 
 /* out = act(a3*y3 + a1*y1 + a0*x + b); optionally accumulates sum/sumsq of `out` into
- * out_stats (the next block's identity-BN statistics). */
+ * out_stats [HC_STAT_REPLICAS][2][C] (the next block's identity-BN statistics). */
 int hc_rep_apply(const void* y3, const void* y1, const void* x, const float* coef, void* out, float* out_stats,
                  int64_t npix, int32_t C, int32_t act, hc_stream_t stream);
 
-/* stats[2][C] += per-channel sum / sum of squares of an NHWC bf16 tensor. */
+/* stats[HC_STAT_REPLICAS][2][C] += per-channel sum / sum of squares of an NHWC bf16 tensor. */
 int hc_channel_stats(const void* x, float* stats, int64_t npix, int32_t C, hc_stream_t stream);
 
 /* Backward of the fused BN+sum+ReLU.  Pass 1: per-channel sums of dz = g*(out>0), dz*y3,

@@ -42,13 +42,14 @@ def test_conv_forward_matches_cpu(N, Cin, Cout, H, W, k, stride):
     w = bf16r(torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5)
     b = torch.randn(Cout)
     ref = F.conv2d(x, w, b, stride, k // 2)
-    stats = torch.zeros(2, Cout, device="cuda")
+    from holocron_amd import _lib
+    stats = torch.zeros(_lib.HC_STAT_REPLICAS, 2, Cout, device="cuda")
     out = cv.conv2d(x.cuda(), w.cuda(), b.cuda(), stride, k // 2, stats=stats)
     assert out.shape == ref.shape
     assert rel_l2(_to_nchw_f32(out), ref) < 3e-3
     # the statistics epilogue sees the fp32 accumulators BEFORE bias/rounding
     nob = F.conv2d(x, w, None, stride, k // 2).double()
-    s = stats.cpu().double()
+    s = stats.cpu().double().sum(0)
     assert rel_l2(s[0], nob.sum((0, 2, 3))) < 2e-4 or (s[0] - nob.sum((0, 2, 3))).abs().max() < 1e-2
     assert rel_l2(s[1], (nob * nob).sum((0, 2, 3))) < 2e-4
     relu = cv.conv2d(x.cuda(), w.cuda(), b.cuda(), stride, k // 2, act=1)
