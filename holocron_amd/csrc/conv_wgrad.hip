@@ -236,8 +236,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     }
 }
 
+// plan_only: size the split count (workspace query) without launching
 template <int MR, int NR>
-int launch_wgrad(const hc_wgrad_desc& d, hipStream_t st) {
+int launch_wgrad(const hc_wgrad_desc& d, hipStream_t st, bool plan_only, int* nsplit_out) {
     constexpr int BA = 64 * MR, BB = 64 * NR;
     constexpr int smem = 2 * (BA + BB) * BKP * 2;
     WgradArgs a;
@@ -248,18 +249,23 @@ int launch_wgrad(const hc_wgrad_desc& d, hipStream_t st) {
     a.n_ci_tiles = (d.Cin + BA - 1) / BA;
     const int n_co_tiles = (d.Cout + BB - 1) / BB;
     const int tiles = a.n_ci_tiles * T * n_co_tiles;
-    int nsplit = (768 + tiles - 1) / tiles;
+    auto kern = wgrad_kernel<MR, NR>;
+    static int occ = 0;
+    if (occ == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, smem) != hipSuccess || n < 1) n = 1;
+        occ = n;
+    }
+    // one resident round of workgroups (a partial second round would cost a full round of time)
+    int nsplit = (256 * occ) / tiles;
     if (nsplit > a.total_steps) nsplit = a.total_steps;
     if (nsplit < 1) nsplit = 1;
     a.steps_per_split = (a.total_steps + nsplit - 1) / nsplit;
     nsplit = (a.total_steps + a.steps_per_split - 1) / a.steps_per_split;
     a.nsplit = nsplit;
-    auto kern = wgrad_kernel<MR, NR>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    *nsplit_out = nsplit;
+    if (plan_only) return HC_OK;
     dim3 grid(a.n_ci_tiles * T, n_co_tiles, nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d.Cout, (d.Cin + 63) / 64), dim3(64 * T), 64 * T * sizeof(float), st,
@@ -267,29 +273,36 @@ int launch_wgrad(const hc_wgrad_desc& d, hipStream_t st) {
     return hc_launch_status();
 }
 
-int wgrad_nsplit(const hc_wgrad_desc& d, int BA, int BB) {
-    const int M = d.N * d.OH * d.OW;
-    const int T = d.KH * d.KW;
-    const int total_steps = (M + BKP - 1) / BKP;
-    const int tiles = ((d.Cin + BA - 1) / BA) * T * ((d.Cout + BB - 1) / BB);
-    int nsplit = (768 + tiles - 1) / tiles;
-    if (nsplit > total_steps) nsplit = total_steps;
-    if (nsplit < 1) nsplit = 1;
-    const int sps = (total_steps + nsplit - 1) / nsplit;
-    return (total_steps + sps - 1) / sps;
+// tile shape (MR, NR) -> ci tile 64*MR, co tile 64*NR: least padded work, then fewest tiles
+struct TileSel { int mr, nr; };
+TileSel select_tiles(const hc_wgrad_desc& d) {
+    static const TileSel opts[] = {{1, 1}, {2, 2}, {3, 1}, {3, 2}};
+    TileSel best = opts[1];
+    double best_cost = 1e30;
+    for (const TileSel& o : opts) {
+        const int ba = 64 * o.mr, bb = 64 * o.nr;
+        const double padded = (double)((d.Cin + ba - 1) / ba * ba) * ((d.Cout + bb - 1) / bb * bb);
+        // small tiles re-read more operand bytes per flop: penalise by 1/ba + 1/bb
+        const double cost = padded * (1.0 + 24.0 * (1.0 / ba + 1.0 / bb));
+        if (cost < best_cost) { best_cost = cost; best = o; }
+    }
+    return best;
 }
 
-bool small_tiles(const hc_wgrad_desc& d) { return d.Cin <= 64 && d.Cout <= 64; }
+int generic_dispatch(const hc_wgrad_desc& d, hipStream_t st, bool plan_only, int* ns) {
+    const TileSel t = select_tiles(d);
+    if (t.mr == 1) return launch_wgrad<1, 1>(d, st, plan_only, ns);
+    if (t.mr == 2) return launch_wgrad<2, 2>(d, st, plan_only, ns);
+    if (t.nr == 1) return launch_wgrad<3, 1>(d, st, plan_only, ns);
+    return launch_wgrad<3, 2>(d, st, plan_only, ns);
+}
 
 }  // namespace
 
 extern "C" int64_t hc_conv_wgrad_ws_bytes(const hc_wgrad_desc* d) {
     if (d == nullptr) return -1;
     int ns = wgrad_tr_nsplit(*d);
-    if (ns == 0) {
-        const int t = small_tiles(*d) ? 64 : 128;
-        ns = wgrad_nsplit(*d, t, t);
-    }
+    if (ns == 0 && generic_dispatch(*d, nullptr, true, &ns) != HC_OK) return -1;
     return (int64_t)ns * d->Cout * d->KH * d->KW * d->Cin * 4;
 }
 
@@ -310,6 +323,5 @@ extern "C" int hc_conv_wgrad(const hc_wgrad_desc* dp, hc_stream_t stream) {
                            reinterpret_cast<const float*>(d.ws), d.dw, ns, d.Cout, T, d.Cin, d.beta);
         return hc_launch_status();
     }
-    if (small_tiles(d)) return launch_wgrad<1, 1>(d, st);
-    return launch_wgrad<2, 2>(d, st);
+    return generic_dispatch(d, st, false, &ns);
 }

@@ -1,4 +1,4 @@
-// Weight gradient for SMALL channel counts (Cin <= 128): HBM-bound layers with huge pixel counts.
+// Weight gradient with the operands staged ONCE per pixel chunk in their natural NHWC layout.
 //
 //   dW[co][ci][kh][kw] = sum_m dy[m][co] * x[pix(m) + tap][ci]
 //
@@ -35,9 +35,17 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds_base, int off) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_base + off));
 }
 
-template <int MR, int TG>
+// registers left for the prefetch ring after the accumulators (4*MR*NR*TG) and fragments
+constexpr int xmax_for(int mr, int nr, int tg) {
+    const int v = (200 - 4 * mr * nr * tg - 16 * nr) / 4;
+    return v > 16 ? 16 : (v < 2 ? 2 : v);
+}
+
+template <int MR, int NR, int TG>
 __global__ __launch_bounds__(512) void wgrad_tr_kernel(const Args a) {
     constexpr int BCI = 16 * MR;
+    constexpr int DMAX = 4 * NR;                 // dy passes: P32 (<=128) / (32/NR pixels per pass)
+    constexpr int XMAX = xmax_for(MR, NR, TG);   // x (row, pass) items per thread; the plan guarantees the bound
     constexpr int NCI = BCI / 8;  // 16-byte chunks per staged x pixel
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const hc_wgrad_desc& d = a.d;
@@ -50,10 +58,11 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(const Args a) {
     const int ci0 = cit * BCI, co0 = cot * a.BCO;
     const int split = blockIdx.y;
     const int T = d.KH * d.KW;
-    // taps of this group: all of them (n_tg == 1) or one kernel row
-    const int kh0 = (a.n_tg == 1) ? 0 : tg;
-    const int nkh = (a.n_tg == 1) ? d.KH : 1;
-    const int ntaps = nkh * d.KW;
+    // taps [t0, t0+ntaps) of this group: the whole kernel, one kernel row, or a single tap
+    const int t0 = tg * TG;
+    // TG always divides T (9|3|1 for 3x3, 1 for 1x1): every group is full, so the tap loop is
+    // straight-line code and the compiler can run the LDS reads ahead of the MFMAs
+    const int kh0 = t0 / d.KW;
     const int s = d.stride;
 
     const __amdgpu_buffer_rsrc_t rsx = make_rsrc(d.x, (unsigned)d.N * d.IH * d.IW * d.Cin * 2u);
@@ -74,11 +83,13 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(const Args a) {
     }
     if (tid < 4) reinterpret_cast<int*>(smem + a.off_zero)[tid] = 0;
 
-    f32x4 acc[TG][MR];
+    f32x4 acc[TG][MR][NR];
 #pragma unroll
     for (int t = 0; t < TG; ++t)
 #pragma unroll
-        for (int m = 0; m < MR; ++m) acc[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) acc[t][m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment lane constants
     const int la = lane & 15, kq = lane >> 4;
@@ -87,77 +98,112 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(const Args a) {
     // CONSECUTIVE pixels -> 8 distinct 32-byte bank slots with the strides of round_stride()
     const int prow = 4 * kq + (la >> 2);
     const int cq = 4 * (la & 3);                         // channel quad within a 16-channel block
-    const int dy_c = 16 * wid + cq;                      // channel within the co tile
-    const bool dy_ok = (dy_c < a.BCO) && (co0 + dy_c < d.Cout);
-    int x_coff[MR];
+    int dy_coff[NR];                                     // byte offset of this lane's channel quad in a dy row
 #pragma unroll
-    for (int m = 0; m < MR; ++m) x_coff[m] = (ci0 + 16 * m + cq < d.Cin) ? (16 * m + cq) * 2 : -1;
+    for (int q = 0; q < NR; ++q) {
+        const int c = 16 * (wid * NR + q) + cq;
+        dy_coff[q] = (c < a.BCO && co0 + c < d.Cout) ? c * 2 : -1;
+    }
+    // x channel offsets: the ci tile (16*MR) always divides Cin, so every lane's quad is valid and
+    // a tr-read address is ONE add: table offset (per pixel group) + [tap offset + channel offset]
+    const int x_c0 = cq * 2;
 
     const int c_begin = split * a.chunks_per_split;
     int c_end = c_begin + a.chunks_per_split;
     if (c_end > a.nchunks) c_end = a.nchunks;
 
-    const int NCO8 = a.BCO / 8;
-    for (int ch = c_begin; ch < c_end; ++ch) {
+    int toff[TG];   // LDS byte offset of every tap of the group inside the staged x image (uniform)
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        const int kh = (t0 + t) / d.KW, kw = (t0 + t) - kh * d.KW;
+        toff[t] = ((kh - kh0) * a.XW + kw) * a.SX;
+    }
+    // staging roles (chunk-invariant)
+    const int NCO8 = a.BCO / 8;                 // 16-byte chunks per dy pixel; NT % NCO8 == 0 always
+    const int dcc = tid % NCO8, dp = tid / NCO8, dpp = NT / NCO8;
+    const int xpp = NT / NCI;                   // x pixels per pass
+    const int xcc = tid % NCI, xp = tid / NCI;
+    const bool xstager = tid < xpp * NCI;
+    const int xrp = (a.XW + xpp - 1) / xpp;     // passes per staged x row
+    const int xitems = a.XR * xrp;              // <= XMAX
+    u32x4 sd[DMAX], sxr[XMAX];
+
+    // issue every global load of chunk `ch` into registers (nothing waits here)
+    auto issue = [&](int ch) {
         const int n = ch / a.chunks_per_img;
         const int oy0 = (ch - n * a.chunks_per_img) * a.R;
-        __syncthreads();  // previous chunk fully consumed (also orders the table writes)
-        // ---- stage dy: P32 pixels x BCO channels, rows past the image / chunk are zero --------
-        {
-            const int rows_left = d.OH - oy0;
-            const int pvalid = (rows_left < a.R ? rows_left : a.R) * d.OW;
-            const unsigned gbase = (unsigned)((n * d.OH + oy0) * d.OW) * (unsigned)d.Cout * 2u + (unsigned)co0 * 2u;
-            const int items = a.P32 * NCO8;
-            for (int i = tid; i < items; i += NT) {
-                const int p = i / NCO8, cc = i - p * NCO8;
-                const bool ok = (p < pvalid) && (co0 + cc * 8 < d.Cout);
-                const unsigned voff = ok ? gbase + (unsigned)p * (unsigned)d.Cout * 2u + cc * 16u : HC_OOB;
-                *reinterpret_cast<u32x4*>(sdy + p * a.SD + cc * 16) = buf_load16(rsy, voff);
-            }
+        const int rows_left = d.OH - oy0;
+        const int pvalid = (rows_left < a.R ? rows_left : a.R) * d.OW;
+        const unsigned gbase = (unsigned)((n * d.OH + oy0) * d.OW) * (unsigned)d.Cout * 2u + (unsigned)co0 * 2u +
+                               (unsigned)dcc * 16u;
+        const bool dcok = co0 + dcc * 8 < d.Cout;
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) {
+            const int p = i * dpp + dp;
+            const bool ok = dcok && (p < pvalid);
+            sd[i] = buf_load16(rsy, ok ? gbase + (unsigned)p * (unsigned)d.Cout * 2u : HC_OOB);
         }
-        // ---- stage x: XR rows x XW cols x BCI channels (zero outside the image) ----------------
-        {
-            const int iy_base = oy0 * s - d.pad + kh0;
-            const int rowitems = a.XW * NCI;
-            for (int xr = 0; xr < a.XR; ++xr) {
-                const int iy = iy_base + xr;
-                const bool rok = (unsigned)iy < (unsigned)d.IH;
-                const unsigned rbase = (unsigned)((n * d.IH + (rok ? iy : 0)) * d.IW) * (unsigned)d.Cin * 2u + (unsigned)ci0 * 2u;
-                char* lrow = sx + xr * a.XW * a.SX;
-                for (int i = tid; i < rowitems; i += NT) {
-                    const int xc = i / NCI, cc = i - xc * NCI;
-                    const int ix = xc - d.pad;
-                    const bool ok = rok && ((unsigned)ix < (unsigned)d.IW) && (ci0 + cc * 8 < d.Cin);
-                    const unsigned voff = ok ? rbase + (unsigned)ix * (unsigned)d.Cin * 2u + cc * 16u : HC_OOB;
-                    *reinterpret_cast<u32x4*>(lrow + xc * a.SX + cc * 16) = buf_load16(rsx, voff);
-                }
-            }
+        const int iy_base = oy0 * s - d.pad + kh0;
+        const bool xcok = xstager && (ci0 + xcc * 8 < d.Cin);
+        const unsigned nbase = (unsigned)(n * d.IH * d.IW) * (unsigned)d.Cin * 2u + (unsigned)ci0 * 2u + (unsigned)xcc * 16u;
+        int xr = 0, ps = 0;
+#pragma unroll
+        for (int j = 0; j < XMAX; ++j) {
+            const int iy = iy_base + xr, ix = ps * xpp + xp - d.pad;
+            const bool ok = xcok && (j < xitems) && ((unsigned)iy < (unsigned)d.IH) && ((unsigned)ix < (unsigned)d.IW);
+            sxr[j] = buf_load16(rsx, ok ? nbase + (unsigned)(iy * d.IW + ix) * (unsigned)d.Cin * 2u : HC_OOB);
+            if (++ps == xrp) { ps = 0; ++xr; }
         }
+    };
+    // registers -> LDS (natural NHWC rows)
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) {
+            const int p = i * dpp + dp;
+            if (p < a.P32) *reinterpret_cast<u32x4*>(sdy + p * a.SD + dcc * 16) = sd[i];
+        }
+        int xr = 0, ps = 0;
+#pragma unroll
+        for (int j = 0; j < XMAX; ++j) {
+            const int xc = ps * xpp + xp;
+            if (xstager && j < xitems && xc < a.XW)
+                *reinterpret_cast<u32x4*>(sx + (xr * a.XW + xc) * a.SX + xcc * 16) = sxr[j];
+            if (++ps == xrp) { ps = 0; ++xr; }
+        }
+    };
+
+    // PREFETCH: keep the next chunk's loads in flight during the MFMA phase (costs DMAX+XMAX
+    // 4-register slots that stay live across the MFMAs)
+    constexpr bool PREFETCH = (4 * MR * NR * TG + 4 * (DMAX + XMAX)) <= 150;
+    if (PREFETCH && c_begin < c_end) issue(c_begin);
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        if (!PREFETCH) issue(ch);   // all loads of the chunk in flight at once, then the LDS stores
+        __syncthreads();   // previous chunk fully consumed (also orders the table writes)
+        commit();
         __syncthreads();
+        if (PREFETCH && ch + 1 < c_end) issue(ch + 1);
         // ---- MFMA over the chunk: 32 pixels per step, every tap from the same staged image -------
         for (int g = 0; g < a.P32; g += 32) {
             const int p0 = g + prow;
-            const int xo0 = tab[p0], xo1 = tab[p0 + 16];
-            bf16x8 fb;
-            {
-                const int o0 = dy_ok ? a.off_dy + p0 * a.SD + dy_c * 2 : a.off_zero;
-                const int o1 = dy_ok ? a.off_dy + (p0 + 16) * a.SD + dy_c * 2 : a.off_zero;
+            const int xb0 = tab[p0] + x_c0, xb1 = tab[p0 + 16] + x_c0;
+            bf16x8 fb[NR];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int o0 = dy_coff[q] >= 0 ? a.off_dy + p0 * a.SD + dy_coff[q] : a.off_zero;
+                const int o1 = dy_coff[q] >= 0 ? a.off_dy + (p0 + 16) * a.SD + dy_coff[q] : a.off_zero;
                 const s16x4 lo = tr_read(smem, o0), hi = tr_read(smem, o1);
-                fb = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                fb[q] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
-                if (t < ntaps) {
-                    const int khl = t / d.KW, kw = t - khl * d.KW;
-                    const int toff = (khl * a.XW + kw) * a.SX;
 #pragma unroll
-                    for (int m = 0; m < MR; ++m) {
-                        const int o0 = x_coff[m] >= 0 ? xo0 + toff + x_coff[m] : a.off_zero;
-                        const int o1 = x_coff[m] >= 0 ? xo1 + toff + x_coff[m] : a.off_zero;
-                        const s16x4 lo = tr_read(smem, o0), hi = tr_read(smem, o1);
-                        const bf16x8 fa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                        acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[t][m], 0, 0, 0);
-                    }
+                for (int m = 0; m < MR; ++m) {
+                    const int tm = toff[t] + 32 * m;   // wave-uniform
+                    const s16x4 lo = tr_read(smem, xb0 + tm), hi = tr_read(smem, xb1 + tm);
+                    const bf16x8 fa = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                    for (int q = 0; q < NR; ++q)
+                        acc[t][m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[q], acc[t][m][q], 0, 0, 0);
                 }
             }
         }
@@ -165,17 +211,19 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(const Args a) {
 
     // ---- slab[split][co][tap][ci]: lane = co column, the 4 accumulator values = 4 consecutive ci ----
     float* ws = reinterpret_cast<float*>(d.ws);
-    const int co = co0 + 16 * wid + la;
-    if (16 * wid + la < a.BCO && co < d.Cout) {
 #pragma unroll
-        for (int t = 0; t < TG; ++t) {
-            if (t < ntaps) {
-                const int tap = kh0 * d.KW + t;
+    for (int q = 0; q < NR; ++q) {
+        const int cl = 16 * (wid * NR + q) + la;
+        const int co = co0 + cl;
+        if (cl < a.BCO && co < d.Cout) {
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const int tap = t0 + t;
                 float* row = ws + (((long)split * d.Cout + co) * T + tap) * d.Cin;
 #pragma unroll
                 for (int m = 0; m < MR; ++m) {
                     const int ci = ci0 + 16 * m + 4 * kq;
-                    if (ci < d.Cin) *reinterpret_cast<f32x4*>(row + ci) = acc[t][m];
+                    if (ci < d.Cin) *reinterpret_cast<f32x4*>(row + ci) = acc[t][m][q];
                 }
             }
         }
@@ -203,33 +251,44 @@ inline int round_stride(int bytes, int stride) {
 struct Plan {
     bool ok;
     Args a;
-    int MR, TG, WN, smem, nsplit;
+    int MR, NR, TG, WN, smem, nsplit;
 };
 
-inline Plan make_plan(const hc_wgrad_desc& d) {
+inline Plan make_plan_nr(const hc_wgrad_desc& d, int NR) {
     Plan pl{};
     pl.ok = false;
     const int T = d.KH * d.KW;
-    if (d.Cin % 16 || d.Cout % 16 || d.Cin > 128 || d.stride < 1 || d.stride > 2) return pl;
+    if (d.Cin % 16 || d.Cout % 16 || d.stride < 1 || d.stride > 2) return pl;
     if (!(T == 9 && d.KH == 3) && T != 1) return pl;
-    const int MR = d.Cin / 16;
-    if (MR != 2 && MR != 3 && MR != 4 && MR != 6 && MR != 8) return pl;
+    // measured on MI355X (profiles/r01_*): for Cin > 128 the k-pipelined generic kernel is faster
+    if (d.Cin > 128 || d.OW > 128) return pl;
+    // ci tile = 16*MR: the largest supported MR that divides Cin/16
+    const int c16 = d.Cin / 16;
+    int MR = 0;
+    for (int m : {8, 6, 4, 3, 2})
+        if (c16 % m == 0) { MR = m; break; }
+    if (MR == 0) return pl;
     int TG = T;
-    if (T == 9 && MR > 4) TG = 3;           // accumulators: TG*MR*4 registers per lane
+    if (T == 9 && MR * NR > 4) TG = 3;       // accumulators: TG*MR*NR*4 registers per lane
+    if (MR * NR * TG > 36) TG = 1;
     Args& a = pl.a;
     a.d = d;
     a.n_tg = T / TG;
-    int WN = d.Cout / 16;
+    a.n_ci_tiles = c16 / MR;
+    const int cob = (d.Cout + 16 * NR - 1) / (16 * NR);  // co blocks of one wave
+    int WN = cob;
     a.n_co_tiles = 1;
-    while (WN > 8) {                          // at most 8 waves (co tile <= 128)
+    const int max_wn = (MR * NR * TG >= 36) ? 6 : 8;
+    while (WN > max_wn) {
         a.n_co_tiles += 1;
-        WN = (d.Cout / 16 + a.n_co_tiles - 1) / a.n_co_tiles;
+        WN = (cob + a.n_co_tiles - 1) / a.n_co_tiles;
     }
-    a.BCO = 16 * WN;
-    a.n_ci_tiles = 1;
-    const int nkh = (a.n_tg == 1) ? d.KH : 1;
+    a.BCO = 16 * NR * WN;
+    const int nkh = (TG >= T) ? d.KH : 1;   // kernel rows spanned by one tap group
     a.SD = round_stride(a.BCO * 2, 1);
-    a.SX = round_stride(d.Cin * 2, d.stride);
+    a.SX = round_stride(16 * MR * 2, d.stride);
+    const int xpp = 64 * WN / (2 * MR);      // staged x pixels per pass of the workgroup
+    const int xmax = xmax_for(MR, NR, TG);
     int R = 112 / d.OW;
     if (R < 1) R = 1;
     if (R > d.OH) R = d.OH;
@@ -244,31 +303,60 @@ inline Plan make_plan(const hc_wgrad_desc& d) {
         a.off_tab = a.off_dy + (a.P32 * a.SD + 255) / 256 * 256;
         a.off_zero = a.off_tab + a.P32 * 4;
         pl.smem = a.off_zero + 16;
-        if (pl.smem <= 72 * 1024 || R == 1) break;
+        const int xitems = a.XR * ((a.XW + xpp - 1) / xpp);
+        if (pl.smem <= 78 * 1024 && xitems <= xmax && a.P32 <= 128) break;
+        if (R == 1) return pl;               // does not fit the prefetch ring: caller falls back
     }
-    if (pl.smem > 150 * 1024) return pl;
     a.chunks_per_img = (d.OH + a.R - 1) / a.R;
     a.nchunks = d.N * a.chunks_per_img;
-    const int tiles = a.n_ci_tiles * a.n_co_tiles * a.n_tg;
-    int nsplit = (640 + tiles - 1) / tiles;
-    if (nsplit > a.nchunks) nsplit = a.nchunks;
-    a.chunks_per_split = (a.nchunks + nsplit - 1) / nsplit;
-    pl.nsplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
     pl.MR = MR;
+    pl.NR = NR;
     pl.TG = TG;
     pl.WN = WN;
     pl.ok = true;
     return pl;
 }
 
-template <int MR, int TG>
-int launch(const Plan& pl, hipStream_t st) {
-    auto kern = wgrad_tr_kernel<MR, TG>;
-    static int attr_smem = 0;
-    if (pl.smem > attr_smem) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_smem = 160 * 1024;
+// One resident round: the number of workgroups equals what the chip holds at once (a second,
+// partial round of workgroups would double the kernel time), each split a contiguous chunk range.
+inline void size_splits(Plan& pl, int blocks_per_cu) {
+    Args& a = pl.a;
+    const int tiles = a.n_ci_tiles * a.n_co_tiles * a.n_tg;
+    int resident = 256 * (blocks_per_cu < 1 ? 1 : blocks_per_cu);
+    int nsplit = resident / tiles;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > a.nchunks) nsplit = a.nchunks;
+    a.chunks_per_split = (a.nchunks + nsplit - 1) / nsplit;
+    pl.nsplit = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+}
+
+inline Plan make_plan(const hc_wgrad_desc& d) {
+    if (d.Cout > 128) {
+        const Plan p2 = make_plan_nr(d, 2);
+        if (p2.ok && p2.a.P >= 64) return p2;   // two co blocks per wave only if the chunk stays long
     }
+    return make_plan_nr(d, 1);
+}
+
+// launch == false: only size the plan (workspace query)
+template <int MR, int NR, int TG>
+int launch(Plan& pl, hipStream_t st, bool do_launch) {
+    auto kern = wgrad_tr_kernel<MR, NR, TG>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    static int occ_cache[9][161];   // [waves][smem KiB] -> workgroups per CU (0 = unknown)
+    const int kib = (pl.smem + 1023) / 1024;
+    int& occ = occ_cache[pl.WN][kib];
+    if (occ == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 64 * pl.WN, pl.smem) != hipSuccess || n < 1) n = 1;
+        occ = n;
+    }
+    size_splits(pl, occ);
+    if (!do_launch) return HC_OK;
     dim3 grid(pl.a.n_ci_tiles * pl.a.n_co_tiles * pl.a.n_tg, pl.nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(64 * pl.WN), pl.smem, st, pl.a);
     return hc_launch_status();
@@ -277,23 +365,32 @@ int launch(const Plan& pl, hipStream_t st) {
 }  // namespace wtr
 
 // entry points used by conv_wgrad.hip's dispatcher
-int wgrad_tr_nsplit(const hc_wgrad_desc& d) {
-    const wtr::Plan pl = wtr::make_plan(d);
-    return pl.ok ? pl.nsplit : 0;
-}
-
-int wgrad_tr_launch(const hc_wgrad_desc& d, hipStream_t st, int* nsplit_out) {
-    const wtr::Plan pl = wtr::make_plan(d);
-    if (!pl.ok) return -1;
-    *nsplit_out = pl.nsplit;
-    const int T = d.KH * d.KW;
-#define WTR_CASE(M, G) \
-    if (pl.MR == M && pl.TG == G) return wtr::launch<M, G>(pl, st);
+static int dispatch(wtr::Plan& pl, hipStream_t st, bool do_launch) {
+    const int T = pl.a.d.KH * pl.a.d.KW;
+#define WTR_CASE(M, N, G) \
+    if (pl.MR == M && pl.NR == N && pl.TG == G) return wtr::launch<M, N, G>(pl, st, do_launch);
     if (T == 1) {
-        WTR_CASE(2, 1) WTR_CASE(3, 1) WTR_CASE(4, 1) WTR_CASE(6, 1) WTR_CASE(8, 1)
+        WTR_CASE(2, 1, 1) WTR_CASE(3, 1, 1) WTR_CASE(4, 1, 1) WTR_CASE(6, 1, 1) WTR_CASE(8, 1, 1)
+        WTR_CASE(2, 2, 1) WTR_CASE(3, 2, 1) WTR_CASE(4, 2, 1) WTR_CASE(6, 2, 1) WTR_CASE(8, 2, 1)
     } else {
-        WTR_CASE(2, 9) WTR_CASE(3, 9) WTR_CASE(4, 9) WTR_CASE(6, 3) WTR_CASE(8, 3)
+        WTR_CASE(2, 1, 9) WTR_CASE(3, 1, 9) WTR_CASE(4, 1, 9) WTR_CASE(6, 1, 3) WTR_CASE(8, 1, 3)
+        WTR_CASE(2, 2, 9) WTR_CASE(3, 2, 3) WTR_CASE(4, 2, 3) WTR_CASE(6, 2, 3) WTR_CASE(8, 2, 1)
     }
 #undef WTR_CASE
     return -1;
+}
+
+int wgrad_tr_nsplit(const hc_wgrad_desc& d) {
+    wtr::Plan pl = wtr::make_plan(d);
+    if (!pl.ok) return 0;
+    if (dispatch(pl, nullptr, false) != HC_OK) return 0;
+    return pl.nsplit;
+}
+
+int wgrad_tr_launch(const hc_wgrad_desc& d, hipStream_t st, int* nsplit_out) {
+    wtr::Plan pl = wtr::make_plan(d);
+    if (!pl.ok) return -1;
+    const int rc = dispatch(pl, st, true);
+    *nsplit_out = pl.nsplit;
+    return rc;
 }

@@ -68,6 +68,60 @@ def init_state(num_blocks, chans, num_classes=10, seed=0):
     return sd
 
 
+def bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundBoth(torch.autograd.Function):
+    """bf16 rounding of a tensor that the HIP path stores in HBM as bf16: the value is rounded on
+    the way forward and its gradient on the way back (both live in bf16 buffers there)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return bf16r(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return bf16r(g)
+
+
+def _round_weight(w):
+    # kernels read bf16-packed copies of the fp32 master weights; gradients stay fp32
+    return w + (bf16r(w) - w).detach()
+
+
+def _bn_emulated(c, y_r, sd, prefix, training):
+    """BatchNorm as the HIP path computes it: statistics from the fp32 conv result `c`, normalisation
+    applied to the bf16-stored values `y_r`; running statistics exactly like nn.BatchNorm2d."""
+    if training:
+        sd[prefix + ".num_batches_tracked"] += 1
+        mean = c.mean((0, 2, 3))
+        var = c.var((0, 2, 3), unbiased=False)
+        with torch.no_grad():
+            n = c.numel() / c.shape[1]
+            sd[prefix + ".running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean)
+            sd[prefix + ".running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var * n / max(n - 1, 1))
+    else:
+        mean, var = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    a = sd[prefix + ".weight"] * torch.rsqrt(var + BN_EPS)
+    return y_r * a.view(1, -1, 1, 1) + (sd[prefix + ".bias"] - a * mean).view(1, -1, 1, 1)
+
+
+def rep_block_bf16(x, sd, prefix, stride, identity, training):
+    """The reference block (repvgg.py:71-73) with bf16 rounding injected exactly where the HIP path
+    keeps bf16 tensors in HBM (x, y3, y1, out and their gradients; packed weights).  Test harness
+    only: it separates kernel bugs from legitimate bf16 effects (ReLU-kink flips, tiny-batch BN)."""
+    w3 = _round_weight(sd[prefix + ".branches.0.0.weight"])
+    w1 = _round_weight(sd[prefix + ".branches.1.0.weight"])
+    c3 = F.conv2d(x, w3, None, stride, 1)
+    c1 = F.conv2d(x, w1, None, stride, 0)
+    out = _bn_emulated(c3, _RoundBoth.apply(c3), sd, prefix + ".branches.0.1", training)
+    out = out + _bn_emulated(c1, _RoundBoth.apply(c1), sd, prefix + ".branches.1.1", training)
+    if identity:
+        out = out + _bn_emulated(x, x, sd, prefix + ".branches.2", training)
+    return _RoundBoth.apply(F.relu(out))
+
+
 def _bn(x, sd, prefix, training):
     # nn.BatchNorm2d.forward: num_batches_tracked += 1, then F.batch_norm with momentum 0.1
     if training:
@@ -87,10 +141,16 @@ def rep_block(x, sd, prefix, stride, identity, training):
     return F.relu(out)
 
 
-def forward(sd, x, num_blocks, chans, training=False, taps=None):
-    """RepVGG.forward (nn.Sequential: features -> pool -> head).  ``taps`` (dict) collects block outputs."""
+def forward(sd, x, num_blocks, chans, training=False, taps=None, emulate_bf16=False):
+    """RepVGG.forward (nn.Sequential: features -> pool -> head).  ``taps`` (dict) collects block outputs.
+    ``emulate_bf16`` switches every block to rep_block_bf16 (test harness, see there)."""
+    if emulate_bf16:
+        x = bf16r(x)
     for prefix, _, _, stride, identity in layout(num_blocks, chans):
-        x = rep_block(x, sd, prefix, stride, identity, training)
+        if emulate_bf16:
+            x = rep_block_bf16(x, sd, prefix, stride, identity, training)
+        else:
+            x = rep_block(x, sd, prefix, stride, identity, training)
         if taps is not None:
             taps[prefix] = x
     x = x.view(x.shape[0], x.shape[1], -1).mean(2)      # GlobalAvgPool2d(flatten=True), downsample.py:70-73
@@ -127,7 +187,7 @@ def trainable_keys(sd):
 
 
 def train_step(sd, opt_state, x, target, num_blocks, chans, lr=1e-3, betas=(0.95, 0.99), eps=1e-6, weight_decay=0.0,
-               label_smoothing=0.1):
+               label_smoothing=0.1, emulate_bf16=False):
     """One reference training step: forward (train mode), CrossEntropyLoss(label_smoothing)
     (references/classification/train.py:194), backward, AdaBelief (train.py:208-209).  In place."""
     from .optim import adabelief_step
@@ -135,7 +195,7 @@ def train_step(sd, opt_state, x, target, num_blocks, chans, lr=1e-3, betas=(0.95
     params = {k: sd[k].detach().requires_grad_(True) for k in keys}
     work = dict(sd)
     work.update(params)
-    logits = forward(work, x, num_blocks, chans, training=True)
+    logits = forward(work, x, num_blocks, chans, training=True, emulate_bf16=emulate_bf16)
     loss = F.cross_entropy(logits, target, label_smoothing=label_smoothing)
     grads = torch.autograd.grad(loss, [params[k] for k in keys])
     opt_state["step"] = opt_state.get("step", 0) + 1

@@ -147,3 +147,17 @@ def test_nms_restatement_cases(golden):
             assert keep.numel() == 49 and torch.equal(keep, torch.sort(c["scores"], descending=True, stable=True).indices)
         if c["pinned_by"].startswith("reference test (identical)"):
             assert keep.tolist() == [0]
+
+
+def test_bf16_emulation_stays_close_to_fp32_oracle(golden):
+    """the bf16-rounding harness (oracle.repvgg.rep_block_bf16) is the same algorithm: on the golden
+    blocks it must agree with the reference to bf16 precision"""
+    for c in golden("repblock.pt"):
+        cin, cout, stride, ident = c["cfg"]
+        sd = _block_sd(c["state"])
+        out = orv.rep_block_bf16(c["x"], sd, "blk", stride, ident, training=True)
+        err = (out - c["out"]).norm() / c["out"].norm()
+        assert err < 6e-3, (c["cfg"], float(err))
+        for k, v in c["state_after"].items():
+            if "running" in k:
+                assert torch.allclose(sd["blk." + k], v, rtol=1e-4, atol=1e-5)
