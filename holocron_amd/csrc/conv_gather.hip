@@ -31,9 +31,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
     constexpr int BC = 32 * MR * WM;  // output-channel tile (A rows)
     constexpr int BP = 32 * NR * WN;  // output-pixel tile (B cols)
     constexpr int NC = BK / 8;        // 16-byte chunks per tile row
-    constexpr int RPP = NT / NC;      // tile rows covered by one pass of the block
-    constexpr int WI = (BC + RPP - 1) / RPP;
-    constexpr int XI = (BP + RPP - 1) / RPP;
     constexpr int WBYTES = BC * BK * 2;
     constexpr int STAGE = (BC + BP) * BK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -51,29 +48,45 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
     const unsigned src_bytes = (unsigned)d.N * IH * IW * srcC * 2u;
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(d.wpk, (unsigned)Cout * T * srcC * 2u);
 
-    // ---- per-thread staging assignment: chunk column xc, rows r0 + i*RPP -------------------
-    const int xc = tid % NC;
-    const int r0 = tid / NC;
-    int x_nb[XI], x_iy0[XI], x_ix0[XI];
+    // ---- staging: direct-to-LDS DMA (buffer_load ... lds), no VGPR round trip, no ds_write ------
+    // One wave instruction fills 1 KiB of LDS linearly (lane i -> +16 i bytes) = RPI tile rows.  The
+    // XOR chunk swizzle of lds_off<BK>() therefore moves to the SOURCE side: the lane that owns
+    // physical chunk pc of row r fetches logical chunk pc ^ f(r) of that row from global memory.
+    constexpr int NW = WM * WN;
+    constexpr int RPI = 512 / BK;            // tile rows per DMA instruction
+    constexpr int WQ = BC / RPI, XQ = BP / RPI;   // DMA instructions per tile
+    constexpr int WJ = (WQ + NW - 1) / NW, XJ = (XQ + NW - 1) / NW;
+    static_assert(BC % RPI == 0 && BP % RPI == 0, "tile rows must be a multiple of the DMA granule");
+    const int lrow = lane / NC, lpc = lane % NC;
+    // Per staged row: byte offset of (tap offset (0,0), this lane's logical chunk) and a bitmask of
+    // the taps whose source pixel is inside the image -> the per-step address is one add + select.
+    unsigned x_base[XJ], x_vmask[XJ];
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        const int row = r0 + i * RPP;
+    for (int j = 0; j < XJ; ++j) {
+        const int row = (wid + j * NW) * RPI + lrow;
         const int m = pbase + row;
-        const bool ok = (row < BP) && (m < M);
+        const bool ok = (wid + j * NW < XQ) && (m < M);
         const int mm = ok ? m : 0;
         const int n = mm / (OHg * OWg);
         const int rem = mm - n * (OHg * OWg);
         const int oi = rem / OWg, oj = rem - oi * OWg;
-        x_nb[i] = n * IH * IW;
-        x_iy0[i] = ok ? oi * cl.istep : -(1 << 20);
-        x_ix0[i] = oj * cl.istep;
+        const int iy0 = oi * cl.istep, ix0 = oj * cl.istep;
+        x_base[j] = (unsigned)((n * IH + iy0) * IW + ix0) * (unsigned)srcC * 2u + (unsigned)((lpc ^ ((row / (16 / NC)) % NC)) * 16);
+        unsigned vm = 0;
+        for (int t = 0; t < cl.ntaps; ++t) {
+            const int tp = cl.tap[t];
+            const int iy = iy0 + (int)(signed char)(tp & 0xff), ix = ix0 + (int)(signed char)((tp >> 8) & 0xff);
+            if (ok && ((unsigned)iy < (unsigned)IH) && ((unsigned)ix < (unsigned)IW)) vm |= 1u << t;
+        }
+        x_vmask[j] = vm;
     }
-    unsigned w_off[WI];
+    unsigned w_off[WJ];
 #pragma unroll
-    for (int i = 0; i < WI; ++i) {
-        const int row = r0 + i * RPP;
+    for (int j = 0; j < WJ; ++j) {
+        const int row = (wid + j * NW) * RPI + lrow;
         const int co = cbase + row;
-        w_off[i] = (row < BC && co < Cout) ? (unsigned)co * T * srcC * 2u + xc * 16u : HC_OOB;
+        const unsigned kc = (unsigned)((lpc ^ ((row / (16 / NC)) % NC)) * 16);
+        w_off[j] = (wid + j * NW < WQ && co < Cout) ? (unsigned)co * T * srcC * 2u + kc : HC_OOB;
     }
 
     f32x16 acc[MR][NR];
@@ -84,57 +97,52 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    u32x4 wreg[WI], xreg[XI];
     const int kcb = srcC / BK;
     const int S = cl.ntaps * kcb;
+    typedef __attribute__((address_space(3))) void lds_void;
 
-    auto load_tiles = [&](int tap, int ck) {
+    auto issue = [&](int stage, int tap, int ck) {
+        char* sw = smem + stage * STAGE;
+        char* sx = sw + WBYTES;
         const int tp = cl.tap[tap];
         const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
         const int sidx = (tp >> 16) & 0xff, wt = (tp >> 24) & 0xff;
         const __amdgpu_buffer_rsrc_t rsx = make_rsrc(sidx ? d.src1 : d.src0, src_bytes);
-        const unsigned kofs = (unsigned)(ck * BK + xc * 8) * 2u;
+        // wave-uniform part of the address: tap shift + channel slice (may be "negative": unsigned wrap is fine)
+        const unsigned tofs = (unsigned)((dy * IW + dx) * srcC * 2 + ck * BK * 2);
 #pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const int iy = x_iy0[i] + dy, ix = x_ix0[i] + dx;
-            const bool ok = ((unsigned)iy < (unsigned)IH) && ((unsigned)ix < (unsigned)IW);
-            const unsigned voff = ok ? (unsigned)(x_nb[i] + iy * IW + ix) * (unsigned)srcC * 2u + kofs : HC_OOB;
-            xreg[i] = buf_load16(rsx, voff);
+        for (int j = 0; j < XJ; ++j) {
+            if (XQ % NW == 0 || wid + j * NW < XQ) {   // wave-uniform
+                const unsigned voff = ((x_vmask[j] >> tap) & 1u) ? x_base[j] + tofs : HC_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_void*)(sx + (wid + j * NW) * 1024), 16, voff, 0, 0, 0);
+            }
         }
         const unsigned wk = (unsigned)(wt * srcC + ck * BK) * 2u;
 #pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const unsigned voff = (w_off[i] == HC_OOB) ? HC_OOB : w_off[i] + wk;
-            wreg[i] = buf_load16(rsw, voff);
+        for (int j = 0; j < WJ; ++j) {
+            if (WQ % NW == 0 || wid + j * NW < WQ) {
+                const unsigned voff = (w_off[j] == HC_OOB) ? HC_OOB : w_off[j] + wk;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(sw + (wid + j * NW) * 1024), 16, voff, 0, 0, 0);
+            }
         }
     };
-    auto store_tiles = [&](int stage) {
-        char* sw = smem + stage * STAGE;
-        char* sx = sw + WBYTES;
+    // Fragment addresses: the swizzle term depends only on (lane, kk) because every fragment starts
+    // at a multiple of 32 rows, so all reads of a k-step are base + compile-time immediates.
+    int frag_off[BK / 16];
 #pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const int row = r0 + i * RPP;
-            if (WI * RPP == BC || row < BC) *reinterpret_cast<u32x4*>(sw + lds_off<BK>(row, xc)) = wreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            const int row = r0 + i * RPP;
-            if (XI * RPP == BP || row < BP) *reinterpret_cast<u32x4*>(sx + lds_off<BK>(row, xc)) = xreg[i];
-        }
-    };
+    for (int kk = 0; kk < BK / 16; ++kk) frag_off[kk] = lds_off<BK>(lane & 31, kk * 2 + (lane >> 5));
+    const int a_row0 = wm * MR * 32 * BK * 2, b_row0 = WBYTES + wn * NR * 32 * BK * 2;
     auto compute = [&](int stage) {
-        const char* sw = smem + stage * STAGE;
-        const char* sx = sw + WBYTES;
-        const int lr = lane & 31, lh = lane >> 5;
+        const char* st = smem + stage * STAGE;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8 a[MR], b[NR];
+            const char* pa = st + a_row0 + frag_off[kk];
+            const char* pb = st + b_row0 + frag_off[kk];
 #pragma unroll
-            for (int mr = 0; mr < MR; ++mr)
-                a[mr] = *reinterpret_cast<const bf16x8*>(sw + lds_off<BK>((wm * MR + mr) * 32 + lr, kk * 2 + lh));
+            for (int mr = 0; mr < MR; ++mr) a[mr] = *reinterpret_cast<const bf16x8*>(pa + mr * 32 * BK * 2);
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr)
-                b[nr] = *reinterpret_cast<const bf16x8*>(sx + lds_off<BK>((wn * NR + nr) * 32 + lr, kk * 2 + lh));
+            for (int nr = 0; nr < NR; ++nr) b[nr] = *reinterpret_cast<const bf16x8*>(pb + nr * 32 * BK * 2);
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
@@ -143,23 +151,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
         }
     };
 
-    // ---- main loop: global->reg prefetch of step s+1 overlaps the MFMAs of step s ----------
-    if (S > 0) {  // a parity class may have no taps (e.g. 1x1 stride-2 dgrad): result is just resid
-        load_tiles(0, 0);
-        store_tiles(0);
-    }
-    __syncthreads();
+    // ---- main loop: the DMA of step s+1 is in flight during the MFMAs of step s; one barrier/step ----
+    if (S > 0) issue(0, 0, 0);   // a parity class may have no taps (1x1 stride-2 dgrad): result is just resid
     int tap = 0, ck = 0;
     for (int s = 0; s < S; ++s) {
-        const bool more = (s + 1 < S);
-        if (more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage s has landed
+        __syncthreads();                                     // ... everybody's has, and compute(s-1) is over
+        if (s + 1 < S) {
             if (++ck == kcb) { ck = 0; ++tap; }
-            load_tiles(tap, ck);
+            issue((s + 1) & 1, tap, ck);
         }
         compute(s & 1);
-        if (more) store_tiles((s + 1) & 1);
-        __syncthreads();
     }
+    __syncthreads();
 
     // ---- epilogue --------------------------------------------------------------------------
     const int lr = lane & 31, lh = lane >> 5;

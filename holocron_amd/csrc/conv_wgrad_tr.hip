@@ -260,8 +260,9 @@ inline Plan make_plan_nr(const hc_wgrad_desc& d, int NR) {
     const int T = d.KH * d.KW;
     if (d.Cin % 16 || d.Cout % 16 || d.stride < 1 || d.stride > 2) return pl;
     if (!(T == 9 && d.KH == 3) && T != 1) return pl;
-    // measured on MI355X (profiles/r01_*): for Cin > 128 the k-pipelined generic kernel is faster
-    if (d.Cin > 128 || d.OW > 128) return pl;
+    // measured on MI355X (scripts/bench_layers.py): beyond 192x256 channels the k-pipelined generic
+    // kernel is faster (1280-wide layers re-stage dy once per ci tile here)
+    if (d.Cin > 192 || d.Cout > 256 || d.OW > 128) return pl;
     // ci tile = 16*MR: the largest supported MR that divides Cin/16
     const int c16 = d.Cin / 16;
     int MR = 0;
