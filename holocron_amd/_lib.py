@@ -38,6 +38,11 @@ class WgradDesc(C.Structure):
                 ("beta", c_int32)]
 
 
+class PackItem(C.Structure):
+    _fields_ = [("w", c_void_p), ("dst", c_void_p), ("Cout", c_int32), ("Cin", c_int32), ("KH", c_int32),
+                ("KW", c_int32), ("mode", c_int32), ("tap0", c_int32), ("T", c_int32), ("pad_", c_int32)]
+
+
 class RepBnDesc(C.Structure):
     _fields_ = [("stats", c_void_p * 3), ("gamma", c_void_p * 3), ("beta", c_void_p * 3),
                 ("running_mean", c_void_p * 3), ("running_var", c_void_p * 3), ("num_batches_tracked", c_void_p * 3),
@@ -78,6 +83,7 @@ SIGNATURES = {
     "hc_conv_wgrad_ws_bytes": (c_int64, [C.POINTER(WgradDesc)]),
     "hc_conv_wgrad": (c_int32, [C.POINTER(WgradDesc), c_void_p]),
     "hc_pack_conv_weight": (c_int32, [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
+    "hc_pack_conv_weights_multi": (c_int32, [c_void_p, c_int32, c_int64, c_void_p]),
     "hc_nchw_to_nhwc_bf16": (c_int32, [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
     "hc_nhwc_bf16_to_nchw": (c_int32, [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
     "hc_im2col_small": (c_int32, [c_void_p, c_void_p] + [c_int32] * 11 + [c_void_p]),

@@ -354,10 +354,34 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
             const int t = (KH - 1 - kh) * KW + (KW - 1 - kw);
             wpk[((long)ci * T + tap0 + t) * Cout + co] = v;
         } else {
-            wpk[(long)co * T + (kh * KW + kw) * Cin + ci] = v;
+            wpk[(long)co * T + tap0 + (kh * KW + kw) * Cin + ci] = v;
         }
     }
 }
+// all conv weights of a model in one launch: blockIdx.y = item
+__global__ void pack_weight_multi_kernel(const hc_pack_item* __restrict__ items) {
+    const hc_pack_item it = items[blockIdx.y];
+    const long total = (long)it.Cout * it.Cin * it.KH * it.KW;
+    bf16_t* wpk = reinterpret_cast<bf16_t*>(it.dst);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int kw = (int)(i % it.KW);
+        long r = i / it.KW;
+        const int kh = (int)(r % it.KH);
+        r /= it.KH;
+        const int ci = (int)(r % it.Cin);
+        const int co = (int)(r / it.Cin);
+        const bf16_t v = f32_to_bf16(it.w[i]);
+        if (it.mode == 0) {
+            wpk[((long)co * it.T + it.tap0 + kh * it.KW + kw) * it.Cin + ci] = v;
+        } else if (it.mode == 1) {
+            const int t = (it.KH - 1 - kh) * it.KW + (it.KW - 1 - kw);
+            wpk[((long)ci * it.T + it.tap0 + t) * it.Cout + co] = v;
+        } else {
+            wpk[(long)co * it.T + it.tap0 + (kh * it.KW + kw) * it.Cin + ci] = v;
+        }
+    }
+}
+
 // im2col for tiny Cin (stem): x NCHW fp32 -> col [N][OH][OW][Kpad] bf16, k = (kh*KW+kw)*Cin+ci
 __global__ void im2col_small_kernel(const float* __restrict__ x, bf16_t* __restrict__ col, int N, int Cin, int H, int W, int OH,
                                     int OW, int KH, int KW, int stride, int pad, int Kpad) {
@@ -522,6 +546,15 @@ int hc_pack_conv_weight(const float* w, void* wpk, int32_t Cout, int32_t Cin, in
     const long total = (long)Cout * Cin * KH * KW;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wpk, Cout, Cin, KH,
                        KW, mode, tap0, T);
+    return hc_launch_status();
+}
+int hc_pack_conv_weights_multi(const hc_pack_item* items, int32_t nitems, int64_t max_elems, hc_stream_t stream) {
+    if (items == nullptr || nitems < 0) return HC_ERR_ARG;
+    if (nitems == 0) return HC_OK;
+    int bx = (int)((max_elems + 255) / 256);
+    if (bx > 64) bx = 64;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(bx, nitems), dim3(256), 0, (hipStream_t)stream, items);
     return hc_launch_status();
 }
 int hc_im2col_small(const float* x, void* col, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t KH,

@@ -12,7 +12,8 @@ import torch
 import torch.nn as nn
 
 from ...nn import GlobalAvgPool2d, init
-from ...nn.repblock_op import RepState, rep_block_forward
+from ... import _lib
+from ...nn.repblock_op import POOL, RepState, rep_block_forward
 from ...ops import conv as cv
 from ..utils import conv_sequence, fuse_conv_bn
 
@@ -126,6 +127,49 @@ class RepVGG(nn.Sequential):
         for stage in self.features:
             for block in stage:
                 block.reparametrize()
+
+    # ---- step-level host work: one multi-tensor weight pack + one zero-filled arena per forward ----
+    def _pack_all(self) -> None:
+        import ctypes as C
+        import numpy as np
+        blocks = [b for stage in self.features for b in stage if isinstance(b.branches, nn.ModuleList) and b._fusable()]
+        stale = []
+        for b in blocks:
+            w3, w1 = b.branches[0][0].weight, b.branches[1][0].weight
+            if not w3.is_cuda:
+                return
+            if b._hc.packed is None or b._hc.packed_key != RepState.weights_key(w3, w1):
+                stale.append((b, w3, w1))
+        if not stale:
+            return
+        items = []
+        for b, w3, w1 in stale:
+            items += b._hc.pack_items(w3, w1)
+        sig = tuple((w.data_ptr(), dst.data_ptr()) for (w, dst, *_r) in items)
+        cache = getattr(self, "_hc_pack_table", None)
+        if cache is None or cache[0] != sig:
+            arr = (_lib.PackItem * len(items))()
+            mx = 0
+            for a, (w, dst, Cout, Cin, KH, KW, mode, tap0, T) in zip(arr, items):
+                a.w, a.dst, a.Cout, a.Cin, a.KH, a.KW, a.mode, a.tap0, a.T = w.data_ptr(), dst.data_ptr(), Cout, Cin, KH, KW, mode, tap0, T
+                mx = max(mx, w.numel())
+            host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+            cache = (sig, host.to(items[0][0].device), len(items), mx)
+            self._hc_pack_table = cache
+        _lib.check(_lib.load().hc_pack_conv_weights_multi(cache[1].data_ptr(), cache[2], cache[3], _lib.stream()),
+                   "hc_pack_conv_weights_multi")
+        for b, w3, w1 in stale:
+            b._hc.packed_key = RepState.weights_key(w3, w1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda:
+            return super().forward(x)   # the blocks raise the "no CPU path" error
+        self._pack_all()
+        POOL.begin(x.device)
+        try:
+            return super().forward(x)
+        finally:
+            POOL.end()
 
 
 _CFG = {

@@ -23,6 +23,47 @@ from ..ops import conv as cv
 STEM_KPAD = 32
 
 
+class ZeroPool:
+    """One zero-filled fp32 arena per training step instead of ~100 tiny ``torch.zeros`` launches:
+    ``begin()`` zeroes the extent used so far with a single memset, ``take(n)`` hands out views.
+    The buffer is allocated during warm-up, so a captured hipGraph keeps using the same addresses."""
+
+    def __init__(self):
+        self.buf = None
+        self.used = 0
+        self.high = 0
+        self.active = False
+
+    def begin(self, device):
+        if self.buf is None or self.buf.device != device or self.buf.numel() < self.high:
+            self.buf = torch.zeros(max(self.high * 2, 1 << 20), dtype=torch.float32, device=device)
+        else:
+            self.buf[: max(self.high, 1)].zero_()
+        self.used = 0
+        self.active = True
+
+    def end(self):
+        self.active = False
+
+    def take(self, shape, device):
+        n = 1
+        for v in shape:
+            n *= v
+        n4 = (n + 3) // 4 * 4
+        if not self.active or self.buf is None or self.used + n4 > self.buf.numel() or self.buf.device != device:
+            self.high = max(self.high, self.used + n4)
+            if self.active:
+                self.used += n4
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        out = self.buf[self.used:self.used + n].view(shape)
+        self.used += n4
+        self.high = max(self.high, self.used)
+        return out
+
+
+POOL = ZeroPool()
+
+
 class RepState:
     """Per-module host state: packed-weight caches, geometry descriptors, BN buffers."""
 
@@ -38,6 +79,43 @@ class RepState:
         self.momentum = 0.1
         self.training = True
         self.last_out_stats = None
+        self.packed = None          # persistent packed-weight buffers (wp3, wp1, wpd)
+        self.packed_key = None
+
+    # ---- packed weights (persistent buffers; refreshed by one multi-tensor launch per model) ----
+    @staticmethod
+    def weights_key(w3, w1):
+        return (w3.data_ptr(), w3._version, w1.data_ptr(), w1._version, cv.weights_epoch())
+
+    def pack_items(self, w3, w1):
+        """[(w, dst, Cout, Cin, KH, KW, mode, tap0, T)] — allocates the destination buffers once."""
+        Cout, Cin = w3.shape[0], w3.shape[1]
+        dev = w3.device
+        stem = (Cin % 16) != 0
+        if self.packed is None or self.packed[0].device != dev:
+            if stem:
+                self.packed = (torch.zeros((Cout, 1, STEM_KPAD), dtype=torch.bfloat16, device=dev),
+                               torch.zeros((Cout, 1, STEM_KPAD), dtype=torch.bfloat16, device=dev), None)
+            else:
+                self.packed = (torch.empty((Cout, 9, Cin), dtype=torch.bfloat16, device=dev),
+                               torch.empty((Cout, 1, Cin), dtype=torch.bfloat16, device=dev),
+                               torch.empty((Cin, 10, Cout), dtype=torch.bfloat16, device=dev))
+            self.packed_key = None
+        wp3, wp1, wpd = self.packed
+        if stem:
+            return [(w3, wp3, Cout, Cin, 3, 3, 2, 0, STEM_KPAD), (w1, wp1, Cout, Cin, 1, 1, 2, 4 * Cin, STEM_KPAD)]
+        return [(w3, wp3, Cout, Cin, 3, 3, 0, 0, 9), (w1, wp1, Cout, Cin, 1, 1, 0, 0, 1),
+                (w3, wpd, Cout, Cin, 3, 3, 1, 0, 10), (w1, wpd, Cout, Cin, 1, 1, 1, 9, 10)]
+
+    def ensure_packed(self, w3, w1):
+        key = self.weights_key(w3, w1)
+        if self.packed_key != key or self.packed is None:
+            lib = _lib.load()
+            for (w, dst, Cout, Cin, KH, KW, mode, tap0, T) in self.pack_items(w3, w1):
+                check(lib.hc_pack_conv_weight(ptr(w.detach()), ptr(dst), Cout, Cin, KH, KW, mode, tap0, T, stream()),
+                      "hc_pack_conv_weight")
+            self.packed_key = key
+        return self.packed
 
     def descs(self, N, Cin, H, W, Cout):
         key = (N, Cin, H, W, Cout)
@@ -61,7 +139,7 @@ def _stats_of(x):
     if st is not None:
         return st
     N, Cc, H, W = x.shape
-    st = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Cc), dtype=torch.float32, device=x.device)
+    st = POOL.take((_lib.HC_STAT_REPLICAS, 2, Cc), x.device)
     check(_lib.load().hc_channel_stats(ptr(x), ptr(st), N * H * W, Cc, stream()), "hc_channel_stats")
     return st
 
@@ -81,17 +159,17 @@ class RepBlockFn(torch.autograd.Function):
             if st.identity:
                 raise NotImplementedError("identity branch with Cin % 16 != 0")
             src = cv.im2col_small(x, 3, 3, st.stride, 1, STEM_KPAD)
-            wp3, wp1 = st.fwd_cache.get((w3, w1), lambda: (
-                cv.pack_weight_im2col(w3, STEM_KPAD), cv.pack_weight_im2col(w1, STEM_KPAD, k0=4 * Cin)))
         else:
             src = cv.to_cl_bf16(x)
             if st.identity and st.training:
                 x_stats = _stats_of(src if src is not x else x)
-            wp3, wp1 = st.fwd_cache.get((w3, w1), lambda: (cv.pack_weight(w3, 0), cv.pack_weight(w1, 0)))
+        if w3.dtype != torch.float32 or not w3.is_contiguous() or not w1.is_contiguous():
+            raise RuntimeError("RepBlock (HIP) expects contiguous fp32 conv weights")
+        wp3, wp1, _ = st.ensure_packed(w3, w1)
         y3 = cv.empty_cl(N, Cout, OH, OW, dev)
         y1 = cv.empty_cl(N, Cout, OH, OW, dev)
         R = _lib.HC_STAT_REPLICAS
-        stats = torch.zeros((2, R, 2, Cout), dtype=torch.float32, device=dev) if st.training else None
+        stats = POOL.take((2, R, 2, Cout), dev) if st.training else None
         fl3 = fl1 = None
         if stem:  # algorithmic flops of the real 3x3 / 1x1 convs, not of the padded im2col GEMM
             fl3, fl1 = 2.0 * N * OH * OW * Cout * 9 * Cin, 2.0 * N * OH * OW * Cout * Cin
@@ -119,8 +197,8 @@ class RepBlockFn(torch.autograd.Function):
         check(lib.hc_rep_bn_finalize(C.byref(d), stream()), "hc_rep_bn_finalize")
 
         out = cv.empty_cl(N, Cout, OH, OW, dev)
-        out_stats = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Cout), dtype=torch.float32, device=dev) \
-            if (st.emit_stats and st.training) else None
+        out_stats = POOL.take((_lib.HC_STAT_REPLICAS, 2, Cout), dev) if (st.emit_stats and st.training) else None
+        ctx.red = POOL.take((4, Cout), dev) if st.training else None   # backward's reduction target, zeroed with the rest
         check(lib.hc_rep_apply(ptr(y3), ptr(y1), ptr(src) if st.identity else None, ptr(coef), ptr(out), ptr(out_stats),
                                N * OH * OW, Cout, 1 if relu else 0, stream()), "hc_rep_apply")
         ctx.st, ctx.relu, ctx.stem = st, relu, stem
@@ -144,7 +222,10 @@ class RepBlockFn(torch.autograd.Function):
         mask_src = out if ctx.relu else torch.ones_like(out)
         xid = src if st.identity else None
 
-        red = torch.zeros((4, Cout), dtype=torch.float32, device=dev)
+        red = ctx.red
+        ctx.red = None
+        if red is None:
+            red = torch.zeros((4, Cout), dtype=torch.float32, device=dev)
         check(lib.hc_rep_bwd_reduce(ptr(g), ptr(mask_src), ptr(y3), ptr(y1), ptr(xid), ptr(red), npix, Cout, stream()),
               "hc_rep_bwd_reduce")
         nb = 3 if st.identity else 2
@@ -173,13 +254,7 @@ class RepBlockFn(torch.autograd.Function):
             if ctx.stem:
                 raise NotImplementedError("input gradient of the im2col stem path")
             _, _, dg = st.descs(N, Cin, H, W, Cout)
-
-            def build():
-                wp = torch.empty((Cin, 10, Cout), dtype=torch.bfloat16, device=dev)
-                cv.pack_weight(w3, 1, out=wp, tap0=0, T=10)
-                cv.pack_weight(w1, 1, out=wp, tap0=9, T=10)
-                return wp
-            wpd = st.bwd_cache.get((w3, w1), build)
+            wpd = st.ensure_packed(w3, w1)[2]
             dx = cv.empty_cl(N, Cin, H, W, dev)
             cv.launch_conv(dg, dy3, wpd, dx, src1=dy1, resid=dxid)
 

@@ -73,10 +73,20 @@ int64_t hc_conv_wgrad_ws_bytes(const hc_wgrad_desc* d);
 int hc_conv_wgrad(const hc_wgrad_desc* d, hc_stream_t stream);
 
 /* fp32 OIHW master weights -> packed bf16.  mode 0: forward  [Cout][KH*KW][Cin];
- * mode 1: data-gradient [Cin][KH*KW (spatially flipped)][Cout].  `tap0`/`T` let several
+ * mode 1: data-gradient [Cin][KH*KW (spatially flipped)][Cout]; mode 2: im2col order (see below).  `tap0`/`T` let several
  * kernels (3x3 + 1x1) share one packed tensor: taps are written at [tap0, tap0+KH*KW). */
 int hc_pack_conv_weight(const float* w, void* wpk, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
                         int32_t mode, int32_t tap0, int32_t T, hc_stream_t stream);
+
+/* Same for many tensors in ONE launch (`items` is a DEVICE array).  mode 2: im2col order
+ * wpk[co][tap0 + (kh*KW+kw)*Cin + ci] with row length T (= padded K); untouched entries keep
+ * their previous contents (zero them once). */
+typedef struct {
+    const float* w;
+    void* dst;
+    int32_t Cout, Cin, KH, KW, mode, tap0, T, pad_;
+} hc_pack_item;
+int hc_pack_conv_weights_multi(const hc_pack_item* items, int32_t nitems, int64_t max_elems, hc_stream_t stream);
 
 /* NCHW fp32 -> NHWC bf16 with channel padding to Cpad (zero filled) and back. */
 int hc_nchw_to_nhwc_bf16(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Cpad,
