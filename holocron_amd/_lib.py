@@ -31,6 +31,13 @@ class ConvDesc(C.Structure):
                 ("cls", ConvClass * 4)]
 
 
+class ConvSmallDesc(C.Structure):
+    _fields_ = [("srcA", c_void_p), ("srcB", c_void_p), ("w3", c_void_p), ("w1", c_void_p), ("out3", c_void_p),
+                ("out1", c_void_p), ("resid", c_void_p), ("stats3", c_void_p), ("stats1", c_void_p),
+                ("w3_rstride", c_int32), ("w1_rstride", c_int32),
+                ("N", c_int32), ("H", c_int32), ("W", c_int32), ("C", c_int32), ("Cout", c_int32), ("mode", c_int32)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("ws", c_void_p),
                 ("N", c_int32), ("IH", c_int32), ("IW", c_int32), ("Cin", c_int32), ("OH", c_int32), ("OW", c_int32),
@@ -80,6 +87,8 @@ def tap(dy, dx, src, wt):
 # name -> (restype, argtypes); every symbol include/holocron_hip.h declares
 SIGNATURES = {
     "hc_conv_gather": (c_int32, [C.POINTER(ConvDesc), c_void_p]),
+    "hc_conv_small": (c_int32, [C.POINTER(ConvSmallDesc), c_void_p]),
+    "hc_conv_small_supported": (c_int32, [C.POINTER(ConvSmallDesc)]),
     "hc_conv_wgrad_ws_bytes": (c_int64, [C.POINTER(WgradDesc)]),
     "hc_conv_wgrad": (c_int32, [C.POINTER(WgradDesc), c_void_p]),
     "hc_pack_conv_weight": (c_int32, [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),

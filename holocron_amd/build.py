@@ -17,6 +17,7 @@ ARCH = "gfx950"
 
 SOURCES = {
     "conv_gather.hip": [],
+    "conv_small.hip": [],
     "conv_wgrad.hip": [],
     "conv_wgrad_tr.hip": [],
     "rep_bn.hip": [],

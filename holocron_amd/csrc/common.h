@@ -20,16 +20,16 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) {
     return __builtin_bit_cast(float, (unsigned int)b << 16);
 }
-// round-to-nearest-even, NaN preserved (same rule as torch's float -> bfloat16)
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-    unsigned int u = __builtin_bit_cast(unsigned int, f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+// fp32 -> bf16, round-to-nearest-even (same rule as torch's float -> bfloat16), on the gfx950
+// hardware converter: ONE v_cvt_pk_bf16_f32 per two values (a software RNE costs ~5 VALU per value,
+// which made every epilogue and every elementwise pass VALU-bound).
+typedef __attribute__((ext_vector_type(2))) __bf16 hc_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float hc_f32x2;
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-    return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+    const hc_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hc_bf16x2));
 }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) { return (unsigned short)(pack_bf16x2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf16lo(unsigned int w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf16hi(unsigned int w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 

@@ -1,0 +1,396 @@
+// Stride-1 3x3 (+ fused 1x1) convolution for SMALL channel counts (C <= 48) on huge images — the
+// HBM-bound 48-channel 112^2 / 56^2 RepVGG layers (reference: RepBlock.forward,
+// holocron/models/classification/repvgg.py:71-73, and its data gradient).
+//
+// The generic gather-conv fetches, per 128-pixel tile, the whole weight matrix (41 KB) and nine
+// shifted copies of the input from L2: ~150 KB for 12 KB of output.  Here a persistent workgroup
+// keeps the packed weights in LDS for its whole lifetime and walks over output-row tiles; for each
+// tile the R+2 input rows (with halo, natural NHWC) are DMA'd once into a double-buffered LDS
+// window and all nine taps are read from it at shifted addresses.  The 1x1 branch is the centre
+// tap with its own weights and accumulator, so x is read ONCE for both branches.
+//
+//   mode 0 (forward) : out3 = W3 (*) A            out1 = W1 . A            (+ BN statistics of both)
+//   mode 1 (dgrad)   : out3 = W3 (*) A + W1 . B + resid      (A = dy3, B = dy1, weights flipped by the packer)
+//
+// MFMA v_mfma_f32_32x32x16_bf16, D[co][pix]: A operand = weights (rows = out channels, 2 x 32), B =
+// pixels (4 waves x 32).  LDS strides are == 112 (mod 256) so that the 16-lane groups of
+// ds_read_b128 hit 16 distinct 16-byte bank slots (rows r*112 mod 256 are all different for the
+// group row sets {0-3,12-15,20-27} / {4-11,16-19,28-31}).
+#include "common.h"
+#include "../../include/holocron_hip.h"
+
+namespace csm {
+
+constexpr int SX = 112;        // bytes per staged pixel (C <= 48 -> <= 96 used)
+constexpr int SXO = 144;       // bytes per pixel of the output staging tile (Cout <= 64 -> <= 128 used)
+constexpr int NT = 256, NW = 4;
+constexpr int MAXJ = 12;       // DMA instructions per wave per window (A) — bound checked on the host
+
+struct Args {
+    hc_conv_small_desc d;
+    int R, P, XWp, ntiles, tiles_per_img;
+    int ws3, ws1;              // LDS row strides (bytes) of the resident weights
+    int off_w1, off_win, win_bytes, off_win2, win2_bytes;   // LDS map (w3 at 0); windows are double buffered
+    int off_stat;              // fp32 [2 tensors][2][64] running BN sums of this workgroup
+    int off_stage;             // output staging tile: [2 tensors][128 px][144 B]
+    int nja, njb;              // DMA instructions per wave for window A / B
+    int qa, qb;                // DMA instructions per window (the last wave pass may be partial)
+    int wrows;                 // weight rows kept in LDS (Cout rounded up to 16; MFMA rows beyond read finite junk)
+};
+
+template <int KC>   // KC = C / 16 (1, 2, 3)
+__global__ __launch_bounds__(NT, 1) void conv_small_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const hc_conv_small_desc& d = a.d;
+    constexpr int C = 16 * KC;
+    constexpr int NCC = C / 8;                 // 16-byte chunks per pixel
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int H = d.H, W = d.W, Cout = d.Cout;
+    const bool dgrad = (d.mode & 1) == 1;
+    const unsigned img_bytes = (unsigned)d.N * H * W * C * 2u;
+    const __amdgpu_buffer_rsrc_t rsa = make_rsrc(d.srcA, img_bytes);
+    const __amdgpu_buffer_rsrc_t rsb = make_rsrc(dgrad ? d.srcB : d.srcA, img_bytes);
+
+    // ---- weights live in REGISTERS for the whole workgroup lifetime (one wave per SIMD: 512 VGPRs) ------
+    // A fragment of (row block m, tap t, k16 chunk kc): lane (row = lane&31, k half = lane>>5) holds the 8
+    // bf16 W[m*32 + row][t][kc*16 + 8*half ..].  Rows >= Cout are zero.
+    // Wave (mb, ph): output-channel block mb = wid & 1 (32 rows) x pixel half ph = wid >> 1 (64 pixels).
+    const int mb = wid & 1, ph = wid >> 1;
+    bf16x8 wreg3[9 * KC], wreg1[KC];
+    {
+        const bf16_t* w3 = reinterpret_cast<const bf16_t*>(d.w3);
+        const bf16_t* w1 = reinterpret_cast<const bf16_t*>(d.w1);
+        const int row = mb * 32 + (lane & 31), lh_ = lane >> 5;
+        const bool ok = row < Cout;
+#pragma unroll
+        for (int i = 0; i < 9 * KC; ++i) {
+            u32x4 v = u32x4{0, 0, 0, 0};
+            if (ok) v = *reinterpret_cast<const u32x4*>(w3 + (long)row * d.w3_rstride + i * 16 + lh_ * 8);
+            wreg3[i] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+            u32x4 v = u32x4{0, 0, 0, 0};
+            if (ok) v = *reinterpret_cast<const u32x4*>(w1 + (long)row * d.w1_rstride + i * 16 + lh_ * 8);
+            wreg1[i] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+
+    float* sstat = reinterpret_cast<float*>(smem + a.off_stat);
+    sstat[tid] = 0.f;   // 256 threads == 2*2*64 entries
+
+    // ---- DMA bookkeeping (tile invariant): window A = (R+2) x (W+2) pixels, window B = R x W pixels ----
+    // LDS position of (instr q, lane) = q*1024 + 16*lane -> pixel = pos/112, chunk = (pos%112)/16
+    int a_rel[MAXJ], a_wr[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int q16 = (wid + j * NW) * 64 + lane;      // 16-byte slot index inside the window
+        const int pix = q16 / 7, cc = q16 - pix * 7;
+        const int wr = pix / a.XWp, wc = pix - wr * a.XWp;
+        const bool ok = (wid + j * NW < a.qa) && (cc < NCC) && (wr < a.R + 2) && (wc >= 1) && (wc <= W);
+        a_rel[j] = ok ? ((wr * W + (wc - 1)) * C + cc * 8) * 2 : -1;
+        a_wr[j] = wr;
+    }
+    int b_rel[MAXJ / 2];
+#pragma unroll
+    for (int j = 0; j < MAXJ / 2; ++j) {
+        const int q16 = (wid + j * NW) * 64 + lane;
+        const int pix = q16 / 7, cc = q16 - pix * 7;
+        const bool ok = dgrad && (wid + j * NW < a.qb) && (cc < NCC) && (pix < a.P);
+        b_rel[j] = ok ? (pix * C + cc * 8) * 2 : -1;
+    }
+
+    auto issue = [&](int tile, int buf) {
+        const int n = tile / a.tiles_per_img;
+        const int oy0 = (tile - n * a.tiles_per_img) * a.R;
+        const int rowbase = ((n * H + oy0 - 1) * W) * C * 2;        // byte offset of window row 0 (may be "negative")
+        char* wa = smem + a.off_win + buf * a.win_bytes;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            if (wid + j * NW < a.qa) {                               // wave-uniform
+                const int iy = oy0 - 1 + a_wr[j];
+                const bool ok = (a_rel[j] >= 0) && ((unsigned)iy < (unsigned)H);
+                const unsigned voff = ok ? (unsigned)(rowbase + a_rel[j]) : HC_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lds_void*)(wa + (wid + j * NW) * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+        if (dgrad) {
+            char* wb = smem + a.off_win2 + buf * a.win2_bytes;
+            const int rows_left = H - oy0;
+            const int pvalid = (rows_left < a.R ? rows_left : a.R) * W;
+            const int base2 = ((n * H + oy0) * W) * C * 2;
+#pragma unroll
+            for (int j = 0; j < MAXJ / 2; ++j) {
+                if (wid + j * NW < a.qb) {
+                    const int q16 = (wid + j * NW) * 64 + lane;
+                    const bool ok = (b_rel[j] >= 0) && (q16 / 7 < pvalid);
+                    const unsigned voff = ok ? (unsigned)(base2 + b_rel[j]) : HC_OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_void*)(wb + (wid + j * NW) * 1024), 16, voff, 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- per-lane compute constants: two 32-pixel blocks per wave -----------------------------------
+    const int lr = lane & 31, lh = lane >> 5;
+    int xoff[2], xoff2[2];
+    bool pin[2];
+    int prr[2];
+#pragma unroll
+    for (int nr = 0; nr < 2; ++nr) {
+        const int p = ph * 64 + nr * 32 + lr;                 // pixel of this lane inside the tile
+        pin[nr] = p < a.P;
+        const int pr = pin[nr] ? p / W : 0, pc = pin[nr] ? p - pr * W : 0;
+        prr[nr] = pr;
+        xoff[nr] = (pr * a.XWp + pc) * SX + lh * 16;          // window A offset of tap (0,0), k-half lh
+        xoff2[nr] = (pin[nr] ? p : 0) * SX + lh * 16;         // window B (no halo)
+    }
+
+    float* stats3 = d.stats3;
+    float* stats1 = d.stats1;
+    bf16_t* out3 = reinterpret_cast<bf16_t*>(d.out3);
+    bf16_t* out1 = reinterpret_cast<bf16_t*>(d.out1);
+    const bf16_t* resid = reinterpret_cast<const bf16_t*>(d.resid);
+
+    float rs1[2][16], rs2[2][16];   // running BN sums [tensor][accumulator register] of this wave's row block
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { rs1[w][r] = 0.f; rs2[w][r] = 0.f; }
+
+    int tile = blockIdx.x;
+    if (tile < a.ntiles) issue(tile, 0);
+    int buf = 0;
+    for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // window `buf` landed everywhere; previous tile fully consumed
+        const int nxt = tile + gridDim.x;
+        if (nxt < a.ntiles) issue(nxt, buf ^ 1);
+
+        const char* wa = smem + a.off_win + buf * a.win_bytes;
+        f32x16 acc3[2], acc1[2];   // [pixel block]
+#pragma unroll
+        for (int nr = 0; nr < 2; ++nr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc3[nr][r] = 0.f; acc1[nr][r] = 0.f; }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            // batch the LDS reads of a whole kernel row (3 taps x KC chunks x 2 pixel blocks) ahead of its MFMAs
+            bf16x8 bfr[3][KC][2];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                    for (int nr = 0; nr < 2; ++nr)
+                        bfr[kw][kc][nr] = *reinterpret_cast<const bf16x8*>(wa + xoff[nr] + (kh * a.XWp + kw) * SX + kc * 32);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                    for (int nr = 0; nr < 2; ++nr) {
+                        acc3[nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg3[(kh * 3 + kw) * KC + kc], bfr[kw][kc][nr], acc3[nr], 0, 0, 0);
+                        if (kh == 1 && kw == 1 && !dgrad)   // the 1x1 branch shares the centre-tap pixels
+                            acc1[nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg1[kc], bfr[kw][kc][nr], acc1[nr], 0, 0, 0);
+                    }
+        }
+        if (dgrad) {   // + W1^T . dy1 (second source, no halo) into the same accumulator
+            const char* wb = smem + a.off_win2 + buf * a.win2_bytes;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+                for (int nr = 0; nr < 2; ++nr) {
+                    const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + xoff2[nr] + kc * 32);
+                    acc3[nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg1[kc], b, acc3[nr], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue: running statistics (forward) and NHWC stores -------------------------------------
+        const int n = tile / a.tiles_per_img;
+        const int oy0 = (tile - n * a.tiles_per_img) * a.R;
+        const int rows_left = H - oy0;
+        const int pvalid = (rows_left < a.R ? rows_left : a.R) * W;     // valid pixels of this tile
+        bool live[2];
+#pragma unroll
+        for (int nr = 0; nr < 2; ++nr) live[nr] = pin[nr] && (oy0 + prr[nr] < H);
+        if (stats3 != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a0_ = live[0] ? acc3[0][r] : 0.f, a1_ = live[1] ? acc3[1][r] : 0.f;
+                const float b0_ = live[0] ? acc1[0][r] : 0.f, b1_ = live[1] ? acc1[1][r] : 0.f;
+                rs1[0][r] += a0_ + a1_; rs2[0][r] += a0_ * a0_ + a1_ * a1_;
+                rs1[1][r] += b0_ + b1_; rs2[1][r] += b0_ * b0_ + b1_ * b1_;
+            }
+        }
+        // Stores: the tile's pixels x Cout channels are ONE contiguous run of NHWC memory.  Stage the tile in
+        // LDS ([tensor][pixel][112 B]) and write it out as 16-byte chunks, thread-linear = fully coalesced.
+        {
+            char* stg = smem + a.off_stage;
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                if (which == 1 && out1 == nullptr) break;
+#pragma unroll
+                for (int nr = 0; nr < 2; ++nr) {
+                    char* row = stg + which * (128 * SXO) + (ph * 64 + nr * 32 + lr) * SXO;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int co = mb * 32 + 8 * q + 4 * lh;
+                        if (co < Cout) {
+                            u32x2 o;
+                            if (which == 0) {
+                                o[0] = pack_bf16x2(acc3[nr][4 * q], acc3[nr][4 * q + 1]);
+                                o[1] = pack_bf16x2(acc3[nr][4 * q + 2], acc3[nr][4 * q + 3]);
+                            } else {
+                                o[0] = pack_bf16x2(acc1[nr][4 * q], acc1[nr][4 * q + 1]);
+                                o[1] = pack_bf16x2(acc1[nr][4 * q + 2], acc1[nr][4 * q + 3]);
+                            }
+                            *reinterpret_cast<u32x2*>(row + co * 2) = o;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const int cpp = Cout / 8;                                   // 16-byte chunks per pixel
+            const int nchunks = pvalid * cpp;
+            const long gbase = ((long)(n * H + oy0) * W) * Cout;       // first element of the tile
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                if (which == 1 && out1 == nullptr) break;
+                const char* st_ = stg + which * (128 * SXO);
+                bf16_t* outp = (which == 0 ? out3 : out1) + gbase;
+                for (int c = tid; c < nchunks; c += NT) {
+                    const int px = c / cpp, part = c - px * cpp;
+                    u32x4 v = *reinterpret_cast<const u32x4*>(st_ + px * SXO + part * 16);
+                    if (which == 0 && resid != nullptr) {
+                        const u32x4 rv = *reinterpret_cast<const u32x4*>(resid + gbase + (long)c * 8);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = pack_bf16x2(bf16lo(v[e]) + bf16lo(rv[e]), bf16hi(v[e]) + bf16hi(rv[e]));
+                    }
+                    *reinterpret_cast<u32x4*>(outp + (long)c * 8) = v;
+                }
+            }
+        }
+    }
+    if (stats3 != nullptr) {   // butterfly over the pixel lanes ONCE, combine the waves in LDS, one flush
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            float s1[16], s2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s1[r] = rs1[which][r]; s2[r] = rs2[which][r]; }
+#pragma unroll
+            for (int w = 8, o = 16; w >= 1; w >>= 1, o >>= 1) {
+                const bool up = (lane & o) != 0;
+#pragma unroll
+                for (int i = 0; i < w; ++i) {
+                    const float k1 = up ? s1[i + w] : s1[i], g1 = up ? s1[i] : s1[i + w];
+                    const float k2 = up ? s2[i + w] : s2[i], g2 = up ? s2[i] : s2[i + w];
+                    s1[i] = k1 + __shfl_xor(g1, o);
+                    s2[i] = k2 + __shfl_xor(g2, o);
+                }
+            }
+            s1[0] += __shfl_xor(s1[0], 1);
+            s2[0] += __shfl_xor(s2[0], 1);
+            if ((lane & 1) == 0) {
+                const int r = 8 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 1) & 1);
+                const int co = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                atomicAdd(&sstat[which * 128 + co], s1[0]);
+                atomicAdd(&sstat[which * 128 + 64 + co], s2[0]);
+            }
+        }
+        __syncthreads();
+        const int which = tid >> 7, kind = (tid >> 6) & 1, co = tid & 63;
+        if (co < Cout) {
+            float* st = (which == 0 ? stats3 : stats1) + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * Cout;
+            atomicAdd(st + kind * Cout + co, sstat[tid]);
+        }
+    }
+}
+
+inline int round112(int bytes) {   // smallest stride >= bytes that is == 112 (mod 256)
+    int s = 112;
+    while (s < bytes) s += 256;
+    return s;
+}
+
+inline bool make_args(const hc_conv_small_desc& d, Args& a, int& smem) {
+    if (d.C % 16 || d.C > 48 || d.Cout % 8 || d.Cout > 64 || d.W > 128 || d.W < 8 || d.H < 1) return false;
+    a.d = d;
+    int R = 128 / d.W;
+    if (R < 1) R = 1;
+    if (R > d.H) R = d.H;
+    a.R = R;
+    a.P = R * d.W;
+    if (a.P > 128) return false;
+    a.XWp = d.W + 2;
+    a.tiles_per_img = (d.H + R - 1) / R;
+    a.ntiles = d.N * a.tiles_per_img;
+    a.ws3 = round112(9 * d.C * 2);
+    a.ws1 = round112(d.C * 2);
+    a.wrows = 0;
+    a.off_w1 = 0;
+    a.off_stage = 0;
+    a.off_win = (2 * 128 * SXO + 1023) / 1024 * 1024;
+    const int winA = (R + 2) * a.XWp * SX;
+    const int qa = (winA + 1023) / 1024;             // DMA instructions for window A
+    a.qa = qa;
+    a.nja = (qa + NW - 1) / NW;
+    a.win_bytes = qa * 1024;
+    a.off_win2 = a.off_win + 2 * a.win_bytes;
+    a.njb = 0;
+    a.qb = 0;
+    a.win2_bytes = 0;
+    if ((d.mode & 1) == 1) {
+        const int winB = a.P * SX;
+        const int qb = (winB + 1023) / 1024;
+        a.qb = qb;
+        a.njb = (qb + NW - 1) / NW;
+        a.win2_bytes = qb * 1024;
+    }
+    a.off_stat = a.off_win2 + 2 * a.win2_bytes;
+    smem = a.off_stat + 1024;
+    // rows 32..63 of the second MFMA row block may lie beyond wrows: they must still be inside the allocation
+    if (a.nja > MAXJ || a.njb > MAXJ / 2 || smem > 160 * 1024 || (d.Cout % 8) != 0) return false;
+    return true;
+}
+
+template <int KC>
+void launch(const Args& a, int grid, int smem, hipStream_t st) {
+    auto kern = conv_small_kernel<KC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, a);
+}
+
+}  // namespace csm
+
+extern "C" int hc_conv_small(const hc_conv_small_desc* dp, hc_stream_t stream) {
+    if (dp == nullptr) return HC_ERR_ARG;
+    const hc_conv_small_desc& d = *dp;
+    if (d.srcA == nullptr || d.w3 == nullptr || d.w1 == nullptr || d.out3 == nullptr) return HC_ERR_ARG;
+    if ((d.mode & 1) == 1 && d.srcB == nullptr) return HC_ERR_ARG;
+    if ((d.mode & 1) == 0 && d.out1 == nullptr) return HC_ERR_ARG;
+    if ((double)d.N * d.H * d.W * d.C * 2.0 >= 2147483000.0) return HC_ERR_ARG;
+    csm::Args a;
+    int smem = 0;
+    if (!csm::make_args(d, a, smem)) return HC_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int grid = a.ntiles < 256 ? a.ntiles : 256;      // one persistent workgroup per CU
+    if (d.C == 16) csm::launch<1>(a, grid, smem, st);
+    else if (d.C == 32) csm::launch<2>(a, grid, smem, st);
+    else csm::launch<3>(a, grid, smem, st);
+    return hc_launch_status();
+}
+
+extern "C" int hc_conv_small_supported(const hc_conv_small_desc* dp) {
+    if (dp == nullptr) return 0;
+    csm::Args a;
+    int smem = 0;
+    return csm::make_args(*dp, a, smem) ? 1 : 0;
+}

@@ -358,27 +358,37 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
         }
     }
 }
-// all conv weights of a model in one launch: blockIdx.y = item
+// all conv weights of a model in one launch: blockIdx.y = item.  Threads walk the OUTPUT (packed)
+// order so the 2-byte stores coalesce; the strided fp32 reads are served by L2/MALL.
 __global__ void pack_weight_multi_kernel(const hc_pack_item* __restrict__ items) {
     const hc_pack_item it = items[blockIdx.y];
-    const long total = (long)it.Cout * it.Cin * it.KH * it.KW;
+    const int KK = it.KH * it.KW;
+    const long total = (long)it.Cout * it.Cin * KK;
     bf16_t* wpk = reinterpret_cast<bf16_t*>(it.dst);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int kw = (int)(i % it.KW);
-        long r = i / it.KW;
-        const int kh = (int)(r % it.KH);
-        r /= it.KH;
-        const int ci = (int)(r % it.Cin);
-        const int co = (int)(r / it.Cin);
-        const bf16_t v = f32_to_bf16(it.w[i]);
-        if (it.mode == 0) {
-            wpk[((long)co * it.T + it.tap0 + kh * it.KW + kw) * it.Cin + ci] = v;
-        } else if (it.mode == 1) {
-            const int t = (it.KH - 1 - kh) * it.KW + (it.KW - 1 - kw);
-            wpk[((long)ci * it.T + it.tap0 + t) * it.Cout + co] = v;
-        } else {
-            wpk[(long)co * it.T + it.tap0 + (kh * it.KW + kw) * it.Cin + ci] = v;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        int co, ci, t;
+        long dst;
+        if (it.mode == 0) {          // [co][tap][ci]
+            ci = (int)(o % it.Cin);
+            const long r = o / it.Cin;
+            t = (int)(r % KK);
+            co = (int)(r / KK);
+            dst = ((long)co * it.T + it.tap0 + t) * it.Cin + ci;
+        } else if (it.mode == 1) {   // [ci][flipped tap][co]
+            co = (int)(o % it.Cout);
+            const long r = o / it.Cout;
+            const int tf = (int)(r % KK);
+            ci = (int)(r / KK);
+            t = KK - 1 - tf;         // flip both kh and kw
+            dst = ((long)ci * it.T + it.tap0 + tf) * it.Cout + co;
+        } else {                     // [co][tap0 + tap*Cin + ci]
+            ci = (int)(o % it.Cin);
+            const long r = o / it.Cin;
+            t = (int)(r % KK);
+            co = (int)(r / KK);
+            dst = (long)co * it.T + it.tap0 + t * it.Cin + ci;
         }
+        wpk[dst] = f32_to_bf16(it.w[((long)co * it.Cin + ci) * KK + t]);
     }
 }
 
@@ -551,8 +561,8 @@ int hc_pack_conv_weight(const float* w, void* wpk, int32_t Cout, int32_t Cin, in
 int hc_pack_conv_weights_multi(const hc_pack_item* items, int32_t nitems, int64_t max_elems, hc_stream_t stream) {
     if (items == nullptr || nitems < 0) return HC_ERR_ARG;
     if (nitems == 0) return HC_OK;
-    int bx = (int)((max_elems + 255) / 256);
-    if (bx > 64) bx = 64;
+    int bx = (int)((max_elems + 1023) / 1024);
+    if (bx > 2048) bx = 2048;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(bx, nitems), dim3(256), 0, (hipStream_t)stream, items);
     return hc_launch_status();

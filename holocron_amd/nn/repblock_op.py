@@ -130,7 +130,11 @@ class RepState:
                 f3 = cv.fwd_desc(N, STEM_KPAD, OH, OW, Cout, 1, 1, 1, 0)
                 f1 = cv.fwd_desc(N, STEM_KPAD, OH, OW, Cout, 1, 1, 1, 0)
                 dg = None
-            self.desc[key] = (f3, f1, dg)
+            sf = sd = None
+            if Cin % 16 == 0 and s == 1:   # small-channel persistent kernel (fused 3x3+1x1, LDS-resident weights)
+                sf = cv.conv_small_desc(N, H, W, Cin, Cout, 0)
+                sd = cv.conv_small_desc(N, H, W, Cout, Cin, 1)
+            self.desc[key] = (f3, f1, dg, sf, sd)
         return self.desc[key]
 
 
@@ -152,7 +156,7 @@ class RepBlockFn(torch.autograd.Function):
         N, _, H, W = x.shape
         dev = x.device
         stem = (Cin % 16) != 0
-        f3, f1, _ = st.descs(N, Cin, H, W, Cout)
+        f3, f1, _, sf, _ = st.descs(N, Cin, H, W, Cout)
         OH, OW = (f3.OH, f3.OW)
         x_stats = None
         if stem:
@@ -173,8 +177,12 @@ class RepBlockFn(torch.autograd.Function):
         fl3 = fl1 = None
         if stem:  # algorithmic flops of the real 3x3 / 1x1 convs, not of the padded im2col GEMM
             fl3, fl1 = 2.0 * N * OH * OW * Cout * 9 * Cin, 2.0 * N * OH * OW * Cout * Cin
-        cv.launch_conv(f3, src, wp3, y3, stats=None if stats is None else stats[0], flops=fl3)
-        cv.launch_conv(f1, src, wp1, y1, stats=None if stats is None else stats[1], flops=fl1)
+        if sf is not None:
+            cv.launch_conv_small_fwd(sf, src, wp3, wp1, y3, y1, None if stats is None else stats[0],
+                                     None if stats is None else stats[1])
+        else:
+            cv.launch_conv(f3, src, wp3, y3, stats=None if stats is None else stats[0], flops=fl3)
+            cv.launch_conv(f1, src, wp1, y1, stats=None if stats is None else stats[1], flops=fl1)
 
         coef = torch.empty((4, Cout), dtype=torch.float32, device=dev)
         save = torch.empty((6, Cout), dtype=torch.float32, device=dev)
@@ -253,10 +261,13 @@ class RepBlockFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if ctx.stem:
                 raise NotImplementedError("input gradient of the im2col stem path")
-            _, _, dg = st.descs(N, Cin, H, W, Cout)
+            _, _, dg, _, sdg = st.descs(N, Cin, H, W, Cout)
             wpd = st.ensure_packed(w3, w1)[2]
             dx = cv.empty_cl(N, Cin, H, W, dev)
-            cv.launch_conv(dg, dy3, wpd, dx, src1=dy1, resid=dxid)
+            if sdg is not None:
+                cv.launch_conv_small_dgrad(sdg, dy3, dy1, wpd, dx, resid=dxid)
+            else:
+                cv.launch_conv(dg, dy3, wpd, dx, src1=dy1, resid=dxid)
 
         if ctx.stem:
             K = STEM_KPAD

@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from .. import _lib
-from .._lib import ConvDesc, WgradDesc, check, ptr, stream, tap
+from .._lib import ConvDesc, ConvSmallDesc, WgradDesc, check, ptr, stream, tap
 
 _WEIGHTS_EPOCH = [0]  # bumped by holocron_amd.optim after every raw-pointer parameter update
 
@@ -237,3 +237,42 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, act=0, stats=None):
     b = None if bias is None else bias.detach().float().contiguous()
     launch_conv(d, src, wpk, out, stats=stats, bias=b, act=act)
     return out
+
+
+# ------------------------------------------------------------------ small-channel stride-1 3x3 (+1x1)
+def conv_small_desc(N, H, W, Cc, Cout, mode):
+    """Descriptor of hc_conv_small, or None when the shape is outside what that kernel supports."""
+    d = ConvSmallDesc()
+    d.N, d.H, d.W, d.C, d.Cout, d.mode = N, H, W, Cc, Cout, mode
+    if not _lib.load().hc_conv_small_supported(C.byref(d)):
+        return None
+    return d
+
+
+def launch_conv_small_fwd(d, x, wp3, wp1, y3, y1, stats3=None, stats1=None):
+    """y3 = conv3x3(x), y1 = conv1x1(x) (stride 1) with wp3 [Cout][9][C], wp1 [Cout][1][C]."""
+    d.srcA, d.srcB, d.w3, d.w1 = ptr(x), None, ptr(wp3), ptr(wp1)
+    d.w3_rstride, d.w1_rstride = 9 * d.C, d.C
+    d.out3, d.out1, d.resid, d.stats3, d.stats1 = ptr(y3), ptr(y1), None, ptr(stats3), ptr(stats1)
+    _launch_small(d, 2.0 * d.N * d.H * d.W * d.Cout * 10 * d.C)
+
+
+def launch_conv_small_dgrad(d, dy3, dy1, wpd, dx, resid=None):
+    """dx = conv3x3^T(dy3) + conv1x1^T(dy1) + resid with wpd [Cin][10][Cout] (mode-1 packing);
+    here d.C = Cout of the forward conv and d.Cout = its Cin."""
+    d.srcA, d.srcB, d.w3 = ptr(dy3), ptr(dy1), ptr(wpd)
+    d.w1 = ptr(wpd) + 9 * d.C * 2
+    d.w3_rstride, d.w1_rstride = 10 * d.C, 10 * d.C
+    d.out3, d.out1, d.resid, d.stats3, d.stats1 = ptr(dx), None, ptr(resid), None, None
+    _launch_small(d, 2.0 * d.N * d.H * d.W * d.Cout * 10 * d.C)
+
+
+def _launch_small(d, flops):
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().hc_conv_small(C.byref(d), stream()), "hc_conv_small")
+        e1.record()
+        PROFILE.append(("conv_small", flops, e0, e1))
+        return
+    check(_lib.load().hc_conv_small(C.byref(d), stream()), "hc_conv_small")

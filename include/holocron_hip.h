@@ -56,6 +56,27 @@ typedef struct {
 } hc_conv_desc;
 int hc_conv_gather(const hc_conv_desc* d, hc_stream_t stream);
 
+/* Stride-1 3x3 (+1x1) convolution specialised for C <= 48 input channels on large images
+ * (persistent workgroups, weights resident in LDS, DMA'd row window with halo).
+ * mode 0: out3 = W3 (*) srcA, out1 = W1 . srcA (+ optional BN statistics, replicated like hc_conv_desc);
+ * mode 1: out3 = W3 (*) srcA + W1 . srcB + resid  (RepBlock data gradient; srcA = dy3, srcB = dy1).
+ * w3/w1 are packed bf16 rows [out channel][tap][C] with the given row strides (elements). */
+typedef struct {
+    const void* srcA;
+    const void* srcB;
+    const void* w3;
+    const void* w1;
+    void* out3;
+    void* out1;
+    const void* resid;
+    float* stats3;
+    float* stats1;
+    int32_t w3_rstride, w1_rstride;
+    int32_t N, H, W, C, Cout, mode;
+} hc_conv_small_desc;
+int hc_conv_small(const hc_conv_small_desc* d, hc_stream_t stream);
+int hc_conv_small_supported(const hc_conv_small_desc* d);
+
 /* Weight gradient dW[co][ci][kh][kw] = sum_m dy[m][co] * x[m + tap][ci].
  * Replaces aten::convolution_backward(weight).  Split-K over output pixels: partial fp32
  * slabs go to `ws` (at least hc_conv_wgrad_ws_bytes bytes), then a reduce kernel writes

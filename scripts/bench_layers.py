@@ -41,6 +41,30 @@ for li in sel:
             out = cv.empty_cl(N, Cout, OH, OH, "cuda")
             stats = torch.zeros(32, 2, Cout, device="cuda")
             us = timeit(lambda: cv.launch_conv(d, x, wp, out, stats=stats))
+        elif which == "small":
+            if k == 1 or s != 1 or Cin > 48:
+                continue
+            w3 = torch.randn(Cout, Cin, 3, 3, device="cuda"); w1 = torch.randn(Cout, Cin, 1, 1, device="cuda")
+            wp3, wp1 = cv.pack_weight(w3, 0), cv.pack_weight(w1, 0)
+            d = cv.conv_small_desc(N, H, H, Cin, Cout, 0)
+            y3 = cv.empty_cl(N, Cout, OH, OH, "cuda"); y1 = cv.empty_cl(N, Cout, OH, OH, "cuda")
+            stats = torch.zeros(2, 32, 2, Cout, device="cuda")
+            flops = 2.0 * N * OH * OH * Cout * Cin * 10
+            us = timeit(lambda: cv.launch_conv_small_fwd(d, x, wp3, wp1, y3, y1, stats[0], stats[1]))
+            print(f"small-fwd(3x3+1x1) {Cin}->{Cout} @{H}: {us:9.1f} us {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
+            us = timeit(lambda: cv.launch_conv_small_fwd(d, x, wp3, wp1, y3, y1, None, None))
+            print(f"small-fwd no stats   {Cin}->{Cout} @{H}: {us:9.1f} us", flush=True)
+            d.mode = 2
+            us = timeit(lambda: cv.launch_conv_small_fwd(d, x, wp3, wp1, y3, y1, None, None))
+            print(f"small-fwd no stats no stores {Cin}->{Cout} @{H}: {us:9.1f} us", flush=True)
+            d.mode = 0
+            wpd = torch.empty((Cin, 10, Cout), dtype=torch.bfloat16, device="cuda")
+            cv.pack_weight(w3, 1, out=wpd, tap0=0, T=10); cv.pack_weight(w1, 1, out=wpd, tap0=9, T=10)
+            dd = cv.conv_small_desc(N, H, H, Cout, Cin, 1)
+            dx = cv.empty_cl(N, Cin, H, H, "cuda")
+            us = timeit(lambda: cv.launch_conv_small_dgrad(dd, dy, dy, wpd, dx, resid=x))
+            print(f"small-dgrad          {Cin}->{Cout} @{H}: {us:9.1f} us {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
+            continue
         else:  # dgrad (dual) measured once per layer
             if k == 1:
                 continue

@@ -123,3 +123,47 @@ def test_layout_roundtrip():
     x = bf16r(torch.randn(2, 24, 5, 7))
     y = cv.to_cl_bf16(x.cuda())
     assert y.is_contiguous(memory_format=torch.channels_last) and torch.equal(y.float().cpu(), x)
+
+
+@pytest.mark.parametrize("N,C,Cout,H,W", [(2, 48, 48, 20, 112), (3, 48, 48, 9, 56), (2, 32, 48, 7, 30), (2, 16, 64, 5, 17),
+                                           (1, 48, 40, 3, 128)])
+def test_conv_small_forward_and_dgrad(N, C, Cout, H, W):
+    """persistent LDS-resident-weight kernel for small channel counts: fused 3x3+1x1 forward with
+    BN statistics, and the two-source data gradient with residual"""
+    from holocron_amd import _lib
+    from holocron_amd.ops import conv as cv
+    torch.manual_seed(C + Cout + W)
+    x = bf16r(torch.randn(N, C, H, W))
+    w3 = bf16r(torch.randn(Cout, C, 3, 3) / (C * 9) ** 0.5)
+    w1 = bf16r(torch.randn(Cout, C, 1, 1) / C ** 0.5)
+    d = cv.conv_small_desc(N, H, W, C, Cout, 0)
+    assert d is not None
+    y3 = cv.empty_cl(N, Cout, H, W, "cuda")
+    y1 = cv.empty_cl(N, Cout, H, W, "cuda")
+    stats = torch.zeros(2, _lib.HC_STAT_REPLICAS, 2, Cout, device="cuda")
+    cv.launch_conv_small_fwd(d, cv.to_cl_bf16(x.cuda()), cv.pack_weight(w3.cuda(), 0), cv.pack_weight(w1.cuda(), 0), y3, y1,
+                             stats[0], stats[1])
+    r3, r1 = F.conv2d(x, w3, None, 1, 1), F.conv2d(x, w1, None, 1, 0)
+    assert rel_l2(_to_nchw_f32(y3), r3) < 3e-3 and rel_l2(_to_nchw_f32(y1), r1) < 3e-3
+    s = stats.cpu().double().sum(1)
+    for ref, st in ((r3, s[0]), (r1, s[1])):
+        assert (st[0] - ref.double().sum((0, 2, 3))).abs().max() < 2e-2 + 2e-4 * ref.abs().sum((0, 2, 3)).max()
+        assert rel_l2(st[1], (ref.double() ** 2).sum((0, 2, 3))) < 2e-4
+    # data gradient of conv3x3(u) + conv1x1(u) for u with Cin_fwd = Cout (here: roles swapped)
+    Cin_f, Cout_f = Cout, C          # forward conv maps Cin_f -> Cout_f; dgrad consumes dy with Cout_f channels
+    if Cin_f % 16 == 0 and Cin_f <= 64:
+        u = torch.randn(N, Cin_f, H, W, requires_grad=True)
+        v3 = bf16r(torch.randn(Cout_f, Cin_f, 3, 3) / (Cout_f * 9) ** 0.5)
+        v1 = bf16r(torch.randn(Cout_f, Cin_f, 1, 1) / Cout_f ** 0.5)
+        o3, o1 = F.conv2d(u, v3, None, 1, 1), F.conv2d(u, v1, None, 1, 0)
+        g3, g1 = bf16r(torch.randn_like(o3)), bf16r(torch.randn_like(o1))
+        res = bf16r(torch.randn(N, Cin_f, H, W))
+        (du,) = torch.autograd.grad((o3 * g3).sum() + (o1 * g1).sum(), u)
+        wpd = torch.empty((Cin_f, 10, Cout_f), dtype=torch.bfloat16, device="cuda")
+        cv.pack_weight(v3.cuda(), 1, out=wpd, tap0=0, T=10)
+        cv.pack_weight(v1.cuda(), 1, out=wpd, tap0=9, T=10)
+        dd = cv.conv_small_desc(N, H, W, Cout_f, Cin_f, 1)
+        assert dd is not None
+        dx = cv.empty_cl(N, Cin_f, H, W, "cuda")
+        cv.launch_conv_small_dgrad(dd, cv.to_cl_bf16(g3.cuda()), cv.to_cl_bf16(g1.cuda()), wpd, dx, resid=cv.to_cl_bf16(res.cuda()))
+        assert rel_l2(_to_nchw_f32(dx), du + res) < 3e-3
