@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libholocron_hip.so")
 
 HC_MAX_TAPS = 12
 HC_MT_CHUNK = 65536
-HC_STAT_REPLICAS = 32
+HC_STAT_REPLICAS = 128
 
 c_void_p, c_int32, c_int64, c_float, c_double = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 

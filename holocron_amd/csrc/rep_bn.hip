@@ -7,6 +7,7 @@
 // keeps the per-channel coefficients in registers.
 #include "common.h"
 #include "../../include/holocron_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -16,11 +17,14 @@ struct EwGrid {
     int blocks;
 };
 // number of blocks such that (blocks*256) % (C/8) == 0 and every thread gets >= ~8 chunks
-inline int ew_blocks(long nchunks, int cg) {
+inline int ew_blocks(long nchunks, int cg, int cpt_default = 8) {
     int a = cg, b = EW_THREADS;
     while (b) { int t = a % b; a = b; b = t; }
     const int unit = cg / a;  // blocks must be a multiple of this
-    long want = nchunks / (EW_THREADS * 8);
+    // chunks per thread: 8 for pure streaming passes; 16 for passes that end in a per-workgroup
+    // reduction (their tail costs as much as streaming a few MB, measured with scripts/bench_ew.py)
+    const int cpt = cpt_default;
+    long want = nchunks / (EW_THREADS * cpt);
     if (want > 2048) want = 2048;
     if (want < 1) want = 1;
     long k = (want + unit - 1) / unit;
@@ -43,9 +47,37 @@ __device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
     for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
 }
 
+// Per-workgroup reduction of per-thread partial sums v[S][8] (8 channels of the thread's channel
+// group) WITHOUT LDS atomics (contended ds_add_f32 costs ~8 us per workgroup here): partials go to
+// LDS [thread][S*8 (+1 pad)], then each output (sum k, channel c) adds the ~256/cg threads that own
+// channel group c/8 and issues ONE global atomic into the replica slab `dst` ([S][C]).
+template <int S>
+__device__ __forceinline__ void block_reduce_flush(const float (&v)[S][8], int cg, int C, float* __restrict__ dst,
+                                                   float* __restrict__ lds, int nsum) {
+    constexpr int STR = S * 8 + 1;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < S; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lds[tid * STR + k * 8 + e] = v[k][e];
+    __syncthreads();
+    const int blockbase = (int)(((long)blockIdx.x * EW_THREADS) % cg);   // channel group of thread 0
+    for (int o = tid; o < nsum * C; o += EW_THREADS) {
+        const int k = o / C, c = o - k * C;
+        const int g = c >> 3, e = c & 7;
+        int first = g - blockbase;
+        if (first < 0) first += cg;
+        float sum = 0.f;
+        for (int t = first; t < EW_THREADS; t += cg) sum += lds[t * STR + k * 8 + e];
+        atomicAdd(dst + (size_t)k * C + c, sum);
+    }
+}
+
 // ---------------------------------------------------------------- forward BN finalize
-__global__ void rep_bn_finalize_kernel(const hc_rep_bn_desc d) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one WAVE per channel: the 64 lanes sum the statistic replicas in parallel, lane 0 finishes
+__global__ __launch_bounds__(256) void rep_bn_finalize_kernel(const hc_rep_bn_desc d) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= d.C) return;
     const float cnt = (float)d.count;
     float shift = 0.f;
@@ -55,20 +87,22 @@ __global__ void rep_bn_finalize_kernel(const hc_rep_bn_desc d) {
         if (d.gamma[b] != nullptr) {
             if (d.training) {
                 float s1 = 0.f, s2 = 0.f;
-                for (int r = 0; r < HC_STAT_REPLICAS; ++r) {
+                for (int r = lane; r < HC_STAT_REPLICAS; r += 64) {
                     s1 += d.stats[b][(2 * r) * d.C + c];
                     s2 += d.stats[b][(2 * r + 1) * d.C + c];
                 }
+                s1 = wave_sum(s1);
+                s2 = wave_sum(s2);
                 mean = s1 / cnt;
                 float var = s2 / cnt - mean * mean;
                 var = var > 0.f ? var : 0.f;
                 invstd = rsqrtf(var + d.eps);
-                if (d.running_mean[b] != nullptr) {
+                if (lane == 0 && d.running_mean[b] != nullptr) {
                     const float unb = d.count > 1 ? var * (cnt / (cnt - 1.f)) : var;
                     d.running_mean[b][c] = (1.f - d.momentum) * d.running_mean[b][c] + d.momentum * mean;
                     d.running_var[b][c] = (1.f - d.momentum) * d.running_var[b][c] + d.momentum * unb;
                 }
-                if (c == 0 && d.num_batches_tracked[b] != nullptr) d.num_batches_tracked[b][0] += 1;
+                if (lane == 0 && c == 0 && d.num_batches_tracked[b] != nullptr) d.num_batches_tracked[b][0] += 1;
             } else {
                 mean = d.running_mean[b][c];
                 invstd = rsqrtf(d.running_var[b][c] + d.eps);
@@ -76,13 +110,15 @@ __global__ void rep_bn_finalize_kernel(const hc_rep_bn_desc d) {
             a = d.gamma[b][c] * invstd;
             shift += d.beta[b][c] - a * mean;
         }
-        d.coef[b * d.C + c] = a;
-        if (d.save != nullptr) {
-            d.save[(2 * b) * d.C + c] = mean;
-            d.save[(2 * b + 1) * d.C + c] = invstd;
+        if (lane == 0) {
+            d.coef[b * d.C + c] = a;
+            if (d.save != nullptr) {
+                d.save[(2 * b) * d.C + c] = mean;
+                d.save[(2 * b + 1) * d.C + c] = invstd;
+            }
         }
     }
-    d.coef[3 * d.C + c] = shift;
+    if (lane == 0) d.coef[3 * d.C + c] = shift;
 }
 
 // ---------------------------------------------------------------- forward apply
@@ -101,13 +137,9 @@ __global__ __launch_bounds__(EW_THREADS) void rep_apply_kernel(const u32x4* __re
     load8f(coef + C + c0, a1);
     if (HAS_ID) load8f(coef + 2 * C + c0, a0);
     load8f(coef + 3 * C + c0, sh);
-    float s1[8], s2[8];
+    float sv[2][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
-    if (STATS) {
-        for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) sred[i] = 0.f;
-        __syncthreads();
-    }
+    for (int i = 0; i < 8; ++i) sv[0][i] = sv[1][i] = 0.f;
     for (long q = gtid; q < nchunks; q += stride) {
         float f3[8], f1[8], f0[8], o[8];
         unpack8(y3[q], f3);
@@ -126,19 +158,10 @@ __global__ __launch_bounds__(EW_THREADS) void rep_apply_kernel(const u32x4* __re
             float r[8];
             unpack8(pk, r);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { s1[i] += r[i]; s2[i] += r[i] * r[i]; }
+            for (int i = 0; i < 8; ++i) { sv[0][i] += r[i]; sv[1][i] += r[i] * r[i]; }
         }
     }
-    if (STATS) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            atomicAdd(&sred[c0 + i], s1[i]);
-            atomicAdd(&sred[C + c0 + i], s2[i]);
-        }
-        __syncthreads();
-        float* rep = out_stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * C;
-        for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) atomicAdd(rep + i, sred[i]);
-    }
+    if (STATS) block_reduce_flush<2>(sv, cg, C, out_stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * C, sred, 2);
 }
 
 // per-channel sum / sum of squares of an NHWC bf16 tensor (identity-branch BN statistics when the
@@ -150,25 +173,17 @@ __global__ __launch_bounds__(EW_THREADS) void channel_stats_kernel(const u32x4* 
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
     const long stride = (long)gridDim.x * EW_THREADS;
     const int c0 = (int)(gtid % cg) * 8;
-    float s1[8], s2[8];
+    float sv[2][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
-    for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) sred[i] = 0.f;
-    __syncthreads();
+    for (int i = 0; i < 8; ++i) sv[0][i] = sv[1][i] = 0.f;
     for (long q = gtid; q < nchunks; q += stride) {
         float f[8];
         unpack8(x[q], f);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
+        for (int i = 0; i < 8; ++i) { sv[0][i] += f[i]; sv[1][i] += f[i] * f[i]; }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        atomicAdd(&sred[c0 + i], s1[i]);
-        atomicAdd(&sred[C + c0 + i], s2[i]);
-    }
-    __syncthreads();
-    float* rep = stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += EW_THREADS) atomicAdd(rep + i, sred[i]);
+    (void)c0;
+    block_reduce_flush<2>(sv, cg, C, stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * C, sred, 2);
 }
 
 // ---------------------------------------------------------------- backward reduce
@@ -182,11 +197,11 @@ __global__ __launch_bounds__(EW_THREADS) void rep_bwd_reduce_kernel(const u32x4*
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
     const long stride = (long)gridDim.x * EW_THREADS;
     const int c0 = (int)(gtid % cg) * 8;
-    float sz[8], s3[8], s1[8], s0[8];
+    float sv[4][8];   // dz, dz*y3, dz*y1, dz*x
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sz[i] = s3[i] = s1[i] = s0[i] = 0.f;
-    for (int i = threadIdx.x; i < 4 * C; i += EW_THREADS) sred[i] = 0.f;
-    __syncthreads();
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sv[k][i] = 0.f;
     for (long q = gtid; q < nchunks; q += stride) {
         float fg[8], fo[8], f3[8], f1[8], f0[8];
         unpack8(g[q], fg);
@@ -197,35 +212,35 @@ __global__ __launch_bounds__(EW_THREADS) void rep_bwd_reduce_kernel(const u32x4*
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float dz = fo[i] > 0.f ? fg[i] : 0.f;
-            sz[i] += dz;
-            s3[i] += dz * f3[i];
-            s1[i] += dz * f1[i];
-            if (HAS_ID) s0[i] += dz * f0[i];
+            sv[0][i] += dz;
+            sv[1][i] += dz * f3[i];
+            sv[2][i] += dz * f1[i];
+            if (HAS_ID) sv[3][i] += dz * f0[i];
         }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        atomicAdd(&sred[c0 + i], sz[i]);
-        atomicAdd(&sred[C + c0 + i], s3[i]);
-        atomicAdd(&sred[2 * C + c0 + i], s1[i]);
-        if (HAS_ID) atomicAdd(&sred[3 * C + c0 + i], s0[i]);
-    }
-    __syncthreads();
-    const int lim = HAS_ID ? 4 * C : 3 * C;
-    for (int i = threadIdx.x; i < lim; i += EW_THREADS) atomicAdd(red + i, sred[i]);
+    (void)c0;
+    block_reduce_flush<4>(sv, cg, C, red + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 4 * C, sred, HAS_ID ? 4 : 3);
 }
 
-__global__ void rep_bn_bwd_finalize_kernel(const hc_rep_bn_bwd_desc d) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_bn_bwd_desc d) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= d.C) return;
     const float cnt = (float)d.count;
-    const float sdz = d.red[c];
+    float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = lane; r < HC_STAT_REPLICAS; r += 64)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rsum[k] += d.red[((size_t)r * 4 + k) * d.C + c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rsum[k] = wave_sum(rsum[k]);
+    if (lane != 0) return;
+    const float sdz = rsum[0];
     const int nb = d.has_identity ? 3 : 2;
     for (int b = 0; b < 3; ++b) {
         float A = 0.f, B = 0.f, Cc = 0.f;
         if (b < nb) {
             const float mean = d.save[(2 * b) * d.C + c], invstd = d.save[(2 * b + 1) * d.C + c];
-            const float sdzy = d.red[(b + 1) * d.C + c];
+            const float sdzy = rsum[b + 1];
             const float dgamma = invstd * (sdzy - mean * sdz);
             const float a = d.gamma[b][c] * invstd;
             A = a;
@@ -449,7 +464,7 @@ extern "C" {
 
 int hc_rep_bn_finalize(const hc_rep_bn_desc* d, hc_stream_t stream) {
     if (d == nullptr || d->coef == nullptr || d->C <= 0) return HC_ERR_ARG;
-    hipLaunchKernelGGL(rep_bn_finalize_kernel, dim3((d->C + 127) / 128), dim3(128), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(rep_bn_finalize_kernel, dim3((d->C + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d);
     return hc_launch_status();
 }
 
@@ -457,9 +472,9 @@ int hc_rep_apply(const void* y3, const void* y1, const void* x, const float* coe
                  int32_t C, int32_t act, hc_stream_t stream) {
     if (y3 == nullptr || y1 == nullptr || coef == nullptr || out == nullptr || (C % 8) != 0) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
-    const int blocks = ew_blocks(nchunks, C / 8);
+    const int blocks = ew_blocks(nchunks, C / 8, out_stats ? 16 : 8);
     hipStream_t st = (hipStream_t)stream;
-    const size_t sm = out_stats ? 2 * C * sizeof(float) : 0;
+    const size_t sm = out_stats ? EW_THREADS * 17 * sizeof(float) : 0;
 #define HC_LAUNCH_APPLY(ID, ST)                                                                                          \
     hipLaunchKernelGGL((rep_apply_kernel<ID, ST>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)y3,             \
                        (const u32x4*)y1, (const u32x4*)x, coef, (u32x4*)out, out_stats, nchunks, C, act)
@@ -475,8 +490,8 @@ int hc_rep_apply(const void* y3, const void* y1, const void* x, const float* coe
 int hc_channel_stats(const void* x, float* stats, int64_t npix, int32_t C, hc_stream_t stream) {
     if (x == nullptr || stats == nullptr || (C % 8) != 0) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
-    const int blocks = ew_blocks(nchunks, C / 8);
-    hipLaunchKernelGGL(channel_stats_kernel, dim3(blocks), dim3(EW_THREADS), 2 * C * sizeof(float), (hipStream_t)stream,
+    const int blocks = ew_blocks(nchunks, C / 8, 16);
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(blocks), dim3(EW_THREADS), EW_THREADS * 17 * sizeof(float), (hipStream_t)stream,
                        (const u32x4*)x, stats, nchunks, C);
     return hc_launch_status();
 }
@@ -485,9 +500,9 @@ int hc_rep_bwd_reduce(const void* g, const void* out, const void* y3, const void
                       int32_t C, hc_stream_t stream) {
     if (g == nullptr || out == nullptr || y3 == nullptr || y1 == nullptr || red == nullptr || (C % 8) != 0) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
-    const int blocks = ew_blocks(nchunks, C / 8);
+    const int blocks = ew_blocks(nchunks, C / 8, 16);
     hipStream_t st = (hipStream_t)stream;
-    const size_t sm = 4 * C * sizeof(float);
+    const size_t sm = EW_THREADS * 33 * sizeof(float);
     if (x != nullptr)
         hipLaunchKernelGGL((rep_bwd_reduce_kernel<true>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)g,
                            (const u32x4*)out, (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, red, nchunks, C);
@@ -499,7 +514,7 @@ int hc_rep_bwd_reduce(const void* g, const void* out, const void* y3, const void
 
 int hc_rep_bn_bwd_finalize(const hc_rep_bn_bwd_desc* d, hc_stream_t stream) {
     if (d == nullptr || d->red == nullptr || d->save == nullptr || d->bcoef == nullptr) return HC_ERR_ARG;
-    hipLaunchKernelGGL(rep_bn_bwd_finalize_kernel, dim3((d->C + 127) / 128), dim3(128), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(rep_bn_bwd_finalize_kernel, dim3((d->C + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d);
     return hc_launch_status();
 }
 

@@ -206,7 +206,7 @@ class RepBlockFn(torch.autograd.Function):
 
         out = cv.empty_cl(N, Cout, OH, OW, dev)
         out_stats = POOL.take((_lib.HC_STAT_REPLICAS, 2, Cout), dev) if (st.emit_stats and st.training) else None
-        ctx.red = POOL.take((4, Cout), dev) if st.training else None   # backward's reduction target, zeroed with the rest
+        ctx.red = POOL.take((_lib.HC_STAT_REPLICAS, 4, Cout), dev) if st.training else None   # backward's reduction target, zeroed with the rest
         check(lib.hc_rep_apply(ptr(y3), ptr(y1), ptr(src) if st.identity else None, ptr(coef), ptr(out), ptr(out_stats),
                                N * OH * OW, Cout, 1 if relu else 0, stream()), "hc_rep_apply")
         ctx.st, ctx.relu, ctx.stem = st, relu, stem
@@ -233,7 +233,7 @@ class RepBlockFn(torch.autograd.Function):
         red = ctx.red
         ctx.red = None
         if red is None:
-            red = torch.zeros((4, Cout), dtype=torch.float32, device=dev)
+            red = torch.zeros((_lib.HC_STAT_REPLICAS, 4, Cout), dtype=torch.float32, device=dev)
         check(lib.hc_rep_bwd_reduce(ptr(g), ptr(mask_src), ptr(y3), ptr(y1), ptr(xid), ptr(red), npix, Cout, stream()),
               "hc_rep_bwd_reduce")
         nb = 3 if st.identity else 2

@@ -21,7 +21,7 @@ extern "C" {
 typedef void* hc_stream_t; /* hipStream_t */
 
 #define HC_MAX_TAPS 12
-#define HC_STAT_REPLICAS 32
+#define HC_STAT_REPLICAS 128
 
 /* One "parity class" of a gather-conv: output sub-grid (i,j) -> output pixel
  * (i*ostep+oy0, j*ostep+ox0); tap t reads source pixel (i*istep+dy[t], j*istep+dx[t]) of
@@ -144,11 +144,11 @@ int hc_rep_apply(const void* y3, const void* y1, const void* x, const float* coe
 int hc_channel_stats(const void* x, float* stats, int64_t npix, int32_t C, hc_stream_t stream);
 
 /* Backward of the fused BN+sum+ReLU.  Pass 1: per-channel sums of dz = g*(out>0), dz*y3,
- * dz*y1, dz*x into red[4][C].  Pass 2 (after hc_rep_bn_bwd_finalize): dy3, dy1, dx_id. */
+ * dz*y1, dz*x into red[HC_STAT_REPLICAS][4][C] (replicas spread the atomics).  Pass 2 (after hc_rep_bn_bwd_finalize): dy3, dy1, dx_id. */
 int hc_rep_bwd_reduce(const void* g, const void* out, const void* y3, const void* y1, const void* x, float* red,
                       int64_t npix, int32_t C, hc_stream_t stream);
 typedef struct {
-    const float* red;          /* [4][C] */
+    const float* red;          /* [HC_STAT_REPLICAS][4][C] */
     const float* save;         /* [6][C] from forward */
     const float* gamma[3];
     float* dgamma[3];

@@ -39,7 +39,7 @@ for li in sel:
             wp = cv.pack_weight(w, 0)
             d = cv.fwd_desc(N, Cin, H, H, Cout, k, k, s, k // 2)
             out = cv.empty_cl(N, Cout, OH, OH, "cuda")
-            stats = torch.zeros(32, 2, Cout, device="cuda")
+            stats = torch.zeros(128, 2, Cout, device="cuda")
             us = timeit(lambda: cv.launch_conv(d, x, wp, out, stats=stats))
         elif which == "small":
             if k == 1 or s != 1 or Cin > 48:
@@ -48,7 +48,7 @@ for li in sel:
             wp3, wp1 = cv.pack_weight(w3, 0), cv.pack_weight(w1, 0)
             d = cv.conv_small_desc(N, H, H, Cin, Cout, 0)
             y3 = cv.empty_cl(N, Cout, OH, OH, "cuda"); y1 = cv.empty_cl(N, Cout, OH, OH, "cuda")
-            stats = torch.zeros(2, 32, 2, Cout, device="cuda")
+            stats = torch.zeros(2, 128, 2, Cout, device="cuda")
             flops = 2.0 * N * OH * OH * Cout * Cin * 10
             us = timeit(lambda: cv.launch_conv_small_fwd(d, x, wp3, wp1, y3, y1, stats[0], stats[1]))
             print(f"small-fwd(3x3+1x1) {Cin}->{Cout} @{H}: {us:9.1f} us {flops / us / 1e6:8.1f} TFLOP/s", flush=True)
