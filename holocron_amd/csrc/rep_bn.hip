@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_b
     const int nb = d.has_identity ? 3 : 2;
     for (int b = 0; b < 3; ++b) {
         float A = 0.f, B = 0.f, Cc = 0.f;
-        if (b < nb) {
+        if (b < nb && d.gamma[b] != nullptr) {
             const float mean = d.save[(2 * b) * d.C + c], invstd = d.save[(2 * b + 1) * d.C + c];
             const float sdzy = rsum[b + 1];
             const float dgamma = invstd * (sdzy - mean * sdz);
@@ -286,6 +286,115 @@ __global__ __launch_bounds__(EW_THREADS) void rep_bwd_apply_kernel(const u32x4* 
         dy3[q] = pack8(o3);
         dy1[q] = pack8(o1);
         if (HAS_ID) dxid[q] = pack8(o0);
+    }
+}
+
+// ---------------------------------------------------------------- generic conv -> BN -> activation (+ residual)
+// The building block of conv_sequence() (holocron/models/utils.py:61-84): y = conv(x) comes from the
+// gather-conv with the statistics epilogue, rep_bn_finalize (single branch) gives (a, shift);
+// out = act(a*y + shift) [+ res].  Backward recomputes z = a*y + shift instead of storing it.
+__device__ __forceinline__ float act_fwd(float v, int act, float slope) {
+    switch (act) {
+        case 1: return v > 0.f ? v : 0.f;
+        case 2: { const float t = fminf(fmaxf(v + 2.f, 0.f), 2.f); return 0.5f * v * t; }
+        case 3: return v > 0.f ? v : slope * v;
+        case 4: { const float sp = v > 20.f ? v : log1pf(__expf(v)); return v * tanhf(sp); }
+        case 5: return v / (1.f + __expf(-v));
+        case 6: return fminf(fmaxf(v, 0.f), 6.f);
+        default: return v;
+    }
+}
+__device__ __forceinline__ float act_bwd(float v, int act, float slope) {   // d act / d v
+    switch (act) {
+        case 1: return v > 0.f ? 1.f : 0.f;
+        case 2: { const float t = v + 2.f; float d = 0.5f * fminf(fmaxf(t, 0.f), 2.f); if (t >= 0.f && t <= 2.f) d += 0.5f * v; return d; }
+        case 3: return v > 0.f ? 1.f : slope;
+        case 4: { const float sp = v > 20.f ? v : log1pf(__expf(v)); const float t = tanhf(sp);
+                  const float sg = 1.f / (1.f + __expf(-v)); return t + v * (1.f - t * t) * sg; }
+        case 5: { const float sg = 1.f / (1.f + __expf(-v)); return sg * (1.f + v * (1.f - sg)); }
+        case 6: return (v > 0.f && v < 6.f) ? 1.f : 0.f;
+        default: return 1.f;
+    }
+}
+
+template <bool HAS_RES>
+__global__ __launch_bounds__(EW_THREADS) void bn_act_apply_kernel(const u32x4* __restrict__ y, const float* __restrict__ coef,
+                                                                  const u32x4* __restrict__ res, u32x4* __restrict__ out,
+                                                                  long nchunks, int C, int act, float slope) {
+    const int cg = C / 8;
+    const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
+    const long stride = (long)gridDim.x * EW_THREADS;
+    const int c0 = (int)(gtid % cg) * 8;
+    float a[8], sh[8];
+    load8f(coef + c0, a);
+    load8f(coef + 3 * C + c0, sh);
+    for (long q = gtid; q < nchunks; q += stride) {
+        float fy[8], fr[8], o[8];
+        unpack8(y[q], fy);
+        if (HAS_RES) unpack8(res[q], fr);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float z = act_fwd(a[i] * fy[i] + sh[i], act, slope);
+            if (HAS_RES) z += fr[i];
+            o[i] = z;
+        }
+        out[q] = pack8(o);
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ y,
+                                                                       const float* __restrict__ coef, float* __restrict__ red,
+                                                                       long nchunks, int C, int act, float slope) {
+    extern __shared__ float sred[];
+    const int cg = C / 8;
+    const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
+    const long stride = (long)gridDim.x * EW_THREADS;
+    const int c0 = (int)(gtid % cg) * 8;
+    float a[8], sh[8];
+    load8f(coef + c0, a);
+    load8f(coef + 3 * C + c0, sh);
+    float sv[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sv[0][i] = sv[1][i] = 0.f;
+    for (long q = gtid; q < nchunks; q += stride) {
+        float fg[8], fy[8];
+        unpack8(g[q], fg);
+        unpack8(y[q], fy);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float dz = fg[i] * act_bwd(a[i] * fy[i] + sh[i], act, slope);
+            sv[0][i] += dz;
+            sv[1][i] += dz * fy[i];
+        }
+    }
+    // same slab layout as the RepBlock reduce ([4][C] per replica): sum dz at k=0, sum dz*y at k=1
+    block_reduce_flush<2>(sv, cg, C, red + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 4 * C, sred, 2);
+}
+
+__global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_apply_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ y,
+                                                                      const float* __restrict__ coef, const float* __restrict__ bc,
+                                                                      u32x4* __restrict__ dy, long nchunks, int C, int act,
+                                                                      float slope) {
+    const int cg = C / 8;
+    const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
+    const long stride = (long)gridDim.x * EW_THREADS;
+    const int c0 = (int)(gtid % cg) * 8;
+    float a[8], sh[8], A[8], B[8], Cc[8];
+    load8f(coef + c0, a);
+    load8f(coef + 3 * C + c0, sh);
+    load8f(bc + c0, A);
+    load8f(bc + C + c0, B);
+    load8f(bc + 2 * C + c0, Cc);
+    for (long q = gtid; q < nchunks; q += stride) {
+        float fg[8], fy[8], o[8];
+        unpack8(g[q], fg);
+        unpack8(y[q], fy);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float dz = fg[i] * act_bwd(a[i] * fy[i] + sh[i], act, slope);
+            o[i] = A[i] * dz + B[i] * fy[i] + Cc[i];
+        }
+        dy[q] = pack8(o);
     }
 }
 
@@ -535,6 +644,39 @@ int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void*
         hipLaunchKernelGGL((rep_bwd_apply_kernel<false>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)g, (const u32x4*)out,
                            (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, bcoef, (u32x4*)dy3, (u32x4*)dy1, (u32x4*)dxid,
                            nchunks, C);
+    return hc_launch_status();
+}
+
+int hc_bn_act_apply(const void* y, const float* coef, const void* res, void* out, int64_t npix, int32_t C, int32_t act, float slope,
+                    hc_stream_t stream) {
+    if (y == nullptr || coef == nullptr || out == nullptr || (C % 8) != 0) return HC_ERR_ARG;
+    const long nchunks = (long)npix * (C / 8);
+    const int blocks = ew_blocks(nchunks, C / 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (res != nullptr)
+        hipLaunchKernelGGL((bn_act_apply_kernel<true>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)y, coef, (const u32x4*)res,
+                           (u32x4*)out, nchunks, C, act, slope);
+    else
+        hipLaunchKernelGGL((bn_act_apply_kernel<false>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)y, coef, (const u32x4*)res,
+                           (u32x4*)out, nchunks, C, act, slope);
+    return hc_launch_status();
+}
+int hc_bn_act_bwd_reduce(const void* g, const void* y, const float* coef, float* red, int64_t npix, int32_t C, int32_t act, float slope,
+                         hc_stream_t stream) {
+    if (g == nullptr || y == nullptr || coef == nullptr || red == nullptr || (C % 8) != 0) return HC_ERR_ARG;
+    const long nchunks = (long)npix * (C / 8);
+    const int blocks = ew_blocks(nchunks, C / 8, 16);
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(blocks), dim3(EW_THREADS), EW_THREADS * 17 * sizeof(float), (hipStream_t)stream,
+                       (const u32x4*)g, (const u32x4*)y, coef, red, nchunks, C, act, slope);
+    return hc_launch_status();
+}
+int hc_bn_act_bwd_apply(const void* g, const void* y, const float* coef, const float* bcoef, void* dy, int64_t npix, int32_t C,
+                        int32_t act, float slope, hc_stream_t stream) {
+    if (g == nullptr || y == nullptr || coef == nullptr || bcoef == nullptr || dy == nullptr || (C % 8) != 0) return HC_ERR_ARG;
+    const long nchunks = (long)npix * (C / 8);
+    const int blocks = ew_blocks(nchunks, C / 8);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u32x4*)g, (const u32x4*)y,
+                       coef, bcoef, (u32x4*)dy, nchunks, C, act, slope);
     return hc_launch_status();
 }
 

@@ -1,1 +1,2 @@
 from .repvgg import *  # noqa: F401,F403
+from .darknetv3 import *  # noqa: F401,F403

@@ -164,6 +164,20 @@ int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void*
                      const float* bcoef, void* dy3, void* dy1, void* dxid, int64_t npix, int32_t C,
                      hc_stream_t stream);
 
+/* ---- generic conv -> BatchNorm(train) -> activation [+ residual]  (conv_sequence, models/utils.py:61-84;
+ * DarkNet ResBlock, darknetv3.py:23-70) ----
+ * y = conv(x) comes from hc_conv_gather with the statistics epilogue; hc_rep_bn_finalize with only
+ * branch 0 set gives coef (a = coef[0][C], shift = coef[3][C]).  act codes as in hc_conv_desc; `slope`
+ * is the LeakyReLU negative slope.  Backward recomputes z = a*y + shift:
+ *   reduce: red[replica][0][C] += sum g*act'(z), red[replica][1][C] += sum g*act'(z)*y  (layout of hc_rep_bwd_reduce)
+ *   hc_rep_bn_bwd_finalize (has_identity = 0) -> bcoef rows 0..2 = A, B, C;  dy = A*g*act'(z) + B*y + C. */
+int hc_bn_act_apply(const void* y, const float* coef, const void* res, void* out, int64_t npix, int32_t C, int32_t act,
+                    float slope, hc_stream_t stream);
+int hc_bn_act_bwd_reduce(const void* g, const void* y, const float* coef, float* red, int64_t npix, int32_t C, int32_t act,
+                         float slope, hc_stream_t stream);
+int hc_bn_act_bwd_apply(const void* g, const void* y, const float* coef, const float* bcoef, void* dy, int64_t npix,
+                        int32_t C, int32_t act, float slope, hc_stream_t stream);
+
 /* Global average pool over H*W (holocron/nn/modules/downsample.py:70-74) on NHWC bf16. */
 int hc_gap_fwd(const void* x, float* y, int32_t N, int32_t HW, int32_t C, hc_stream_t stream);
 int hc_gap_bwd(const float* dy, void* dx, int32_t N, int32_t HW, int32_t C, hc_stream_t stream);

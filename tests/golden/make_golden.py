@@ -186,6 +186,49 @@ def gen_repvgg_small():
                              "eval_logits_rep": ev_rep})
 
 
+def gen_darknet():
+    """DarkNet ResBlock unit + two training steps of a small DarknetV3 (reference modules)."""
+    g = torch.Generator().manual_seed(17)
+    dk = ref.models.classification.darknetv3
+    cases = []
+    for (planes, hw) in [(32, 10), (64, 7)]:
+        torch.manual_seed(planes)
+        blk = dk.ResBlock(planes, planes // 2, torch.nn.LeakyReLU(0.1, inplace=True), torch.nn.BatchNorm2d)
+        ref.nn.init.init_module(blk, "leaky_relu")
+        _randomize_bn(blk, g)
+        for p in blk.parameters():
+            if p.dim() == 4:
+                p.data = bf16r(p.data)
+        sd0 = {k: v.clone() for k, v in blk.state_dict().items()}
+        x = bf16r(torch.randn((2, planes, hw, hw), generator=g)).requires_grad_(True)
+        blk.train()
+        out = blk(x)
+        r = bf16r(torch.randn(out.shape, generator=g))
+        params = list(blk.parameters())
+        grads = torch.autograd.grad((out * r).sum(), [x] + params)
+        cases.append({"planes": planes, "state": sd0, "x": x.detach(), "r": r, "out": out.detach(), "dx": grads[0],
+                      "dparams": dict(zip([n for n, _ in blk.named_parameters()], grads[1:])),
+                      "state_after": {k: v.clone() for k, v in blk.state_dict().items()}})
+    torch.manual_seed(33)
+    layout = [(32, 1), (64, 2)]
+    m = dk.DarknetV3(layout, num_classes=10, stem_channels=16)
+    _randomize_bn(m, g)
+    for p in m.parameters():
+        if p.dim() == 4:
+            p.data = bf16r(p.data)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    x = bf16r(torch.rand((4, 3, 32, 32), generator=g))
+    t = torch.randint(0, 10, (4,), generator=g)
+    m.train()
+    logits = m(x)
+    loss = torch.nn.functional.cross_entropy(logits, t)
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in m.named_parameters()}
+    save("darknet.pt", {"resblocks": cases, "layout": layout, "stem": 16, "state": sd0, "x": x, "target": t,
+                        "logits": logits.detach(), "loss": loss.detach(), "grads": grads,
+                        "state_after": {k: v.clone() for k, v in m.state_dict().items()}})
+
+
 def gen_nms():
     """torchvision.ops.nms is absent: these vectors come from the restated algorithm (oracle/tv_ops.py),
     plus the two situations the reference's own tests pin (tests/test_models_detection.py:158-163: disjoint
@@ -213,4 +256,5 @@ if __name__ == "__main__":
     gen_optim()
     gen_repblock()
     gen_repvgg_small()
+    gen_darknet()
     gen_nms()

@@ -161,3 +161,27 @@ def test_bf16_emulation_stays_close_to_fp32_oracle(golden):
         for k, v in c["state_after"].items():
             if "running" in k:
                 assert torch.allclose(sd["blk." + k], v, rtol=1e-4, atol=1e-5)
+
+
+def test_darknet_oracle_matches_reference(golden):
+    from oracle import darknet as od
+    g = golden("darknet.pt")
+    for c in g["resblocks"]:
+        sd = {"b." + k: v.clone() for k, v in c["state"].items()}
+        keys = [k for k in orv.trainable_keys(sd)]
+        for k in keys:
+            sd[k].requires_grad_(True)
+        x = c["x"].clone().requires_grad_(True)
+        out = od.res_block(x, sd, "b", True)
+        assert torch.equal(out, c["out"])
+        grads = torch.autograd.grad((out * c["r"]).sum(), [x] + [sd[k] for k in keys])
+        assert torch.allclose(grads[0], c["dx"], rtol=1e-4, atol=1e-5)
+        for k, gr in zip(keys, grads[1:]):
+            assert torch.allclose(gr, c["dparams"][k[2:]], rtol=1e-4, atol=1e-4), k
+        eb = od.res_block(c["x"], {"b." + k: v.clone() for k, v in c["state"].items()}, "b", True, emulate_bf16=True)
+        assert (eb - c["out"]).norm() / c["out"].norm() < 6e-3
+    sd = {k: v.clone() for k, v in g["state"].items()}
+    logits = od.forward(sd, g["x"], g["layout"], training=True)
+    assert torch.allclose(logits, g["logits"], rtol=1e-4, atol=1e-5)
+    for k, v in g["state_after"].items():
+        assert torch.allclose(sd[k].float(), v.float(), rtol=1e-4, atol=1e-5), k
