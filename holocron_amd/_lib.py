@@ -103,9 +103,14 @@ SIGNATURES = {
     "hc_rep_bwd_reduce": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_void_p]),
     "hc_rep_bn_bwd_finalize": (c_int32, [C.POINTER(RepBnBwdDesc), c_void_p]),
     "hc_rep_bwd_apply": (c_int32, [c_void_p] * 9 + [c_int64, c_int32, c_void_p]),
-    "hc_bn_act_apply": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_int32, c_float, c_void_p]),
-    "hc_bn_act_bwd_reduce": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_int32, c_float, c_void_p]),
-    "hc_bn_act_bwd_apply": (c_int32, [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "hc_bn_act_apply": (c_int32, [c_void_p] * 6 + [c_int32, c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "hc_bn_act_bwd_reduce": (c_int32, [c_void_p, c_int32] + [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "hc_bn_act_bwd_apply": (c_int32, [c_void_p, c_int32] + [c_void_p] * 6 + [c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "hc_nhwc_copy": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int64, c_int32, c_void_p]),
+    "hc_upsample2x_fwd": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32] + [c_int32] * 4 + [c_void_p]),
+    "hc_upsample2x_bwd": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32] + [c_int32] * 4 + [c_void_p]),
+    "hc_spp_fwd": (c_int32, [c_void_p] * 3 + [c_int32] * 4 + [c_void_p]),
+    "hc_spp_bwd": (c_int32, [c_void_p] * 3 + [c_int32] * 4 + [c_void_p]),
     "hc_gap_fwd": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "hc_gap_bwd": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "hc_adabelief_step": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
@@ -118,6 +123,21 @@ SIGNATURES = {
     "hc_focal_loss_fwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int64, c_int32, c_float, c_void_p]),
     "hc_focal_loss_bwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int64, c_float, c_void_p]),
     "hc_ce_fwd_bwd": (c_int32, [c_void_p] * 4 + [c_int32, c_int32, c_float, c_void_p]),
+    "hc_poly_loss_hard_fwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int64, c_int32, c_float, c_void_p]),
+    "hc_poly_loss_hard_bwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int64, c_float, c_void_p]),
+    "hc_poly_loss_soft_fwd": (c_int32, [c_void_p] * 4 + [c_int32, c_int32, c_int64, c_int32, c_float, c_void_p]),
+    "hc_poly_loss_soft_bwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int64, c_int32, c_float, c_void_p]),
+    "hc_dice_sums": (c_int32, [c_void_p] * 3 + [c_int32, c_int32, c_int64, c_void_p]),
+    "hc_dice_bwd": (c_int32, [c_void_p] * 3 + [c_int32, c_int32, c_int64, c_void_p]),
+    "hc_dropblock_mask": (c_int32, [c_void_p] * 3 + [c_int32] * 4 + [c_float, c_void_p]),
+    "hc_dropblock_apply": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_int64, c_int32, c_int32, c_void_p]),
+    "hc_yolo_decode": (c_int32, [c_void_p, c_int32, c_int64, c_int64, c_int64] + [c_int32] * 5 + [c_void_p, c_float]
+                       + [c_void_p] * 4 + [c_int32, c_void_p]),
+    "hc_yolo_assign": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p] + [c_int32] * 4 + [c_void_p] * 3),
+    "hc_yolo_loss_fwd": (c_int32, [c_void_p, c_int32, c_int64, c_int64, c_int64] + [c_int32] * 5 + [c_void_p, c_float]
+                         + [c_void_p] * 7),
+    "hc_yolo_loss_bwd": (c_int32, [c_void_p, c_int32, c_int64, c_int64, c_int64] + [c_int32] * 5 + [c_void_p, c_float]
+                         + [c_void_p] * 8),
     "hc_version": (C.c_char_p, []),
 }
 

@@ -22,8 +22,11 @@ SOURCES = {
     "conv_wgrad_tr.hip": [],
     "rep_bn.hip": [],
     "optim.hip": [],
+    "nhwc_ops.hip": [],
     # separate torch kernels in the reference round after every op: no fused multiply-add here
     "pointwise.hip": ["-ffp-contract=off"],
+    "losses.hip": ["-ffp-contract=off"],
+    "yolo.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

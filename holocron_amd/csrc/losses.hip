@@ -1,0 +1,291 @@
+// Poly-1 loss, Dice loss partial sums and DropBlock (reference: holocron/nn/functional.py:465-613).
+// All three are HBM/latency-bound pointwise or small-reduction work on fp32 NCHW-style [N][K][S] tensors.
+#include "common.h"
+#include "../../include/holocron_hip.h"
+
+namespace {
+
+inline int grid_for(long total, int threads = 256, int cap = 8192) {
+    long b = (total + threads - 1) / threads;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------- poly-1 loss (functional.py:540-613)
+// hard labels: one thread per (n, s) position; loss = -logpt + eps (1 - exp(logpt)), times weight[target]
+__global__ void poly_hard_fwd_kernel(const float* __restrict__ x, const long* __restrict__ target, const float* __restrict__ weight,
+                                     float* __restrict__ loss_el, uint8_t* __restrict__ valid, int N, int K, long S,
+                                     int ignore_index, float eps) {
+    const long total = (long)N * S;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long n = t / S, s = t % S;
+        const float* px = x + n * K * S + s;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, px[(long)k * S]);
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += expf(px[(long)k * S] - mx);
+        const long tg = target[t];
+        const float logpt = (px[tg * S] - mx) - logf(se);
+        float l = -1.f * logpt + eps * (1.f - expf(logpt));
+        if (weight != nullptr) l = weight[tg] * l;
+        loss_el[t] = l;
+        valid[t] = !(ignore_index >= 0 && ignore_index < K && tg == ignore_index);
+    }
+}
+__global__ void poly_hard_bwd_kernel(const float* __restrict__ x, const long* __restrict__ target, const float* __restrict__ weight,
+                                     const float* __restrict__ dloss, float* __restrict__ dx, int N, int K, long S, float eps) {
+    const long total = (long)N * S;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long n = t / S, s = t % S;
+        const float* px = x + n * K * S + s;
+        float* pdx = dx + n * K * S + s;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, px[(long)k * S]);
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += expf(px[(long)k * S] - mx);
+        const long tg = target[t];
+        const float lse = logf(se);
+        const float pt = expf((px[tg * S] - mx) - lse);
+        const float w = weight != nullptr ? weight[tg] : 1.f;
+        const float gup = dloss[t] * w * (-1.f - eps * pt);  // dL/dlogpt
+        for (int k = 0; k < K; ++k) {
+            const float pk = expf((px[(long)k * S] - mx) - lse);
+            pdx[(long)k * S] = gup * ((k == tg ? 1.f : 0.f) - pk);
+        }
+    }
+}
+// soft labels: l_k = logp_k * t_k ; per-position output = sum over kept classes of w_k (-l_k + eps (1 - exp l_k))
+__global__ void poly_soft_fwd_kernel(const float* __restrict__ x, const float* __restrict__ target, const float* __restrict__ weight,
+                                     float* __restrict__ loss_pos, int N, int K, long S, int ignore_index, float eps) {
+    const long total = (long)N * S;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long n = t / S, s = t % S;
+        const float* px = x + n * K * S + s;
+        const float* pt = target + n * K * S + s;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, px[(long)k * S]);
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += expf(px[(long)k * S] - mx);
+        const float lse = logf(se);
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) {
+            if (k == ignore_index) continue;  // only reachable for 0 <= ignore_index < K
+            const float l = ((px[(long)k * S] - mx) - lse) * pt[(long)k * S];
+            float v = -1.f * l + eps * (1.f - expf(l));
+            if (weight != nullptr) v = weight[k] * v;
+            acc += v;
+        }
+        loss_pos[t] = acc;
+    }
+}
+__global__ void poly_soft_bwd_kernel(const float* __restrict__ x, const float* __restrict__ target, const float* __restrict__ weight,
+                                     const float* __restrict__ dloss, float* __restrict__ dx, int N, int K, long S,
+                                     int ignore_index, float eps) {
+    const long total = (long)N * S;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long n = t / S, s = t % S;
+        const float* px = x + n * K * S + s;
+        const float* pt = target + n * K * S + s;
+        float* pdx = dx + n * K * S + s;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, px[(long)k * S]);
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += expf(px[(long)k * S] - mx);
+        const float lse = logf(se);
+        const float gup = dloss[t];
+        // g_k = dL/dlogp_k ; dx_j = g_j - p_j * sum_k g_k
+        float gsum = 0.f;
+        for (int k = 0; k < K; ++k) {
+            if (k == ignore_index) continue;
+            const float tk = pt[(long)k * S];
+            const float l = ((px[(long)k * S] - mx) - lse) * tk;
+            const float w = weight != nullptr ? weight[k] : 1.f;
+            gsum += gup * w * (-1.f - eps * expf(l)) * tk;
+        }
+        for (int k = 0; k < K; ++k) {
+            const float logp = (px[(long)k * S] - mx) - lse;
+            float g = 0.f;
+            if (k != ignore_index) {
+                const float tk = pt[(long)k * S];
+                const float w = weight != nullptr ? weight[k] : 1.f;
+                g = gup * w * (-1.f - eps * expf(logp * tk)) * tk;
+            }
+            pdx[(long)k * S] = g - expf(logp) * gsum;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- dice partial sums (functional.py:503-537)
+// sums[0][k] = sum x*t ; sums[1][k] = sum x ; sums[2][k] = sum t over (n, s).  grid (blocks, K)
+__global__ __launch_bounds__(256) void dice_sums_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                        float* __restrict__ sums, int N, int K, long S) {
+    const int k = blockIdx.y;
+    const long total = (long)N * S;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / S, s = i % S;
+        const long off = (n * K + k) * S + s;
+        const float xv = x[off], tv = t[off];
+        a += xv * tv;
+        b += xv;
+        c += tv;
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    __shared__ float sh[3][4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = a; sh[1][w] = b; sh[2][w] = c; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float v = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+        atomicAdd(&sums[threadIdx.x * K + k], v);
+    }
+}
+// dx = d(sum x*t)_k * t + d(sum x)_k
+__global__ void dice_bwd_kernel(const float* __restrict__ t, const float* __restrict__ dsums, float* __restrict__ dx, int N, int K,
+                                long S) {
+    const long total = (long)N * K * S;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)((i / S) % K);
+        dx[i] = dsums[k] * t[i] + dsums[K + k];
+    }
+}
+
+// ---------------------------------------------------------------- DropBlock (functional.py:465-500)
+// keep[n,h,w] = 1 - max over the bs x bs window (stride 1, pad bs/2) of (noise <= gamma); count += sum keep
+__global__ __launch_bounds__(256) void dropblock_mask_kernel(const float* __restrict__ noise, float* __restrict__ keep,
+                                                             float* __restrict__ count, int N, int H, int W, int bs, float gamma) {
+    const long total = (long)N * H * W;
+    const int r = bs / 2;
+    float local = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W), h = (int)((i / W) % H);
+        const long n = i / ((long)W * H);
+        const float* pn = noise + n * H * W;
+        bool drop = false;
+        for (int dy = -r; dy <= r; ++dy) {
+            const int yy = h + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -r; dx <= r; ++dx) {
+                const int xx = w + dx;
+                if (xx < 0 || xx >= W) continue;
+                drop |= pn[yy * W + xx] <= gamma;
+            }
+        }
+        const float kv = drop ? 0.f : 1.f;
+        keep[i] = kv;
+        local += kv;
+    }
+    local = wave_sum(local);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(count, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+// y = x * keep[n,h,w] * (count > 0 ? numel / count : 1).  layout 0: [N][C][HW] (NCHW), 1: [N][HW][C] (NHWC)
+template <bool BF16>
+__global__ void dropblock_apply_kernel(const void* __restrict__ xv, const float* __restrict__ keep, const float* __restrict__ count,
+                                       void* __restrict__ yv, long N, int Cc, long HW, int nhwc) {
+    const long total = N * Cc * HW;
+    const float cnt = count[0];
+    const float scale = cnt > 0.f ? (float)(N * HW) / cnt : 1.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long pos;
+        if (nhwc) pos = i / Cc;
+        else pos = (i / (HW * Cc)) * HW + (i % HW);
+        const float m = keep[pos];
+        // x *= mask ; x *= numel / one_count (two roundings, like the reference's two in-place multiplies)
+        if (BF16) {
+            float v = bf16_to_f32(((const bf16_t*)xv)[i]) * m;
+            v = bf16_to_f32(f32_to_bf16(v));
+            ((bf16_t*)yv)[i] = f32_to_bf16(v * scale);
+        } else {
+            ((float*)yv)[i] = (((const float*)xv)[i] * m) * scale;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hc_poly_loss_hard_fwd(const float* x, const int64_t* target, const float* weight, float* loss_el, uint8_t* valid, int32_t N,
+                          int32_t K, int64_t S, int32_t ignore_index, float eps, hc_stream_t stream) {
+    if (x == nullptr || target == nullptr || loss_el == nullptr || valid == nullptr || K <= 0) return HC_ERR_ARG;
+    if ((long)N * S == 0) return HC_OK;
+    hipLaunchKernelGGL(poly_hard_fwd_kernel, dim3(grid_for((long)N * S)), dim3(256), 0, (hipStream_t)stream, x,
+                       (const long*)target, weight, loss_el, valid, N, K, (long)S, ignore_index, eps);
+    return hc_launch_status();
+}
+int hc_poly_loss_hard_bwd(const float* x, const int64_t* target, const float* weight, const float* dloss_el, float* dx, int32_t N,
+                          int32_t K, int64_t S, float eps, hc_stream_t stream) {
+    if (x == nullptr || target == nullptr || dloss_el == nullptr || dx == nullptr || K <= 0) return HC_ERR_ARG;
+    if ((long)N * S == 0) return HC_OK;
+    hipLaunchKernelGGL(poly_hard_bwd_kernel, dim3(grid_for((long)N * S)), dim3(256), 0, (hipStream_t)stream, x,
+                       (const long*)target, weight, dloss_el, dx, N, K, (long)S, eps);
+    return hc_launch_status();
+}
+int hc_poly_loss_soft_fwd(const float* x, const float* target, const float* weight, float* loss_pos, int32_t N, int32_t K,
+                          int64_t S, int32_t ignore_index, float eps, hc_stream_t stream) {
+    if (x == nullptr || target == nullptr || loss_pos == nullptr || K <= 0) return HC_ERR_ARG;
+    if ((long)N * S == 0) return HC_OK;
+    const int ign = (ignore_index >= 0 && ignore_index < K) ? ignore_index : -1;
+    hipLaunchKernelGGL(poly_soft_fwd_kernel, dim3(grid_for((long)N * S)), dim3(256), 0, (hipStream_t)stream, x, target, weight,
+                       loss_pos, N, K, (long)S, ign, eps);
+    return hc_launch_status();
+}
+int hc_poly_loss_soft_bwd(const float* x, const float* target, const float* weight, const float* dloss_pos, float* dx, int32_t N,
+                          int32_t K, int64_t S, int32_t ignore_index, float eps, hc_stream_t stream) {
+    if (x == nullptr || target == nullptr || dloss_pos == nullptr || dx == nullptr || K <= 0) return HC_ERR_ARG;
+    if ((long)N * S == 0) return HC_OK;
+    const int ign = (ignore_index >= 0 && ignore_index < K) ? ignore_index : -1;
+    hipLaunchKernelGGL(poly_soft_bwd_kernel, dim3(grid_for((long)N * S)), dim3(256), 0, (hipStream_t)stream, x, target, weight,
+                       dloss_pos, dx, N, K, (long)S, ign, eps);
+    return hc_launch_status();
+}
+
+int hc_dice_sums(const float* x, const float* target, float* sums, int32_t N, int32_t K, int64_t S, hc_stream_t stream) {
+    if (x == nullptr || target == nullptr || sums == nullptr || K <= 0 || N < 0 || S < 0) return HC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, sizeof(float) * 3 * K, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if ((long)N * S == 0) return HC_OK;
+    int bx = grid_for((long)N * S, 256, 1024);
+    if ((long)bx * K > 16384) bx = (int)(16384 / K > 0 ? 16384 / K : 1);
+    hipLaunchKernelGGL(dice_sums_kernel, dim3(bx, K), dim3(256), 0, st, x, target, sums, N, K, (long)S);
+    return hc_launch_status();
+}
+int hc_dice_bwd(const float* target, const float* dsums, float* dx, int32_t N, int32_t K, int64_t S, hc_stream_t stream) {
+    if (target == nullptr || dsums == nullptr || dx == nullptr || K <= 0) return HC_ERR_ARG;
+    if ((long)N * S == 0) return HC_OK;
+    hipLaunchKernelGGL(dice_bwd_kernel, dim3(grid_for((long)N * K * S)), dim3(256), 0, (hipStream_t)stream, target, dsums, dx, N, K,
+                       (long)S);
+    return hc_launch_status();
+}
+
+int hc_dropblock_mask(const float* noise, float* keep, float* count, int32_t N, int32_t H, int32_t W, int32_t block_size,
+                      float gamma, hc_stream_t stream) {
+    if (noise == nullptr || keep == nullptr || count == nullptr || block_size < 1 || (block_size & 1) == 0) return HC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(count, 0, sizeof(float), st) != hipSuccess) return HC_ERR_LAUNCH;
+    if ((long)N * H * W == 0) return HC_OK;
+    hipLaunchKernelGGL(dropblock_mask_kernel, dim3(grid_for((long)N * H * W, 256, 2048)), dim3(256), 0, st, noise, keep, count, N,
+                       H, W, block_size, gamma);
+    return hc_launch_status();
+}
+int hc_dropblock_apply(const void* x, const float* keep, const float* count, void* y, int64_t N, int32_t C, int64_t HW,
+                       int32_t dtype, int32_t nhwc, hc_stream_t stream) {
+    if (x == nullptr || keep == nullptr || count == nullptr || y == nullptr || (dtype != 0 && dtype != 1)) return HC_ERR_ARG;
+    const long total = (long)N * C * HW;
+    if (total == 0) return HC_OK;
+    if (dtype == 0)
+        hipLaunchKernelGGL(dropblock_apply_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, keep, count, y,
+                           (long)N, C, (long)HW, nhwc);
+    else
+        hipLaunchKernelGGL(dropblock_apply_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, keep, count, y,
+                           (long)N, C, (long)HW, nhwc);
+    return hc_launch_status();
+}
+
+}  // extern "C"

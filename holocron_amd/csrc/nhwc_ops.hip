@@ -1,0 +1,226 @@
+// Data-movement passes of the CSP / PAN / SPP stacks on NHWC bf16 activations (reference:
+// holocron/models/classification/darknetv4.py:112-115 chunk+cat, holocron/models/detection/yolov4.py:134-139
+// upsample+cat, holocron/nn/modules/downsample.py:154-167 SPP).  All are pure HBM traffic: a thread moves
+// 16-byte chunks (8 channels); source and destination carry their own channels-per-pixel ("ld") and
+// channel offset so that a concat is written in place by its producers instead of by an extra pass.
+#include "common.h"
+#include "../../include/holocron_hip.h"
+
+namespace {
+
+inline int grid_for(long total, int threads = 256, int cap = 16384) {
+    long b = (total + threads - 1) / threads;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf16lo(v[i]); f[2 * i + 1] = bf16hi(v[i]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// dst[p][dc0 + c] = src[p][sc0 + c], c < C ; everything in units of 8 channels
+__global__ void nhwc_copy_kernel(const u32x4* __restrict__ src, int sld8, int sc8, u32x4* __restrict__ dst, int dld8, int dc8,
+                                 long npix, int c8) {
+    const long total = npix * c8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / c8;
+        const int c = (int)(i - p * c8);
+        dst[p * dld8 + dc8 + c] = src[p * sld8 + sc8 + c];
+    }
+}
+
+// nearest x2: dst[n][2h+a][2w+b] = src[n][h][w]
+__global__ void upsample2x_fwd_kernel(const u32x4* __restrict__ src, int sld8, int sc8, u32x4* __restrict__ dst, int dld8, int dc8,
+                                      int N, int H, int W, int c8) {
+    const long total = (long)N * 2 * H * 2 * W * c8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / c8;
+        const int c = (int)(i - p * c8);
+        const int ow = (int)(p % (2 * W));
+        const int oh = (int)((p / (2 * W)) % (2 * H));
+        const long n = p / ((long)4 * W * H);
+        const long sp = (n * H + (oh >> 1)) * W + (ow >> 1);
+        dst[p * dld8 + dc8 + c] = src[sp * sld8 + sc8 + c];
+    }
+}
+// dsrc[n][h][w] = sum of the four dst gradients (fp32 accumulation, one bf16 rounding)
+__global__ void upsample2x_bwd_kernel(const u32x4* __restrict__ g, int gld8, int gc8, u32x4* __restrict__ dx, int xld8, int xc8,
+                                      int N, int H, int W, int c8) {
+    const long total = (long)N * H * W * c8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / c8;
+        const int c = (int)(i - p * c8);
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        const long n = p / ((long)W * H);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const long gp = (n * 2 * H + 2 * h + a) * (2 * W) + 2 * w + b;
+                float f[8];
+                unpack8(g[gp * gld8 + gc8 + c], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += f[e];
+            }
+        dx[p * xld8 + xc8 + c] = pack8(acc);
+    }
+}
+
+// SPP with windows 5/9/13 (stride 1, pad k/2, -inf padding): out[p] = [x | max5 | max9 | max13] and the argmax of
+// each window as a byte (dy+6)*13 + (dx+6).  Ties keep the FIRST maximum in row-major window order, the rule of
+// torch's max_pool2d, so that the gradient lands on the same element.
+__global__ __launch_bounds__(256) void spp_fwd_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out, u32x2* __restrict__ idx,
+                                                      int N, int H, int W, int c8) {
+    const long total = (long)N * H * W * c8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / c8;
+        const int c = (int)(i - p * c8);
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        const long n = p / ((long)W * H);
+        float m[3][8];
+        unsigned int am[3][8];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { m[k][e] = -INFINITY; am[k][e] = 6 * 13 + 6; }
+        for (int dy = -6; dy <= 6; ++dy) {
+            const int yy = h + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -6; dx <= 6; ++dx) {
+                const int xx = w + dx;
+                if (xx < 0 || xx >= W) continue;
+                float f[8];
+                unpack8(x[((n * H + yy) * W + xx) * c8 + c], f);
+                const unsigned int code = (unsigned int)((dy + 6) * 13 + (dx + 6));
+                const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
+                const int r = ady > adx ? ady : adx;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (f[e] > m[2][e]) { m[2][e] = f[e]; am[2][e] = code; }
+                    if (r <= 4 && f[e] > m[1][e]) { m[1][e] = f[e]; am[1][e] = code; }
+                    if (r <= 2 && f[e] > m[0][e]) { m[0][e] = f[e]; am[0][e] = code; }
+                }
+            }
+        }
+        const long ob = p * 4 * c8 + c;
+        out[ob] = x[p * c8 + c];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            out[ob + (k + 1) * c8] = pack8(m[k]);
+            u32x2 pk;
+            pk[0] = am[k][0] | (am[k][1] << 8) | (am[k][2] << 16) | (am[k][3] << 24);
+            pk[1] = am[k][4] | (am[k][5] << 8) | (am[k][6] << 16) | (am[k][7] << 24);
+            idx[((long)k * N * H * W + p) * c8 + c] = pk;
+        }
+    }
+}
+// dx[p] = g[p][x part] + sum over the windows containing p of g[q][pool k] where argmax_k(q) == p
+__global__ __launch_bounds__(256) void spp_bwd_kernel(const u32x4* __restrict__ g, const u32x2* __restrict__ idx, u32x4* __restrict__ dx,
+                                                      int N, int H, int W, int c8) {
+    const long total = (long)N * H * W * c8;
+    const long npix = (long)N * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / c8;
+        const int c = (int)(i - p * c8);
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        const long n = p / ((long)W * H);
+        float acc[8];
+        unpack8(g[p * 4 * c8 + c], acc);
+        for (int dy = -6; dy <= 6; ++dy) {
+            const int qy = h + dy;   // output position q whose window may contain p
+            if (qy < 0 || qy >= H) continue;
+            for (int dx_ = -6; dx_ <= 6; ++dx_) {
+                const int qx = w + dx_;
+                if (qx < 0 || qx >= W) continue;
+                const long q = (n * H + qy) * W + qx;
+                // p seen from q has offset (-dy, -dx_)
+                const unsigned int code = (unsigned int)((6 - dy) * 13 + (6 - dx_));
+                const int ady = dy < 0 ? -dy : dy, adx = dx_ < 0 ? -dx_ : dx_;
+                const int r = ady > adx ? ady : adx;
+                const int k0 = r <= 2 ? 0 : (r <= 4 ? 1 : 2);
+                for (int k = k0; k < 3; ++k) {
+                    const u32x2 pk = idx[((long)k * npix + q) * c8 + c];
+                    bool any = false;
+                    bool hit[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        hit[e] = ((pk[e >> 2] >> (8 * (e & 3))) & 0xffu) == code;
+                        any |= hit[e];
+                    }
+                    if (!any) continue;
+                    float f[8];
+                    unpack8(g[q * 4 * c8 + (k + 1) * c8 + c], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += hit[e] ? f[e] : 0.f;
+                }
+            }
+        }
+        dx[p * c8 + c] = pack8(acc);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hc_nhwc_copy(const void* src, int32_t src_ld, int32_t src_c0, void* dst, int32_t dst_ld, int32_t dst_c0, int64_t npix, int32_t C,
+                 hc_stream_t stream) {
+    if (src == nullptr || dst == nullptr || npix < 0) return HC_ERR_ARG;
+    if ((src_ld | src_c0 | dst_ld | dst_c0 | C) & 7) return HC_ERR_ARG;
+    if (C <= 0 || src_c0 + C > src_ld || dst_c0 + C > dst_ld) return HC_ERR_ARG;
+    if (npix == 0) return HC_OK;
+    hipLaunchKernelGGL(nhwc_copy_kernel, dim3(grid_for(npix * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src,
+                       src_ld / 8, src_c0 / 8, (u32x4*)dst, dst_ld / 8, dst_c0 / 8, (long)npix, C / 8);
+    return hc_launch_status();
+}
+
+int hc_upsample2x_fwd(const void* src, int32_t src_ld, int32_t src_c0, void* dst, int32_t dst_ld, int32_t dst_c0, int32_t N, int32_t H,
+                      int32_t W, int32_t C, hc_stream_t stream) {
+    if (src == nullptr || dst == nullptr) return HC_ERR_ARG;
+    if ((src_ld | src_c0 | dst_ld | dst_c0 | C) & 7) return HC_ERR_ARG;
+    if (C <= 0 || src_c0 + C > src_ld || dst_c0 + C > dst_ld) return HC_ERR_ARG;
+    if ((long)N * H * W == 0) return HC_OK;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for((long)N * 4 * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const u32x4*)src, src_ld / 8, src_c0 / 8, (u32x4*)dst, dst_ld / 8, dst_c0 / 8, N, H, W, C / 8);
+    return hc_launch_status();
+}
+int hc_upsample2x_bwd(const void* g, int32_t g_ld, int32_t g_c0, void* dx, int32_t dx_ld, int32_t dx_c0, int32_t N, int32_t H, int32_t W,
+                      int32_t C, hc_stream_t stream) {
+    if (g == nullptr || dx == nullptr) return HC_ERR_ARG;
+    if ((g_ld | g_c0 | dx_ld | dx_c0 | C) & 7) return HC_ERR_ARG;
+    if (C <= 0 || g_c0 + C > g_ld || dx_c0 + C > dx_ld) return HC_ERR_ARG;
+    if ((long)N * H * W == 0) return HC_OK;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const u32x4*)g, g_ld / 8, g_c0 / 8, (u32x4*)dx, dx_ld / 8, dx_c0 / 8, N, H, W, C / 8);
+    return hc_launch_status();
+}
+
+int hc_spp_fwd(const void* x, void* out, void* idx, int32_t N, int32_t H, int32_t W, int32_t C, hc_stream_t stream) {
+    if (x == nullptr || out == nullptr || idx == nullptr || C <= 0 || (C & 7)) return HC_ERR_ARG;
+    if ((long)N * H * W == 0) return HC_OK;
+    hipLaunchKernelGGL(spp_fwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const u32x4*)x, (u32x4*)out, (u32x2*)idx, N, H, W, C / 8);
+    return hc_launch_status();
+}
+int hc_spp_bwd(const void* g, const void* idx, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, hc_stream_t stream) {
+    if (g == nullptr || dx == nullptr || idx == nullptr || C <= 0 || (C & 7)) return HC_ERR_ARG;
+    if ((long)N * H * W == 0) return HC_OK;
+    hipLaunchKernelGGL(spp_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const u32x4*)g, (const u32x2*)idx, (u32x4*)dx, N, H, W, C / 8);
+    return hc_launch_status();
+}
+
+}  // extern "C"

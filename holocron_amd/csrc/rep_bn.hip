@@ -317,52 +317,74 @@ __device__ __forceinline__ float act_bwd(float v, int act, float slope) {   // d
     }
 }
 
+// DropBlock after the activation (conv_sequence order conv -> BN -> act -> DropBlock, models/utils.py:75-84) rides
+// in the same pass: keep [npix] fp32 0/1 and count[1] = sum(keep) come from hc_dropblock_mask.
+__device__ __forceinline__ float drop_scale(const float* __restrict__ count, long npix) {
+    const float cnt = count[0];
+    return cnt > 0.f ? (float)npix / cnt : 1.f;
+}
+
+// The output (apply) and the incoming gradient (backward) may live inside a wider concat buffer: `ld8` is their
+// channels-per-pixel / 8 (the pointer already includes the channel offset).
 template <bool HAS_RES>
 __global__ __launch_bounds__(EW_THREADS) void bn_act_apply_kernel(const u32x4* __restrict__ y, const float* __restrict__ coef,
-                                                                  const u32x4* __restrict__ res, u32x4* __restrict__ out,
-                                                                  long nchunks, int C, int act, float slope) {
+                                                                  const u32x4* __restrict__ res, const float* __restrict__ keep,
+                                                                  const float* __restrict__ count, u32x4* __restrict__ out,
+                                                                  int out_ld8, long npix, int C, int act, float slope) {
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
-    const long stride = (long)gridDim.x * EW_THREADS;
-    const int c0 = (int)(gtid % cg) * 8;
+    const long stride = (long)gridDim.x * EW_THREADS;   // multiple of cg
+    const int cgi = (int)(gtid % cg);
+    const int c0 = cgi * 8;
+    const long pstep = stride / cg;
     float a[8], sh[8];
     load8f(coef + c0, a);
     load8f(coef + 3 * C + c0, sh);
-    for (long q = gtid; q < nchunks; q += stride) {
+    const float dsc = keep != nullptr ? drop_scale(count, npix) : 1.f;
+    for (long p = gtid / cg; p < npix; p += pstep) {
+        const long q = p * cg + cgi;
         float fy[8], fr[8], o[8];
         unpack8(y[q], fy);
         if (HAS_RES) unpack8(res[q], fr);
+        const float kp = keep != nullptr ? keep[p] * dsc : 1.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float z = act_fwd(a[i] * fy[i] + sh[i], act, slope);
+            if (keep != nullptr) z *= kp;
             if (HAS_RES) z += fr[i];
             o[i] = z;
         }
-        out[q] = pack8(o);
+        out[p * out_ld8 + cgi] = pack8(o);
     }
 }
 
-__global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ y,
-                                                                       const float* __restrict__ coef, float* __restrict__ red,
-                                                                       long nchunks, int C, int act, float slope) {
+__global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32x4* __restrict__ g, int g_ld8,
+                                                                       const u32x4* __restrict__ y, const float* __restrict__ coef,
+                                                                       const float* __restrict__ keep, const float* __restrict__ count,
+                                                                       float* __restrict__ red, long npix, int C, int act,
+                                                                       float slope) {
     extern __shared__ float sred[];
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
     const long stride = (long)gridDim.x * EW_THREADS;
-    const int c0 = (int)(gtid % cg) * 8;
+    const int cgi = (int)(gtid % cg);
+    const int c0 = cgi * 8;
+    const long pstep = stride / cg;
     float a[8], sh[8];
     load8f(coef + c0, a);
     load8f(coef + 3 * C + c0, sh);
+    const float dsc = keep != nullptr ? drop_scale(count, npix) : 1.f;
     float sv[2][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) sv[0][i] = sv[1][i] = 0.f;
-    for (long q = gtid; q < nchunks; q += stride) {
+    for (long p = gtid / cg; p < npix; p += pstep) {
         float fg[8], fy[8];
-        unpack8(g[q], fg);
-        unpack8(y[q], fy);
+        unpack8(g[p * g_ld8 + cgi], fg);
+        unpack8(y[p * cg + cgi], fy);
+        const float kp = keep != nullptr ? keep[p] * dsc : 1.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float dz = fg[i] * act_bwd(a[i] * fy[i] + sh[i], act, slope);
+            const float dz = fg[i] * kp * act_bwd(a[i] * fy[i] + sh[i], act, slope);
             sv[0][i] += dz;
             sv[1][i] += dz * fy[i];
         }
@@ -371,27 +393,33 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32
     block_reduce_flush<2>(sv, cg, C, red + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 4 * C, sred, 2);
 }
 
-__global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_apply_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ y,
-                                                                      const float* __restrict__ coef, const float* __restrict__ bc,
-                                                                      u32x4* __restrict__ dy, long nchunks, int C, int act,
-                                                                      float slope) {
+__global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_apply_kernel(const u32x4* __restrict__ g, int g_ld8,
+                                                                      const u32x4* __restrict__ y, const float* __restrict__ coef,
+                                                                      const float* __restrict__ bc, const float* __restrict__ keep,
+                                                                      const float* __restrict__ count, u32x4* __restrict__ dy,
+                                                                      long npix, int C, int act, float slope) {
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
     const long stride = (long)gridDim.x * EW_THREADS;
-    const int c0 = (int)(gtid % cg) * 8;
+    const int cgi = (int)(gtid % cg);
+    const int c0 = cgi * 8;
+    const long pstep = stride / cg;
     float a[8], sh[8], A[8], B[8], Cc[8];
     load8f(coef + c0, a);
     load8f(coef + 3 * C + c0, sh);
     load8f(bc + c0, A);
     load8f(bc + C + c0, B);
     load8f(bc + 2 * C + c0, Cc);
-    for (long q = gtid; q < nchunks; q += stride) {
+    const float dsc = keep != nullptr ? drop_scale(count, npix) : 1.f;
+    for (long p = gtid / cg; p < npix; p += pstep) {
+        const long q = p * cg + cgi;
         float fg[8], fy[8], o[8];
-        unpack8(g[q], fg);
+        unpack8(g[p * g_ld8 + cgi], fg);
         unpack8(y[q], fy);
+        const float kp = keep != nullptr ? keep[p] * dsc : 1.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float dz = fg[i] * act_bwd(a[i] * fy[i] + sh[i], act, slope);
+            const float dz = fg[i] * kp * act_bwd(a[i] * fy[i] + sh[i], act, slope);
             o[i] = A[i] * dz + B[i] * fy[i] + Cc[i];
         }
         dy[q] = pack8(o);
@@ -647,39 +675,43 @@ int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void*
     return hc_launch_status();
 }
 
-int hc_bn_act_apply(const void* y, const float* coef, const void* res, void* out, int64_t npix, int32_t C, int32_t act, float slope,
-                    hc_stream_t stream) {
-    if (y == nullptr || coef == nullptr || out == nullptr || (C % 8) != 0) return HC_ERR_ARG;
+int hc_bn_act_apply(const void* y, const float* coef, const void* res, const float* keep, const float* count, void* out,
+                    int32_t out_ld, int64_t npix, int32_t C, int32_t act, float slope, hc_stream_t stream) {
+    if (y == nullptr || coef == nullptr || out == nullptr || (C % 8) != 0 || (out_ld % 8) != 0 || out_ld < C) return HC_ERR_ARG;
+    if ((keep == nullptr) != (count == nullptr)) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8);
     hipStream_t st = (hipStream_t)stream;
     if (res != nullptr)
         hipLaunchKernelGGL((bn_act_apply_kernel<true>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)y, coef, (const u32x4*)res,
-                           (u32x4*)out, nchunks, C, act, slope);
+                           keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope);
     else
         hipLaunchKernelGGL((bn_act_apply_kernel<false>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)y, coef, (const u32x4*)res,
-                           (u32x4*)out, nchunks, C, act, slope);
+                           keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope);
     return hc_launch_status();
 }
-int hc_bn_act_bwd_reduce(const void* g, const void* y, const float* coef, float* red, int64_t npix, int32_t C, int32_t act, float slope,
-                         hc_stream_t stream) {
-    if (g == nullptr || y == nullptr || coef == nullptr || red == nullptr || (C % 8) != 0) return HC_ERR_ARG;
+int hc_bn_act_bwd_reduce(const void* g, int32_t g_ld, const void* y, const float* coef, const float* keep, const float* count,
+                         float* red, int64_t npix, int32_t C, int32_t act, float slope, hc_stream_t stream) {
+    if (g == nullptr || y == nullptr || coef == nullptr || red == nullptr || (C % 8) != 0 || (g_ld % 8) != 0 || g_ld < C) return HC_ERR_ARG;
+    if ((keep == nullptr) != (count == nullptr)) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8, 16);
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(blocks), dim3(EW_THREADS), EW_THREADS * 17 * sizeof(float), (hipStream_t)stream,
-                       (const u32x4*)g, (const u32x4*)y, coef, red, nchunks, C, act, slope);
+                       (const u32x4*)g, g_ld / 8, (const u32x4*)y, coef, keep, count, red, (long)npix, C, act, slope);
     return hc_launch_status();
 }
-int hc_bn_act_bwd_apply(const void* g, const void* y, const float* coef, const float* bcoef, void* dy, int64_t npix, int32_t C,
-                        int32_t act, float slope, hc_stream_t stream) {
-    if (g == nullptr || y == nullptr || coef == nullptr || bcoef == nullptr || dy == nullptr || (C % 8) != 0) return HC_ERR_ARG;
+int hc_bn_act_bwd_apply(const void* g, int32_t g_ld, const void* y, const float* coef, const float* bcoef, const float* keep,
+                        const float* count, void* dy, int64_t npix, int32_t C, int32_t act, float slope, hc_stream_t stream) {
+    if (g == nullptr || y == nullptr || coef == nullptr || bcoef == nullptr || dy == nullptr || (C % 8) != 0 || (g_ld % 8) != 0 ||
+        g_ld < C)
+        return HC_ERR_ARG;
+    if ((keep == nullptr) != (count == nullptr)) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u32x4*)g, (const u32x4*)y,
-                       coef, bcoef, (u32x4*)dy, nchunks, C, act, slope);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u32x4*)g, g_ld / 8,
+                       (const u32x4*)y, coef, bcoef, keep, count, (u32x4*)dy, (long)npix, C, act, slope);
     return hc_launch_status();
 }
-
 int hc_gap_fwd(const void* x, float* y, int32_t N, int32_t HW, int32_t C, hc_stream_t stream) {
     if (x == nullptr || y == nullptr || (C % 8) != 0) return HC_ERR_ARG;
     const long t = (long)N * (C / 8);

@@ -1,0 +1,336 @@
+// YOLOv4 detection layer: box decoding, target assignment, the four-part loss with its gradient, and the
+// candidate filter in front of NMS (reference: holocron/models/detection/yolov4.py:269-420).
+//
+// One thread owns one (image, cell, anchor) predictor = 5 + num_classes logits.  The logits are read in place
+// from whatever layout the head conv left them in, described by element strides (sn, sc, sp) for image, channel
+// and pixel: NHWC bf16 with a padded channel count (our conv path) or NCHW fp32 (a plain tensor handed to the
+// layer).  Channel index = anchor * (5 + nc) + k, as the reference's reshape(b, A, 5 + nc, h, w) implies.
+// Compiled with -ffp-contract=off: the decode follows the reference's operation order.
+#include "common.h"
+#include "../../include/holocron_hip.h"
+
+namespace {
+
+struct Logits {
+    const void* p;
+    int bf16;
+    long sn, sc, sp;
+    __device__ __forceinline__ float get(long n, long pix, int ch) const {
+        const long off = n * sn + pix * sp + (long)ch * sc;
+        return bf16 ? bf16_to_f32(((const bf16_t*)p)[off]) : ((const float*)p)[off];
+    }
+};
+struct Grads {
+    void* p;
+    int bf16;
+    long sn, sc, sp;
+    __device__ __forceinline__ void put(long n, long pix, int ch, float v) const {
+        const long off = n * sn + pix * sp + (long)ch * sc;
+        if (bf16) ((bf16_t*)p)[off] = f32_to_bf16(v);
+        else ((float*)p)[off] = v;
+    }
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+struct Box { float x1, y1, x2, y2; };
+
+// yolov4.py:279-293.  raw_wh = exp(t_wh) * anchor before the clamp (needed by the gradient)
+__device__ __forceinline__ Box decode_box(float tx, float ty, float tw, float th, int cx, int cy, int W, int H, float aw, float ah,
+                                          float scale_xy, float* sx, float* sy, float* rw, float* rh) {
+    const float sgx = sigmoidf_(tx), sgy = sigmoidf_(ty);
+    float bx = scale_xy * sgx - 0.5f * (scale_xy - 1.f);
+    float by = scale_xy * sgy - 0.5f * (scale_xy - 1.f);
+    bx = (bx + (float)cx) / (float)W;
+    by = (by + (float)cy) / (float)H;
+    const float w0 = expf(tw) * aw, h0 = expf(th) * ah;
+    const float bw = fminf(fmaxf(w0, 0.f), 2.f), bh = fminf(fmaxf(h0, 0.f), 2.f);
+    Box b;
+    b.x1 = bx - 0.5f * bw;
+    b.y1 = by - 0.5f * bh;
+    b.x2 = b.x1 + bw;
+    b.y2 = b.y1 + bh;
+    if (sx) { *sx = sgx; *sy = sgy; *rw = w0; *rh = h0; }
+    return b;
+}
+
+__device__ __forceinline__ float iou_of(const Box a, const Box b) {
+    const float area1 = (a.x2 - a.x1) * (a.y2 - a.y1), area2 = (b.x2 - b.x1) * (b.y2 - b.y1);
+    const float w = fmaxf(fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1), 0.f);
+    const float h = fmaxf(fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1), 0.f);
+    const float inter = w * h;
+    return inter / ((area1 + area2) - inter);
+}
+__device__ __forceinline__ float penalty_of(const Box a, const Box b) {   // ops/boxes.py:69-103
+    const float ex = fmaxf(a.x2, b.x2) - fminf(a.x1, b.x1), ey = fmaxf(a.y2, b.y2) - fminf(a.y1, b.y1);
+    const float c2 = ex * ex + ey * ey;
+    const float sx = (a.x1 + a.x2) - (b.x1 + b.x2), sy = (a.y1 + a.y2) - (b.y1 + b.y2);
+    return ((sx * sx + sy * sy) / 4.f) / c2;
+}
+// torch.max / torch.min split the gradient evenly on ties
+__device__ __forceinline__ float gt_w(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
+
+// d iou / d a (a = predicted box), accumulated as g * d
+__device__ __forceinline__ void iou_grad(const Box a, const Box b, float g, float (&d)[4]) {
+    const float aw = a.x2 - a.x1, ah = a.y2 - a.y1;
+    const float area1 = aw * ah, area2 = (b.x2 - b.x1) * (b.y2 - b.y1);
+    const float w0 = fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1), h0 = fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1);
+    const float w = fmaxf(w0, 0.f), h = fmaxf(h0, 0.f);
+    const float inter = w * h;
+    const float uni = (area1 + area2) - inter;
+    // iou = inter / uni ; d = (dinter * uni - inter * duni) / uni^2 ; duni = darea1 - dinter
+    const float gi = g * (1.f / uni + inter / (uni * uni));   // coefficient of d inter
+    const float ga = -g * inter / (uni * uni);                // coefficient of d area1
+    const float mw = w0 >= 0.f ? 1.f : 0.f, mh = h0 >= 0.f ? 1.f : 0.f;   // clamp(min=0) passes the gradient at 0
+    const float dw = gi * h * mw, dh = gi * w * mh;           // d / d w0, d / d h0
+    d[0] += -dw * gt_w(a.x1, b.x1) - ga * ah;
+    d[1] += -dh * gt_w(a.y1, b.y1) - ga * aw;
+    d[2] += dw * gt_w(b.x2, a.x2) + ga * ah;
+    d[3] += dh * gt_w(b.y2, a.y2) + ga * aw;
+}
+__device__ __forceinline__ void penalty_grad(const Box a, const Box b, float g, float (&d)[4]) {
+    const float ex = fmaxf(a.x2, b.x2) - fminf(a.x1, b.x1), ey = fmaxf(a.y2, b.y2) - fminf(a.y1, b.y1);
+    const float c2 = ex * ex + ey * ey;
+    const float sx = (a.x1 + a.x2) - (b.x1 + b.x2), sy = (a.y1 + a.y2) - (b.y1 + b.y2);
+    const float cd2 = (sx * sx + sy * sy) / 4.f;
+    const float gn = g / c2;                 // coefficient of d cd2
+    const float gc = -g * cd2 / (c2 * c2);   // coefficient of d c2
+    const float gex = gc * 2.f * ex, gey = gc * 2.f * ey;
+    d[0] += gn * sx * 0.5f - gex * gt_w(b.x1, a.x1);
+    d[1] += gn * sy * 0.5f - gey * gt_w(b.y1, a.y1);
+    d[2] += gn * sx * 0.5f + gex * gt_w(a.x2, b.x2);
+    d[3] += gn * sy * 0.5f + gey * gt_w(a.y2, b.y2);
+}
+
+// ---------------------------------------------------------------- decode (+ eval-time scores)
+__global__ void yolo_decode_kernel(Logits x, int N, int H, int W, int A, int nc, const float* __restrict__ anchors, float scale_xy,
+                                   float* __restrict__ boxes, float* __restrict__ obj, float* __restrict__ score,
+                                   long* __restrict__ label, int clamp01) {
+    const long total = (long)N * H * W * A;
+    const int D = 5 + nc;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int a = (int)(t % A);
+        const long pixg = t / A;
+        const long pix = pixg % ((long)H * W);
+        const long n = pixg / ((long)H * W);
+        const int cx = (int)(pix % W), cy = (int)(pix / W);
+        const int c0 = a * D;
+        Box b = decode_box(x.get(n, pix, c0), x.get(n, pix, c0 + 1), x.get(n, pix, c0 + 2), x.get(n, pix, c0 + 3), cx, cy, W, H,
+                           anchors[2 * a], anchors[2 * a + 1], scale_xy, nullptr, nullptr, nullptr, nullptr);
+        if (clamp01) {
+            b.x1 = fminf(fmaxf(b.x1, 0.f), 1.f); b.y1 = fminf(fmaxf(b.y1, 0.f), 1.f);
+            b.x2 = fminf(fmaxf(b.x2, 0.f), 1.f); b.y2 = fminf(fmaxf(b.y2, 0.f), 1.f);
+        }
+        boxes[4 * t] = b.x1; boxes[4 * t + 1] = b.y1; boxes[4 * t + 2] = b.x2; boxes[4 * t + 3] = b.y2;
+        if (obj != nullptr) {
+            const float so = sigmoidf_(x.get(n, pix, c0 + 4));
+            obj[t] = so;
+            if (score != nullptr) {
+                // (sigmoid(scores)).max(-1): first maximum on ties
+                float best = -1.f;
+                int bi = 0;
+                for (int k = 0; k < nc; ++k) {
+                    const float s = sigmoidf_(x.get(n, pix, c0 + 5 + k));
+                    if (s > best) { best = s; bi = k; }
+                }
+                score[t] = best * so;
+                label[t] = bi;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- target assignment (yolov4.py:350-373)
+__global__ void yolo_assign_kernel(const float* __restrict__ gt, const int* __restrict__ gt_img, int G, const float* __restrict__ anchors,
+                                   int H, int W, int A, uint8_t* __restrict__ obj_mask, uint8_t* __restrict__ cell_gt) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const float x1 = gt[4 * g], y1 = gt[4 * g + 1], x2 = gt[4 * g + 2], y2 = gt[4 * g + 3];
+    // centres: mean of (x1, x2) and (y1, y2), scaled by the grid and truncated (.to(long))
+    const long cx = (long)(((x1 + x2) / 2.f) * (float)W), cy = (long)(((y1 + y2) / 2.f) * (float)H);
+    if (cx < 0 || cx >= W || cy < 0 || cy >= H) return;   // the reference would raise an index error here
+    const float gw = x2 - x1, gh = y2 - y1;
+    // box_iou(cat(-wh, wh), cat(-anchor, anchor)).argmax(1): boxes centred on the origin
+    const float area1 = (gw - (-gw)) * (gh - (-gh));
+    float best = -INFINITY;
+    int ba = 0;
+    for (int a = 0; a < A; ++a) {
+        const float aw = anchors[2 * a], ah = anchors[2 * a + 1];
+        const float area2 = (aw - (-aw)) * (ah - (-ah));
+        const float w = fmaxf(fminf(gw, aw) - fmaxf(-gw, -aw), 0.f), h = fmaxf(fminf(gh, ah) - fmaxf(-gh, -ah), 0.f);
+        const float inter = w * h;
+        const float iou = inter / ((area1 + area2) - inter);
+        if (iou > best) { best = iou; ba = a; }
+    }
+    const long cell = ((long)gt_img[g] * H + cy) * W + cx;
+    obj_mask[cell * A + ba] = 1;
+    cell_gt[cell] = 1;
+}
+
+// ---------------------------------------------------------------- losses (yolov4.py:375-420)
+// sums[0] += (sigmoid(o) - iou_max)^2 over assigned predictors, sums[1] += sigmoid(o)^2 over predictors of cells
+// without a ground-truth centre, sums[2] += min_k (1 - iou_k + penalty_k), sums[3] += mean_c BCE(logit_c, onehot)
+template <bool BWD>
+__global__ __launch_bounds__(256) void yolo_loss_kernel(Logits x, Grads dx, int N, int H, int W, int A, int nc,
+                                                        const float* __restrict__ anchors, float scale_xy,
+                                                        const float* __restrict__ gt, const long* __restrict__ gt_label,
+                                                        const int* __restrict__ gt_off, const uint8_t* __restrict__ obj_mask,
+                                                        const uint8_t* __restrict__ cell_gt, float* __restrict__ sums,
+                                                        const float* __restrict__ gcoef) {
+    const long total = (long)N * H * W * A;
+    const int D = 5 + nc;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float gc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (BWD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gc[i] = gcoef[i];
+    }
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int a = (int)(t % A);
+        const long pixg = t / A;
+        const long pix = pixg % ((long)H * W);
+        const long n = pixg / ((long)H * W);
+        const int c0 = a * D;
+        const float so = sigmoidf_(x.get(n, pix, c0 + 4));
+        float go = 0.f;   // d / d objectness logit
+        if (!cell_gt[pixg]) {
+            acc[1] += so * so;
+            if (BWD) go += gc[1] * 2.f * so * so * (1.f - so);
+        }
+        const bool is_obj = obj_mask[t] != 0;
+        const int k0 = gt_off[n], k1 = gt_off[n + 1];
+        if (is_obj && k1 > k0) {
+            const int cx = (int)(pix % W), cy = (int)(pix / W);
+            float sx, sy, rw, rh;
+            const Box b = decode_box(x.get(n, pix, c0), x.get(n, pix, c0 + 1), x.get(n, pix, c0 + 2), x.get(n, pix, c0 + 3), cx, cy,
+                                     W, H, anchors[2 * a], anchors[2 * a + 1], scale_xy, &sx, &sy, &rw, &rh);
+            float iou_max = -INFINITY, loss_min = INFINITY;
+            int kmax = k0, kmin = k0;
+            for (int k = k0; k < k1; ++k) {
+                const Box gb = {gt[4 * k], gt[4 * k + 1], gt[4 * k + 2], gt[4 * k + 3]};
+                const float iou = iou_of(b, gb);
+                const float l = (1.f - iou) + penalty_of(b, gb);
+                if (iou > iou_max) { iou_max = iou; kmax = k; }
+                if (l < loss_min) { loss_min = l; kmin = k; }
+            }
+            const float diff = so - iou_max;
+            acc[0] += diff * diff;
+            acc[2] += loss_min;
+            const int lab = (int)gt_label[kmax];
+            float bce = 0.f;
+            for (int c = 0; c < nc; ++c) {
+                const float v = x.get(n, pix, c0 + 5 + c);
+                const float tgt = c == lab ? 1.f : 0.f;
+                bce += fmaxf(v, 0.f) - v * tgt + log1pf(expf(-fabsf(v)));
+                if (BWD) dx.put(n, pix, c0 + 5 + c, gc[3] * (sigmoidf_(v) - tgt) / (float)nc);
+            }
+            acc[3] += bce / (float)nc;
+            if (BWD) {
+                go += gc[0] * 2.f * diff * so * (1.f - so);
+                float d[4] = {0.f, 0.f, 0.f, 0.f};
+                // the objectness target is the (differentiable) IoU itself: d/d iou of (so - iou)^2
+                const Box gmax = {gt[4 * kmax], gt[4 * kmax + 1], gt[4 * kmax + 2], gt[4 * kmax + 3]};
+                iou_grad(b, gmax, gc[0] * (-2.f * diff), d);
+                const Box gmin = {gt[4 * kmin], gt[4 * kmin + 1], gt[4 * kmin + 2], gt[4 * kmin + 3]};
+                iou_grad(b, gmin, -gc[2], d);
+                penalty_grad(b, gmin, gc[2], d);
+                // (x1, y1, x2, y2) -> (bx, by, bw, bh) -> logits
+                const float gbx = d[0] + d[2], gby = d[1] + d[3];
+                const float gbw = 0.5f * (d[2] - d[0]), gbh = 0.5f * (d[3] - d[1]);
+                dx.put(n, pix, c0, gbx * scale_xy * sx * (1.f - sx) / (float)W);
+                dx.put(n, pix, c0 + 1, gby * scale_xy * sy * (1.f - sy) / (float)H);
+                dx.put(n, pix, c0 + 2, (rw >= 0.f && rw <= 2.f) ? gbw * rw : 0.f);
+                dx.put(n, pix, c0 + 3, (rh >= 0.f && rh <= 2.f) ? gbh * rh : 0.f);
+            }
+        } else if (BWD) {
+            for (int c = 0; c < 4; ++c) dx.put(n, pix, c0 + c, 0.f);
+            for (int c = 0; c < nc; ++c) dx.put(n, pix, c0 + 5 + c, 0.f);
+        }
+        if (BWD) dx.put(n, pix, c0 + 4, go);
+    }
+    if (!BWD) {
+        __shared__ float sh[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = wave_sum(acc[i]);
+            if ((threadIdx.x & 63) == 0) sh[i][threadIdx.x >> 6] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) atomicAdd(&sums[threadIdx.x], sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+    }
+}
+
+inline int grid_for(long total, int threads = 256, int cap = 4096) {
+    long b = (total + threads - 1) / threads;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hc_yolo_decode(const void* logits, int32_t dtype, int64_t sn, int64_t sc, int64_t sp, int32_t N, int32_t H, int32_t W, int32_t A,
+                   int32_t num_classes, const float* anchors, float scale_xy, float* boxes, float* obj, float* score, int64_t* label,
+                   int32_t clamp01, hc_stream_t stream) {
+    if (logits == nullptr || anchors == nullptr || boxes == nullptr || A <= 0 || num_classes < 0 || (dtype != 0 && dtype != 1))
+        return HC_ERR_ARG;
+    if ((score == nullptr) != (label == nullptr) || (score != nullptr && obj == nullptr)) return HC_ERR_ARG;
+    const long total = (long)N * H * W * A;
+    if (total == 0) return HC_OK;
+    const Logits x = {logits, dtype, (long)sn, (long)sc, (long)sp};
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, N, H, W, A, num_classes,
+                       anchors, scale_xy, boxes, obj, score, (long*)label, clamp01);
+    return hc_launch_status();
+}
+
+int hc_yolo_assign(const float* gt_boxes, const int32_t* gt_img, int32_t G, const float* anchors, int32_t N, int32_t H, int32_t W,
+                   int32_t A, uint8_t* obj_mask, uint8_t* cell_gt, hc_stream_t stream) {
+    if (obj_mask == nullptr || cell_gt == nullptr || anchors == nullptr || G < 0 || A <= 0) return HC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t cells = (size_t)N * H * W;
+    if (hipMemsetAsync(obj_mask, 0, cells * A, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hipMemsetAsync(cell_gt, 0, cells, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (G == 0) return HC_OK;
+    if (gt_boxes == nullptr || gt_img == nullptr) return HC_ERR_ARG;
+    hipLaunchKernelGGL(yolo_assign_kernel, dim3((G + 127) / 128), dim3(128), 0, st, gt_boxes, gt_img, G, anchors, H, W, A, obj_mask,
+                       cell_gt);
+    return hc_launch_status();
+}
+
+int hc_yolo_loss_fwd(const void* logits, int32_t dtype, int64_t sn, int64_t sc, int64_t sp, int32_t N, int32_t H, int32_t W, int32_t A,
+                     int32_t num_classes, const float* anchors, float scale_xy, const float* gt_boxes, const int64_t* gt_labels,
+                     const int32_t* gt_off, const uint8_t* obj_mask, const uint8_t* cell_gt, float* sums, hc_stream_t stream) {
+    if (logits == nullptr || anchors == nullptr || gt_off == nullptr || obj_mask == nullptr || cell_gt == nullptr || sums == nullptr ||
+        (dtype != 0 && dtype != 1) || A <= 0)
+        return HC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, 4 * sizeof(float), st) != hipSuccess) return HC_ERR_LAUNCH;
+    const long total = (long)N * H * W * A;
+    if (total == 0) return HC_OK;
+    const Logits x = {logits, dtype, (long)sn, (long)sc, (long)sp};
+    const Grads none = {nullptr, 0, 0, 0, 0};
+    hipLaunchKernelGGL((yolo_loss_kernel<false>), dim3(grid_for(total, 256, 1024)), dim3(256), 0, st, x, none, N, H, W, A, num_classes,
+                       anchors, scale_xy, gt_boxes, (const long*)gt_labels, gt_off, obj_mask, cell_gt, sums, (const float*)nullptr);
+    return hc_launch_status();
+}
+
+int hc_yolo_loss_bwd(const void* logits, int32_t dtype, int64_t sn, int64_t sc, int64_t sp, int32_t N, int32_t H, int32_t W, int32_t A,
+                     int32_t num_classes, const float* anchors, float scale_xy, const float* gt_boxes, const int64_t* gt_labels,
+                     const int32_t* gt_off, const uint8_t* obj_mask, const uint8_t* cell_gt, const float* gcoef, void* dlogits,
+                     hc_stream_t stream) {
+    if (logits == nullptr || anchors == nullptr || gt_off == nullptr || obj_mask == nullptr || cell_gt == nullptr || gcoef == nullptr ||
+        dlogits == nullptr || (dtype != 0 && dtype != 1) || A <= 0)
+        return HC_ERR_ARG;
+    const long total = (long)N * H * W * A;
+    if (total == 0) return HC_OK;
+    const Logits x = {logits, dtype, (long)sn, (long)sc, (long)sp};
+    const Grads dx = {dlogits, dtype, (long)sn, (long)sc, (long)sp};
+    hipLaunchKernelGGL((yolo_loss_kernel<true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dx, N, H, W, A,
+                       num_classes, anchors, scale_xy, gt_boxes, (const long*)gt_labels, gt_off, obj_mask, cell_gt, (float*)nullptr,
+                       gcoef);
+    return hc_launch_status();
+}
+
+}  // extern "C"

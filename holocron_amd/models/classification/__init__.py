@@ -1,2 +1,3 @@
 from .repvgg import *  # noqa: F401,F403
 from .darknetv3 import *  # noqa: F401,F403
+from .darknetv4 import *  # noqa: F401,F403

@@ -12,7 +12,8 @@ from typing import Any, Callable, List, Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
-from ...nn import GlobalAvgPool2d
+from ... import _lib
+from ...nn import DropBlock2d, GlobalAvgPool2d
 from ...nn.convbn_op import run_conv_sequence
 from ...nn.init import init_module
 from ...nn.repblock_op import POOL
@@ -25,8 +26,6 @@ class _FusedSequential(nn.Sequential):
     """nn.Sequential whose conv/bn/act runs execute fused on the HIP path."""
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
-        if not x.is_cuda:
-            return super().forward(x)
         return run_conv_sequence(self, x)
 
 
@@ -39,21 +38,24 @@ class ResBlock(nn.Module):
                  drop_layer: Optional[Callable[..., nn.Module]] = None,
                  conv_layer: Optional[Callable[..., nn.Module]] = None) -> None:
         super().__init__()
-        if drop_layer is not None:
-            raise NotImplementedError("DropBlock in ResBlock is outside the HIP path built so far")
         bias = norm_layer is None
         self.conv = nn.Sequential(
             *conv_sequence(planes, mid_planes, act_layer, norm_layer, drop_layer, conv_layer, kernel_size=1, bias=bias),
             *conv_sequence(mid_planes, planes, act_layer, norm_layer, drop_layer, conv_layer, kernel_size=3, padding=1, bias=bias),
         )
         self.downsample = None
+        if drop_layer is not None:
+            self.dropblock = DropBlock2d(0.1, 7, inplace=True)
         if hasattr(self.conv[-1], "inplace"):
             self.conv[-1].inplace = False
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if not x.is_cuda:
-            return self.conv(x) + x
-        return run_conv_sequence(self.conv, x, residual=x)
+        out = run_conv_sequence(self.conv, x, residual=x)
+        if hasattr(self, "dropblock"):
+            out = self.dropblock(out)
+        return out
+
+    forward_hip = forward
 
 
 class DarknetBodyV3(nn.Sequential):
@@ -109,8 +111,7 @@ class DarknetV3(nn.Sequential):
         self.default_cfg = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
-        if not x.is_cuda:
-            return super().forward(x)
+        _lib.require_gpu(x)
         POOL.begin(x.device)
         try:
             return super().forward(x)

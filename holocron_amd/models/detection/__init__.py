@@ -1,0 +1,1 @@
+from .yolov4 import *  # noqa: F401,F403

@@ -37,6 +37,44 @@ def act_code(act):
     return None
 
 
+def cl_ld(t):
+    """Channels per pixel of the buffer a bf16 NHWC tensor (possibly a channel-slice view of a wider concat
+    buffer) lives in, or None when the tensor is not such a view."""
+    if t.dtype != torch.bfloat16 or t.dim() != 4:
+        return None
+    N, Cc, H, W = t.shape
+    ld = t.stride(3) if W > 1 else (t.stride(2) if H > 1 else (t.stride(0) if N > 1 else Cc))
+    if Cc > 1 and t.stride(1) != 1:
+        return None
+    if ld < Cc or ld % 8 or Cc % 8 or t.data_ptr() % 16:
+        return None
+    if (W > 1 and t.stride(3) != ld) or (H > 1 and t.stride(2) != W * ld) or (N > 1 and t.stride(0) != H * W * ld):
+        return None
+    return ld
+
+
+def as_cl_view(t):
+    """(tensor, ld): the tensor itself when the kernels can read it in place, else a dense NHWC bf16 copy."""
+    ld = cl_ld(t)
+    if ld is not None:
+        return t, ld
+    t = cv.to_cl_bf16(t)
+    return t, t.shape[1]
+
+
+def dropblock_keep(N, H, W, drop_prob, block_size, device):
+    """keep map [N][H][W] and its sum (device scalar) for DropBlock with ``gamma = drop_prob / block_size**2``."""
+    if block_size % 2 == 0:
+        raise RuntimeError("dropblock2d: block_size must be odd (mask and input shapes do not broadcast otherwise)")
+    from . import functional as Fh
+    noise = Fh._noise((N, H, W), device).float().contiguous()
+    keep = torch.empty((N, H, W), dtype=torch.float32, device=device)
+    count = torch.empty((1,), dtype=torch.float32, device=device)
+    check(_lib.load().hc_dropblock_mask(ptr(noise), ptr(keep), ptr(count), N, H, W, block_size,
+                                        drop_prob / block_size**2, stream()), "hc_dropblock_mask")
+    return keep, count
+
+
 class ConvState:
     """Host state of one conv+bn pair: packed weights and geometry descriptors."""
 
@@ -48,9 +86,10 @@ class ConvState:
 
 class ConvBnActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, res, st, meta):
+    def forward(ctx, x, w, gamma, beta, res, st, meta, out_holder=None):
         lib = _lib.load()
-        stride, pad, act, slope, bnbuf, eps, momentum, training = meta
+        out = None if out_holder is None else out_holder[0]
+        stride, pad, act, slope, bnbuf, eps, momentum, training, drop = meta
         Cout, Cin, KH, KW = w.shape
         N, _, H, W = x.shape
         dev = x.device
@@ -95,8 +134,17 @@ class ConvBnActFn(torch.autograd.Function):
         check(lib.hc_rep_bn_finalize(C.byref(d), stream()), "hc_rep_bn_finalize")
 
         resc = None if res is None else cv.to_cl_bf16(res)
-        out = cv.empty_cl(N, Cout, OH, OW, dev)
-        check(lib.hc_bn_act_apply(ptr(y), ptr(coef), ptr(resc), ptr(out), npix, Cout, act, slope, stream()), "hc_bn_act_apply")
+        keep = count = None
+        if drop is not None and training and drop[0] > 0:
+            keep, count = dropblock_keep(N, OH, OW, drop[0], drop[1], dev)
+        if out is None:
+            out = cv.empty_cl(N, Cout, OH, OW, dev)
+        out_ld = cl_ld(out)
+        if out_ld is None or tuple(out.shape) != (N, Cout, OH, OW):
+            raise _lib.HipError("conv_bn_act: `out` must be an NHWC bf16 view of shape %s" % ((N, Cout, OH, OW),))
+        check(lib.hc_bn_act_apply(ptr(y), ptr(coef), ptr(resc), ptr(keep), ptr(count), ptr(out), out_ld, npix, Cout, act, slope,
+                                  stream()), "hc_bn_act_apply")
+        ctx.drop = (keep, count)
         ctx.st, ctx.meta2 = st, (stride, pad, act, slope, im2col, training)
         ctx.geom = (N, Cin, H, W, Cout, KH, KW, OH, OW)
         ctx.red = POOL.take((_lib.HC_STAT_REPLICAS, 4, Cout), dev) if training else None
@@ -114,14 +162,15 @@ class ConvBnActFn(torch.autograd.Function):
         src, y, coef, save, gamma, w = ctx.saved_tensors
         N, Cin, H, W, Cout, KH, KW, OH, OW = ctx.geom
         dev = g.device
-        g = cv.to_cl_bf16(g)
+        g, g_ld = as_cl_view(g)
+        keep, count = ctx.drop
         npix = N * OH * OW
         red = ctx.red
         ctx.red = None
         if red is None:
             red = torch.zeros((_lib.HC_STAT_REPLICAS, 4, Cout), dtype=torch.float32, device=dev)
-        check(lib.hc_bn_act_bwd_reduce(ptr(g), ptr(y), ptr(coef), ptr(red), npix, Cout, act, slope, stream()),
-              "hc_bn_act_bwd_reduce")
+        check(lib.hc_bn_act_bwd_reduce(ptr(g), g_ld, ptr(y), ptr(coef), ptr(keep), ptr(count), ptr(red), npix, Cout, act, slope,
+                                       stream()), "hc_bn_act_bwd_reduce")
         dgam = torch.empty((Cout,), dtype=torch.float32, device=dev)
         dbet = torch.empty((Cout,), dtype=torch.float32, device=dev)
         bcoef = torch.empty((9, Cout), dtype=torch.float32, device=dev)
@@ -133,8 +182,8 @@ class ConvBnActFn(torch.autograd.Function):
         d.C, d.count, d.has_identity, d.accumulate = Cout, npix, 0, 0
         check(lib.hc_rep_bn_bwd_finalize(C.byref(d), stream()), "hc_rep_bn_bwd_finalize")
         dy = torch.empty_like(y)
-        check(lib.hc_bn_act_bwd_apply(ptr(g), ptr(y), ptr(coef), ptr(bcoef), ptr(dy), npix, Cout, act, slope, stream()),
-              "hc_bn_act_bwd_apply")
+        check(lib.hc_bn_act_bwd_apply(ptr(g), g_ld, ptr(y), ptr(coef), ptr(bcoef), ptr(keep), ptr(count), ptr(dy), npix, Cout, act,
+                                      slope, stream()), "hc_bn_act_bwd_apply")
 
         dx = None
         if ctx.needs_input_grad[0]:
@@ -153,7 +202,85 @@ class ConvBnActFn(torch.autograd.Function):
             check(lib.hc_unpack_im2col_grad(ptr(dwc), ptr(dw), Cout, Cin, KH, KW, Kpad, 0, stream()), "hc_unpack_im2col_grad")
         else:
             dw = cv.conv_wgrad(src, dy, Cin, Cout, KH, KW, stride, pad)
-        return dx, dw, dgam, dbet, (g if ctx.has_res else None), None, None
+        return dx, dw, dgam, dbet, (g if ctx.has_res else None), None, None, None
+
+
+class ConvBiasFn(torch.autograd.Function):
+    """Plain conv + bias, no normalisation / activation (the YOLO head outputs, yolov4.py:480,536,598).  The output
+    keeps ``ceil16(Cout)`` channels per pixel (zero weights / bias in the pad rows); callers slice the logical view."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, st, meta):
+        stride, pad = meta
+        Cout, Cin, KH, KW = w.shape
+        N, _, H, W = x.shape
+        dev = x.device
+        if Cin % 16:
+            raise NotImplementedError("conv+bias on the HIP path needs Cin % 16 == 0")
+        Cp = (Cout + 15) // 16 * 16   # the data-gradient conv reads dy with Cp channels per pixel: % 16
+        src = cv.to_cl_bf16(x)
+
+        def padded():
+            if Cp == Cout:
+                return w
+            return torch.cat([w, w.new_zeros((Cp - Cout, Cin, KH, KW))], 0)
+        wpk = st.fwd_cache.get((w,), lambda: cv.pack_weight(padded(), 0))
+        bp = torch.zeros((Cp,), dtype=torch.float32, device=dev)
+        if bias is not None:
+            bp[:Cout] = bias.detach().float()
+        key = ("fb", N, Cin, H, W, Cp, KH, KW, stride, pad)
+        if key not in st.desc:
+            st.desc[key] = cv.fwd_desc(N, Cin, H, W, Cp, KH, KW, stride, pad)
+        fd = st.desc[key]
+        y = cv.empty_cl(N, Cp, fd.OH, fd.OW, dev)
+        cv.launch_conv(fd, src, wpk, y, bias=bp, act=0)
+        ctx.st, ctx.meta2 = st, (stride, pad, Cp, bias is not None)
+        ctx.geom = (N, Cin, H, W, Cout, KH, KW, fd.OH, fd.OW)
+        ctx.save_for_backward(src, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        src, w = ctx.saved_tensors
+        st = ctx.st
+        stride, pad, Cp, has_bias = ctx.meta2
+        N, Cin, H, W, Cout, KH, KW, OH, OW = ctx.geom
+        dev = g.device
+        dy = cv.to_cl_bf16(g)
+        lib = _lib.load()
+        db = None
+        if has_bias:
+            stats = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Cp), dtype=torch.float32, device=dev)
+            check(lib.hc_channel_stats(ptr(dy), ptr(stats), N * OH * OW, Cp, stream()), "hc_channel_stats")
+            db = stats[:, 0].sum(0)[:Cout]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            key = ("db", N, Cin, H, W, Cp, KH, KW, stride, pad)
+            if key not in st.desc:
+                st.desc[key] = cv.dgrad_desc(N, Cin, H, W, Cp, [(KH, KW, pad, 0, 0)], stride)
+
+            def padded():
+                if Cp == Cout:
+                    return w
+                return torch.cat([w, w.new_zeros((Cp - Cout, Cin, KH, KW))], 0)
+            wpd = st.bwd_cache.get((w,), lambda: cv.pack_weight(padded(), 1))
+            dx = cv.empty_cl(N, Cin, H, W, dev)
+            cv.launch_conv(st.desc[key], dy, wpd, dx)
+        dw = cv.conv_wgrad(src, dy, Cin, Cp, KH, KW, stride, pad)[:Cout]
+        return dx, dw, db, None, None
+
+
+def conv_bias(x, conv):
+    """``conv(x)`` for a bias-carrying nn.Conv2d with no BN / activation after it, as an NHWC bf16 tensor whose
+    channel count is rounded up to a multiple of 16 (the extra channels are exact zeros)."""
+    st = getattr(conv, "_hc", None)
+    if st is None:
+        st = conv._hc = ConvState()
+    if not (type(conv) is nn.Conv2d and conv.groups == 1 and conv.dilation == (1, 1) and conv.padding_mode == "zeros"
+            and conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1]
+            and conv.padding[0] == conv.padding[1]):
+        raise NotImplementedError("conv_bias: unsupported convolution geometry for the HIP path")
+    return ConvBiasFn.apply(x, conv.weight, conv.bias, st, (conv.stride[0], conv.padding[0]))
 
 
 def fusable(conv, bn, act):
@@ -162,45 +289,100 @@ def fusable(conv, bn, act):
             and conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1]
             and conv.padding[0] == conv.padding[1] and conv.stride[0] in (1, 2)
             and conv.kernel_size[0] * conv.kernel_size[1] <= _lib.HC_MAX_TAPS and conv.padding_mode == "zeros"
-            and conv.out_channels % 8 == 0 and act_code(act) is not None)
+            and conv.out_channels % 16 == 0 and act_code(act) is not None)
 
 
-def conv_bn_act(x, conv, bn, act=None, residual=None):
-    """out = act(bn(conv(x))) [+ residual] on the fused HIP path."""
+def conv_bn_act(x, conv, bn, act=None, residual=None, drop=None, out=None):
+    """out = dropblock(act(bn(conv(x)))) [+ residual] on the fused HIP path.  ``drop``: a DropBlock2d-like module
+    (attributes ``drop_prob``, ``block_size``) applied after the activation, or None.  ``out``: NHWC bf16 slice of a
+    concat buffer to write the result into."""
     st = getattr(conv, "_hc", None)
     if st is None:
         st = conv._hc = ConvState()
     code, slope = act_code(act)
     momentum = 0.1 if bn.momentum is None else bn.momentum
+    dp = None
+    if drop is not None and drop.training and drop.drop_prob > 0:
+        dp = (float(drop.drop_prob), int(drop.block_size))
     meta = (conv.stride[0], conv.padding[0], code, slope,
-            (bn.running_mean, bn.running_var, bn.num_batches_tracked), bn.eps, momentum, bn.training)
-    return ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, residual, st, meta)
+            (bn.running_mean, bn.running_var, bn.num_batches_tracked), bn.eps, momentum, bn.training, dp)
+    return ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, residual, st, meta, None if out is None else [out])
 
 
-def run_conv_sequence(seq, x, residual=None):
-    """Execute the modules of a ``conv_sequence`` list / nn.Sequential, fusing every
-    [Conv2d, BatchNorm2d, activation?] run into one conv_bn_act call.  ``residual`` is added to the
-    output of the LAST fused unit (DarkNet ResBlock: ``out = conv(x); out += identity``)."""
+def _is_act(m):
+    return m is not None and not isinstance(m, (nn.Conv2d, nn.BatchNorm2d)) and act_code(m) is not None
+
+
+def plan_conv_sequence(seq):
+    """Group the modules of a ``conv_sequence`` list / nn.Sequential into execution units:
+    ("fused", conv, bn, act, drop) | ("convbias", conv) | ("spp", m) | ("drop", m) | ("block", m)."""
+    from .modules import DropBlock2d, SPP
     mods = list(seq)
     i, n = 0, len(mods)
     units = []
     while i < n:
         m = mods[i]
-        if i + 1 < n and isinstance(m, nn.Conv2d) and isinstance(mods[i + 1], nn.BatchNorm2d):
-            act = mods[i + 2] if (i + 2 < n and act_code(mods[i + 2]) is not None and mods[i + 2] is not None
-                                  and not isinstance(mods[i + 2], (nn.Conv2d, nn.BatchNorm2d))) else None
-            if fusable(m, mods[i + 1], act):
-                units.append(("fused", m, mods[i + 1], act))
-                i += 3 if act is not None else 2
+        if isinstance(m, nn.Conv2d):
+            if i + 1 < n and isinstance(mods[i + 1], nn.BatchNorm2d):
+                j = i + 2
+                act = None
+                if j < n and _is_act(mods[j]):
+                    act = mods[j]
+                    j += 1
+                drop = None
+                if j < n and isinstance(mods[j], DropBlock2d):
+                    drop = mods[j]
+                    j += 1
+                if not fusable(m, mods[i + 1], act):
+                    raise NotImplementedError(f"conv/bn/act unit outside the HIP path: {m}, {mods[i + 1]}, {act}")
+                units.append(("fused", m, mods[i + 1], act, drop))
+                i = j
                 continue
-        units.append(("module", m))
-        i += 1
-    last_fused = max((k for k, u in enumerate(units) if u[0] == "fused"), default=-1)
-    for k, u in enumerate(units):
-        if u[0] == "fused":
-            x = conv_bn_act(x, u[1], u[2], u[3], residual if (k == last_fused and k == len(units) - 1) else None)
+            if m.bias is not None:
+                units.append(("convbias", m))
+                i += 1
+                continue
+            raise NotImplementedError(f"bias-free convolution without BatchNorm is outside the HIP path: {m}")
+        if isinstance(m, SPP):
+            units.append(("spp", m))
+        elif isinstance(m, DropBlock2d):
+            units.append(("drop", m))
+        elif hasattr(m, "forward_hip"):
+            units.append(("block", m))
         else:
+            raise NotImplementedError(f"{type(m).__name__} has no HIP execution path in run_conv_sequence")
+        i += 1
+    return units
+
+
+def run_conv_sequence(seq, x, residual=None, out=None, padded_out=False):
+    """Execute the modules of a ``conv_sequence`` list / nn.Sequential on the HIP path, fusing every
+    [Conv2d, BatchNorm2d, activation?, DropBlock2d?] run into one conv_bn_act call.  ``residual`` is added to the
+    output of the LAST unit (DarkNet ResBlock: ``out = conv(x); out += identity``) and ``out`` (a concat slice)
+    receives it; both need the last unit to be a fused one.  ``padded_out``: leave the channel padding of a final
+    bias conv in place (the YOLO layer kernels read the padded NHWC logits directly)."""
+    units = getattr(seq, "_hc_plan", None)
+    if units is None or getattr(seq, "_hc_plan_len", -1) != len(seq):
+        units = plan_conv_sequence(seq)
+        try:
+            seq._hc_plan, seq._hc_plan_len = units, len(seq)
+        except AttributeError:
+            pass
+    last = len(units) - 1
+    if (residual is not None or out is not None) and (last < 0 or units[last][0] != "fused"):
+        raise NotImplementedError("residual / out need the sequence to end with a fused conv unit")
+    for k, u in enumerate(units):
+        kind = u[0]
+        if kind == "fused":
+            x = conv_bn_act(x, u[1], u[2], u[3], residual if k == last else None, u[4], out if k == last else None)
+        elif kind == "convbias":
+            x = conv_bias(x, u[1])
+            if x.shape[1] != u[1].out_channels and not (padded_out and k == last):
+                x = x[:, :u[1].out_channels]
+        elif kind == "spp":
             x = u[1](x)
-    if residual is not None and not (last_fused == len(units) - 1 and last_fused >= 0):
-        x = x + residual
+        elif kind == "drop":
+            x = u[1](x)
+        else:
+            x = u[1].forward_hip(x)
     return x

@@ -6,7 +6,7 @@ from torch import Tensor, nn
 
 from . import functional as F
 
-__all__ = ["HardMish", "GlobalAvgPool2d", "FocalLoss"]
+__all__ = ["HardMish", "GlobalAvgPool2d", "FocalLoss", "DiceLoss", "PolyLoss", "DropBlock2d", "SPP"]
 
 
 class HardMish(nn.Module):
@@ -45,6 +45,8 @@ class _Loss(nn.Module):
         super().__init__()
         if isinstance(weight, (float, int)):
             self.register_buffer("weight", torch.Tensor([weight, 1 - weight]))
+        elif isinstance(weight, list):
+            self.register_buffer("weight", torch.Tensor(weight))
         else:
             self.register_buffer("weight", weight)
         self.ignore_index = ignore_index
@@ -65,3 +67,68 @@ class FocalLoss(_Loss):
 
     def extra_repr(self) -> str:
         return f"gamma={self.gamma}, reduction='{self.reduction}'"
+
+
+class DiceLoss(_Loss):
+    """Dice loss module (holocron/nn/modules/loss.py:195-219)."""
+
+    def __init__(self, weight=None, gamma: float = 1.0, eps: float = 1e-8) -> None:
+        super().__init__(weight)
+        self.gamma = gamma
+        self.eps = eps
+
+    def forward(self, x: Tensor, target: Tensor) -> Tensor:
+        return F.dice_loss(x, target, self.weight, self.gamma, self.eps)
+
+    def extra_repr(self) -> str:
+        return f"reduction='{self.reduction}', gamma={self.gamma}, eps={self.eps}"
+
+
+class PolyLoss(_Loss):
+    """Poly-1 loss module (holocron/nn/modules/loss.py:222-246)."""
+
+    def __init__(self, *args, eps: float = 2.0, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.eps = eps
+
+    def forward(self, x: Tensor, target: Tensor) -> Tensor:
+        return F.poly_loss(x, target, self.eps, self.weight, self.ignore_index, self.reduction)
+
+    def extra_repr(self) -> str:
+        return f"eps={self.eps}, reduction='{self.reduction}'"
+
+
+class DropBlock2d(nn.Module):
+    """DropBlock module (holocron/nn/modules/dropblock.py:14-41); ``drop_prob = p / block_size**2`` and the
+    functional divides by ``block_size**2`` again, exactly as the reference does."""
+
+    def __init__(self, p: float = 0.1, block_size: int = 7, inplace: bool = False) -> None:
+        super().__init__()
+        self.p = p
+        self.block_size = block_size
+        self.inplace = inplace
+
+    @property
+    def drop_prob(self) -> float:
+        return self.p / self.block_size**2
+
+    def forward(self, x: Tensor) -> Tensor:
+        return F.dropblock2d(x, self.drop_prob, self.block_size, self.inplace, self.training)
+
+    def extra_repr(self) -> str:
+        return f"p={self.p}, block_size={self.block_size}, inplace={self.inplace}"
+
+
+class SPP(nn.ModuleList):
+    """Spatial pyramid pooling (holocron/nn/modules/downsample.py:154-167): ``cat([x] + [maxpool_k(x)], dim=1)`` with
+    stride 1 and same padding.  The HIP kernel covers the (5, 9, 13) pyramid YOLOv4 uses (yolov4.py:188)."""
+
+    def __init__(self, kernel_sizes) -> None:
+        super().__init__([nn.MaxPool2d(k, stride=1, padding=k // 2) for k in kernel_sizes])
+        self.kernel_sizes = list(kernel_sizes)
+
+    def forward(self, x: Tensor) -> Tensor:
+        from ..ops.nhwc import spp_cl
+        if self.kernel_sizes != [5, 9, 13]:
+            raise NotImplementedError("the HIP SPP kernel implements the (5, 9, 13) pyramid only")
+        return spp_cl(x)

@@ -1,0 +1,187 @@
+"""Data movement of the CSP / PAN / SPP stacks on NHWC bf16 activations (kernels: csrc/nhwc_ops.hip).
+
+Reference call sites: ``x.chunk(2, dim=1)`` / ``torch.cat(..., dim=1)`` (holocron/models/classification/
+darknetv4.py:112-115), ``nn.Upsample(scale_factor=2)`` + cat (holocron/models/detection/yolov4.py:64,134-139),
+``SPP`` (holocron/nn/modules/downsample.py:154-167).
+
+A concat is a buffer allocated up front whose channel slices are handed to the producers (``cat_buffer`` /
+``slice_of``): ``cat_cl`` then only checks that every part already sits in place (copying the ones that do not),
+and its backward hands out slices of the incoming gradient, which the fused BN/activation backward kernels read
+in place (``g_ld``).
+"""
+from typing import List, Optional, Sequence
+
+import torch
+
+from .. import _lib
+from .._lib import check, ptr, stream
+from .conv import empty_cl, to_cl_bf16
+
+
+def slice_of(buf: torch.Tensor, c0: int, Cc: int) -> torch.Tensor:
+    """Channels [c0, c0 + Cc) of a dense NHWC bf16 buffer as a tensor that shares its memory but is NOT an autograd
+    view of it (custom Functions return it as a fresh output)."""
+    N, Ct, H, W = buf.shape
+    if c0 % 8 or Cc % 8 or c0 + Cc > Ct:
+        raise _lib.HipError("channel slices of NHWC buffers must be multiples of 8 channels")
+    out = torch.empty((0,), dtype=buf.dtype, device=buf.device)
+    out.set_(buf.untyped_storage(), buf.storage_offset() + c0, (N, Cc, H, W), (H * W * Ct, 1, W * Ct, Ct))
+    return out
+
+
+def cat_buffer(N: int, channels: Sequence[int], H: int, W: int, device) -> (torch.Tensor, List[torch.Tensor]):
+    """Dense NHWC buffer for ``torch.cat(parts, dim=1)`` and the slices its producers should write into."""
+    buf = empty_cl(N, sum(channels), H, W, device)
+    parts, c0 = [], 0
+    for c in channels:
+        parts.append(slice_of(buf, c0, c))
+        c0 += c
+    return buf, parts
+
+
+def _ld(t):
+    from ..nn.convbn_op import cl_ld
+    return cl_ld(t)
+
+
+def _copy(src, dst, Cc):
+    """dst[:, :Cc] = src[:, :Cc] for two NHWC bf16 tensors / slices."""
+    N, _, H, W = src.shape
+    check(_lib.load().hc_nhwc_copy(ptr(src), _ld(src), 0, ptr(dst), _ld(dst), 0, N * H * W, Cc, stream()), "hc_nhwc_copy")
+
+
+class _CatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, holder, *parts):
+        buf = holder[0]
+        N, Ct, H, W = buf.shape
+        c0 = 0
+        base = buf.data_ptr()
+        chans = []
+        for p in parts:
+            Cc = p.shape[1]
+            if not (p.data_ptr() == base + 2 * c0 and _ld(p) == Ct):
+                src = p if _ld(p) is not None else to_cl_bf16(p)
+                _copy(src, slice_of(buf, c0, Cc), Cc)
+            chans.append(Cc)
+            c0 += Cc
+        ctx.chans = chans
+        return slice_of(buf, 0, Ct)
+
+    @staticmethod
+    def backward(ctx, g):
+        if _ld(g) is None:
+            g = to_cl_bf16(g)
+        if _ld(g) != g.shape[1]:
+            g = g.contiguous(memory_format=torch.channels_last)
+        outs, c0 = [], 0
+        for Cc in ctx.chans:
+            outs.append(slice_of(g, c0, Cc))
+            c0 += Cc
+        return (None, *outs)
+
+
+def cat_cl(parts: Sequence[torch.Tensor], buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``torch.cat(parts, dim=1)`` on NHWC bf16 tensors.  With ``buf`` (from ``cat_buffer``) the parts that were
+    produced in place are not copied."""
+    _lib.require_gpu(*parts)
+    N, _, H, W = parts[0].shape
+    if any(p.shape[1] % 8 for p in parts):
+        raise _lib.HipError("cat_cl: channel counts must be multiples of 8")
+    if buf is None:
+        buf = empty_cl(N, sum(p.shape[1] for p in parts), H, W, parts[0].device)
+    return _CatFn.apply([buf], *parts)
+
+
+class _Chunk2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = to_cl_bf16(x)
+        N, Ct, H, W = x.shape
+        h = Ct // 2
+        a, b = empty_cl(N, h, H, W, x.device), empty_cl(N, h, H, W, x.device)
+        lib = _lib.load()
+        check(lib.hc_nhwc_copy(ptr(x), Ct, 0, ptr(a), h, 0, N * H * W, h, stream()), "hc_nhwc_copy")
+        check(lib.hc_nhwc_copy(ptr(x), Ct, h, ptr(b), h, 0, N * H * W, h, stream()), "hc_nhwc_copy")
+        return a, b
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        N, h, H, W = ga.shape
+        dx = empty_cl(N, 2 * h, H, W, ga.device)
+        for k, g in enumerate((ga, gb)):
+            if _ld(g) is None:
+                g = to_cl_bf16(g)
+            check(_lib.load().hc_nhwc_copy(ptr(g), _ld(g), 0, ptr(dx), 2 * h, k * h, N * H * W, h, stream()), "hc_nhwc_copy")
+        return dx
+
+
+def chunk2_cl(x: torch.Tensor):
+    """``x.chunk(2, dim=1)`` as two dense NHWC tensors (darknetv4.py:114)."""
+    _lib.require_gpu(x)
+    if x.shape[1] % 16:
+        raise _lib.HipError("chunk2_cl: channel count must be a multiple of 16")
+    return _Chunk2Fn.apply(x)
+
+
+class _Upsample2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, holder):
+        x = x if _ld(x) is not None else to_cl_bf16(x)
+        N, Cc, H, W = x.shape
+        out = holder[0] if holder is not None else empty_cl(N, Cc, 2 * H, 2 * W, x.device)
+        if tuple(out.shape) != (N, Cc, 2 * H, 2 * W) or _ld(out) is None:
+            raise _lib.HipError("upsample2x: bad `out` view")
+        check(_lib.load().hc_upsample2x_fwd(ptr(x), _ld(x), 0, ptr(out), _ld(out), 0, N, H, W, Cc, stream()), "hc_upsample2x_fwd")
+        ctx.geom = (N, Cc, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, Cc, H, W = ctx.geom
+        if _ld(g) is None:
+            g = to_cl_bf16(g)
+        dx = empty_cl(N, Cc, H, W, g.device)
+        check(_lib.load().hc_upsample2x_bwd(ptr(g), _ld(g), 0, ptr(dx), Cc, 0, N, H, W, Cc, stream()), "hc_upsample2x_bwd")
+        return dx, None
+
+
+def upsample2x_cl(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Nearest-neighbour x2 upsampling (``nn.Upsample(scale_factor=2, mode="nearest")``), optionally written
+    straight into a concat slice."""
+    _lib.require_gpu(x)
+    if x.shape[1] % 8:
+        raise _lib.HipError("upsample2x_cl: channel count must be a multiple of 8")
+    return _Upsample2xFn.apply(x, None if out is None else [out])
+
+
+class _SppFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = to_cl_bf16(x)
+        N, Cc, H, W = x.shape
+        out = empty_cl(N, 4 * Cc, H, W, x.device)
+        idx = torch.empty((3, N, H, W, Cc), dtype=torch.uint8, device=x.device)
+        check(_lib.load().hc_spp_fwd(ptr(x), ptr(out), ptr(idx), N, H, W, Cc, stream()), "hc_spp_fwd")
+        ctx.save_for_backward(idx)
+        ctx.geom = (N, Cc, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        N, Cc, H, W = ctx.geom
+        g = to_cl_bf16(g)
+        if _ld(g) != 4 * Cc:
+            g = g.contiguous(memory_format=torch.channels_last)
+        dx = empty_cl(N, Cc, H, W, g.device)
+        check(_lib.load().hc_spp_bwd(ptr(g), ptr(idx), ptr(dx), N, H, W, Cc, stream()), "hc_spp_bwd")
+        return dx
+
+
+def spp_cl(x: torch.Tensor) -> torch.Tensor:
+    """``SPP([5, 9, 13])``: cat([x, maxpool5(x), maxpool9(x), maxpool13(x)], dim=1), stride 1, same padding."""
+    _lib.require_gpu(x)
+    if x.shape[1] % 8:
+        raise _lib.HipError("spp_cl: channel count must be a multiple of 8")
+    return _SppFn.apply(x)

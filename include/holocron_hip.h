@@ -170,13 +170,36 @@ int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void*
  * branch 0 set gives coef (a = coef[0][C], shift = coef[3][C]).  act codes as in hc_conv_desc; `slope`
  * is the LeakyReLU negative slope.  Backward recomputes z = a*y + shift:
  *   reduce: red[replica][0][C] += sum g*act'(z), red[replica][1][C] += sum g*act'(z)*y  (layout of hc_rep_bwd_reduce)
- *   hc_rep_bn_bwd_finalize (has_identity = 0) -> bcoef rows 0..2 = A, B, C;  dy = A*g*act'(z) + B*y + C. */
-int hc_bn_act_apply(const void* y, const float* coef, const void* res, void* out, int64_t npix, int32_t C, int32_t act,
-                    float slope, hc_stream_t stream);
-int hc_bn_act_bwd_reduce(const void* g, const void* y, const float* coef, float* red, int64_t npix, int32_t C, int32_t act,
-                         float slope, hc_stream_t stream);
-int hc_bn_act_bwd_apply(const void* g, const void* y, const float* coef, const float* bcoef, void* dy, int64_t npix,
-                        int32_t C, int32_t act, float slope, hc_stream_t stream);
+ *   hc_rep_bn_bwd_finalize (has_identity = 0) -> bcoef rows 0..2 = A, B, C;  dy = A*g*act'(z) + B*y + C.
+ * DropBlock placed after the activation (conv -> BN -> act -> DropBlock, models/utils.py:75-84) rides in the same
+ * pass when keep/count (outputs of hc_dropblock_mask) are given: out = act(z)*keep*scale [+ res]; pass NULL for none.
+ * `out_ld` / `g_ld`: channels per pixel of the buffer the output / incoming gradient lives in (>= C, % 8 == 0; the
+ * pointer already includes the channel offset) so that a channel concat (darknetv4.py:115, yolov4.py:137) is
+ * written in place by its producers and its gradient is read in place. */
+int hc_bn_act_apply(const void* y, const float* coef, const void* res, const float* keep, const float* count, void* out,
+                    int32_t out_ld, int64_t npix, int32_t C, int32_t act, float slope, hc_stream_t stream);
+int hc_bn_act_bwd_reduce(const void* g, int32_t g_ld, const void* y, const float* coef, const float* keep,
+                         const float* count, float* red, int64_t npix, int32_t C, int32_t act, float slope,
+                         hc_stream_t stream);
+int hc_bn_act_bwd_apply(const void* g, int32_t g_ld, const void* y, const float* coef, const float* bcoef,
+                        const float* keep, const float* count, void* dy, int64_t npix, int32_t C, int32_t act,
+                        float slope, hc_stream_t stream);
+
+/* ---- NHWC bf16 data movement of the CSP / PAN / SPP stacks (darknetv4.py:112-115, yolov4.py:134-139,
+ * nn/modules/downsample.py:154-167).  `*_ld` = channels per pixel of the buffer, `*_c0` = first channel; all % 8. ----
+ * copy: dst[p][dst_c0 + c] = src[p][src_c0 + c], c < C  (chunk / cat and their gradients).
+ * upsample2x: nearest-neighbour x2 (nn.Upsample(scale_factor=2), yolov4.py:64); bwd sums the four gradients.
+ * spp: out [N][H][W][4C] = [x | maxpool5 | maxpool9 | maxpool13] (stride 1, pad k/2); idx uint8 [3][N][H][W][C]
+ *      holds each window's argmax ((dy+6)*13 + dx+6; ties -> first in row-major order like torch's max_pool2d);
+ *      bwd gathers the gradients whose argmax is the pixel. */
+int hc_nhwc_copy(const void* src, int32_t src_ld, int32_t src_c0, void* dst, int32_t dst_ld, int32_t dst_c0, int64_t npix,
+                 int32_t C, hc_stream_t stream);
+int hc_upsample2x_fwd(const void* src, int32_t src_ld, int32_t src_c0, void* dst, int32_t dst_ld, int32_t dst_c0, int32_t N,
+                      int32_t H, int32_t W, int32_t C, hc_stream_t stream);
+int hc_upsample2x_bwd(const void* g, int32_t g_ld, int32_t g_c0, void* dx, int32_t dx_ld, int32_t dx_c0, int32_t N,
+                      int32_t H, int32_t W, int32_t C, hc_stream_t stream);
+int hc_spp_fwd(const void* x, void* out, void* idx, int32_t N, int32_t H, int32_t W, int32_t C, hc_stream_t stream);
+int hc_spp_bwd(const void* g, const void* idx, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, hc_stream_t stream);
 
 /* Global average pool over H*W (holocron/nn/modules/downsample.py:70-74) on NHWC bf16. */
 int hc_gap_fwd(const void* x, float* y, int32_t N, int32_t HW, int32_t C, hc_stream_t stream);
@@ -256,6 +279,64 @@ int hc_focal_loss_bwd(const float* x, const int64_t* target, const float* weight
  * references/classification/train.py:194); per-sample loss and dlogits of the MEAN loss. */
 int hc_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss_el, float* dlogits, int32_t N, int32_t K,
                   float label_smoothing, hc_stream_t stream);
+
+/* Poly-1 loss (holocron/nn/functional.py:540-613).  Hard labels: target int64 [N][S], loss_el [N*S] =
+ * w[t]*(-logp_t + eps*(1 - p_t)), valid as for focal.  Soft labels: target fp32 [N][K][S], loss_pos [N*S] =
+ * sum over classes k != ignore_index (when 0 <= ignore_index < K) of w[k]*(-l_k + eps*(1 - exp l_k)),
+ * l_k = log_softmax(x)_k * target_k (functional.py:578-610). */
+int hc_poly_loss_hard_fwd(const float* x, const int64_t* target, const float* weight, float* loss_el, uint8_t* valid,
+                          int32_t N, int32_t K, int64_t S, int32_t ignore_index, float eps, hc_stream_t stream);
+int hc_poly_loss_hard_bwd(const float* x, const int64_t* target, const float* weight, const float* dloss_el, float* dx,
+                          int32_t N, int32_t K, int64_t S, float eps, hc_stream_t stream);
+int hc_poly_loss_soft_fwd(const float* x, const float* target, const float* weight, float* loss_pos, int32_t N,
+                          int32_t K, int64_t S, int32_t ignore_index, float eps, hc_stream_t stream);
+int hc_poly_loss_soft_bwd(const float* x, const float* target, const float* weight, const float* dloss_pos, float* dx,
+                          int32_t N, int32_t K, int64_t S, int32_t ignore_index, float eps, hc_stream_t stream);
+
+/* Dice loss reductions (holocron/nn/functional.py:523-524): sums fp32 [3][K] = per class sum over (n, s) of
+ * x*t, x, t for x, target fp32 [N][K][S]; the K-sized rational expression stays on the host side.
+ * Backward: dx = dsums[0][k]*t + dsums[1][k]. */
+int hc_dice_sums(const float* x, const float* target, float* sums, int32_t N, int32_t K, int64_t S, hc_stream_t stream);
+int hc_dice_bwd(const float* target, const float* dsums, float* dx, int32_t N, int32_t K, int64_t S, hc_stream_t stream);
+
+/* DropBlock (holocron/nn/functional.py:465-500).  noise fp32 [N][H][W] uniform samples; keep out fp32
+ * [N][H][W] = 1 - maxpool_{bs x bs, stride 1, pad bs/2}(noise <= gamma); count out fp32[1] = sum(keep)
+ * (kept on the device: the reference's `if one_count > 0` host sync becomes a device-side select).
+ * apply: y = (x * keep) * (count > 0 ? N*HW / count : 1); dtype 0 fp32 / 1 bf16, nhwc 0: [N][C][HW], 1: [N][HW][C];
+ * y may alias x (in-place).  block_size must be odd (the reference's shapes only broadcast for odd sizes). */
+int hc_dropblock_mask(const float* noise, float* keep, float* count, int32_t N, int32_t H, int32_t W, int32_t block_size,
+                      float gamma, hc_stream_t stream);
+int hc_dropblock_apply(const void* x, const float* keep, const float* count, void* y, int64_t N, int32_t C, int64_t HW,
+                       int32_t dtype, int32_t nhwc, hc_stream_t stream);
+
+/* ---- YOLOv4 detection layer (holocron/models/detection/yolov4.py:269-420) ----
+ * The logits of one scale are read in place: dtype 0 = fp32, 1 = bf16; element strides sn / sc / sp for image,
+ * channel and pixel (NHWC bf16 with padded channels: sc = 1, sp = ld; NCHW fp32: sc = H*W, sp = 1); channel =
+ * anchor * (5 + num_classes) + k.  anchors fp32 [A][2] (fractions of the image), all outputs in (h, w, anchor) order.
+ * decode (_format_outputs, :269-300): boxes fp32 [N][H][W][A][4] = xyxy from
+ *   b_xy = (scale_xy*sigmoid(t_xy) - 0.5*(scale_xy - 1) + cell) / (W, H), b_wh = clamp(exp(t_wh)*anchor, 0, 2);
+ *   optional obj = sigmoid(objectness); optional score = max_c sigmoid(cls_c) * obj and label = argmax (post_process,
+ *   :302-336); clamp01 clamps the boxes to [0, 1] like post_process does.
+ * assign (_build_targets, :350-373): obj_mask uint8 [N][H][W][A] = 1 at the cell of each ground-truth centre and the
+ *   anchor with the best origin-centred IoU; cell_gt uint8 [N][H][W] = 1 where noobj_mask is cleared.  gt_img int32 [G].
+ * loss (_compute_losses, :394-420): sums fp32 [4] = raw sums of (sigmoid(o) - max_k IoU)^2, sigmoid(o)^2 over cells
+ *   without ground truth, min_k (1 - IoU_k + penalty_k) (ciou_loss == diou_loss in the reference), mean_c BCE; the host
+ *   applies lambda / N.  gt_off int32 [N+1] = per-image ranges into gt_boxes / gt_labels.
+ * loss_bwd: dlogits (same dtype / strides as logits) = sum_i gcoef[i] * d sums[i] / d logits, including the gradient
+ *   that reaches the boxes through the IoU objectness target (the reference does not detach it). */
+int hc_yolo_decode(const void* logits, int32_t dtype, int64_t sn, int64_t sc, int64_t sp, int32_t N, int32_t H, int32_t W,
+                   int32_t A, int32_t num_classes, const float* anchors, float scale_xy, float* boxes, float* obj,
+                   float* score, int64_t* label, int32_t clamp01, hc_stream_t stream);
+int hc_yolo_assign(const float* gt_boxes, const int32_t* gt_img, int32_t G, const float* anchors, int32_t N, int32_t H,
+                   int32_t W, int32_t A, uint8_t* obj_mask, uint8_t* cell_gt, hc_stream_t stream);
+int hc_yolo_loss_fwd(const void* logits, int32_t dtype, int64_t sn, int64_t sc, int64_t sp, int32_t N, int32_t H, int32_t W,
+                     int32_t A, int32_t num_classes, const float* anchors, float scale_xy, const float* gt_boxes,
+                     const int64_t* gt_labels, const int32_t* gt_off, const uint8_t* obj_mask, const uint8_t* cell_gt,
+                     float* sums, hc_stream_t stream);
+int hc_yolo_loss_bwd(const void* logits, int32_t dtype, int64_t sn, int64_t sc, int64_t sp, int32_t N, int32_t H, int32_t W,
+                     int32_t A, int32_t num_classes, const float* anchors, float scale_xy, const float* gt_boxes,
+                     const int64_t* gt_labels, const int32_t* gt_off, const uint8_t* obj_mask, const uint8_t* cell_gt,
+                     const float* gcoef, void* dlogits, hc_stream_t stream);
 
 const char* hc_version(void);
 

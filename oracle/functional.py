@@ -25,3 +25,62 @@ def focal_loss(x, target, weight=None, ignore_index=-100, reduction="mean", gamm
     if reduction == "mean":
         return loss[valid].mean()
     return loss.view(*target.shape)
+
+
+def poly_loss(x, target, eps=2.0, weight=None, ignore_index=-100, reduction="mean"):  # functional.py:540-613
+    K = x.shape[1]
+    logp = F.log_softmax(x, dim=1)
+    hard = target.ndim == x.ndim - 1
+    if hard:
+        if target.dtype != torch.long:
+            raise TypeError("target dtype is expected to be torch.int64")
+        tflat = target.reshape(-1)
+        l = logp.transpose(1, 0).flatten(1).gather(0, tflat[None, :])[0]          # :571
+    else:
+        if target.ndim != x.ndim or target.shape[0] != x.shape[0] or target.shape[1] != x.shape[1]:
+            raise ValueError("invalid target shape")
+        l = logp * target                                                          # :576
+    loss = -1 * l + eps * (1 - l.exp())                                            # :579
+    if weight is not None:
+        w = weight.to(x.dtype)
+        loss = w.gather(0, tflat) * loss if hard else w.reshape(1, -1) * loss       # :586-589
+    if hard:
+        valid = torch.ones_like(tflat, dtype=torch.bool)
+        if 0 <= ignore_index < K:
+            valid = tflat != ignore_index
+        if reduction == "sum":
+            return loss[valid].sum()
+        if reduction == "mean":
+            return loss[valid].mean()
+        return loss
+    valid = torch.ones((K,), dtype=torch.bool)
+    if 0 <= ignore_index < K:
+        valid[ignore_index] = False
+    if reduction == "sum":
+        return loss[:, valid].sum()
+    if reduction == "mean":
+        return loss[:, valid].sum(1).mean()
+    return loss[:, valid].sum(1)
+
+
+def dice_loss(x, target, weight=None, gamma=1.0, eps=1e-8):  # functional.py:503-537
+    inter = gamma * (x * target).flatten(2).sum((0, 2))
+    cardinality = (x + gamma * target).flatten(2).sum((0, 2))
+    dice = (inter + eps) / (cardinality + eps)
+    if weight is None:
+        return 1 - (1 + 1 / gamma) * dice.mean()
+    w = weight.to(x.dtype)
+    return 1 - (1 + 1 / gamma) * (w * dice).sum() / w.sum()
+
+
+def dropblock2d(x, drop_prob, block_size, noise, training=True):  # functional.py:465-500 with the noise made explicit
+    if not training or drop_prob == 0:
+        return x
+    gamma = drop_prob / block_size**2
+    mask = (noise <= gamma).to(x.dtype)
+    mask = 1 - F.max_pool2d(mask, kernel_size=(block_size, block_size), stride=(1, 1), padding=block_size // 2)
+    one_count = mask.sum()
+    out = x * mask.unsqueeze(1)
+    if one_count > 0:
+        out = out * (mask.numel() / one_count)
+    return out

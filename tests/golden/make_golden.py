@@ -229,6 +229,152 @@ def gen_darknet():
                         "state_after": {k: v.clone() for k, v in m.state_dict().items()}})
 
 
+def gen_losses():
+    """poly-1 / dice losses and DropBlock of the reference (functional.py:465-613).  DropBlock's uniform noise
+    is captured (torch.rand is wrapped while the reference runs) so that the same noise can be replayed."""
+    g = torch.Generator().manual_seed(21)
+    Fr = ref.nn.functional
+    poly = []
+    for (shape, K, soft, w, ign, eps, red) in [
+            ((6,), 5, False, False, -100, 2.0, "mean"), ((2, 4, 4), 7, False, True, 3, 2.0, "mean"),
+            ((2, 4, 4), 7, False, True, 3, 1.0, "sum"), ((3, 5), 4, False, False, -100, 2.0, "none"),
+            ((8,), 6, True, False, -100, 2.0, "mean"), ((8,), 6, True, True, 2, 2.0, "mean"),
+            ((8,), 6, True, True, 2, 0.5, "sum"), ((8,), 6, True, False, 1, 2.0, "none"),
+            ((2, 3, 3), 5, True, False, 4, 2.0, "mean")]:
+        xs = (shape[0], K) + tuple(shape[1:])
+        x = (torch.randn(xs, generator=g) * 2).requires_grad_(True)
+        if soft:
+            t = torch.softmax(torch.randn(xs, generator=g), dim=1)
+        else:
+            t = torch.randint(0, K, shape, generator=g)
+        weight = torch.rand((K,), generator=g) + 0.5 if w else None
+        loss = Fr.poly_loss(x, t, eps, weight, ign, red)
+        rr = torch.rand(loss.shape, generator=g) if red == "none" else torch.tensor(1.0)
+        (gx,) = torch.autograd.grad((loss * rr).sum(), x)
+        poly.append({"x": x.detach(), "target": t, "weight": weight, "ignore_index": ign, "eps": eps, "reduction": red,
+                     "loss": loss.detach(), "r": rr, "dx": gx})
+    dice = []
+    for (xs, w, gamma, eps) in [((2, 4, 9, 9), False, 1.0, 1e-8), ((3, 5, 16), True, 2.0, 1e-8), ((2, 3, 4, 4), True, 0.5, 1e-3),
+                                ((1, 2, 50), False, 1.0, 1e-8)]:
+        x = torch.softmax(torch.randn(xs, generator=g), dim=1).requires_grad_(True)
+        t = torch.zeros(xs).scatter_(1, torch.randint(0, xs[1], (xs[0], 1) + tuple(xs[2:]), generator=g), 1.0)
+        weight = torch.rand((xs[1],), generator=g) + 0.5 if w else None
+        loss = Fr.dice_loss(x, t, weight, gamma, eps)
+        (gx,) = torch.autograd.grad(loss, x)
+        dice.append({"x": x.detach(), "target": t, "weight": weight, "gamma": gamma, "eps": eps, "loss": loss.detach(), "dx": gx})
+    drop = []
+    real_rand = torch.rand
+    for (xs, p, bs, inplace) in [((2, 3, 16, 16), 0.2 * 9, 3, False), ((2, 8, 19, 19), 0.1 * 49 * 4, 7, True),
+                                 ((1, 4, 8, 8), 0.5 * 25, 5, False), ((2, 2, 6, 6), 1e-9, 3, False), ((1, 2, 5, 5), 9.0, 3, False)]:
+        x = torch.randn(xs, generator=g)
+        noise = real_rand((xs[0],) + tuple(xs[2:]), generator=g)
+        torch.rand = lambda *a, **k: noise.clone()
+        try:
+            xin = x.clone().requires_grad_(True)
+            y = Fr.dropblock2d(xin * 1.0, p, bs, inplace, True)
+        finally:
+            torch.rand = real_rand
+        r = real_rand(y.shape, generator=g)
+        (gx,) = torch.autograd.grad((y * r).sum(), xin)
+        drop.append({"x": x, "noise": noise, "drop_prob": p, "block_size": bs, "inplace": inplace, "y": y.detach(), "r": r, "dx": gx})
+    save("losses.pt", {"poly": poly, "dice": dice, "dropblock": drop})
+
+
+def _rand_targets(n_per_image, nc, g, same_cell=False):
+    tg = []
+    for k in n_per_image:
+        b = torch.rand((k, 4), generator=g)
+        b[:, :2] *= b[:, 2:]                      # the reference tests' recipe (tests/test_models_detection.py:40-42)
+        b = torch.cat([b[:, :2], b[:, 2:].clamp(min=0.05)], 1)
+        b[:, 2:] = torch.maximum(b[:, 2:], b[:, :2] + 0.02).clamp(max=0.999)
+        if same_cell and k >= 2:
+            b[1] = b[0] + torch.tensor([0.001, 0.002, 0.003, 0.001])
+        tg.append({"boxes": b, "labels": torch.randint(0, nc, (k,), generator=g)})
+    return tg
+
+
+class _RecordRand:
+    """Wrap torch.rand while the reference runs so that DropBlock's noise (functional.py:482) can be replayed."""
+
+    def __init__(self, g):
+        self.g, self.real, self.draws = g, torch.rand, []
+
+    def __enter__(self):
+        def rand(*size, **kw):
+            kw.pop("device", None)
+            t = self.real(*size, generator=self.g, **kw)
+            self.draws.append(t.clone())
+            return t
+        torch.rand = rand
+        return self
+
+    def __exit__(self, *a):
+        torch.rand = self.real
+
+
+def gen_yolo():
+    """YoloLayer (decode / targets / losses / post-process) on random logits, and one training step of a reduced
+    YOLOv4 whose weights are reproducible from the seed (the mirror's constructor consumes the RNG identically)."""
+    import importlib
+    ry = importlib.import_module("ref_holocron.models.detection.yolov4")
+    g = torch.Generator().manual_seed(29)
+    layer_cases = []
+    anchors = torch.tensor([[36, 75], [76, 55], [72, 146]], dtype=torch.float32) / 608
+    for (N, H, W, nc, counts, scale_xy, same) in [(2, 5, 5, 4, [2, 3], 1.2, False), (3, 7, 6, 3, [1, 0, 4], 1.1, True),
+                                                  (2, 4, 4, 1, [0, 0], 1.05, False), (1, 9, 9, 20, [6], 1.2, True)]:
+        layer = ry.YoloLayer(anchors.clone(), num_classes=nc, scale_xy=scale_xy)
+        x = (torch.randn((N, 3 * (5 + nc), H, W), generator=g) * 1.5).requires_grad_(True)
+        tg = _rand_targets(counts, nc, g, same)
+        layer.train()
+        boxes, b_o, b_s = layer._format_outputs(x)
+        losses = layer(x, tg)
+        wts = {"obj_loss": 1.0, "noobj_loss": 0.7, "bbox_loss": 1.3, "clf_loss": 0.9}
+        (dx,) = torch.autograd.grad(sum(wts[k] * v.sum() for k, v in losses.items()), x)
+        layer.eval()
+        with torch.no_grad():
+            dets = layer(x.detach().clone())
+        layer_cases.append({"x": x.detach(), "target": tg, "nc": nc, "scale_xy": scale_xy, "anchors": anchors.clone(),
+                            "boxes": boxes.detach(), "losses": {k: v.detach() for k, v in losses.items()}, "weights": wts,
+                            "dx": dx, "detections": dets})
+    # reduced YOLOv4: one block per stage, 16 stem channels, 5 classes, 2 x 3 x 128 x 128
+    layout = [(64, 1), (128, 1), (256, 1), (512, 1), (1024, 1)]
+    torch.manual_seed(41)
+    m = ry.YOLOv4(layout, num_classes=5, stem_channels=16)
+    gh = torch.Generator().manual_seed(43)
+    for seq in (m.head.head1, m.head.head2_2, m.head.head3):       # the zero-initialised output convs would hide the backbone
+        seq[-1].weight.data = torch.randn(seq[-1].weight.shape, generator=gh) * 0.05
+        seq[-1].bias.data = torch.randn(seq[-1].bias.shape, generator=gh) * 0.5
+    for mod in m.modules():
+        if isinstance(mod, ref.nn.DropBlock2d):
+            mod.p = 0.1 * 49 * 2                                   # gamma = 0.2 / 49: blocks really get dropped
+    x = torch.rand((2, 3, 256, 256), generator=g)
+    tg = _rand_targets([3, 2], 5, g)
+    m.train()
+    gn = torch.Generator().manual_seed(47)                         # the draws are replayed from this seed, not stored
+    with _RecordRand(gn) as rec:
+        losses = m(x, tg)
+    total = sum(v.sum() for v in losses.values())
+    total.backward()
+    names = ["backbone.stem.0.weight", "backbone.stem.1.weight", "backbone.stages.0.base_layer.0.weight",
+             "backbone.stages.2.main.0.conv.0.weight", "backbone.stages.2.main.0.conv.5.weight",
+             "backbone.stages.4.transition.1.bias", "neck.fpn.1.weight", "neck.fpn.14.bias", "neck.pan2.conv1.0.weight",
+             "neck.pan1.conv2.1.weight", "head.head1.3.weight", "head.head1.3.bias", "head.head2_2.3.weight",
+             "head.head3.24.weight", "head.head3.24.bias", "head.pre_head3.1.weight"]
+    params = dict(m.named_parameters())
+    grads = {n: params[n].grad.clone() for n in names}
+    gnorm = {n: float(p.grad.norm()) for n, p in params.items() if p.grad is not None}
+    rstats = {k: v.clone() for k, v in m.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+    m.eval()
+    with torch.no_grad():
+        dets = m(x)
+    save("yolo.pt", {"layers": layer_cases,
+                     "model": {"layout": layout, "seed": 41, "head_seed": 43, "num_classes": 5, "stem_channels": 16,
+                               "drop_p": 0.1 * 49 * 2, "x": x, "target": tg, "noise_seed": 47, "n_draws": len(rec.draws),
+                               "dropped_fraction": [float((d <= 0.2 / 49).float().mean()) for d in rec.draws[:3]],
+                               "losses": {k: v.detach() for k, v in losses.items()}, "grads": grads, "grad_norms": gnorm,
+                               "running": rstats, "n_detections": [int(d["boxes"].shape[0]) for d in dets]}})
+
+
 def gen_nms():
     """torchvision.ops.nms is absent: these vectors come from the restated algorithm (oracle/tv_ops.py),
     plus the two situations the reference's own tests pin (tests/test_models_detection.py:158-163: disjoint
@@ -251,10 +397,7 @@ def gen_nms():
 
 
 if __name__ == "__main__":
-    gen_boxes()
-    gen_functional()
-    gen_optim()
-    gen_repblock()
-    gen_repvgg_small()
-    gen_darknet()
-    gen_nms()
+    gens = {"boxes": gen_boxes, "functional": gen_functional, "optim": gen_optim, "repblock": gen_repblock,
+            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "nms": gen_nms}
+    for name in (sys.argv[1:] or list(gens)):
+        gens[name]()

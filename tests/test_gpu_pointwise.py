@@ -85,6 +85,58 @@ def test_hard_mish_and_focal(golden):
         h.nn.FocalLoss(reduction="bogus")
 
 
+def test_poly_dice_dropblock(golden):
+    import holocron_amd as h
+    Fh = h.nn.functional
+    g = golden("losses.pt")
+    for c in g["poly"]:
+        x = c["x"].cuda().requires_grad_(True)
+        w = None if c["weight"] is None else c["weight"].cuda()
+        loss = Fh.poly_loss(x, c["target"].cuda(), c["eps"], w, c["ignore_index"], c["reduction"])
+        assert loss.shape == c["loss"].shape
+        assert torch.allclose(loss.detach().cpu(), c["loss"], rtol=2e-5, atol=2e-6)
+        (loss * c["r"].cuda()).sum().backward()
+        assert torch.allclose(x.grad.cpu(), c["dx"], rtol=2e-4, atol=2e-6)
+    with pytest.raises(TypeError):
+        Fh.poly_loss(torch.zeros(2, 3).cuda(), torch.zeros(2).cuda())            # functional.py:568-569
+    with pytest.raises(ValueError):
+        Fh.poly_loss(torch.zeros(2, 3).cuda(), torch.zeros(2, 4).cuda())         # functional.py:574-575
+    assert isinstance(h.nn.PolyLoss(eps=1.0)(torch.randn(4, 3).cuda(), torch.randint(0, 3, (4,)).cuda()).item(), float)
+    for c in g["dice"]:
+        x = c["x"].cuda().requires_grad_(True)
+        w = None if c["weight"] is None else c["weight"].cuda()
+        loss = Fh.dice_loss(x, c["target"].cuda(), w, c["gamma"], c["eps"])
+        assert torch.allclose(loss.detach().cpu(), c["loss"], rtol=1e-5, atol=1e-6)
+        loss.backward()
+        assert torch.allclose(x.grad.cpu(), c["dx"], rtol=1e-4, atol=1e-7)
+    # identities the reference tests pin (tests/test_nn_loss.py): perfect prediction -> ~0
+    t = torch.zeros(2, 3, 8, 8).scatter_(1, torch.randint(0, 3, (2, 1, 8, 8)), 1.0).cuda()
+    assert abs(float(h.nn.DiceLoss()(t, t))) < 1e-6
+    for c in g["dropblock"]:
+        x = c["x"].cuda().requires_grad_(True)
+        xin = x * 1.0
+        y = Fh.dropblock2d(xin, c["drop_prob"], c["block_size"], c["inplace"], True, noise=c["noise"].cuda())
+        if c["inplace"]:
+            assert y.data_ptr() == xin.data_ptr()
+        assert torch.allclose(y.detach().cpu(), c["y"], rtol=1e-6, atol=0)
+        (y * c["r"].cuda()).sum().backward()
+        assert torch.allclose(x.grad.cpu(), c["dx"], rtol=1e-6, atol=0)
+    # bf16 channels_last activations take the same kernel (the layout the conv path hands over)
+    c = g["dropblock"][1]
+    xb = c["x"].cuda().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    yb = Fh.dropblock2d(xb, c["drop_prob"], c["block_size"], False, True, noise=c["noise"].cuda())
+    from oracle import functional as of
+    ref = of.dropblock2d(xb.float().cpu(), c["drop_prob"], c["block_size"], c["noise"])
+    assert torch.allclose(yb.float().cpu(), ref, rtol=1.6e-2, atol=1e-6)
+    # eval / p == 0: identity, same object (functional.py:476-477)
+    m = h.nn.DropBlock2d(0.1, 3).eval()
+    z = torch.rand(1, 2, 4, 4).cuda()
+    assert m(z) is z
+    m.train()
+    out = m(z)
+    assert out.shape == z.shape
+
+
 def test_adabelief_matches_reference(golden):
     import holocron_amd as h
     for c in golden("optim.pt")["adabelief"]:

@@ -1,5 +1,8 @@
 """CPU: pin the oracle (oracle/) against golden vectors produced by the reference itself."""
+import pytest
 import torch
+
+from conftest import rel_l2
 
 from oracle import boxes as ob
 from oracle import functional as of
@@ -42,6 +45,100 @@ def test_functional_match_reference(golden):
         assert torch.allclose(loss, c["loss"], rtol=1e-6, atol=1e-7)
         (dx,) = torch.autograd.grad((loss * c["r"]).sum(), x)
         assert torch.allclose(dx, c["dx"], rtol=1e-5, atol=1e-7)
+
+
+def test_losses_match_reference(golden):
+    g = golden("losses.pt")
+    for c in g["poly"]:
+        x = c["x"].clone().requires_grad_(True)
+        loss = of.poly_loss(x, c["target"], c["eps"], c["weight"], c["ignore_index"], c["reduction"])
+        assert loss.shape == c["loss"].shape and torch.allclose(loss, c["loss"], rtol=1e-6, atol=1e-7)
+        (dx,) = torch.autograd.grad((loss * c["r"]).sum(), x)
+        assert torch.allclose(dx, c["dx"], rtol=1e-5, atol=1e-7)
+    for c in g["dice"]:
+        x = c["x"].clone().requires_grad_(True)
+        loss = of.dice_loss(x, c["target"], c["weight"], c["gamma"], c["eps"])
+        assert torch.equal(loss, c["loss"])
+        (dx,) = torch.autograd.grad(loss, x)
+        assert torch.allclose(dx, c["dx"], rtol=1e-6, atol=1e-9)
+    for c in g["dropblock"]:
+        x = c["x"].clone().requires_grad_(True)
+        y = of.dropblock2d(x, c["drop_prob"], c["block_size"], c["noise"])
+        assert torch.equal(y, c["y"])
+        (dx,) = torch.autograd.grad((y * c["r"]).sum(), x)
+        assert torch.equal(dx, c["dx"])
+    with pytest.raises(TypeError):
+        of.poly_loss(torch.zeros(2, 3), torch.zeros(2))
+    with pytest.raises(ValueError):
+        of.poly_loss(torch.zeros(2, 3), torch.zeros(2, 4))
+
+
+def test_yolo_layer_matches_reference(golden):
+    from oracle import yolo as oy
+    for c in golden("yolo.pt")["layers"]:
+        x = c["x"].clone().requires_grad_(True)
+        boxes, _, _ = oy.format_outputs(x, c["anchors"], c["nc"], c["scale_xy"])
+        assert torch.allclose(boxes, c["boxes"], rtol=1e-6, atol=1e-7)
+        losses = oy.compute_losses(x, c["target"], c["anchors"], c["nc"], c["scale_xy"])
+        for k, v in c["losses"].items():
+            assert torch.allclose(losses[k].reshape(v.shape), v, rtol=1e-5, atol=1e-7), k
+        (dx,) = torch.autograd.grad(sum(c["weights"][k] * v.sum() for k, v in losses.items()), x)
+        assert torch.allclose(dx, c["dx"], rtol=1e-4, atol=1e-8)
+        dets = oy.post_process(c["x"], c["anchors"], c["nc"], c["scale_xy"])
+        for d, r in zip(dets, c["detections"]):
+            assert torch.equal(d["labels"], r["labels"]) and torch.equal(d["boxes"], r["boxes"])
+            assert torch.equal(d["scores"], r["scores"])
+
+
+def _yolo_golden_state(gm):
+    """The golden model's weights are reproducible from its seeds: the mirror's constructors consume the RNG exactly
+    like the reference's (asserted against the reference when the golden file is generated)."""
+    import holocron_amd as h
+    torch.manual_seed(gm["seed"])
+    m = h.models.detection.YOLOv4(gm["layout"], num_classes=gm["num_classes"], stem_channels=gm["stem_channels"])
+    gh = torch.Generator().manual_seed(gm["head_seed"])
+    for seq in (m.head.head1, m.head.head2_2, m.head.head3):
+        seq[-1].weight.data = torch.randn(seq[-1].weight.shape, generator=gh) * 0.05
+        seq[-1].bias.data = torch.randn(seq[-1].bias.shape, generator=gh) * 0.5
+    return m
+
+
+class _NoiseReplay:
+    """DropBlock draws of the golden run, regenerated from their seed (same CPU generator, same order and shapes)."""
+
+    def __init__(self, seed):
+        self.g, self.n = torch.Generator().manual_seed(seed), 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        raise RuntimeError("shape-less draw")
+
+    def draw(self, shape):
+        self.n += 1
+        return torch.rand(tuple(shape), generator=self.g)
+
+
+def test_yolov4_oracle_matches_reference(golden):
+    from oracle import yolov4 as ov
+    gm = golden("yolo.pt")["model"]
+    m = _yolo_golden_state(gm)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    leaves = {n: sd[n].requires_grad_(True) for n in gm["grads"]}
+    cfg = ov.Cfg(act="mish", drop=(gm["drop_p"], 7), noise=_NoiseReplay(gm["noise_seed"]), training=True)
+    losses, _ = ov.train_losses(sd, gm["x"], gm["target"], gm["layout"], gm["num_classes"], cfg)
+    for k, v in gm["losses"].items():
+        assert torch.allclose(losses[k].reshape(v.shape), v, rtol=2e-4, atol=1e-6), (k, losses[k], v)
+    grads = torch.autograd.grad(sum(v.sum() for v in losses.values()), list(leaves.values()))
+    for (n, _), g in zip(leaves.items(), grads):
+        assert rel_l2(g, gm["grads"][n]) < 2e-3, (n, rel_l2(g, gm["grads"][n]))
+    for n, v in gm["running"].items():
+        assert torch.allclose(sd[n].detach(), v, rtol=1e-3, atol=1e-5), n
+    cfg = ov.Cfg(act="mish", drop=(gm["drop_p"], 7), training=False)
+    with torch.no_grad():
+        dets = ov.detect(sd, gm["x"], gm["layout"], gm["num_classes"], cfg)
+    assert [int(d["boxes"].shape[0]) for d in dets] == gm["n_detections"]
 
 
 def test_optim_match_reference(golden):
