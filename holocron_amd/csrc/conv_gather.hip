@@ -18,8 +18,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case 1: return v > 0.f ? v : 0.f;
         case 2: { float t = fminf(fmaxf(v + 2.f, 0.f), 2.f); return 0.5f * v * t; }
         case 3: return v > 0.f ? v : 0.1f * v;
-        case 4: { float sp = v > 20.f ? v : log1pf(__expf(v)); return v * tanhf(sp); }
-        case 5: return v / (1.f + __expf(-v));
+        case 4: { const float e = __expf(fminf(v, 20.f)), n = e * (e + 2.f); return v * n * __builtin_amdgcn_rcpf(n + 2.f); }
+        case 5: return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
         case 6: return fminf(fmaxf(v, 0.f), 6.f);
         default: return v;
     }

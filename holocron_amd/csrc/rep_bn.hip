@@ -298,8 +298,11 @@ __device__ __forceinline__ float act_fwd(float v, int act, float slope) {
         case 1: return v > 0.f ? v : 0.f;
         case 2: { const float t = fminf(fmaxf(v + 2.f, 0.f), 2.f); return 0.5f * v * t; }
         case 3: return v > 0.f ? v : slope * v;
-        case 4: { const float sp = v > 20.f ? v : log1pf(__expf(v)); return v * tanhf(sp); }
-        case 5: return v / (1.f + __expf(-v));
+        case 4: {   // mish = x tanh(softplus x) = x n / (n + 2), n = e^x (e^x + 2): one v_exp_f32 and one v_rcp_f32
+            const float e = __expf(fminf(v, 20.f)), n = e * (e + 2.f);
+            return v * n * __builtin_amdgcn_rcpf(n + 2.f);
+        }
+        case 5: return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
         case 6: return fminf(fmaxf(v, 0.f), 6.f);
         default: return v;
     }
@@ -309,9 +312,12 @@ __device__ __forceinline__ float act_bwd(float v, int act, float slope) {   // d
         case 1: return v > 0.f ? 1.f : 0.f;
         case 2: { const float t = v + 2.f; float d = 0.5f * fminf(fmaxf(t, 0.f), 2.f); if (t >= 0.f && t <= 2.f) d += 0.5f * v; return d; }
         case 3: return v > 0.f ? 1.f : slope;
-        case 4: { const float sp = v > 20.f ? v : log1pf(__expf(v)); const float t = tanhf(sp);
-                  const float sg = 1.f / (1.f + __expf(-v)); return t + v * (1.f - t * t) * sg; }
-        case 5: { const float sg = 1.f / (1.f + __expf(-v)); return sg * (1.f + v * (1.f - sg)); }
+        case 4: {   // d/dx [x t], t = n / (n + 2): t' = 4 e (e + 1) / (n + 2)^2
+            const float e = __expf(fminf(v, 20.f)), n = e * (e + 2.f);
+            const float r = __builtin_amdgcn_rcpf(n + 2.f);
+            return n * r + 4.f * v * e * (e + 1.f) * r * r;
+        }
+        case 5: { const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-v)); return sg * (1.f + v * (1.f - sg)); }
         case 6: return (v > 0.f && v < 6.f) ? 1.f : 0.f;
         default: return 1.f;
     }

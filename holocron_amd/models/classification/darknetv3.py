@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from ... import _lib
 from ...nn import DropBlock2d, GlobalAvgPool2d
-from ...nn.convbn_op import run_conv_sequence
+from ...nn.convbn_op import prepack_model_convs, run_conv_sequence
 from ...nn.init import init_module
 from ...nn.repblock_op import POOL
 from ..utils import conv_sequence
@@ -112,6 +112,7 @@ class DarknetV3(nn.Sequential):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
         _lib.require_gpu(x)
+        prepack_model_convs(self)
         POOL.begin(x.device)
         try:
             return super().forward(x)

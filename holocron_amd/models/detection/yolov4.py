@@ -21,7 +21,7 @@ from torch import Tensor
 from ... import _lib
 from ..._lib import check, ptr, stream
 from ...nn import SPP, DropBlock2d
-from ...nn.convbn_op import cl_ld, run_conv_sequence
+from ...nn.convbn_op import cl_ld, prepack_model_convs, run_conv_sequence
 from ...nn.init import init_module
 from ...nn.repblock_op import POOL
 from ...ops.boxes import nms
@@ -328,6 +328,7 @@ class YOLOv4(nn.Module):
         if self.training and target is None:
             raise ValueError("`target` needs to be specified in training mode")
         _lib.require_gpu(x)
+        prepack_model_convs(self)
         POOL.begin(x.device)
         try:
             feats = self.backbone(x)

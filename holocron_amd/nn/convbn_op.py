@@ -386,3 +386,53 @@ def run_conv_sequence(seq, x, residual=None, out=None, padded_out=False):
         else:
             x = u[1].forward_hip(x)
     return x
+
+
+def prepack_model_convs(model):
+    """Step-level host work for models built from conv_sequence units: repack the bf16 forward / data-gradient weight
+    images of every stale bias-free convolution with ONE hc_pack_conv_weights_multi launch (instead of two launches
+    per convolution) and hand them to the per-conv caches."""
+    import numpy as np
+    convs = getattr(model, "_hc_convs", None)
+    if convs is None:
+        convs = [m for m in model.modules() if type(m) is nn.Conv2d and m.groups == 1 and m.bias is None
+                 and m.in_channels % 16 == 0 and m.out_channels % 16 == 0 and m.weight.dtype == torch.float32]
+        model._hc_convs = convs
+    epoch = cv.weights_epoch()
+    items, touched = [], []
+    for conv in convs:
+        w = conv.weight
+        if not w.is_cuda:
+            return
+        st = getattr(conv, "_hc", None)
+        if st is None:
+            st = conv._hc = ConvState()
+        key = ((w.data_ptr(), w._version), epoch)
+        if getattr(st, "packed_key", None) == key and st.fwd_cache._key == key:
+            continue
+        Cout, Cin, KH, KW = w.shape
+        T = KH * KW
+        if getattr(st, "wf", None) is None or st.wf.device != w.device:
+            st.wf = torch.empty((Cout, T, Cin), dtype=torch.bfloat16, device=w.device)
+            st.wb = torch.empty((Cin, T, Cout), dtype=torch.bfloat16, device=w.device)
+        items.append((w, st.wf, Cout, Cin, KH, KW, 0, 0, T))
+        items.append((w, st.wb, Cout, Cin, KH, KW, 1, 0, T))
+        touched.append((st, key))
+    if not items:
+        return
+    sig = tuple((w.data_ptr(), dst.data_ptr()) for (w, dst, *_r) in items)
+    cache = getattr(model, "_hc_pack_table", None)
+    if cache is None or cache[0] != sig:
+        arr = (_lib.PackItem * len(items))()
+        mx = 0
+        for a, (w, dst, Cout, Cin, KH, KW, mode, tap0, T) in zip(arr, items):
+            a.w, a.dst, a.Cout, a.Cin, a.KH, a.KW, a.mode, a.tap0, a.T = w.data_ptr(), dst.data_ptr(), Cout, Cin, KH, KW, mode, tap0, T
+            mx = max(mx, w.numel())
+        host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+        cache = (sig, host.to(items[0][0].device), len(items), mx)
+        model._hc_pack_table = cache
+    check(_lib.load().hc_pack_conv_weights_multi(cache[1].data_ptr(), cache[2], cache[3], stream()), "hc_pack_conv_weights_multi")
+    for st, key in touched:
+        st.packed_key = key
+        st.fwd_cache._key, st.fwd_cache._val = key, st.wf
+        st.bwd_cache._key, st.bwd_cache._val = key, st.wb
