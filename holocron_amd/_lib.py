@@ -47,20 +47,20 @@ class WgradDesc(C.Structure):
 
 class PackItem(C.Structure):
     _fields_ = [("w", c_void_p), ("dst", c_void_p), ("Cout", c_int32), ("Cin", c_int32), ("KH", c_int32),
-                ("KW", c_int32), ("mode", c_int32), ("tap0", c_int32), ("T", c_int32), ("pad_", c_int32)]
+                ("KW", c_int32), ("mode", c_int32), ("tap0", c_int32), ("T", c_int32), ("ld", c_int32)]
 
 
 class RepBnDesc(C.Structure):
     _fields_ = [("stats", c_void_p * 3), ("gamma", c_void_p * 3), ("beta", c_void_p * 3),
                 ("running_mean", c_void_p * 3), ("running_var", c_void_p * 3), ("num_batches_tracked", c_void_p * 3),
                 ("coef", c_void_p), ("save", c_void_p), ("C", c_int32), ("count", c_int64),
-                ("eps", c_float), ("momentum", c_float), ("training", c_int32)]
+                ("eps", c_float), ("momentum", c_float), ("training", c_int32), ("c_valid", c_int32)]
 
 
 class RepBnBwdDesc(C.Structure):
     _fields_ = [("red", c_void_p), ("save", c_void_p), ("gamma", c_void_p * 3), ("dgamma", c_void_p * 3),
                 ("dbeta", c_void_p * 3), ("bcoef", c_void_p), ("C", c_int32), ("count", c_int64),
-                ("has_identity", c_int32), ("accumulate", c_int32)]
+                ("has_identity", c_int32), ("accumulate", c_int32), ("c_valid", c_int32)]
 
 
 class MtChunk(C.Structure):
@@ -103,7 +103,7 @@ SIGNATURES = {
     "hc_rep_bwd_reduce": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_void_p]),
     "hc_rep_bn_bwd_finalize": (c_int32, [C.POINTER(RepBnBwdDesc), c_void_p]),
     "hc_rep_bwd_apply": (c_int32, [c_void_p] * 9 + [c_int64, c_int32, c_void_p]),
-    "hc_bn_act_apply": (c_int32, [c_void_p] * 6 + [c_int32, c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "hc_bn_act_apply": (c_int32, [c_void_p] * 3 + [c_int32] + [c_void_p] * 3 + [c_int32, c_int64, c_int32, c_int32, c_float, c_void_p]),
     "hc_bn_act_bwd_reduce": (c_int32, [c_void_p, c_int32] + [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_float, c_void_p]),
     "hc_bn_act_bwd_apply": (c_int32, [c_void_p, c_int32] + [c_void_p] * 6 + [c_int64, c_int32, c_int32, c_float, c_void_p]),
     "hc_nhwc_copy": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int64, c_int32, c_void_p]),
@@ -138,6 +138,16 @@ SIGNATURES = {
                          + [c_void_p] * 7),
     "hc_yolo_loss_bwd": (c_int32, [c_void_p, c_int32, c_int64, c_int64, c_int64] + [c_int32] * 5 + [c_void_p, c_float]
                          + [c_void_p] * 8),
+    "hc_dw3x3_pack": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "hc_dw3x3_fwd": (c_int32, [c_void_p] * 4 + [c_int32] * 5 + [c_void_p]),
+    "hc_dw3x3_dgrad": (c_int32, [c_void_p] * 4 + [c_int32] * 5 + [c_void_p]),
+    "hc_dw3x3_wgrad_ws_bytes": (c_int64, [c_int32]),
+    "hc_dw3x3_wgrad": (c_int32, [c_void_p] * 4 + [c_int32] * 7 + [c_void_p]),
+    "hc_max_fwd": (c_int32, [c_void_p] * 3 + [c_int64, c_void_p]),
+    "hc_max_bwd": (c_int32, [c_void_p] * 5 + [c_int64, c_void_p]),
+    "hc_se_scale_fwd": (c_int32, [c_void_p] * 3 + [c_int64, c_int64, c_int32, c_int32, c_void_p]),
+    "hc_se_scale_bwd_gate": (c_int32, [c_void_p] * 5 + [c_int64, c_int64, c_int32, c_int32, c_void_p]),
+    "hc_se_scale_bwd_apply": (c_int32, [c_void_p] * 5 + [c_int64, c_int64, c_int32, c_int32, c_void_p]),
     "hc_version": (C.c_char_p, []),
 }
 

@@ -23,6 +23,7 @@ SOURCES = {
     "rep_bn.hip": [],
     "optim.hip": [],
     "nhwc_ops.hip": [],
+    "dwconv.hip": [],
     # separate torch kernels in the reference round after every op: no fused multiply-add here
     "pointwise.hip": ["-ffp-contract=off"],
     "losses.hip": ["-ffp-contract=off"],

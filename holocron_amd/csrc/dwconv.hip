@@ -1,0 +1,484 @@
+// Depthwise 3x3 convolution on NHWC bf16 (reference call sites: ReXBlock's groups=C conv,
+// holocron/models/classification/rexnet.py:111-124, and FReLU, holocron/nn/modules/activation.py:58-82).
+// 9 MAC per output element: pure HBM traffic, so everything here is about moving each activation once with
+// 16-byte accesses.  A thread owns 8 channels (one 16-byte chunk) and walks strips of TW output pixels along W;
+// the 3 x (TW*stride + 2) input window of a strip is loaded once and reused by the TW outputs.  The launch keeps a
+// thread's channel group fixed, so the 72 weights stay in registers and the BatchNorm statistics (sum, sum of
+// squares of the fp32 results, like the MFMA conv epilogue) are register running sums flushed once per workgroup.
+#include "common.h"
+#include "../../include/holocron_hip.h"
+
+namespace {
+
+constexpr int DW_THREADS = 256;
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf16lo(v[i]); f[2 * i + 1] = bf16hi(v[i]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// blocks such that (blocks * 256) % cg == 0 (a thread's channel group never changes)
+inline int dw_blocks(long items, int cg, int per_thread) {
+    int a = cg, b = DW_THREADS;
+    while (b) { int t = a % b; a = b; b = t; }
+    const int unit = cg / a;
+    long want = items / ((long)DW_THREADS * per_thread);
+    if (want > 4096) want = 4096;
+    if (want < 1) want = 1;
+    const long k = (want + unit - 1) / unit;
+    return (int)(k * unit);
+}
+
+// per-workgroup reduction of v[S][8] over the threads that share a channel group, then one atomic per (k, c)
+template <int S>
+__device__ __forceinline__ void block_reduce_flush(const float (&v)[S][8], int cg, int C, float* __restrict__ dst, float* __restrict__ lds) {
+    constexpr int STR = S * 8 + 1;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < S; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lds[tid * STR + k * 8 + e] = v[k][e];
+    __syncthreads();
+    const int blockbase = (int)(((long)blockIdx.x * DW_THREADS) % cg);
+    for (int o = tid; o < S * C; o += DW_THREADS) {
+        const int k = o / C, c = o - k * C;
+        const int g = c >> 3, e = c & 7;
+        int first = g - blockbase;
+        if (first < 0) first += cg;
+        float sum = 0.f;
+        for (int t = first; t < DW_THREADS; t += cg) sum += lds[t * STR + k * 8 + e];
+        atomicAdd(dst + (size_t)k * C + c, sum);
+    }
+}
+
+// ---------------------------------------------------------------- forward (and stride-1 data gradient with flipped taps)
+// w: fp32 [9][C] (tap-major).  y[n][oh][ow][c] = sum_t w[t][c] * x[n][oh*S + kh - 1][ow*S + kw - 1][c]
+template <int STRIDE, int TW>
+__global__ __launch_bounds__(DW_THREADS) void dw3x3_fwd_kernel(const u32x4* __restrict__ x, const float* __restrict__ w,
+                                                               u32x4* __restrict__ y, float* __restrict__ stats, int N, int H, int W,
+                                                               int OH, int OW, int C) {
+    extern __shared__ float sred[];
+    const int cg = C / 8;
+    const long gtid = (long)blockIdx.x * DW_THREADS + threadIdx.x;
+    const long nthreads = (long)gridDim.x * DW_THREADS;
+    const int cgi = (int)(gtid % cg);
+    const int strips_w = (OW + TW - 1) / TW;
+    const long nstrips = (long)N * OH * strips_w;
+    float wr[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(w + (size_t)t * C + cgi * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(w + (size_t)t * C + cgi * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wr[t][e] = a[e]; wr[t][4 + e] = b[e]; }
+    }
+    float sv[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sv[0][e] = sv[1][e] = 0.f;
+    constexpr int IWN = (TW - 1) * STRIDE + 3;   // input columns a strip touches
+    for (long s = gtid / cg; s < nstrips; s += nthreads / cg) {
+        const int sw = (int)(s % strips_w);
+        const long r = s / strips_w;
+        const int oh = (int)(r % OH);
+        const long n = r / OH;
+        const int ow0 = sw * TW;
+        float acc[TW][8];
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * STRIDE + kh - 1;
+            if (ih < 0 || ih >= H) continue;
+            const u32x4* row = x + ((n * H + ih) * (long)W) * cg + cgi;
+#pragma unroll
+            for (int c = 0; c < IWN; ++c) {
+                const int iw = ow0 * STRIDE + c - 1;
+                if (iw < 0 || iw >= W) continue;
+                float f[8];
+                unpack8(row[(long)iw * cg], f);
+#pragma unroll
+                for (int j = 0; j < TW; ++j) {
+                    const int kw = c - j * STRIDE;
+                    if (kw < 0 || kw > 2) continue;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[j][e] += wr[kh * 3 + kw][e] * f[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const int ow = ow0 + j;
+            if (ow >= OW) break;
+            y[((n * OH + oh) * (long)OW + ow) * cg + cgi] = pack8(acc[j]);
+            if (stats != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sv[0][e] += acc[j][e]; sv[1][e] += acc[j][e] * acc[j][e]; }
+            }
+        }
+    }
+    if (stats != nullptr) block_reduce_flush<2>(sv, cg, C, stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * C, sred);
+}
+
+// ---------------------------------------------------------------- stride-2 data gradient
+// dx[n][h][w][c] = sum over taps with (h + 1 - kh) and (w + 1 - kw) even of w[kh][kw][c] * dy[n][(h+1-kh)/2][(w+1-kw)/2][c]
+__global__ __launch_bounds__(DW_THREADS) void dw3x3_dgrad_s2_kernel(const u32x4* __restrict__ dy, const float* __restrict__ w,
+                                                                    u32x4* __restrict__ dx, int N, int H, int W, int OH, int OW, int C) {
+    const int cg = C / 8;
+    const long gtid = (long)blockIdx.x * DW_THREADS + threadIdx.x;
+    const long nthreads = (long)gridDim.x * DW_THREADS;
+    const int cgi = (int)(gtid % cg);
+    float wr[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(w + (size_t)t * C + cgi * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(w + (size_t)t * C + cgi * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wr[t][e] = a[e]; wr[t][4 + e] = b[e]; }
+    }
+    const long npix = (long)N * H * W;
+    for (long p = gtid / cg; p < npix; p += nthreads / cg) {
+        const int iw = (int)(p % W);
+        const int ih = (int)((p / W) % H);
+        const long n = p / ((long)W * H);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int t = ih + 1 - kh;
+            if (t < 0 || (t & 1)) continue;
+            const int oh = t >> 1;
+            if (oh >= OH) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int u = iw + 1 - kw;
+                if (u < 0 || (u & 1)) continue;
+                const int ow = u >> 1;
+                if (ow >= OW) continue;
+                float f[8];
+                unpack8(dy[((n * OH + oh) * (long)OW + ow) * cg + cgi], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += wr[kh * 3 + kw][e] * f[e];
+            }
+        }
+        dx[p * cg + cgi] = pack8(acc);
+    }
+}
+
+// ---------------------------------------------------------------- weight gradient
+// dw[replica][t][c] += sum over (n, oh, ow) of dy * x(tap t)
+template <int STRIDE>
+__global__ __launch_bounds__(DW_THREADS) void dw3x3_wgrad_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ dy,
+                                                                 float* __restrict__ dw, int N, int H, int W, int OH, int OW, int C) {
+    extern __shared__ float sred[];
+    const int cg = C / 8;
+    const long gtid = (long)blockIdx.x * DW_THREADS + threadIdx.x;
+    const long nthreads = (long)gridDim.x * DW_THREADS;
+    const int cgi = (int)(gtid % cg);
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    const long npix = (long)N * OH * OW;
+    for (long p = gtid / cg; p < npix; p += nthreads / cg) {
+        const int ow = (int)(p % OW);
+        const int oh = (int)((p / OW) % OH);
+        const long n = p / ((long)OW * OH);
+        float g[8];
+        unpack8(dy[p * cg + cgi], g);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * STRIDE + kh - 1;
+            if (ih < 0 || ih >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * STRIDE + kw - 1;
+                if (iw < 0 || iw >= W) continue;
+                float f[8];
+                unpack8(x[((n * H + ih) * (long)W + iw) * cg + cgi], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[kh * 3 + kw][e] += g[e] * f[e];
+            }
+        }
+    }
+    block_reduce_flush<9>(acc, cg, C, dw + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 9 * C, sred);
+}
+
+// dw OIHW fp32 [C][1][3][3] = sum over replicas of slab [R][9][Cpad]
+__global__ void dw3x3_wgrad_finish_kernel(const float* __restrict__ slab, float* __restrict__ dw, int C, int Cpad, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 9) return;
+    const int c = i / 9, t = i - c * 9;
+    float s = 0.f;
+    for (int r = 0; r < HC_STAT_REPLICAS; ++r) s += slab[((size_t)r * 9 + t) * Cpad + c];
+    dw[i] = accumulate ? dw[i] + s : s;
+}
+// w OIHW fp32 [C][1][3][3] -> tap-major fp32 [9][Cpad] (zero padded), optionally flipped (stride-1 data gradient)
+__global__ void dw3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int C, int Cpad, int flip) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cpad * 9) return;
+    const int t = i / Cpad, c = i - t * Cpad;
+    out[i] = c < C ? w[c * 9 + (flip ? 8 - t : t)] : 0.f;
+}
+
+// elementwise max of two NHWC bf16 tensors (FReLU: max(x, bn(conv(x))), activation.py:79-82) and its gradient split
+__global__ void max_fwd_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b, u32x4* __restrict__ o, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float fa[8], fb[8], fo[8];
+        unpack8(a[i], fa);
+        unpack8(b[i], fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fo[e] = fmaxf(fa[e], fb[e]);
+        o[i] = pack8(fo);
+    }
+}
+__global__ void max_bwd_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b, const u32x4* __restrict__ g,
+                               u32x4* __restrict__ da, u32x4* __restrict__ db, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float fa[8], fb[8], fg[8], oa[8], ob[8];
+        unpack8(a[i], fa);
+        unpack8(b[i], fb);
+        unpack8(g[i], fg);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {   // torch.max(a, b): ties split the gradient evenly
+            const float wa = fa[e] > fb[e] ? 1.f : (fa[e] == fb[e] ? 0.5f : 0.f);
+            oa[e] = fg[e] * wa;
+            ob[e] = fg[e] * (1.f - wa);
+        }
+        da[i] = pack8(oa);
+        db[i] = pack8(ob);
+    }
+}
+
+// ---------------------------------------------------------------- squeeze-excite gate (rexnet.py:63-66) + ReLU6
+// out = relu6(z * sigmoid(l[n][c])) ; z NHWC bf16 [N][HW][C], l bf16 [N][C] (gate logits).  act: 0 none, 6 relu6.
+__global__ __launch_bounds__(DW_THREADS) void se_scale_fwd_kernel(const u32x4* __restrict__ z, const u32x4* __restrict__ l,
+                                                                  u32x4* __restrict__ out, long N, long HW, int C, int act) {
+    const int cg = C / 8;
+    const long total = N * HW * cg;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cg);
+        const long n = i / (HW * cg);
+        float fz[8], fl[8], o[8];
+        unpack8(z[i], fz);
+        unpack8(l[n * cg + c], fl);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-fl[e]));
+            float v = fz[e] * sg;
+            if (act == 6) v = fminf(fmaxf(v, 0.f), 6.f);
+            o[e] = v;
+        }
+        out[i] = pack8(o);
+    }
+}
+// dgate[n][c] = sum_hw g * mask * z (fp32) ; grid (blocks_per_image, N): a thread keeps its channel group
+__global__ __launch_bounds__(DW_THREADS) void se_scale_bwd_reduce_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ z,
+                                                                         const u32x4* __restrict__ l, float* __restrict__ dgate,
+                                                                         long HW, int C, int act) {
+    extern __shared__ float sred[];
+    const int cg = C / 8;
+    const long n = blockIdx.y;
+    const long gtid = (long)blockIdx.x * DW_THREADS + threadIdx.x;
+    const long nthreads = (long)gridDim.x * DW_THREADS;
+    const int cgi = (int)(gtid % cg);
+    float fl[8], sg[8];
+    unpack8(l[n * cg + cgi], fl);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sg[e] = __builtin_amdgcn_rcpf(1.f + __expf(-fl[e]));
+    float sv[1][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sv[0][e] = 0.f;
+    for (long p = gtid / cg; p < HW; p += nthreads / cg) {
+        const long q = (n * HW + p) * cg + cgi;
+        float fg[8], fz[8];
+        unpack8(g[q], fg);
+        unpack8(z[q], fz);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = fz[e] * sg[e];
+            const float m = (act == 6) ? ((v > 0.f && v < 6.f) ? 1.f : 0.f) : 1.f;
+            sv[0][e] += fg[e] * m * fz[e];
+        }
+    }
+    block_reduce_flush<1>(sv, cg, C, dgate + n * C, sred);
+}
+// dl[n][c] = dgate * s (1 - s) (bf16)  — tiny
+__global__ void se_gate_grad_kernel(const float* __restrict__ dgate, const bf16_t* __restrict__ l, bf16_t* __restrict__ dl, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = 1.f / (1.f + __expf(-bf16_to_f32(l[i])));
+    dl[i] = f32_to_bf16(dgate[i] * s * (1.f - s));
+}
+// dz = g * mask * s + dpool[n][c] / HW   (dpool: gradient of the global average pool input, fp32 [N][C])
+__global__ __launch_bounds__(DW_THREADS) void se_scale_bwd_apply_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ z,
+                                                                        const u32x4* __restrict__ l, const float* __restrict__ dpool,
+                                                                        u32x4* __restrict__ dz, long N, long HW, int C, int act) {
+    const int cg = C / 8;
+    const long total = N * HW * cg;
+    const float inv = 1.f / (float)HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cg);
+        const long n = i / (HW * cg);
+        float fg[8], fz[8], fl[8], o[8];
+        unpack8(g[i], fg);
+        unpack8(z[i], fz);
+        unpack8(l[n * cg + c], fl);
+        const float* dp = dpool + n * C + c * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-fl[e]));
+            const float v = fz[e] * sg;
+            const float m = (act == 6) ? ((v > 0.f && v < 6.f) ? 1.f : 0.f) : 1.f;
+            o[e] = fg[e] * m * sg + dp[e] * inv;
+        }
+        dz[i] = pack8(o);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hc_dw3x3_pack(const float* w, float* out, int32_t C, int32_t Cpad, int32_t flip, hc_stream_t stream) {
+    if (w == nullptr || out == nullptr || C <= 0 || Cpad < C || (Cpad % 8) != 0) return HC_ERR_ARG;
+    hipLaunchKernelGGL(dw3x3_pack_kernel, dim3((Cpad * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, out, C, Cpad, flip);
+    return hc_launch_status();
+}
+
+int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride,
+                 hc_stream_t stream) {
+    if (x == nullptr || wpk == nullptr || y == nullptr || C <= 0 || (C % 8) != 0 || (stride != 1 && stride != 2)) return HC_ERR_ARG;
+    const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+    if ((long)N * OH * OW == 0) return HC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int cg = C / 8;
+    const size_t lds = stats != nullptr ? (size_t)DW_THREADS * 17 * sizeof(float) : 0;
+    if (stride == 1) {
+        constexpr int TW = 4;
+        const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
+        hipLaunchKernelGGL((dw3x3_fwd_kernel<1, TW>), dim3(dw_blocks(items, cg, 2)), dim3(DW_THREADS), lds, st, (const u32x4*)x, wpk,
+                           (u32x4*)y, stats, N, H, W, OH, OW, C);
+    } else {
+        constexpr int TW = 2;
+        const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
+        hipLaunchKernelGGL((dw3x3_fwd_kernel<2, TW>), dim3(dw_blocks(items, cg, 2)), dim3(DW_THREADS), lds, st, (const u32x4*)x, wpk,
+                           (u32x4*)y, stats, N, H, W, OH, OW, C);
+    }
+    return hc_launch_status();
+}
+
+int hc_dw3x3_dgrad(const void* dy, const float* wpk, const float* wpk_flipped, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                   int32_t stride, hc_stream_t stream) {
+    if (dy == nullptr || dx == nullptr || C <= 0 || (C % 8) != 0 || (stride != 1 && stride != 2)) return HC_ERR_ARG;
+    if ((long)N * H * W == 0) return HC_OK;
+    if (stride == 1) {   // correlation of dy with the flipped taps
+        if (wpk_flipped == nullptr) return HC_ERR_ARG;
+        return hc_dw3x3_fwd(dy, wpk_flipped, dx, nullptr, N, H, W, C, 1, stream);
+    }
+    if (wpk == nullptr) return HC_ERR_ARG;
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const int cg = C / 8;
+    hipLaunchKernelGGL(dw3x3_dgrad_s2_kernel, dim3(dw_blocks((long)N * H * W * cg, cg, 4)), dim3(DW_THREADS), 0, (hipStream_t)stream,
+                       (const u32x4*)dy, wpk, (u32x4*)dx, N, H, W, OH, OW, C);
+    return hc_launch_status();
+}
+
+int64_t hc_dw3x3_wgrad_ws_bytes(int32_t C) { return (int64_t)HC_STAT_REPLICAS * 9 * C * sizeof(float); }
+
+int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Creal,
+                   int32_t stride, int32_t accumulate, hc_stream_t stream) {
+    if (x == nullptr || dy == nullptr || ws == nullptr || dw == nullptr || C <= 0 || (C % 8) != 0 || Creal <= 0 || Creal > C ||
+        (stride != 1 && stride != 2))
+        return HC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, (size_t)hc_dw3x3_wgrad_ws_bytes(C), st) != hipSuccess) return HC_ERR_LAUNCH;
+    const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+    const int cg = C / 8;
+    const long items = (long)N * OH * OW * cg;
+    if (items > 0) {
+        const size_t lds = (size_t)DW_THREADS * 73 * sizeof(float);
+        if (stride == 1)
+            hipLaunchKernelGGL((dw3x3_wgrad_kernel<1>), dim3(dw_blocks(items, cg, 16)), dim3(DW_THREADS), lds, st, (const u32x4*)x,
+                               (const u32x4*)dy, (float*)ws, N, H, W, OH, OW, C);
+        else
+            hipLaunchKernelGGL((dw3x3_wgrad_kernel<2>), dim3(dw_blocks(items, cg, 16)), dim3(DW_THREADS), lds, st, (const u32x4*)x,
+                               (const u32x4*)dy, (float*)ws, N, H, W, OH, OW, C);
+    }
+    hipLaunchKernelGGL(dw3x3_wgrad_finish_kernel, dim3((Creal * 9 + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, Creal, C,
+                       accumulate);
+    return hc_launch_status();
+}
+
+int hc_max_fwd(const void* a, const void* b, void* out, int64_t nelem, hc_stream_t stream) {
+    if (a == nullptr || b == nullptr || out == nullptr || nelem < 0 || (nelem % 8) != 0) return HC_ERR_ARG;
+    if (nelem == 0) return HC_OK;
+    long blocks = (nelem / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(max_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)a, (const u32x4*)b, (u32x4*)out,
+                       (long)(nelem / 8));
+    return hc_launch_status();
+}
+int hc_max_bwd(const void* a, const void* b, const void* g, void* da, void* db, int64_t nelem, hc_stream_t stream) {
+    if (a == nullptr || b == nullptr || g == nullptr || da == nullptr || db == nullptr || nelem < 0 || (nelem % 8) != 0) return HC_ERR_ARG;
+    if (nelem == 0) return HC_OK;
+    long blocks = (nelem / 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(max_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)a, (const u32x4*)b,
+                       (const u32x4*)g, (u32x4*)da, (u32x4*)db, (long)(nelem / 8));
+    return hc_launch_status();
+}
+
+int hc_se_scale_fwd(const void* z, const void* gate_logits, void* out, int64_t N, int64_t HW, int32_t C, int32_t act, hc_stream_t stream) {
+    if (z == nullptr || gate_logits == nullptr || out == nullptr || C <= 0 || (C % 8) != 0 || (act != 0 && act != 6)) return HC_ERR_ARG;
+    const long total = (long)N * HW * (C / 8);
+    if (total == 0) return HC_OK;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(se_scale_fwd_kernel, dim3((int)blocks), dim3(DW_THREADS), 0, (hipStream_t)stream, (const u32x4*)z,
+                       (const u32x4*)gate_logits, (u32x4*)out, (long)N, (long)HW, C, act);
+    return hc_launch_status();
+}
+int hc_se_scale_bwd_gate(const void* g, const void* z, const void* gate_logits, float* dgate, void* dlogits, int64_t N, int64_t HW,
+                         int32_t C, int32_t act, hc_stream_t stream) {
+    if (g == nullptr || z == nullptr || gate_logits == nullptr || dgate == nullptr || dlogits == nullptr || C <= 0 || (C % 8) != 0 ||
+        (act != 0 && act != 6) || N > 65535)
+        return HC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if ((long)N * C == 0) return HC_OK;
+    if (hipMemsetAsync(dgate, 0, sizeof(float) * (size_t)N * C, st) != hipSuccess) return HC_ERR_LAUNCH;
+    const int cg = C / 8;
+    if (HW > 0) {
+        int bx = dw_blocks((long)HW * cg, cg, 8);
+        hipLaunchKernelGGL(se_scale_bwd_reduce_kernel, dim3(bx, (unsigned)N), dim3(DW_THREADS), DW_THREADS * 9 * sizeof(float), st,
+                           (const u32x4*)g, (const u32x4*)z, (const u32x4*)gate_logits, dgate, (long)HW, C, act);
+    }
+    const long n = (long)N * C;
+    hipLaunchKernelGGL(se_gate_grad_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, st, (const float*)dgate,
+                       (const bf16_t*)gate_logits, (bf16_t*)dlogits, n);
+    return hc_launch_status();
+}
+int hc_se_scale_bwd_apply(const void* g, const void* z, const void* gate_logits, const float* dpool, void* dz, int64_t N, int64_t HW,
+                          int32_t C, int32_t act, hc_stream_t stream) {
+    if (g == nullptr || z == nullptr || gate_logits == nullptr || dpool == nullptr || dz == nullptr || C <= 0 || (C % 8) != 0 ||
+        (act != 0 && act != 6))
+        return HC_ERR_ARG;
+    const long total = (long)N * HW * (C / 8);
+    if (total == 0) return HC_OK;
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(se_scale_bwd_apply_kernel, dim3((int)blocks), dim3(DW_THREADS), 0, (hipStream_t)stream, (const u32x4*)g,
+                       (const u32x4*)z, (const u32x4*)gate_logits, dpool, (u32x4*)dz, (long)N, (long)HW, C, act);
+    return hc_launch_status();
+}
+
+}  // extern "C"

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void rep_bn_finalize_kernel(const hc_rep_bn_de
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         float a = 0.f, mean = 0.f, invstd = 0.f;
-        if (d.gamma[b] != nullptr) {
+        // channels >= c_valid are layout padding: zero affine, no parameters / running statistics behind them
+        if (d.gamma[b] != nullptr && (d.c_valid <= 0 || c < d.c_valid)) {
             if (d.training) {
                 float s1 = 0.f, s2 = 0.f;
                 for (int r = lane; r < HC_STAT_REPLICAS; r += 64) {
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_b
     const int nb = d.has_identity ? 3 : 2;
     for (int b = 0; b < 3; ++b) {
         float A = 0.f, B = 0.f, Cc = 0.f;
-        if (b < nb && d.gamma[b] != nullptr) {
+        if (b < nb && d.gamma[b] != nullptr && (d.c_valid <= 0 || c < d.c_valid)) {
             const float mean = d.save[(2 * b) * d.C + c], invstd = d.save[(2 * b + 1) * d.C + c];
             const float sdzy = rsum[b + 1];
             const float dgamma = invstd * (sdzy - mean * sdz);
@@ -334,9 +335,10 @@ __device__ __forceinline__ float drop_scale(const float* __restrict__ count, lon
 // channels-per-pixel / 8 (the pointer already includes the channel offset).
 template <bool HAS_RES>
 __global__ __launch_bounds__(EW_THREADS) void bn_act_apply_kernel(const u32x4* __restrict__ y, const float* __restrict__ coef,
-                                                                  const u32x4* __restrict__ res, const float* __restrict__ keep,
-                                                                  const float* __restrict__ count, u32x4* __restrict__ out,
-                                                                  int out_ld8, long npix, int C, int act, float slope) {
+                                                                  const u32x4* __restrict__ res, int res_cg,
+                                                                  const float* __restrict__ keep, const float* __restrict__ count,
+                                                                  u32x4* __restrict__ out, int out_ld8, long npix, int C, int act,
+                                                                  float slope) {
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
     const long stride = (long)gridDim.x * EW_THREADS;   // multiple of cg
@@ -351,13 +353,15 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_apply_kernel(const u32x4* _
         const long q = p * cg + cgi;
         float fy[8], fr[8], o[8];
         unpack8(y[q], fy);
-        if (HAS_RES) unpack8(res[q], fr);
+        // the residual may cover only the first res_cg channel groups (ReXBlock: out[:, :Cin] += x, rexnet.py:141)
+        const bool has_r = HAS_RES && cgi < res_cg;
+        if (has_r) unpack8(res[p * res_cg + cgi], fr);
         const float kp = keep != nullptr ? keep[p] * dsc : 1.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float z = act_fwd(a[i] * fy[i] + sh[i], act, slope);
             if (keep != nullptr) z *= kp;
-            if (HAS_RES) z += fr[i];
+            if (has_r) z += fr[i];
             o[i] = z;
         }
         out[p * out_ld8 + cgi] = pack8(o);
@@ -526,19 +530,19 @@ __global__ void pack_weight_multi_kernel(const hc_pack_item* __restrict__ items)
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
         int co, ci, t;
         long dst;
-        if (it.mode == 0) {          // [co][tap][ci]
+        if (it.mode == 0) {          // [co][tap][ci], rows of ld >= Cin elements (zero padding left untouched)
             ci = (int)(o % it.Cin);
             const long r = o / it.Cin;
             t = (int)(r % KK);
             co = (int)(r / KK);
-            dst = ((long)co * it.T + it.tap0 + t) * it.Cin + ci;
+            dst = ((long)co * it.T + it.tap0 + t) * (it.ld > 0 ? it.ld : it.Cin) + ci;
         } else if (it.mode == 1) {   // [ci][flipped tap][co]
             co = (int)(o % it.Cout);
             const long r = o / it.Cout;
             const int tf = (int)(r % KK);
             ci = (int)(r / KK);
             t = KK - 1 - tf;         // flip both kh and kw
-            dst = ((long)ci * it.T + it.tap0 + tf) * it.Cout + co;
+            dst = ((long)ci * it.T + it.tap0 + tf) * (it.ld > 0 ? it.ld : it.Cout) + co;
         } else {                     // [co][tap0 + tap*Cin + ci]
             ci = (int)(o % it.Cin);
             const long r = o / it.Cin;
@@ -681,19 +685,20 @@ int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void*
     return hc_launch_status();
 }
 
-int hc_bn_act_apply(const void* y, const float* coef, const void* res, const float* keep, const float* count, void* out,
-                    int32_t out_ld, int64_t npix, int32_t C, int32_t act, float slope, hc_stream_t stream) {
+int hc_bn_act_apply(const void* y, const float* coef, const void* res, int32_t res_C, const float* keep, const float* count,
+                    void* out, int32_t out_ld, int64_t npix, int32_t C, int32_t act, float slope, hc_stream_t stream) {
     if (y == nullptr || coef == nullptr || out == nullptr || (C % 8) != 0 || (out_ld % 8) != 0 || out_ld < C) return HC_ERR_ARG;
+    if (res != nullptr && (res_C <= 0 || res_C > C || (res_C % 8) != 0)) return HC_ERR_ARG;
     if ((keep == nullptr) != (count == nullptr)) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8);
     hipStream_t st = (hipStream_t)stream;
     if (res != nullptr)
         hipLaunchKernelGGL((bn_act_apply_kernel<true>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)y, coef, (const u32x4*)res,
-                           keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope);
+                           res_C / 8, keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope);
     else
         hipLaunchKernelGGL((bn_act_apply_kernel<false>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)y, coef, (const u32x4*)res,
-                           keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope);
+                           0, keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope);
     return hc_launch_status();
 }
 int hc_bn_act_bwd_reduce(const void* g, int32_t g_ld, const void* y, const float* coef, const float* keep, const float* count,

@@ -142,8 +142,8 @@ class ConvBnActFn(torch.autograd.Function):
         out_ld = cl_ld(out)
         if out_ld is None or tuple(out.shape) != (N, Cout, OH, OW):
             raise _lib.HipError("conv_bn_act: `out` must be an NHWC bf16 view of shape %s" % ((N, Cout, OH, OW),))
-        check(lib.hc_bn_act_apply(ptr(y), ptr(coef), ptr(resc), ptr(keep), ptr(count), ptr(out), out_ld, npix, Cout, act, slope,
-                                  stream()), "hc_bn_act_apply")
+        check(lib.hc_bn_act_apply(ptr(y), ptr(coef), ptr(resc), Cout if resc is not None else 0, ptr(keep), ptr(count), ptr(out),
+                                  out_ld, npix, Cout, act, slope, stream()), "hc_bn_act_apply")
         ctx.drop = (keep, count)
         ctx.st, ctx.meta2 = st, (stride, pad, act, slope, im2col, training)
         ctx.geom = (N, Cin, H, W, Cout, KH, KW, OH, OW)

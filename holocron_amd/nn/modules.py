@@ -6,7 +6,7 @@ from torch import Tensor, nn
 
 from . import functional as F
 
-__all__ = ["HardMish", "GlobalAvgPool2d", "FocalLoss", "DiceLoss", "PolyLoss", "DropBlock2d", "SPP"]
+__all__ = ["HardMish", "GlobalAvgPool2d", "FocalLoss", "DiceLoss", "PolyLoss", "DropBlock2d", "SPP", "FReLU"]
 
 
 class HardMish(nn.Module):
@@ -132,3 +132,22 @@ class SPP(nn.ModuleList):
         if self.kernel_sizes != [5, 9, 13]:
             raise NotImplementedError("the HIP SPP kernel implements the (5, 9, 13) pyramid only")
         return spp_cl(x)
+
+
+class FReLU(nn.Module):
+    """Funnel activation (holocron/nn/modules/activation.py:58-82): ``max(x, bn(depthwise_conv(x)))``.  The depthwise
+    3x3 conv, the BatchNorm passes and the max run on the HIP kernels (channel counts are padded to 16 internally)."""
+
+    def __init__(self, in_channels: int, kernel_size: int = 3) -> None:
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size, padding=kernel_size // 2, groups=in_channels)
+        self.bn = nn.BatchNorm2d(in_channels)
+
+    def forward(self, x: Tensor) -> Tensor:
+        from .mbconv_op import _PadChannelsFn, ceil16, elementwise_max, padded_conv_bn_act
+        if self.conv.kernel_size != (3, 3):
+            raise NotImplementedError("the HIP depthwise kernel implements kernel_size=3 (the FReLU default)")
+        c = x.shape[1]
+        xp = _PadChannelsFn.apply(x, ceil16(c))
+        out = elementwise_max(xp, padded_conv_bn_act(xp, self.conv, self.bn, None))
+        return out if out.shape[1] == c else out[:, :c]

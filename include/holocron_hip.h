@@ -105,7 +105,8 @@ int hc_pack_conv_weight(const float* w, void* wpk, int32_t Cout, int32_t Cin, in
 typedef struct {
     const float* w;
     void* dst;
-    int32_t Cout, Cin, KH, KW, mode, tap0, T, pad_;
+    int32_t Cout, Cin, KH, KW, mode, tap0, T;
+    int32_t ld; /* elements per packed row when the destination is channel padded (mode 0: >= Cin, mode 1: >= Cout); 0 = dense */
 } hc_pack_item;
 int hc_pack_conv_weights_multi(const hc_pack_item* items, int32_t nitems, int64_t max_elems, hc_stream_t stream);
 
@@ -132,6 +133,8 @@ typedef struct {
     int64_t count;             /* N*H*W */
     float eps, momentum;
     int32_t training;          /* 0: use running stats (eval) */
+    int32_t c_valid;           /* > 0: channels >= c_valid are layout padding: a = shift = 0, parameter / running
+                                  statistic arrays hold only c_valid entries */
 } hc_rep_bn_desc;
 int hc_rep_bn_finalize(const hc_rep_bn_desc* d, hc_stream_t stream);
 
@@ -158,6 +161,7 @@ typedef struct {
     int64_t count;
     int32_t has_identity;
     int32_t accumulate;        /* 1: dgamma/dbeta += */
+    int32_t c_valid;           /* > 0: channels >= c_valid are layout padding (A = B = C = 0, nothing written) */
 } hc_rep_bn_bwd_desc;
 int hc_rep_bn_bwd_finalize(const hc_rep_bn_bwd_desc* d, hc_stream_t stream);
 int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void* y1, const void* x,
@@ -175,9 +179,11 @@ int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void*
  * pass when keep/count (outputs of hc_dropblock_mask) are given: out = act(z)*keep*scale [+ res]; pass NULL for none.
  * `out_ld` / `g_ld`: channels per pixel of the buffer the output / incoming gradient lives in (>= C, % 8 == 0; the
  * pointer already includes the channel offset) so that a channel concat (darknetv4.py:115, yolov4.py:137) is
- * written in place by its producers and its gradient is read in place. */
-int hc_bn_act_apply(const void* y, const float* coef, const void* res, const float* keep, const float* count, void* out,
-                    int32_t out_ld, int64_t npix, int32_t C, int32_t act, float slope, hc_stream_t stream);
+ * written in place by its producers and its gradient is read in place.
+ * `res` (optional) has res_C <= C channels per pixel and is added to the first res_C channels (ReXBlock shortcut,
+ * rexnet.py:140-141; res_C == C for the DarkNet residual). */
+int hc_bn_act_apply(const void* y, const float* coef, const void* res, int32_t res_C, const float* keep, const float* count,
+                    void* out, int32_t out_ld, int64_t npix, int32_t C, int32_t act, float slope, hc_stream_t stream);
 int hc_bn_act_bwd_reduce(const void* g, int32_t g_ld, const void* y, const float* coef, const float* keep,
                          const float* count, float* red, int64_t npix, int32_t C, int32_t act, float slope,
                          hc_stream_t stream);
@@ -337,6 +343,36 @@ int hc_yolo_loss_bwd(const void* logits, int32_t dtype, int64_t sn, int64_t sc, 
                      int32_t A, int32_t num_classes, const float* anchors, float scale_xy, const float* gt_boxes,
                      const int64_t* gt_labels, const int32_t* gt_off, const uint8_t* obj_mask, const uint8_t* cell_gt,
                      const float* gcoef, void* dlogits, hc_stream_t stream);
+
+/* ---- depthwise 3x3 convolution, pad 1, stride 1 | 2, NHWC bf16 (ReXBlock, rexnet.py:111-124; FReLU,
+ * nn/modules/activation.py:58-82).  C % 8 == 0 (pad channels carry zero weights).  wpk: fp32 tap-major [9][C] from
+ * hc_dw3x3_pack (flip = 1 gives the taps of the stride-1 data gradient).  fwd optionally accumulates the BatchNorm
+ * statistics sum / sum of squares of the fp32 results into stats [HC_STAT_REPLICAS][2][C] (zeroed by the caller).
+ * wgrad: dw fp32 OIHW [Creal][1][3][3] (= or +=); ws scratch of hc_dw3x3_wgrad_ws_bytes(C). ---- */
+int hc_dw3x3_pack(const float* w, float* out, int32_t C, int32_t Cpad, int32_t flip, hc_stream_t stream);
+int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t N, int32_t H, int32_t W, int32_t C,
+                 int32_t stride, hc_stream_t stream);
+int hc_dw3x3_dgrad(const void* dy, const float* wpk, const float* wpk_flipped, void* dx, int32_t N, int32_t H, int32_t W,
+                   int32_t C, int32_t stride, hc_stream_t stream);
+int64_t hc_dw3x3_wgrad_ws_bytes(int32_t C);
+int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N, int32_t H, int32_t W, int32_t C,
+                   int32_t Creal, int32_t stride, int32_t accumulate, hc_stream_t stream);
+
+/* elementwise max of two NHWC bf16 tensors and its gradient (FReLU: max(x, bn(conv(x))), activation.py:79-82; ties
+ * split the gradient evenly like torch.max). nelem % 8 == 0. */
+int hc_max_fwd(const void* a, const void* b, void* out, int64_t nelem, hc_stream_t stream);
+int hc_max_bwd(const void* a, const void* b, const void* g, void* da, void* db, int64_t nelem, hc_stream_t stream);
+
+/* Squeeze-excite gate of ReXNet (rexnet.py:63-66) fused with the ReLU6 that follows it (rexnet.py:129):
+ * out = act(z * sigmoid(l[n][c])), z NHWC bf16 [N][HW][C], l bf16 [N][C] gate logits, act 0 | 6 (ReLU6).
+ * bwd_gate: dgate fp32 [N][C] = sum_hw g*mask*z and dlogits bf16 [N][C] = dgate * s (1 - s);
+ * bwd_apply: dz = g*mask*s + dpool[n][c] / HW with dpool fp32 [N][C] the gradient of the pooled input. */
+int hc_se_scale_fwd(const void* z, const void* gate_logits, void* out, int64_t N, int64_t HW, int32_t C, int32_t act,
+                    hc_stream_t stream);
+int hc_se_scale_bwd_gate(const void* g, const void* z, const void* gate_logits, float* dgate, void* dlogits, int64_t N,
+                         int64_t HW, int32_t C, int32_t act, hc_stream_t stream);
+int hc_se_scale_bwd_apply(const void* g, const void* z, const void* gate_logits, const float* dpool, void* dz, int64_t N,
+                          int64_t HW, int32_t C, int32_t act, hc_stream_t stream);
 
 const char* hc_version(void);
 

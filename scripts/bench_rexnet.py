@@ -1,0 +1,55 @@
+"""Secondary measurement: rexnet1_0x bf16 training step (fwd + CE + bwd + AdaBelief), synthetic
+224 x 224, per-GPU batch 256, on one MI355X.  Prints one JSON line.
+
+    python scripts/bench_rexnet.py --batch 256 --steps 10 --warmup 3
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import holocron_amd as h  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = h.models.rexnet1_0x().to(dev).train()
+    opt = h.optim.AdaBelief(m.parameters(), lr=1e-3, betas=(0.95, 0.99), eps=1e-6, weight_decay=0)
+    x = torch.rand((a.batch, 3, 224, 224), device=dev)
+    t = torch.randint(0, 1000, (a.batch,), device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(m(x).float(), t)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(a.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    # algorithmic HBM bytes/img fwd >= 30 MB (bf16, BN/act fused); train ~ 3.5x
+    print(json.dumps({"metric": "images/sec train step (fwd+CE+bwd+AdaBelief), rexnet1_0x 224^2", "value": a.batch / dt,
+                      "unit": "img/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3, "dtype": "bf16",
+                      "data": "synthetic", "config": {"workload": f"rexnet1_0x 224^2 bs{a.batch}"},
+                      "hbm_floor_ms": 30e6 * 3.5 * a.batch / 6.29e12 * 1e3, "loss": float(loss),
+                      "peak_mem_GB": torch.cuda.max_memory_allocated() / 2**30}))
+
+
+if __name__ == "__main__":
+    main()

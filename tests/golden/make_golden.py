@@ -375,6 +375,65 @@ def gen_yolo():
                                "running": rstats, "n_detections": [int(d["boxes"].shape[0]) for d in dets]}})
 
 
+def gen_rexnet():
+    """Reference ReXBlocks (with / without expansion, squeeze-excite, stride 2, partial-width shortcut), FReLU, and one
+    training step of rexnet1_0x whose weights are reproducible from the seed."""
+    import importlib
+    rx = importlib.import_module("ref_holocron.models.classification.rexnet")
+    g = torch.Generator().manual_seed(53)
+    blocks = []
+    for (cin, c, t, stride, se, hw) in [(32, 16, 1, 1, False, 12), (16, 27, 6, 2, False, 12), (38, 50, 6, 2, True, 10),
+                                        (50, 61, 6, 1, True, 7), (61, 61, 6, 1, True, 5)]:
+        torch.manual_seed(cin + c)
+        blk = rx.ReXBlock(cin, c, t, stride, use_se=se)
+        ref.nn.init.init_module(blk, "relu")
+        _randomize_bn(blk, g)
+        for p in blk.parameters():
+            if p.dim() == 4:
+                p.data = bf16r(p.data)
+        sd0 = {k: v.clone() for k, v in blk.state_dict().items()}
+        x = bf16r(torch.randn((3, cin, hw, hw), generator=g)).requires_grad_(True)
+        blk.train()
+        out = blk(x)
+        r = bf16r(torch.randn(out.shape, generator=g))
+        names = [n for n, _ in blk.named_parameters()]
+        grads = torch.autograd.grad((out * r).sum(), [x] + list(blk.parameters()))
+        blocks.append({"cfg": (cin, c, t, stride, se), "state": sd0, "x": x.detach(), "r": r, "out": out.detach(), "dx": grads[0],
+                       "dparams": dict(zip(names, grads[1:])),
+                       "state_after": {k: v.clone() for k, v in blk.state_dict().items() if "running" in k or "tracked" in k}})
+    torch.manual_seed(7)
+    fr = ref.nn.FReLU(24)
+    _randomize_bn(fr, g)
+    fr.conv.bias.data = torch.randn((24,), generator=g) * 0.3
+    sd0 = {k: v.clone() for k, v in fr.state_dict().items()}
+    x = bf16r(torch.randn((2, 24, 9, 9), generator=g)).requires_grad_(True)
+    fr.train()
+    out = fr(x)
+    r = bf16r(torch.randn(out.shape, generator=g))
+    names = [n for n, _ in fr.named_parameters()]
+    grads = torch.autograd.grad((out * r).sum(), [x] + list(fr.parameters()))
+    frelu = {"state": sd0, "x": x.detach(), "r": r, "out": out.detach(), "dx": grads[0], "dparams": dict(zip(names, grads[1:])),
+             "state_after": {k: v.clone() for k, v in fr.state_dict().items()}}
+    torch.manual_seed(51)
+    m = rx.rexnet1_0x(num_classes=10, dropout_ratio=0.0)
+    x = bf16r(torch.rand((4, 3, 96, 96), generator=g))
+    t = torch.randint(0, 10, (4,), generator=g)
+    m.train()
+    logits = m(x)
+    loss = torch.nn.functional.cross_entropy(logits, t)
+    loss.backward()
+    params = dict(m.named_parameters())
+    keep = ["features.0.weight", "features.1.weight", "features.3.conv.0.weight", "features.4.conv.0.weight", "features.6.conv.3.weight",
+            "features.6.conv.5.conv.0.weight", "features.6.conv.5.conv.3.bias", "features.10.conv.7.weight", "features.18.conv.4.weight",
+            "features.20.weight", "head.1.weight", "head.1.bias"]
+    save("rexnet.pt", {"blocks": blocks, "frelu": frelu,
+                       "model": {"seed": 51, "num_classes": 10, "x": x, "target": t, "logits": logits.detach(), "loss": loss.detach(),
+                                 "grads": {n: params[n].grad.clone() for n in keep},
+                                 "grad_norms": {n: float(p.grad.norm()) for n, p in params.items()},
+                                 "running": {k: v.clone() for k, v in m.state_dict().items()
+                                             if k.endswith("running_mean") or k.endswith("running_var")}}})
+
+
 def gen_nms():
     """torchvision.ops.nms is absent: these vectors come from the restated algorithm (oracle/tv_ops.py),
     plus the two situations the reference's own tests pin (tests/test_models_detection.py:158-163: disjoint
@@ -398,6 +457,6 @@ def gen_nms():
 
 if __name__ == "__main__":
     gens = {"boxes": gen_boxes, "functional": gen_functional, "optim": gen_optim, "repblock": gen_repblock,
-            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "nms": gen_nms}
+            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "nms": gen_nms}
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()

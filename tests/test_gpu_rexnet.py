@@ -1,0 +1,134 @@
+"""MI355X parity tests of the depthwise / squeeze-excite / channel-padded units, FReLU and ReXNet
+(reference: holocron/models/classification/rexnet.py, holocron/nn/modules/activation.py:58-82)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import close_frac, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).float()
+
+
+def test_depthwise_conv_kernels_vs_torch():
+    """hc_dw3x3_{fwd,dgrad,wgrad} through the padded conv unit with an identity BatchNorm (eval mode is not enough:
+    training statistics are part of the kernel), stride 1 and 2, channel counts that need padding."""
+    import holocron_amd as h
+    from holocron_amd.nn.mbconv_op import padded_conv_bn_act
+    g = torch.Generator().manual_seed(3)
+    for (Cc, H, W, stride) in [(24, 9, 7, 1), (40, 12, 10, 2), (162, 6, 5, 1), (16, 5, 5, 2)]:
+        conv = torch.nn.Conv2d(Cc, Cc, 3, stride, 1, groups=Cc, bias=False)
+        bn = torch.nn.BatchNorm2d(Cc)
+        conv.weight.data = torch.randn(conv.weight.shape, generator=g) * 0.3
+        bn.weight.data = torch.rand((Cc,), generator=g) + 0.5
+        bn.bias.data = torch.randn((Cc,), generator=g) * 0.2
+        x = _bf16(torch.randn((3, Cc, H, W), generator=g))
+        xr = x.clone().requires_grad_(True)
+        yr = F.relu6(bn(conv(xr)))
+        r = _bf16(torch.randn(yr.shape, generator=g))
+        gr = torch.autograd.grad((yr * r).sum(), [xr, conv.weight, bn.weight, bn.bias])
+        rm_ref = bn.running_mean.clone()
+        import copy
+        cg, bg = copy.deepcopy(conv).cuda(), torch.nn.BatchNorm2d(Cc).cuda()
+        bg.weight.data, bg.bias.data = bn.weight.data.cuda(), bn.bias.data.cuda()
+        xg = x.cuda().requires_grad_(True)
+        y = padded_conv_bn_act(xg, cg, bg, torch.nn.ReLU6())
+        Cp = (Cc + 15) // 16 * 16
+        assert y.shape[1] == Cp and (Cp == Cc or float(y[:, Cc:].detach().float().abs().max()) == 0.0)
+        assert rel_l2(y[:, :Cc].float().cpu(), yr.detach()) < 6e-3
+        (y[:, :Cc].float() * r.cuda()).sum().backward()
+        assert rel_l2(xg.grad.float().cpu(), gr[0]) < 2e-2
+        assert rel_l2(cg.weight.grad.cpu(), gr[1]) < 2e-2
+        assert rel_l2(bg.weight.grad.cpu(), gr[2]) < 3e-2 and rel_l2(bg.bias.grad.cpu(), gr[3]) < 2e-2
+        assert rel_l2(bg.running_mean.cpu(), rm_ref) < 2e-3
+
+
+def _run_block_case(c):
+    import holocron_amd as h
+    from oracle import rexnet as orx
+    cin, cout, t, stride, se = c["cfg"]
+    blk = h.models.ReXBlock(cin, cout, t, stride, use_se=se)
+    blk.load_state_dict(c["state"])
+    blk = blk.cuda().train()
+    x = c["x"].cuda().requires_grad_(True)
+    out = blk(x)
+    assert out.shape == c["out"].shape
+    # sharp check: the bf16-emulating oracle on the same inputs
+    sd = {"b." + k: v.clone() for k, v in c["state"].items()}
+    names = list(c["dparams"])
+    leaves = [sd["b." + n].requires_grad_(True) for n in names]
+    xe = c["x"].clone().requires_grad_(True)
+    oe = orx.rex_block(xe, sd, "b", stride, stride == 1 and cin <= cout, True, emu=True)
+    ge = torch.autograd.grad((oe * c["r"]).sum(), [xe] + leaves)
+    assert rel_l2(out.float().cpu(), oe.detach()) < 1e-2, (c["cfg"], rel_l2(out.float().cpu(), oe.detach()))
+    assert rel_l2(out.float().cpu(), c["out"]) < 3e-2            # and the fp32 reference itself
+    (out.float() * c["r"].cuda()).sum().backward()
+    assert rel_l2(x.grad.float().cpu(), ge[0]) < 5e-2, (c["cfg"], "dx", rel_l2(x.grad.float().cpu(), ge[0]))
+    params = dict(blk.named_parameters())
+    for n, gg in zip(names, ge[1:]):
+        if float(gg.abs().max()) < 1e-6:
+            continue
+        e = rel_l2(params[n].grad.float().cpu(), gg)
+        assert e < 6e-2, (c["cfg"], n, e)
+        assert rel_l2(params[n].grad.float().cpu(), c["dparams"][n]) < 0.15, (c["cfg"], n)
+    for k, v in c["state_after"].items():
+        if "running" in k:
+            assert rel_l2(blk.state_dict()[k].cpu(), v) < 1e-2, k
+
+
+def test_rexblocks_match_reference_and_bf16_oracle(golden):
+    for c in golden("rexnet.pt")["blocks"]:
+        _run_block_case(c)
+
+
+def test_frelu_matches_reference(golden):
+    import holocron_amd as h
+    f = golden("rexnet.pt")["frelu"]
+    m = h.nn.FReLU(24)
+    m.load_state_dict(f["state"])
+    m = m.cuda().train()
+    x = f["x"].cuda().requires_grad_(True)
+    out = m(x)
+    assert out.shape == f["out"].shape
+    assert rel_l2(out.float().cpu(), f["out"]) < 5e-3
+    (out.float() * f["r"].cuda()).sum().backward()
+    # max(x, t) has a kink at x == t: where bf16 rounding of t flips the selection the gradient moves by O(1)
+    assert close_frac(x.grad.float().cpu(), f["dx"], 2e-2, 2e-2) > 0.97, rel_l2(x.grad.float().cpu(), f["dx"])
+    params = dict(m.named_parameters())
+    for n, gg in f["dparams"].items():
+        if float(gg.abs().max()) < 1e-4:     # the conv bias in front of a training-mode BatchNorm has no gradient
+            assert float(params[n].grad.abs().max()) < 1e-4
+            continue
+        assert rel_l2(params[n].grad.float().cpu(), gg) < 8e-2, (n, rel_l2(params[n].grad.float().cpu(), gg))
+    assert rel_l2(m.bn.running_mean.cpu(), f["state_after"]["bn.running_mean"]) < 2e-3
+    # tests/test_nn_activation.py: output shape equals input shape, for channel counts that need padding too
+    assert h.nn.FReLU(3).cuda()(torch.rand(2, 3, 8, 8).cuda()).shape == (2, 3, 8, 8)
+
+
+def test_rexnet1_0x_train_step_matches_reference(golden):
+    import holocron_amd as h
+    gm = golden("rexnet.pt")["model"]
+    torch.manual_seed(gm["seed"])
+    m = h.models.rexnet1_0x(num_classes=gm["num_classes"], dropout_ratio=0.0).cuda().train()
+    logits = m(gm["x"].cuda())
+    assert logits.shape == gm["logits"].shape
+    # 50 conv units deep with batch statistics over 4 x 3 x 3 positions at the end: bf16 storage rounding is amplified
+    # to the 10 % level at the logits (the bf16-emulating oracle deviates from the fp32 reference just as much); the
+    # sharp comparisons are the per-block tests above
+    assert rel_l2(logits.float().cpu(), gm["logits"]) < 0.25, rel_l2(logits.float().cpu(), gm["logits"])
+    loss = F.cross_entropy(logits.float(), gm["target"].cuda())
+    assert abs(float(loss) - float(gm["loss"])) < 0.1 * float(gm["loss"])
+    loss.backward()
+    params = dict(m.named_parameters())
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params.values())
+    for n in ("head.1.weight", "head.1.bias"):
+        got, ref = params[n].grad.float().cpu(), gm["grads"][n]
+        assert float(F.cosine_similarity(got.flatten(), ref.flatten(), dim=0)) > 0.95, n
+    for n in ("features.1.running_mean", "features.3.conv.1.running_var"):
+        assert rel_l2(m.state_dict()[n].cpu(), gm["running"][n]) < 1e-2, n
+    m.eval()
+    with torch.no_grad():
+        assert m(gm["x"].cuda()).shape == (4, 10)
