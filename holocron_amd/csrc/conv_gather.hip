@@ -244,6 +244,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[mr][nr][4 * q + e];
+                if (d.pix_scale != nullptr) {   // NormConv2d: rstd_p * (sum_k W p_k - mean_p * sum_k W)  (functional.py:345-349)
+                    const float ps = d.pix_scale[pix], pm = d.pix_shift[pix];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < Cout) v[e] = ps * (v[e] - pm * d.ch_coef[co + e]);
+                }
                 if (d.bias != nullptr) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)

@@ -345,6 +345,63 @@ __global__ __launch_bounds__(DW_THREADS) void se_scale_bwd_apply_kernel(const u3
     }
 }
 
+// ---------------------------------------------------------------- NormConv2d helpers (functional.py:322-413)
+// one wave per output pixel: lanes stride over (tap, 16-byte channel chunk)
+__global__ __launch_bounds__(DW_THREADS) void patch_stats_kernel(const u32x4* __restrict__ x, int ld8, float* __restrict__ mean,
+                                                                 float* __restrict__ rstd, int N, int H, int W, int OH, int OW, int C,
+                                                                 int KH, int KW, int stride, int pad, float eps) {
+    const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const long npix = (long)N * OH * OW;
+    if (pix >= npix) return;
+    const int ow = (int)(pix % OW), oh = (int)((pix / OW) % OH);
+    const long n = pix / ((long)OW * OH);
+    const int cg = (C + 7) / 8;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < KH * KW * cg; i += 64) {
+        const int t = i / cg, c = i - t * cg;
+        const int ih = oh * stride + t / KW - pad, iw = ow * stride + t % KW - pad;
+        if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+        float f[8];
+        unpack8(x[((n * H + ih) * (long)W + iw) * ld8 + c], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (c * 8 + e < C) { s1 += f[e]; s2 += f[e] * f[e]; }
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        const float k = (float)(C * KH * KW);
+        const float m = s1 / k;
+        float var = s2 / k - m * m;
+        var = var > 0.f ? var : 0.f;
+        mean[pix] = m;
+        rstd[pix] = rsqrtf(var + eps);
+    }
+}
+__global__ __launch_bounds__(DW_THREADS) void normconv_bwd_scale_kernel(const u32x4* __restrict__ g, const float* __restrict__ mean,
+                                                                        const float* __restrict__ rstd, u32x4* __restrict__ gs,
+                                                                        float* __restrict__ red, long npix, int C) {
+    extern __shared__ float sred[];
+    const int cg = C / 8;
+    const long gtid = (long)blockIdx.x * DW_THREADS + threadIdx.x;
+    const long nthreads = (long)gridDim.x * DW_THREADS;
+    const int cgi = (int)(gtid % cg);
+    float sv[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sv[0][e] = sv[1][e] = 0.f;
+    for (long p = gtid / cg; p < npix; p += nthreads / cg) {
+        float f[8], o[8];
+        unpack8(g[p * cg + cgi], f);
+        const float r = rstd[p], rm = r * mean[p];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o[e] = f[e] * r; sv[0][e] += f[e]; sv[1][e] += f[e] * rm; }
+        gs[p * cg + cgi] = pack8(o);
+    }
+    block_reduce_flush<2>(sv, cg, C, red + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * C, sred);
+}
+
 }  // namespace
 
 extern "C" {
@@ -478,6 +535,28 @@ int hc_se_scale_bwd_apply(const void* g, const void* z, const void* gate_logits,
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(se_scale_bwd_apply_kernel, dim3((int)blocks), dim3(DW_THREADS), 0, (hipStream_t)stream, (const u32x4*)g,
                        (const u32x4*)z, (const u32x4*)gate_logits, dpool, (u32x4*)dz, (long)N, (long)HW, C, act);
+    return hc_launch_status();
+}
+
+int hc_patch_stats(const void* x, int32_t x_ld, float* mean, float* rstd, int32_t N, int32_t H, int32_t W, int32_t C, int32_t KH,
+                   int32_t KW, int32_t stride, int32_t pad, float eps, hc_stream_t stream) {
+    if (x == nullptr || mean == nullptr || rstd == nullptr || C <= 0 || x_ld < C || (x_ld % 8) != 0 || KH < 1 || KW < 1 || stride < 1 ||
+        pad < 0)
+        return HC_ERR_ARG;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    const long npix = (long)N * OH * OW;
+    if (npix <= 0) return HC_OK;
+    hipLaunchKernelGGL(patch_stats_kernel, dim3((unsigned)((npix + 3) / 4)), dim3(DW_THREADS), 0, (hipStream_t)stream, (const u32x4*)x,
+                       x_ld / 8, mean, rstd, N, H, W, OH, OW, C, KH, KW, stride, pad, eps);
+    return hc_launch_status();
+}
+int hc_normconv_bwd_scale(const void* g, const float* mean, const float* rstd, void* gs, float* red, int64_t npix, int32_t C,
+                          hc_stream_t stream) {
+    if (g == nullptr || mean == nullptr || rstd == nullptr || gs == nullptr || red == nullptr || C <= 0 || (C % 8) != 0) return HC_ERR_ARG;
+    if (npix == 0) return HC_OK;
+    const int cg = C / 8;
+    hipLaunchKernelGGL(normconv_bwd_scale_kernel, dim3(dw_blocks((long)npix * cg, cg, 8)), dim3(DW_THREADS),
+                       DW_THREADS * 17 * sizeof(float), (hipStream_t)stream, (const u32x4*)g, mean, rstd, (u32x4*)gs, red, (long)npix, C);
     return hc_launch_status();
 }
 

@@ -172,6 +172,78 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const u32x4* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- SlimConv2d gate + fold (nn/modules/conv.py:352-364)
+// x NHWC bf16 [N][HW][ld] with C real channels, l bf16 [N][lld] gate logits, s = sigmoid(l), h = C / 2:
+//   top[j] = x[j] s[j] + x[j+h] s[j+h] ;  bot[j] = x[j] s[C-1-j] + x[j+h] s[C-1-j-h]      (w.flip(dims=(1,)))
+// outputs NHWC bf16 with old channels per pixel (pad channels are written as zeros).  Scalar 2-byte accesses: the
+// fold pairs channel j with j + C/2, which is not 16-byte friendly for the small widths this layer is used at.
+__global__ void slim_fold_fwd_kernel(const bf16_t* __restrict__ x, int ld, const bf16_t* __restrict__ l, int lld,
+                                     bf16_t* __restrict__ top, bf16_t* __restrict__ bot, int old, long N, long HW, int C) {
+    const int h = C / 2;
+    const long total = N * HW * old;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % old);
+        const long p = i / old;
+        const long n = p / HW;
+        float t = 0.f, b = 0.f;
+        if (j < h) {
+            const bf16_t* px = x + p * ld;
+            const bf16_t* pl = l + n * lld;
+            const float x0 = bf16_to_f32(px[j]), x1 = bf16_to_f32(px[j + h]);
+            const float s0 = 1.f / (1.f + __expf(-bf16_to_f32(pl[j]))), s1 = 1.f / (1.f + __expf(-bf16_to_f32(pl[j + h])));
+            const float f0 = 1.f / (1.f + __expf(-bf16_to_f32(pl[C - 1 - j]))), f1 = 1.f / (1.f + __expf(-bf16_to_f32(pl[C - 1 - j - h])));
+            t = x0 * s0 + x1 * s1;
+            b = x0 * f0 + x1 * f1;
+        }
+        top[i] = f32_to_bf16(t);
+        bot[i] = f32_to_bf16(b);
+    }
+}
+// ds[n][c] = sum_hw gtop[c mod h] x[c] + gbot[(C-1-c) mod h] x[C-1-c] ; dl = ds * s (1 - s).  one block per (n, c)
+__global__ __launch_bounds__(256) void slim_fold_bwd_gate_kernel(const bf16_t* __restrict__ x, int ld, const bf16_t* __restrict__ l,
+                                                                 int lld, const bf16_t* __restrict__ gtop,
+                                                                 const bf16_t* __restrict__ gbot, int old, bf16_t* __restrict__ dl,
+                                                                 long HW, int C) {
+    const int c = blockIdx.x;
+    const long n = blockIdx.y;
+    const int h = C / 2;
+    const int cf = C - 1 - c;
+    float acc = 0.f;
+    for (long q = threadIdx.x; q < HW; q += blockDim.x) {
+        const long p = n * HW + q;
+        acc += bf16_to_f32(gtop[p * old + (c % h)]) * bf16_to_f32(x[p * ld + c]) +
+               bf16_to_f32(gbot[p * old + (cf % h)]) * bf16_to_f32(x[p * ld + cf]);
+    }
+    acc = wave_sum(acc);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float s = 1.f / (1.f + __expf(-bf16_to_f32(l[n * lld + c])));
+        dl[n * lld + c] = f32_to_bf16((sh[0] + sh[1] + sh[2] + sh[3]) * s * (1.f - s));
+    }
+}
+// dx[c] = gtop[c mod h] s[c] + gbot[c mod h] s[C-1-c] + dpool[n][c] / HW   (pad channels: 0)
+__global__ void slim_fold_bwd_apply_kernel(const bf16_t* __restrict__ l, int lld, const bf16_t* __restrict__ gtop,
+                                           const bf16_t* __restrict__ gbot, int old, const float* __restrict__ dpool, int dld,
+                                           bf16_t* __restrict__ dx, int ld, long N, long HW, int C) {
+    const int h = C / 2;
+    const long total = N * HW * ld;
+    const float inv = 1.f / (float)HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ld);
+        const long p = i / ld;
+        const long n = p / HW;
+        float v = 0.f;
+        if (c < C) {
+            const bf16_t* pl = l + n * lld;
+            const float s = 1.f / (1.f + __expf(-bf16_to_f32(pl[c]))), f = 1.f / (1.f + __expf(-bf16_to_f32(pl[C - 1 - c])));
+            v = bf16_to_f32(gtop[p * old + (c % h)]) * s + bf16_to_f32(gbot[p * old + (c % h)]) * f + dpool[n * dld + c] * inv;
+        }
+        dx[i] = f32_to_bf16(v);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -220,6 +292,42 @@ int hc_spp_bwd(const void* g, const void* idx, void* dx, int32_t N, int32_t H, i
     if ((long)N * H * W == 0) return HC_OK;
     hipLaunchKernelGGL(spp_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
                        (const u32x4*)g, (const u32x2*)idx, (u32x4*)dx, N, H, W, C / 8);
+    return hc_launch_status();
+}
+
+int hc_slim_fold_fwd(const void* x, int32_t x_ld, const void* gate_logits, int32_t l_ld, void* top, void* bot, int32_t out_ld, int64_t N,
+                     int64_t HW, int32_t C, hc_stream_t stream) {
+    if (x == nullptr || gate_logits == nullptr || top == nullptr || bot == nullptr || C < 2 || (C & 1) || x_ld < C || l_ld < C ||
+        out_ld < C / 2)
+        return HC_ERR_ARG;
+    const long total = (long)N * HW * out_ld;
+    if (total == 0) return HC_OK;
+    hipLaunchKernelGGL(slim_fold_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_ld,
+                       (const bf16_t*)gate_logits, l_ld, (bf16_t*)top, (bf16_t*)bot, out_ld, (long)N, (long)HW, C);
+    return hc_launch_status();
+}
+int hc_slim_fold_bwd_gate(const void* x, int32_t x_ld, const void* gate_logits, int32_t l_ld, const void* gtop, const void* gbot,
+                          int32_t out_ld, void* dlogits, int64_t N, int64_t HW, int32_t C, hc_stream_t stream) {
+    if (x == nullptr || gate_logits == nullptr || gtop == nullptr || gbot == nullptr || dlogits == nullptr || C < 2 || (C & 1) ||
+        x_ld < C || l_ld < C || out_ld < C / 2 || N > 65535)
+        return HC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if ((long)N * l_ld == 0) return HC_OK;
+    if (hipMemsetAsync(dlogits, 0, (size_t)N * l_ld * 2, st) != hipSuccess) return HC_ERR_LAUNCH;
+    hipLaunchKernelGGL(slim_fold_bwd_gate_kernel, dim3(C, (unsigned)N), dim3(256), 0, st, (const bf16_t*)x, x_ld,
+                       (const bf16_t*)gate_logits, l_ld, (const bf16_t*)gtop, (const bf16_t*)gbot, out_ld, (bf16_t*)dlogits, (long)HW, C);
+    return hc_launch_status();
+}
+int hc_slim_fold_bwd_apply(const void* gate_logits, int32_t l_ld, const void* gtop, const void* gbot, int32_t out_ld, const float* dpool,
+                           int32_t dpool_ld, void* dx, int32_t x_ld, int64_t N, int64_t HW, int32_t C, hc_stream_t stream) {
+    if (gate_logits == nullptr || gtop == nullptr || gbot == nullptr || dpool == nullptr || dx == nullptr || C < 2 || (C & 1) ||
+        x_ld < C || l_ld < C || out_ld < C / 2 || dpool_ld < C)
+        return HC_ERR_ARG;
+    const long total = (long)N * HW * x_ld;
+    if (total == 0) return HC_OK;
+    hipLaunchKernelGGL(slim_fold_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)gate_logits, l_ld, (const bf16_t*)gtop, (const bf16_t*)gbot, out_ld, dpool, dpool_ld, (bf16_t*)dx,
+                       x_ld, (long)N, (long)HW, C);
     return hc_launch_status();
 }
 

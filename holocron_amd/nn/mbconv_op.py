@@ -375,3 +375,55 @@ def padded_conv_bias(x, conv):
     if x.shape[1] != cin_p or cl_ld(x) != cin_p:
         x = _PadChannelsFn.apply(x, cin_p)
     return PadConvBiasFn.apply(x, conv.weight, conv.bias, st, (conv.stride[0], conv.padding[0]))
+
+
+class SlimGateFn(torch.autograd.Function):
+    """SlimConv2d's channel gate and fold (nn/modules/conv.py:352-364): returns the two half-width tensors
+    ``fold(x * w)`` and ``fold(x * flip(w))`` with ``w = sigmoid(mlp(mean_hw(x)))`` as channel-padded NHWC bf16.  Like
+    SeGateFn the tiny gate network runs in a private autograd graph differentiated inside this node's backward."""
+
+    @staticmethod
+    def forward(ctx, x, mlp, channels):
+        lib = _lib.load()
+        N, Cp, H, W = x.shape
+        h = channels // 2
+        hp = ceil16(h)
+        pooled = torch.empty((N, Cp), dtype=torch.float32, device=x.device)
+        check(lib.hc_gap_fwd(ptr(x), ptr(pooled), N, H * W, Cp, stream()), "hc_gap_fwd")
+        with torch.enable_grad():
+            p_in = pooled.to(torch.bfloat16).view(N, Cp, 1, 1).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            logits = mlp(p_in)
+        lg = logits.detach().reshape(N, -1).contiguous()
+        if lg.dtype != torch.bfloat16 or lg.shape[1] < channels:
+            raise _lib.HipError("SlimConv2d gate must return bf16 logits for every channel")
+        top, bot = cv.empty_cl(N, hp, H, W, x.device), cv.empty_cl(N, hp, H, W, x.device)
+        check(lib.hc_slim_fold_fwd(ptr(x), Cp, ptr(lg), lg.shape[1], ptr(top), ptr(bot), hp, N, H * W, channels, stream()),
+              "hc_slim_fold_fwd")
+        ctx.graph = (p_in, logits)
+        ctx.channels = channels
+        ctx.save_for_backward(x, lg)
+        return top, bot
+
+    @staticmethod
+    def backward(ctx, gtop, gbot):
+        x, lg = ctx.saved_tensors
+        p_in, logits = ctx.graph
+        ctx.graph = None
+        lib = _lib.load()
+        N, Cp, H, W = x.shape
+        Cc = ctx.channels
+        hp = ceil16(Cc // 2)
+
+        def dense(g):
+            g = cv.to_cl_bf16(g)
+            return g if cl_ld(g) == hp else g.contiguous(memory_format=torch.channels_last)
+        gtop, gbot = dense(gtop), dense(gbot)
+        dl = torch.empty_like(lg)
+        check(lib.hc_slim_fold_bwd_gate(ptr(x), Cp, ptr(lg), lg.shape[1], ptr(gtop), ptr(gbot), hp, ptr(dl), N, H * W, Cc, stream()),
+              "hc_slim_fold_bwd_gate")
+        torch.autograd.backward(logits, dl.view(logits.shape).to(logits.dtype))
+        dpool = p_in.grad.reshape(N, Cp).float().contiguous()
+        dx = torch.empty_like(x)
+        check(lib.hc_slim_fold_bwd_apply(ptr(lg), lg.shape[1], ptr(gtop), ptr(gbot), hp, ptr(dpool), Cp, ptr(dx), Cp, N, H * W, Cc,
+                                         stream()), "hc_slim_fold_bwd_apply")
+        return dx, None, None

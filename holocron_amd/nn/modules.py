@@ -6,7 +6,7 @@ from torch import Tensor, nn
 
 from . import functional as F
 
-__all__ = ["HardMish", "GlobalAvgPool2d", "FocalLoss", "DiceLoss", "PolyLoss", "DropBlock2d", "SPP", "FReLU"]
+__all__ = ["HardMish", "GlobalAvgPool2d", "FocalLoss", "DiceLoss", "PolyLoss", "DropBlock2d", "SPP", "FReLU", "SlimConv2d", "NormConv2d"]
 
 
 class HardMish(nn.Module):
@@ -151,3 +151,56 @@ class FReLU(nn.Module):
         xp = _PadChannelsFn.apply(x, ceil16(c))
         out = elementwise_max(xp, padded_conv_bn_act(xp, self.conv, self.bn, None))
         return out if out.shape[1] == c else out[:, :c]
+
+
+class SlimConv2d(nn.Module):
+    """SlimConv2d (holocron/nn/modules/conv.py:262-370): channel gate from the pooled input, "fold" of the two halves
+    weighted by the gate / the flipped gate, a kxk conv on the top path and 1x1 -> kxk on the bottom path, concatenated
+    to 3C/4 channels.  Gate + fold is one kernel (hc_slim_fold_*), the convolutions are the padded gather-conv units."""
+
+    def __init__(self, in_channels: int, kernel_size: int, stride: int = 1, padding: int = 0, dilation: int = 1, groups: int = 1,
+                 bias: bool = True, padding_mode: str = "zeros", r: int = 32, L: int = 2) -> None:  # noqa: N803
+        super().__init__()
+        self.fc1 = nn.Conv2d(in_channels, max(in_channels // r, L), 1)
+        self.bn = nn.BatchNorm2d(max(in_channels // r, L))
+        self.fc2 = nn.Conv2d(max(in_channels // r, L), in_channels, 1)
+        self.conv_top = nn.Conv2d(in_channels // 2, in_channels // 2, kernel_size, stride, padding, dilation, groups, bias, padding_mode)
+        self.conv_bot1 = nn.Conv2d(in_channels // 2, in_channels // 4, 1)
+        self.conv_bot2 = nn.Conv2d(in_channels // 4, in_channels // 4, kernel_size, stride, padding, dilation, groups, bias,
+                                   padding_mode)
+
+    def _gate_logits(self, pooled: Tensor) -> Tensor:
+        from .mbconv_op import padded_conv_bias, padded_conv_bn_act
+        z = padded_conv_bn_act(pooled, self.fc1, self.bn, nn.ReLU())      # bn(fc1(z)) then relu (conv.py:355-356)
+        return padded_conv_bias(z, self.fc2)
+
+    def forward(self, x: Tensor) -> Tensor:
+        from .mbconv_op import SlimGateFn, _PadChannelsFn, ceil16, padded_conv_bias
+        c = x.shape[1]
+        if c % 4 or c != self.fc1.in_channels:
+            raise ValueError("SlimConv2d expects the configured number of input channels (a multiple of 4)")
+        for conv in (self.conv_top, self.conv_bot2):
+            if conv.groups != 1 or conv.dilation != (1, 1) or conv.padding_mode != "zeros":
+                raise NotImplementedError("SlimConv2d on the HIP path: groups=1, dilation=1, zero padding only")
+        top, bot = SlimGateFn.apply(_PadChannelsFn.apply(x, ceil16(c)), self._gate_logits, c)
+        top = padded_conv_bias(top, self.conv_top)
+        bot = padded_conv_bias(padded_conv_bias(bot, self.conv_bot1), self.conv_bot2)
+        return torch.cat((top[:, :c // 2], bot[:, :c // 4]), dim=1)
+
+
+class NormConv2d(nn.modules.conv._ConvNd):
+    """Normalised convolution (holocron/nn/modules/conv.py:55-147): every unfolded input patch is standardised (mean and
+    biased variance over its Cin*KH*KW entries, ``eps`` inside the square root) before the filters are applied.  Same
+    constructor, parameters and ``state_dict`` as the reference; see holocron_amd/nn/normconv_op.py for the kernels."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, stride: int = 1, padding: int = 0, dilation: int = 1,
+                 groups: int = 1, bias: bool = True, padding_mode: str = "zeros", eps: float = 1e-14) -> None:
+        pair = nn.modules.utils._pair
+        super().__init__(in_channels, out_channels, pair(kernel_size), pair(stride), pair(padding), pair(dilation), False, pair(0),
+                         groups, bias, padding_mode)
+        self.normalize_slices = False     # the reference stores False here (conv.py:118) and always normalises
+        self.eps = eps
+
+    def forward(self, x: Tensor) -> Tensor:
+        from .normconv_op import norm_conv2d_module
+        return norm_conv2d_module(x, self)

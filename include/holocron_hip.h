@@ -53,6 +53,11 @@ typedef struct {
     int32_t T;          /* taps stored in wpk */
     int32_t nclass;
     hc_conv_class cls[4];
+    /* optional patch normalisation of NormConv2d (holocron/nn/functional.py:345-349), applied to the fp32 accumulator
+     * before bias: v = pix_scale[pixel] * (v - pix_shift[pixel] * ch_coef[channel]); all three NULL otherwise */
+    const float* pix_scale;  /* fp32 [N*OH*OW]: rsqrt(var + eps) of each unfolded patch */
+    const float* pix_shift;  /* fp32 [N*OH*OW]: mean of each unfolded patch */
+    const float* ch_coef;    /* fp32 [Cout]: sum over (ci, kh, kw) of the (bf16-rounded) weights */
 } hc_conv_desc;
 int hc_conv_gather(const hc_conv_desc* d, hc_stream_t stream);
 
@@ -373,6 +378,29 @@ int hc_se_scale_bwd_gate(const void* g, const void* z, const void* gate_logits, 
                          int64_t HW, int32_t C, int32_t act, hc_stream_t stream);
 int hc_se_scale_bwd_apply(const void* g, const void* z, const void* gate_logits, const float* dpool, void* dz, int64_t N,
                           int64_t HW, int32_t C, int32_t act, hc_stream_t stream);
+
+/* SlimConv2d channel gate + fold (holocron/nn/modules/conv.py:352-364): s = sigmoid(gate_logits),
+ * top[j] = x[j] s[j] + x[j+C/2] s[j+C/2], bot[j] = x[j] s[C-1-j] + x[j+C/2] s[C-1-j-C/2], j < C/2.
+ * x NHWC bf16 with x_ld >= C channels per pixel, gate_logits bf16 [N][l_ld], top/bot NHWC bf16 with out_ld >= C/2
+ * channels per pixel (pad channels zeroed).  bwd_gate: dlogits bf16 [N][l_ld]; bwd_apply: dx (x_ld wide) including
+ * dpool[n][c] / HW, the gradient that reaches x through the global average pool of the gate. */
+int hc_slim_fold_fwd(const void* x, int32_t x_ld, const void* gate_logits, int32_t l_ld, void* top, void* bot, int32_t out_ld,
+                     int64_t N, int64_t HW, int32_t C, hc_stream_t stream);
+int hc_slim_fold_bwd_gate(const void* x, int32_t x_ld, const void* gate_logits, int32_t l_ld, const void* gtop, const void* gbot,
+                          int32_t out_ld, void* dlogits, int64_t N, int64_t HW, int32_t C, hc_stream_t stream);
+int hc_slim_fold_bwd_apply(const void* gate_logits, int32_t l_ld, const void* gtop, const void* gbot, int32_t out_ld,
+                           const float* dpool, int32_t dpool_ld, void* dx, int32_t x_ld, int64_t N, int64_t HW, int32_t C,
+                           hc_stream_t stream);
+
+/* NormConv2d helpers (holocron/nn/modules/conv.py:55-147, holocron/nn/functional.py:322-413).
+ * patch_stats: mean / rsqrt(biased var + eps) over the Cin*KH*KW entries of every unfolded patch (zero padding
+ *   counts as zeros) of x NHWC bf16 [N][H][W][x_ld] with C real channels -> fp32 [N*OH*OW] each.
+ * bwd_scale: gs = g * rstd[pixel] (bf16, the dy of the weight-gradient GEMM) and red fp32 [HC_STAT_REPLICAS][2][C] +=
+ *   per-channel sums of g (bias gradient) and g * rstd * mean (the correction dW[co][k] -= sum_p g r m). */
+int hc_patch_stats(const void* x, int32_t x_ld, float* mean, float* rstd, int32_t N, int32_t H, int32_t W, int32_t C, int32_t KH,
+                   int32_t KW, int32_t stride, int32_t pad, float eps, hc_stream_t stream);
+int hc_normconv_bwd_scale(const void* g, const float* mean, const float* rstd, void* gs, float* red, int64_t npix, int32_t C,
+                          hc_stream_t stream);
 
 const char* hc_version(void);
 

@@ -84,3 +84,40 @@ def dropblock2d(x, drop_prob, block_size, noise, training=True):  # functional.p
     if one_count > 0:
         out = out * (mask.numel() / one_count)
     return out
+
+
+def slim_conv2d(x, sd, stride=1, padding=0, training=True, bn_eps=1e-5, bn_momentum=0.1):
+    """SlimConv2d.forward (holocron/nn/modules/conv.py:352-370) over a state_dict (fc1, bn, fc2, conv_top, conv_bot1,
+    conv_bot2); training-mode BatchNorm updates the running statistics in ``sd``."""
+    z = x.mean(dim=(2, 3), keepdim=True)
+    z = F.conv2d(z, sd["fc1.weight"], sd["fc1.bias"])
+    if training:
+        sd["bn.num_batches_tracked"] += 1
+    z = F.batch_norm(z, sd["bn.running_mean"], sd["bn.running_var"], sd["bn.weight"], sd["bn.bias"], training, bn_momentum, bn_eps)
+    z = F.conv2d(torch.relu(z), sd["fc2.weight"], sd["fc2.bias"])
+    w = torch.sigmoid(z)
+    h = x.shape[1] // 2
+    xw = x * w
+    top = xw[:, :h] + xw[:, h:]
+    xw = x * w.flip(dims=(1,))
+    bot = xw[:, :h] + xw[:, h:]
+    top = F.conv2d(top, sd["conv_top.weight"], sd.get("conv_top.bias"), stride, padding)
+    bot = F.conv2d(bot, sd["conv_bot1.weight"], sd["conv_bot1.bias"])
+    bot = F.conv2d(bot, sd["conv_bot2.weight"], sd.get("conv_bot2.bias"), stride, padding)
+    return torch.cat((top, bot), dim=1)
+
+
+def norm_conv2d(x, weight, bias=None, stride=1, padding=0, eps=1e-14):
+    """norm_conv2d / _xcorr2d with normalize_slices=True (holocron/nn/functional.py:322-413), without the in-place
+    updates (so that it is differentiable w.r.t. x as well; the reference is not)."""
+    kh, kw = weight.shape[-2:]
+    h, w = x.shape[-2:]
+    p = F.unfold(x, (kh, kw), dilation=1, padding=padding, stride=stride).transpose(1, 2)        # [N, L, Cin*kh*kw]
+    scale = (p.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
+    p = (p - p.mean(-1, keepdim=True)) * scale
+    out = p @ weight.view(weight.size(0), -1).t()
+    if bias is not None:
+        out = out + bias
+    oh = (h + 2 * padding - (kh - 1) - 1) // stride + 1
+    ow = (w + 2 * padding - (kw - 1) - 1) // stride + 1
+    return out.transpose(1, 2).reshape(-1, weight.shape[0], oh, ow)

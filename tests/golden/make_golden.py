@@ -434,6 +434,45 @@ def gen_rexnet():
                                              if k.endswith("running_mean") or k.endswith("running_var")}}})
 
 
+def gen_convs():
+    """SlimConv2d and NormConv2d of the reference (holocron/nn/modules/conv.py:55-147,262-370)."""
+    g = torch.Generator().manual_seed(61)
+    slim = []
+    for (cin, k, stride, pad, r, hw, n) in [(32, 3, 1, 1, 8, 10, 3), (8, 3, 1, 1, 32, 7, 4), (64, 1, 1, 0, 16, 6, 2), (16, 3, 2, 1, 4, 9, 3)]:
+        torch.manual_seed(cin + k)
+        m = ref.nn.SlimConv2d(cin, k, stride=stride, padding=pad, r=r)
+        _randomize_bn(m, g)
+        for p in m.parameters():
+            if p.dim() == 4:
+                p.data = bf16r(p.data)
+        sd0 = {kk: v.clone() for kk, v in m.state_dict().items()}
+        x = bf16r(torch.randn((n, cin, hw, hw), generator=g)).requires_grad_(True)
+        m.train()
+        out = m(x)
+        rr = bf16r(torch.randn(out.shape, generator=g))
+        names = [nn_ for nn_, _ in m.named_parameters()]
+        grads = torch.autograd.grad((out * rr).sum(), [x] + list(m.parameters()))
+        slim.append({"cfg": (cin, k, stride, pad, r), "state": sd0, "x": x.detach(), "r": rr, "out": out.detach(), "dx": grads[0],
+                     "dparams": dict(zip(names, grads[1:])),
+                     "state_after": {kk: v.clone() for kk, v in m.state_dict().items() if "running" in kk}})
+    norm = []
+    for (cin, cout, k, stride, pad, mode, hw, n) in [(16, 24, 3, 1, 1, "zeros", 8, 2), (32, 16, 3, 2, 1, "zeros", 9, 2),
+                                                    (8, 8, 3, 1, 1, "reflect", 6, 2), (16, 32, 1, 1, 0, "zeros", 5, 3)]:
+        torch.manual_seed(cin + cout + k)
+        m = ref.nn.NormConv2d(cin, cout, k, stride=stride, padding=pad, padding_mode=mode)
+        m.weight.data = bf16r(m.weight.data)
+        sd0 = {kk: v.clone() for kk, v in m.state_dict().items()}
+        # the reference normalises the unfolded patches in place (functional.py:347-349): autograd refuses to
+        # back-propagate into an input that requires grad, so (like tests/test_nn_conv.py:7-13) only dW / db exist
+        x = bf16r(torch.randn((n, cin, hw, hw), generator=g) + 0.5)
+        out = m(x)
+        rr = bf16r(torch.randn(out.shape, generator=g))
+        grads = torch.autograd.grad((out * rr).sum(), [m.weight, m.bias])
+        norm.append({"cfg": (cin, cout, k, stride, pad, mode), "state": sd0, "x": x, "r": rr, "out": out.detach(),
+                     "dw": grads[0], "db": grads[1]})
+    save("convs.pt", {"slim": slim, "norm": norm})
+
+
 def gen_nms():
     """torchvision.ops.nms is absent: these vectors come from the restated algorithm (oracle/tv_ops.py),
     plus the two situations the reference's own tests pin (tests/test_models_detection.py:158-163: disjoint
@@ -457,6 +496,6 @@ def gen_nms():
 
 if __name__ == "__main__":
     gens = {"boxes": gen_boxes, "functional": gen_functional, "optim": gen_optim, "repblock": gen_repblock,
-            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "nms": gen_nms}
+            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "convs": gen_convs, "nms": gen_nms}
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()

@@ -104,13 +104,31 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().hc_version().startswith(b"holocron_hip")
 
 
-def test_struct_sizes_match_header_layout():
-    # natural alignment, no packing pragmas: ctypes and hipcc agree when field order/types agree
-    assert ctypes.sizeof(_lib.ConvClass) == 7 * 4 + 12 * 4
-    assert ctypes.sizeof(_lib.ConvDesc) == 7 * 8 + 4 + 9 * 4 + 4 * ctypes.sizeof(_lib.ConvClass) + 0
-    assert ctypes.sizeof(_lib.MtChunk) == 5 * 8 + 4 * 4
-    assert ctypes.sizeof(_lib.AdaBeliefGroup) == 5 * 8 + 2 * 4
-    assert ctypes.sizeof(_lib.LarsGroup) == 4 * 8 + 2 * 4
+def test_struct_sizes_match_header_layout(tmp_path):
+    """sizeof / offsetof of every struct of include/holocron_hip.h as the host C compiler lays it out (natural
+    alignment, same rules as hipcc for these plain structs) against the ctypes mirrors of holocron_amd/_lib.py."""
+    import subprocess
+    pairs = {"hc_conv_class": _lib.ConvClass, "hc_conv_desc": _lib.ConvDesc, "hc_conv_small_desc": _lib.ConvSmallDesc,
+             "hc_wgrad_desc": _lib.WgradDesc, "hc_pack_item": _lib.PackItem, "hc_rep_bn_desc": _lib.RepBnDesc,
+             "hc_rep_bn_bwd_desc": _lib.RepBnBwdDesc, "hc_mt_chunk": _lib.MtChunk, "hc_adabelief_group": _lib.AdaBeliefGroup,
+             "hc_lars_group": _lib.LarsGroup}
+    last = {"hc_conv_desc": "ch_coef", "hc_pack_item": "ld", "hc_rep_bn_desc": "c_valid", "hc_rep_bn_bwd_desc": "c_valid",
+            "hc_conv_small_desc": "mode", "hc_wgrad_desc": "beta"}
+    src = tmp_path / "sz.c"
+    lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{os.path.join(ROOT, "include", "holocron_hip.h")}"', "int main(void) {"]
+    for name in pairs:
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+    for name, field in last.items():
+        lines.append(f'  printf("{name}.{field} %zu\\n", offsetof({name}, {field}));')
+    lines += ["  return 0;", "}"]
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, cls in pairs.items():
+        assert int(out[name]) == ctypes.sizeof(cls), name
+    for name, field in last.items():
+        assert int(out[f"{name}.{field}"]) == getattr(pairs[name], field).offset, (name, field)
 
 
 def test_cpu_tensors_are_rejected_loudly():

@@ -180,6 +180,32 @@ def test_rexnet_oracle_matches_reference(golden):
         assert rel_l2(gg, gm["grads"][n]) < 5e-3, (n, rel_l2(gg, gm["grads"][n]))
 
 
+def test_slim_and_norm_conv_oracles_match_reference(golden):
+    import torch.nn.functional as F
+    g = golden("convs.pt")
+    for c in g["slim"]:
+        cin, k, stride, pad, r = c["cfg"]
+        sd = {kk: v.clone() for kk, v in c["state"].items()}
+        names = list(c["dparams"])
+        leaves = [sd[n].requires_grad_(True) for n in names]
+        x = c["x"].clone().requires_grad_(True)
+        out = of.slim_conv2d(x, sd, stride, pad, True)
+        assert torch.allclose(out, c["out"], rtol=1e-5, atol=1e-6)
+        grads = torch.autograd.grad((out * c["r"]).sum(), [x] + leaves)
+        assert rel_l2(grads[0], c["dx"]) < 1e-5
+        for n, gg in zip(names, grads[1:]):
+            assert rel_l2(gg, c["dparams"][n]) < 1e-4 or float(c["dparams"][n].abs().max()) < 1e-5, n
+    for c in g["norm"]:
+        cin, cout, k, stride, pad, mode = c["cfg"]
+        w = c["state"]["weight"].clone().requires_grad_(True)
+        b = c["state"]["bias"].clone().requires_grad_(True)
+        x = c["x"] if mode == "zeros" else F.pad(c["x"], (pad,) * 4, mode=mode)
+        out = of.norm_conv2d(x, w, b, stride, pad if mode == "zeros" else 0)
+        assert torch.allclose(out, c["out"], rtol=1e-4, atol=1e-5)
+        dw, db = torch.autograd.grad((out * c["r"]).sum(), [w, b])
+        assert rel_l2(dw, c["dw"]) < 1e-4 and rel_l2(db, c["db"]) < 1e-5
+
+
 def test_optim_match_reference(golden):
     g = golden("optim.pt")
     for c in g["adabelief"]:
