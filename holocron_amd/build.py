@@ -20,6 +20,7 @@ SOURCES = {
     "conv_small.hip": [],
     "conv_wgrad.hip": [],
     "conv_wgrad_tr.hip": [],
+    "conv_wgrad_dma.hip": [],
     "rep_bn.hip": [],
     "optim.hip": [],
     "nhwc_ops.hip": [],

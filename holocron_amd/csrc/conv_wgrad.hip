@@ -14,6 +14,8 @@
 
 // small-channel specialisation (conv_wgrad_tr.hip)
 int wgrad_tr_nsplit(const hc_wgrad_desc& d);
+int wgrad_dma_nsplit(const hc_wgrad_desc& d);      // conv_wgrad_dma.hip
+int wgrad_dma_launch(const hc_wgrad_desc& d, hipStream_t st, int* nsplit_out);
 int wgrad_tr_launch(const hc_wgrad_desc& d, hipStream_t st, int* nsplit_out);
 
 namespace {
@@ -301,7 +303,8 @@ int generic_dispatch(const hc_wgrad_desc& d, hipStream_t st, bool plan_only, int
 
 extern "C" int64_t hc_conv_wgrad_ws_bytes(const hc_wgrad_desc* d) {
     if (d == nullptr) return -1;
-    int ns = wgrad_tr_nsplit(*d);
+    int ns = wgrad_dma_nsplit(*d);
+    if (ns == 0) ns = wgrad_tr_nsplit(*d);
     if (ns == 0 && generic_dispatch(*d, nullptr, true, &ns) != HC_OK) return -1;
     return (int64_t)ns * d->Cout * d->KH * d->KW * d->Cin * 4;
 }
@@ -315,7 +318,8 @@ extern "C" int hc_conv_wgrad(const hc_wgrad_desc* dp, hc_stream_t stream) {
     if ((double)d.N * d.OH * d.OW * d.Cout * 2.0 >= 4294967280.0) return HC_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int ns = 0;
-    const int rc = wgrad_tr_launch(d, st, &ns);
+    int rc = wgrad_dma_launch(d, st, &ns);
+    if (rc < 0) rc = wgrad_tr_launch(d, st, &ns);
     if (rc >= 0) {
         if (rc != HC_OK) return rc;
         const int T = d.KH * d.KW;

@@ -15,6 +15,7 @@
 // MFMA: v_mfma_f32_16x16x32_bf16, A = x (rows = ci), B = dy (cols = co), k = 32 output pixels.
 // Output: fp32 slabs [split][co][tap][ci], reduced by wgrad_reduce_kernel (conv_wgrad.hip).
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/holocron_hip.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -262,7 +263,9 @@ inline Plan make_plan_nr(const hc_wgrad_desc& d, int NR) {
     if (!(T == 9 && d.KH == 3) && T != 1) return pl;
     // measured on MI355X (scripts/bench_layers.py): beyond 192x256 channels the k-pipelined generic
     // kernel is faster (1280-wide layers re-stage dy once per ci tile here)
-    if (d.Cin > 192 || d.Cout > 256 || d.OW > 128) return pl;
+    static const int max_cin = getenv("HC_WTR_CIN") ? atoi(getenv("HC_WTR_CIN")) : 192;     // experiment knobs
+    static const int max_cout = getenv("HC_WTR_COUT") ? atoi(getenv("HC_WTR_COUT")) : 256;
+    if (d.Cin > max_cin || d.Cout > max_cout || d.OW > 128) return pl;
     // ci tile = 16*MR: the largest supported MR that divides Cin/16
     const int c16 = d.Cin / 16;
     int MR = 0;

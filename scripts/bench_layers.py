@@ -9,7 +9,9 @@ LAYERS = [  # Cin, Cout, H(in), stride
     (192, 192, 14, 1), (192, 1280, 14, 2), (1280, 1280, 7, 1),
 ]
 which = sys.argv[1] if len(sys.argv) > 1 else "wgrad"
-N = 256
+N = int(os.environ.get("BL_N", "256"))
+if os.environ.get("BL_SHAPES"):   # "Cin,Cout,H,stride;..."
+    LAYERS = [tuple(int(v) for v in t.split(",")) for t in os.environ["BL_SHAPES"].split(";")]
 sel = [int(a) for a in sys.argv[2:]] if len(sys.argv) > 2 else range(len(LAYERS))
 
 
