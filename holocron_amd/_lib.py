@@ -78,6 +78,11 @@ class LarsGroup(C.Structure):
                 ("nesterov", c_int32), ("pad_", c_int32)]
 
 
+class DropItem(C.Structure):
+    _fields_ = [("off", c_int64), ("N", c_int32), ("H", c_int32), ("W", c_int32), ("block_size", c_int32), ("gamma", c_float),
+                ("pad_", c_int32)]
+
+
 def tap(dy, dx, src, wt):
     """HC_TAP of the header."""
     u = (dy & 0xff) | ((dx & 0xff) << 8) | ((src & 0xff) << 16) | ((wt & 0xff) << 24)
@@ -130,6 +135,7 @@ SIGNATURES = {
     "hc_dice_sums": (c_int32, [c_void_p] * 3 + [c_int32, c_int32, c_int64, c_void_p]),
     "hc_dice_bwd": (c_int32, [c_void_p] * 3 + [c_int32, c_int32, c_int64, c_void_p]),
     "hc_dropblock_mask": (c_int32, [c_void_p] * 3 + [c_int32] * 4 + [c_float, c_void_p]),
+    "hc_dropblock_mask_batched": (c_int32, [c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hc_dropblock_apply": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_int64, c_int32, c_int32, c_void_p]),
     "hc_yolo_decode": (c_int32, [c_void_p, c_int32, c_int64, c_int64, c_int64] + [c_int32] * 5 + [c_void_p, c_float]
                        + [c_void_p] * 4 + [c_int32, c_void_p]),

@@ -207,6 +207,44 @@ __global__ void dropblock_apply_kernel(const void* __restrict__ xv, const float*
     }
 }
 
+// all DropBlock masks of a training step in ONE launch: blockIdx.y = layer.  noise / keep are arenas, item.off the
+// layer's first element in both; counts[layer] += sum(keep)
+__global__ __launch_bounds__(256) void dropblock_mask_batched_kernel(const hc_drop_item* __restrict__ items, const float* __restrict__ noise,
+                                                                     float* __restrict__ keep, float* __restrict__ counts) {
+    const hc_drop_item it = items[blockIdx.y];
+    const int H = it.H, W = it.W, r = it.block_size / 2;
+    const long total = (long)it.N * H * W;
+    const float* pn0 = noise + it.off;
+    float* pk = keep + it.off;
+    float local = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W), h = (int)((i / W) % H);
+        const long n = i / ((long)W * H);
+        const float* pn = pn0 + n * H * W;
+        bool drop = false;
+        for (int dy = -r; dy <= r; ++dy) {
+            const int yy = h + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -r; dx <= r; ++dx) {
+                const int xx = w + dx;
+                if (xx < 0 || xx >= W) continue;
+                drop |= pn[yy * W + xx] <= it.gamma;
+            }
+        }
+        const float kv = drop ? 0.f : 1.f;
+        pk[i] = kv;
+        local += kv;
+    }
+    local = wave_sum(local);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = sh[0] + sh[1] + sh[2] + sh[3];
+        if (v != 0.f) atomicAdd(counts + blockIdx.y, v);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -285,6 +323,19 @@ int hc_dropblock_apply(const void* x, const float* keep, const float* count, voi
     else
         hipLaunchKernelGGL(dropblock_apply_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, keep, count, y,
                            (long)N, C, (long)HW, nhwc);
+    return hc_launch_status();
+}
+
+int hc_dropblock_mask_batched(const hc_drop_item* items, int32_t nitems, int64_t max_pixels, const float* noise, float* keep,
+                              float* counts, hc_stream_t stream) {
+    if (nitems < 0 || (nitems > 0 && (items == nullptr || noise == nullptr || keep == nullptr || counts == nullptr))) return HC_ERR_ARG;
+    if (nitems == 0) return HC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(counts, 0, sizeof(float) * (size_t)nitems, st) != hipSuccess) return HC_ERR_LAUNCH;
+    int bx = (int)((max_pixels + 255) / 256);
+    if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(dropblock_mask_batched_kernel, dim3(bx, nitems), dim3(256), 0, st, items, noise, keep, counts);
     return hc_launch_status();
 }
 

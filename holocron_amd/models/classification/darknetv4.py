@@ -15,6 +15,7 @@ import torch.nn as nn
 from ... import _lib
 from ...nn import GlobalAvgPool2d
 from ...nn.convbn_op import prepack_model_convs, run_conv_sequence
+from ...nn.functional import drop_plan_scope
 from ...nn.init import init_module
 from ...nn.repblock_op import POOL
 from ...ops.nhwc import cat_buffer, cat_cl, chunk2_cl
@@ -107,7 +108,8 @@ class DarknetV4(nn.Sequential):
         prepack_model_convs(self)
         POOL.begin(x.device)
         try:
-            return super().forward(x)
+            with drop_plan_scope(self, x.device):
+                return super().forward(x)
         finally:
             POOL.end()
 

@@ -22,6 +22,7 @@ from ... import _lib
 from ..._lib import check, ptr, stream
 from ...nn import SPP, DropBlock2d
 from ...nn.convbn_op import cl_ld, prepack_model_convs, run_conv_sequence
+from ...nn.functional import drop_plan_scope
 from ...nn.init import init_module
 from ...nn.repblock_op import POOL
 from ...ops.boxes import nms
@@ -331,9 +332,10 @@ class YOLOv4(nn.Module):
         prepack_model_convs(self)
         POOL.begin(x.device)
         try:
-            feats = self.backbone(x)
-            x20, x13, x6 = self.neck(feats)
-            return self.head((x20, x13, x6), target)
+            with drop_plan_scope(self, x.device):
+                feats = self.backbone(x)
+                x20, x13, x6 = self.neck(feats)
+                return self.head((x20, x13, x6), target)
         finally:
             POOL.end()
 

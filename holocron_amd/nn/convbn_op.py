@@ -63,16 +63,9 @@ def as_cl_view(t):
 
 
 def dropblock_keep(N, H, W, drop_prob, block_size, device):
-    """keep map [N][H][W] and its sum (device scalar) for DropBlock with ``gamma = drop_prob / block_size**2``."""
-    if block_size % 2 == 0:
-        raise RuntimeError("dropblock2d: block_size must be odd (mask and input shapes do not broadcast otherwise)")
+    """keep map + count of one DropBlock call (batched per step when a DropPlan is active, see nn/functional.py)."""
     from . import functional as Fh
-    noise = Fh._noise((N, H, W), device).float().contiguous()
-    keep = torch.empty((N, H, W), dtype=torch.float32, device=device)
-    count = torch.empty((1,), dtype=torch.float32, device=device)
-    check(_lib.load().hc_dropblock_mask(ptr(noise), ptr(keep), ptr(count), N, H, W, block_size,
-                                        drop_prob / block_size**2, stream()), "hc_dropblock_mask")
-    return keep, count
+    return Fh.dropblock_keep(N, H, W, drop_prob, block_size, device)
 
 
 class ConvState:

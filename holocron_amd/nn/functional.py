@@ -218,18 +218,10 @@ def dice_loss(x: Tensor, target: Tensor, weight: Optional[Tensor] = None, gamma:
 
 class _DropBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, noise, gamma, block_size, inplace):
-        _lib.require_gpu(x, noise)
-        if block_size % 2 == 0:
-            # F.max_pool2d(kernel=bs, stride=1, padding=bs//2) grows the map by one for even sizes and the
-            # reference then fails to broadcast (functional.py:485-491)
-            raise RuntimeError("dropblock2d: block_size must be odd (mask and input shapes do not broadcast otherwise)")
+    def forward(ctx, x, keep, count, inplace):
+        _lib.require_gpu(x, keep)
         N, Cc, H, W = x.shape
         lib = _lib.load()
-        nz = noise.float().contiguous()
-        keep = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
-        count = torch.empty((1,), dtype=torch.float32, device=x.device)
-        check(lib.hc_dropblock_mask(ptr(nz), ptr(keep), ptr(count), N, H, W, block_size, gamma, stream()), "hc_dropblock_mask")
         nhwc = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
         if x.dtype not in (torch.float32, torch.bfloat16) or not (nhwc or x.is_contiguous()):
             raise _lib.HipError("dropblock2d expects a dense fp32 or bf16 tensor (NCHW or channels_last)")
@@ -254,13 +246,130 @@ class _DropBlockFn(torch.autograd.Function):
         dx = torch.empty_like(dy)
         check(_lib.load().hc_dropblock_apply(ptr(dy), ptr(keep), ptr(count), ptr(dx), N, Cc, HW,
                                              0 if dy.dtype == torch.float32 else 1, int(nhwc), stream()), "hc_dropblock_apply")
-        return dx, None, None, None, None
+        return dx, None, None, None
 
 
 def _noise(shape, device) -> Tensor:
     """Uniform samples for DropBlock (functional.py:482).  A module-level hook so that parity tests can replay the
     draws recorded from the reference."""
     return torch.rand(shape, device=device)
+
+
+_DEFAULT_NOISE = _noise
+
+
+class DropPlan:
+    """Step-level batching of DropBlock (YOLOv4 runs it 123 times per forward): after a recording pass that notes the
+    (N, H, W, drop_prob, block_size) of every call, ONE ``torch.rand`` and ONE ``hc_dropblock_mask_batched`` launch at the
+    start of each forward produce every keep-map and its count; the calls then just pick up their slices.  Any shape
+    mismatch (or a test-installed ``_noise`` hook) drops back to the per-call kernels."""
+
+    def __init__(self):
+        self.entries = []        # recorded (N, H, W, drop_prob, block_size)
+        self.ready = False
+        self.cursor = 0
+        self.table = None
+
+    def begin(self, device, training):
+        self.cursor = 0
+        self.live = False
+        if not training or _noise is not _DEFAULT_NOISE:
+            self.recording = False
+            return
+        if not self.ready:
+            self.entries, self.recording = [], True
+            return
+        self.recording = False
+        import ctypes as C
+        import numpy as np
+        if self.table is None or self.table[0].device != device:
+            arr = (_lib.DropItem * len(self.entries))()
+            off = 0
+            mx = 0
+            for a, (N, H, W, p, bs) in zip(arr, self.entries):
+                a.off, a.N, a.H, a.W, a.block_size, a.gamma = off, N, H, W, bs, p / bs**2
+                off += N * H * W
+                mx = max(mx, N * H * W)
+            host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+            self.table = (host.to(device), off, mx, [a.off for a in arr])
+        tab, total, mx, _ = self.table
+        if total == 0:
+            return
+        noise = torch.rand((total,), device=device)
+        self.keep = torch.empty((total,), dtype=torch.float32, device=device)
+        self.counts = torch.empty((len(self.entries),), dtype=torch.float32, device=device)
+        check(_lib.load().hc_dropblock_mask_batched(tab.data_ptr(), len(self.entries), mx, ptr(noise), ptr(self.keep), ptr(self.counts),
+                                                    stream()), "hc_dropblock_mask_batched")
+        self.live = True
+
+    def end(self):
+        if getattr(self, "recording", False):
+            self.ready = True
+            self.table = None
+        elif self.live and self.cursor != len(self.entries):
+            self.ready = False        # fewer calls than planned: re-record next time
+        self.live = False
+
+    def take(self, N, H, W, drop_prob, block_size):
+        """(keep, count) of the next DropBlock call, or None when the call has to run its own kernels."""
+        if getattr(self, "recording", False):
+            self.entries.append((N, H, W, drop_prob, block_size))
+            return None
+        if not self.live:
+            return None
+        i = self.cursor
+        if i >= len(self.entries) or self.entries[i] != (N, H, W, drop_prob, block_size):
+            self.live, self.ready = False, False     # the model changed shape: abandon the plan for this forward
+            return None
+        self.cursor += 1
+        off = self.table[3][i]
+        return self.keep[off:off + N * H * W].view(N, H, W), self.counts[i:i + 1]
+
+
+_ACTIVE_PLAN = [None]
+
+
+class drop_plan_scope:
+    """``with drop_plan_scope(model, device):`` around a model forward activates the model's DropPlan."""
+
+    def __init__(self, model, device):
+        plan = getattr(model, "_hc_drop_plan", None)
+        if plan is None:
+            plan = model._hc_drop_plan = DropPlan()
+        self.plan, self.device, self.training = plan, device, model.training
+
+    def __enter__(self):
+        self.prev = _ACTIVE_PLAN[0]
+        _ACTIVE_PLAN[0] = self.plan
+        self.plan.begin(self.device, self.training)
+        return self.plan
+
+    def __exit__(self, *exc):
+        _ACTIVE_PLAN[0] = self.prev
+        if exc[0] is None:
+            self.plan.end()
+        else:
+            self.plan.live, self.plan.recording = False, False
+        return False
+
+
+def dropblock_keep(N, H, W, drop_prob, block_size, device):
+    """keep map [N][H][W] and its sum (device scalar) for DropBlock with ``gamma = drop_prob / block_size**2``."""
+    if block_size % 2 == 0:
+        # F.max_pool2d(kernel=bs, stride=1, padding=bs//2) grows the map by one for even sizes and the reference then
+        # fails to broadcast (functional.py:485-491)
+        raise RuntimeError("dropblock2d: block_size must be odd (mask and input shapes do not broadcast otherwise)")
+    plan = _ACTIVE_PLAN[0]
+    if plan is not None:
+        got = plan.take(N, H, W, float(drop_prob), int(block_size))
+        if got is not None:
+            return got
+    noise = _noise((N, H, W), device).float().contiguous()
+    keep = torch.empty((N, H, W), dtype=torch.float32, device=device)
+    count = torch.empty((1,), dtype=torch.float32, device=device)
+    check(_lib.load().hc_dropblock_mask(ptr(noise), ptr(keep), ptr(count), N, H, W, block_size, drop_prob / block_size**2, stream()),
+          "hc_dropblock_mask")
+    return keep, count
 
 
 def dropblock2d(x: Tensor, drop_prob: float, block_size: int, inplace: bool = False, training: bool = True,
@@ -272,10 +381,19 @@ def dropblock2d(x: Tensor, drop_prob: float, block_size: int, inplace: bool = Fa
     The reference's host-side ``if one_count > 0`` is a device-side select here (no sync)."""
     if not training or drop_prob == 0:
         return x
-    gamma = drop_prob / block_size**2
+    _lib.require_gpu(x)
+    N, _, H, W = x.shape
     if noise is None:
-        noise = _noise((x.shape[0], *x.shape[2:]), x.device)
-    return _DropBlockFn.apply(x, noise, float(gamma), int(block_size), inplace)
+        keep, count = dropblock_keep(N, H, W, float(drop_prob), int(block_size), x.device)
+    else:
+        if block_size % 2 == 0:
+            raise RuntimeError("dropblock2d: block_size must be odd (mask and input shapes do not broadcast otherwise)")
+        nz = noise.float().contiguous()
+        keep = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
+        count = torch.empty((1,), dtype=torch.float32, device=x.device)
+        check(_lib.load().hc_dropblock_mask(ptr(nz), ptr(keep), ptr(count), N, H, W, int(block_size), drop_prob / block_size**2,
+                                            stream()), "hc_dropblock_mask")
+    return _DropBlockFn.apply(x, keep, count, inplace)
 
 
 class _GapFn(torch.autograd.Function):

@@ -319,6 +319,16 @@ int hc_dropblock_mask(const float* noise, float* keep, float* count, int32_t N, 
                       float gamma, hc_stream_t stream);
 int hc_dropblock_apply(const void* x, const float* keep, const float* count, void* y, int64_t N, int32_t C, int64_t HW,
                        int32_t dtype, int32_t nhwc, hc_stream_t stream);
+/* every DropBlock mask of a training step (YOLOv4 has 123) in one launch: `items` is a DEVICE array, noise / keep are
+ * arenas indexed by item.off, counts fp32 [nitems] (zeroed here), max_pixels = largest N*H*W (sizes the grid). */
+typedef struct {
+    int64_t off;
+    int32_t N, H, W, block_size;
+    float gamma;
+    int32_t pad_;
+} hc_drop_item;
+int hc_dropblock_mask_batched(const hc_drop_item* items, int32_t nitems, int64_t max_pixels, const float* noise, float* keep,
+                              float* counts, hc_stream_t stream);
 
 /* ---- YOLOv4 detection layer (holocron/models/detection/yolov4.py:269-420) ----
  * The logits of one scale are read in place: dtype 0 = fp32, 1 = bf16; element strides sn / sc / sp for image,

@@ -137,6 +137,36 @@ def test_poly_dice_dropblock(golden):
     assert out.shape == z.shape
 
 
+def test_dropblock_batched_masks_equal_per_call_masks():
+    """hc_dropblock_mask_batched (one launch per step) against hc_dropblock_mask per layer on the same noise."""
+    import ctypes as C
+    import numpy as np
+    from holocron_amd import _lib
+    from holocron_amd._lib import check, ptr, stream
+    lib = _lib.load()
+    shapes = [(2, 9, 11, 3, 0.05), (3, 19, 19, 7, 0.004), (1, 5, 4, 5, 0.2), (2, 16, 16, 7, 1e-9)]
+    total = sum(n * h * w for n, h, w, _, _ in shapes)
+    noise = torch.rand((total,), device="cuda")
+    arr = (_lib.DropItem * len(shapes))()
+    off = 0
+    for a, (n, h, w, bs, gamma) in zip(arr, shapes):
+        a.off, a.N, a.H, a.W, a.block_size, a.gamma = off, n, h, w, bs, gamma
+        off += n * h * w
+    tab = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).cuda()
+    keep = torch.empty((total,), device="cuda")
+    counts = torch.empty((len(shapes),), device="cuda")
+    check(lib.hc_dropblock_mask_batched(tab.data_ptr(), len(shapes), max(n * h * w for n, h, w, _, _ in shapes), ptr(noise), ptr(keep),
+                                        ptr(counts), stream()), "hc_dropblock_mask_batched")
+    off = 0
+    for i, (n, h, w, bs, gamma) in enumerate(shapes):
+        k1 = torch.empty((n * h * w,), device="cuda")
+        c1 = torch.empty((1,), device="cuda")
+        nz = noise[off:off + n * h * w].contiguous()
+        check(lib.hc_dropblock_mask(ptr(nz), ptr(k1), ptr(c1), n, h, w, bs, gamma, stream()), "hc_dropblock_mask")
+        assert torch.equal(keep[off:off + n * h * w], k1) and float(counts[i]) == float(c1)
+        off += n * h * w
+
+
 def test_adabelief_matches_reference(golden):
     import holocron_amd as h
     for c in golden("optim.pt")["adabelief"]:

@@ -364,8 +364,24 @@ def test_cspdarknet53_mish_forward_backward_smoke():
     import holocron_amd as h
     torch.manual_seed(0)
     m = h.models.cspdarknet53_mish(num_classes=10).cuda().train()
+    for mod in m.modules():
+        if isinstance(mod, h.nn.DropBlock2d):
+            mod.p = 0.1 * 49 * 2
     x = torch.rand((2, 3, 64, 64), device="cuda")
-    out = m(x)
+    out = m(x)                                   # records the DropBlock call sequence
     assert out.shape == (2, 10) and torch.isfinite(out).all()
     out.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    plan = m._hc_drop_plan
+    ndrop = sum(isinstance(mod, h.nn.DropBlock2d) for mod in m.modules())
+    assert plan.ready and len(plan.entries) == ndrop
+    outs = []
+    for _ in range(2):                           # one rand + one batched mask launch per forward from now on
+        m.zero_grad()
+        out = m(x)
+        assert plan.cursor == ndrop and torch.isfinite(out).all()
+        out.sum().backward()
+        outs.append(out.detach())
+    assert not torch.equal(outs[0], outs[1])     # fresh noise every step
+    m(torch.rand((2, 3, 96, 96), device="cuda")).sum().backward()     # another resolution: the plan is re-recorded
+    assert len(m._hc_drop_plan.entries) == ndrop
