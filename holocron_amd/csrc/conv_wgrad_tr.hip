@@ -25,7 +25,8 @@ namespace wtr {
 
 struct Args {
     hc_wgrad_desc d;
-    int R, P, P32;             // output rows per chunk, valid pixels, padded to 32
+    int R, P, P32;             // output rows per chunk, pixels per chunk (R * CW), padded to 32
+    int CW, nseg;              // output columns per chunk and column segments per row (wide images: OW > 128)
     int XR, XW, SX, SD;        // staged x region rows/cols, LDS row strides (bytes) of x and dy
     int chunks_per_img, nchunks, chunks_per_split;
     int n_ci_tiles, n_co_tiles, n_tg, BCO;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(const Args a) {
     for (int p = tid; p < a.P32; p += NT) {
         int off = 0;
         if (p < a.P) {
-            const int r = p / d.OW, c = p - r * d.OW;
+            const int r = p / a.CW, c = p - r * a.CW;
             off = ((r * s) * a.XW + c * s) * a.SX;
         }
         tab[p] = off;
@@ -128,21 +129,32 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(const Args a) {
     const int xrp = (a.XW + xpp - 1) / xpp;     // passes per staged x row
     const int xitems = a.XR * xrp;              // <= XMAX
     u32x4 sd[DMAX], sxr[XMAX];
+    // dy slot i of this thread = chunk pixel (dr, dc): chunk-invariant, so the divisions happen once
+    int d_r[DMAX], d_c[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) {
+        const int p = i * dpp + dp;
+        d_r[i] = p / a.CW;
+        d_c[i] = p - d_r[i] * a.CW;
+    }
 
     // issue every global load of chunk `ch` into registers (nothing waits here)
     auto issue = [&](int ch) {
         const int n = ch / a.chunks_per_img;
-        const int oy0 = (ch - n * a.chunks_per_img) * a.R;
-        const int rows_left = d.OH - oy0;
-        const int pvalid = (rows_left < a.R ? rows_left : a.R) * d.OW;
-        const unsigned gbase = (unsigned)((n * d.OH + oy0) * d.OW) * (unsigned)d.Cout * 2u + (unsigned)co0 * 2u +
+        const int rem = ch - n * a.chunks_per_img;
+        const int rc = rem / a.nseg;
+        const int ox0 = (rem - rc * a.nseg) * a.CW;
+        const int oy0 = rc * a.R;
+        const int rows_left = d.OH - oy0, cols_left = d.OW - ox0;
+        const int rvalid = rows_left < a.R ? rows_left : a.R;
+        const int cvalid = cols_left < a.CW ? cols_left : a.CW;
+        const unsigned gbase = (unsigned)((n * d.OH + oy0) * d.OW + ox0) * (unsigned)d.Cout * 2u + (unsigned)co0 * 2u +
                                (unsigned)dcc * 16u;
         const bool dcok = co0 + dcc * 8 < d.Cout;
 #pragma unroll
         for (int i = 0; i < DMAX; ++i) {
-            const int p = i * dpp + dp;
-            const bool ok = dcok && (p < pvalid);
-            sd[i] = buf_load16(rsy, ok ? gbase + (unsigned)p * (unsigned)d.Cout * 2u : HC_OOB);
+            const bool ok = dcok && (d_r[i] < rvalid) && (d_c[i] < cvalid);
+            sd[i] = buf_load16(rsy, ok ? gbase + (unsigned)(d_r[i] * d.OW + d_c[i]) * (unsigned)d.Cout * 2u : HC_OOB);
         }
         const int iy_base = oy0 * s - d.pad + kh0;
         const bool xcok = xstager && (ci0 + xcc * 8 < d.Cin);
@@ -150,7 +162,7 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(const Args a) {
         int xr = 0, ps = 0;
 #pragma unroll
         for (int j = 0; j < XMAX; ++j) {
-            const int iy = iy_base + xr, ix = ps * xpp + xp - d.pad;
+            const int iy = iy_base + xr, ix = ox0 * s + ps * xpp + xp - d.pad;
             const bool ok = xcok && (j < xitems) && ((unsigned)iy < (unsigned)d.IH) && ((unsigned)ix < (unsigned)d.IW);
             sxr[j] = buf_load16(rsx, ok ? nbase + (unsigned)(iy * d.IW + ix) * (unsigned)d.Cin * 2u : HC_OOB);
             if (++ps == xrp) { ps = 0; ++xr; }
@@ -255,7 +267,7 @@ struct Plan {
     int MR, NR, TG, WN, smem, nsplit;
 };
 
-inline Plan make_plan_nr(const hc_wgrad_desc& d, int NR) {
+inline Plan make_plan_seg(const hc_wgrad_desc& d, int NR, int nseg) {
     Plan pl{};
     pl.ok = false;
     const int T = d.KH * d.KW;
@@ -265,7 +277,9 @@ inline Plan make_plan_nr(const hc_wgrad_desc& d, int NR) {
     // kernel is faster (1280-wide layers re-stage dy once per ci tile here)
     static const int max_cin = getenv("HC_WTR_CIN") ? atoi(getenv("HC_WTR_CIN")) : 192;     // experiment knobs
     static const int max_cout = getenv("HC_WTR_COUT") ? atoi(getenv("HC_WTR_COUT")) : 256;
-    if (d.Cin > max_cin || d.Cout > max_cout || d.OW > 128) return pl;
+    if (d.Cin > max_cin || d.Cout > max_cout) return pl;
+    // images wider than a chunk (128 pixels) are cut into column segments, each staged with its own halo
+    const int CW = (d.OW + nseg - 1) / nseg;
     // ci tile = 16*MR: the largest supported MR that divides Cin/16
     const int c16 = d.Cin / 16;
     int MR = 0;
@@ -293,15 +307,17 @@ inline Plan make_plan_nr(const hc_wgrad_desc& d, int NR) {
     a.SX = round_stride(16 * MR * 2, d.stride);
     const int xpp = 64 * WN / (2 * MR);      // staged x pixels per pass of the workgroup
     const int xmax = xmax_for(MR, NR, TG);
-    int R = 112 / d.OW;
+    a.CW = CW;
+    a.nseg = nseg;
+    int R = 112 / CW;
     if (R < 1) R = 1;
     if (R > d.OH) R = d.OH;
     for (;; --R) {
         a.R = R;
-        a.P = R * d.OW;
+        a.P = R * CW;
         a.P32 = (a.P + 31) / 32 * 32;
         a.XR = (R - 1) * d.stride + nkh;
-        a.XW = (d.OW - 1) * d.stride + d.KW;
+        a.XW = (CW - 1) * d.stride + d.KW;
         const int xbytes = a.XR * a.XW * a.SX;
         a.off_dy = (xbytes + 255) / 256 * 256;
         a.off_tab = a.off_dy + (a.P32 * a.SD + 255) / 256 * 256;
@@ -311,7 +327,7 @@ inline Plan make_plan_nr(const hc_wgrad_desc& d, int NR) {
         if (pl.smem <= 78 * 1024 && xitems <= xmax && a.P32 <= 128) break;
         if (R == 1) return pl;               // does not fit the prefetch ring: caller falls back
     }
-    a.chunks_per_img = (d.OH + a.R - 1) / a.R;
+    a.chunks_per_img = ((d.OH + a.R - 1) / a.R) * nseg;
     a.nchunks = d.N * a.chunks_per_img;
     pl.MR = MR;
     pl.NR = NR;
@@ -319,6 +335,18 @@ inline Plan make_plan_nr(const hc_wgrad_desc& d, int NR) {
     pl.WN = WN;
     pl.ok = true;
     return pl;
+}
+
+// fewest column segments whose halo-extended x rows fit the staging registers / LDS
+inline Plan make_plan_nr(const hc_wgrad_desc& d, int NR) {
+    const int seg0 = (d.OW + 127) / 128;
+    for (int nseg = seg0; nseg <= seg0 + 6 && (d.OW + nseg - 1) / nseg >= 16; ++nseg) {
+        const Plan pl = make_plan_seg(d, NR, nseg);
+        if (pl.ok) return pl;
+    }
+    Plan none{};
+    none.ok = false;
+    return none;
 }
 
 // One resident round: the number of workgroups equals what the chip holds at once (a second,
