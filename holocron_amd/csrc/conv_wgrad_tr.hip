@@ -43,7 +43,9 @@ constexpr int xmax_for(int mr, int nr, int tg) {
     return v > 16 ? 16 : (v < 2 ? 2 : v);
 }
 
-template <int MR, int NR, int TG>
+// SEG: the image is wider than a chunk and is cut into column segments (a separate instantiation so that the
+// full-row kernels keep their register budget)
+template <int MR, int NR, int TG, bool SEG>
 __global__ __launch_bounds__(512) void wgrad_tr_kernel(const Args a) {
     constexpr int BCI = 16 * MR;
     constexpr int DMAX = 4 * NR;                 // dy passes: P32 (<=128) / (32/NR pixels per pass)
@@ -129,21 +131,13 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(const Args a) {
     const int xrp = (a.XW + xpp - 1) / xpp;     // passes per staged x row
     const int xitems = a.XR * xrp;              // <= XMAX
     u32x4 sd[DMAX], sxr[XMAX];
-    // dy slot i of this thread = chunk pixel (dr, dc): chunk-invariant, so the divisions happen once
-    int d_r[DMAX], d_c[DMAX];
-#pragma unroll
-    for (int i = 0; i < DMAX; ++i) {
-        const int p = i * dpp + dp;
-        d_r[i] = p / a.CW;
-        d_c[i] = p - d_r[i] * a.CW;
-    }
 
     // issue every global load of chunk `ch` into registers (nothing waits here)
     auto issue = [&](int ch) {
         const int n = ch / a.chunks_per_img;
         const int rem = ch - n * a.chunks_per_img;
-        const int rc = rem / a.nseg;
-        const int ox0 = (rem - rc * a.nseg) * a.CW;
+        const int rc = SEG ? rem / a.nseg : rem;
+        const int ox0 = SEG ? (rem - rc * a.nseg) * a.CW : 0;
         const int oy0 = rc * a.R;
         const int rows_left = d.OH - oy0, cols_left = d.OW - ox0;
         const int rvalid = rows_left < a.R ? rows_left : a.R;
@@ -151,10 +145,21 @@ __global__ __launch_bounds__(512) void wgrad_tr_kernel(const Args a) {
         const unsigned gbase = (unsigned)((n * d.OH + oy0) * d.OW + ox0) * (unsigned)d.Cout * 2u + (unsigned)co0 * 2u +
                                (unsigned)dcc * 16u;
         const bool dcok = co0 + dcc * 8 < d.Cout;
+        if (!SEG) {                  // full rows: the chunk's pixels are contiguous in dy
+            const int pvalid = rvalid * d.OW;
 #pragma unroll
-        for (int i = 0; i < DMAX; ++i) {
-            const bool ok = dcok && (d_r[i] < rvalid) && (d_c[i] < cvalid);
-            sd[i] = buf_load16(rsy, ok ? gbase + (unsigned)(d_r[i] * d.OW + d_c[i]) * (unsigned)d.Cout * 2u : HC_OOB);
+            for (int i = 0; i < DMAX; ++i) {
+                const int p = i * dpp + dp;
+                sd[i] = buf_load16(rsy, (dcok && p < pvalid) ? gbase + (unsigned)p * (unsigned)d.Cout * 2u : HC_OOB);
+            }
+        } else {                     // column segment: (row, col) of every slot (wide images only; costs a division per slot)
+#pragma unroll
+            for (int i = 0; i < DMAX; ++i) {
+                const int p = i * dpp + dp;
+                const int r = p / a.CW, c = p - r * a.CW;
+                const bool ok = dcok && (r < rvalid) && (c < cvalid);
+                sd[i] = buf_load16(rsy, ok ? gbase + (unsigned)(r * d.OW + c) * (unsigned)d.Cout * 2u : HC_OOB);
+            }
         }
         const int iy_base = oy0 * s - d.pad + kh0;
         const bool xcok = xstager && (ci0 + xcc * 8 < d.Cin);
@@ -371,9 +376,9 @@ inline Plan make_plan(const hc_wgrad_desc& d) {
 }
 
 // launch == false: only size the plan (workspace query)
-template <int MR, int NR, int TG>
+template <int MR, int NR, int TG, bool SEG>
 int launch(Plan& pl, hipStream_t st, bool do_launch) {
-    auto kern = wgrad_tr_kernel<MR, NR, TG>;
+    auto kern = wgrad_tr_kernel<MR, NR, TG, SEG>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -400,7 +405,8 @@ int launch(Plan& pl, hipStream_t st, bool do_launch) {
 static int dispatch(wtr::Plan& pl, hipStream_t st, bool do_launch) {
     const int T = pl.a.d.KH * pl.a.d.KW;
 #define WTR_CASE(M, N, G) \
-    if (pl.MR == M && pl.NR == N && pl.TG == G) return wtr::launch<M, N, G>(pl, st, do_launch);
+    if (pl.MR == M && pl.NR == N && pl.TG == G) \
+        return pl.a.nseg > 1 ? wtr::launch<M, N, G, true>(pl, st, do_launch) : wtr::launch<M, N, G, false>(pl, st, do_launch);
     if (T == 1) {
         WTR_CASE(2, 1, 1) WTR_CASE(3, 1, 1) WTR_CASE(4, 1, 1) WTR_CASE(6, 1, 1) WTR_CASE(8, 1, 1)
         WTR_CASE(2, 2, 1) WTR_CASE(3, 2, 1) WTR_CASE(4, 2, 1) WTR_CASE(6, 2, 1) WTR_CASE(8, 2, 1)
