@@ -35,6 +35,7 @@ struct Args {
     int M;                       // output pixels
     int total_steps, steps_per_split;
     int n_co_tiles, n_ci_tiles, n_tg;
+    int adv_n, adv_oh, adv_ow;   // 32 pixels expressed in (images, rows, columns)
 };
 
 constexpr int NS = 3;            // pipeline stages
@@ -47,6 +48,22 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* base, int off) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// buffer_load ... lds issued through inline assembly: the compiler's wait-count insertion treats the builtin as a store
+// to LDS that every later LDS read (and every barrier) must wait for with vmcnt(0), which serialises the pipeline.
+// The explicit `s_waitcnt vmcnt(n)` + barrier in the main loop is the only ordering these loads need.
+__device__ __forceinline__ void dma16(const u32x4 rsrc, unsigned lds_off, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_off), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ u32x4 raw_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    u32x4 r;
+    r[0] = (unsigned)a;
+    r[1] = (unsigned)(a >> 32) & 0xffffu;
+    r[2] = bytes;
+    r[3] = 0x00020000u;
+    return r;
+}
+
 template <int WM, int WN, int TG>
 __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const Args a) {
     constexpr int NW = WM * WN;
@@ -55,8 +72,9 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const Args a) {
     constexpr int NI = NSUB * 4;                     // DMA instructions per stage
     constexpr int CEILI = (NI + NW - 1) / NW;        // per wave (padded with zero-fill dummies: constant vmcnt)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    char* dummy = smem + NS * STAGE;                 // 1 KB sink of the padding instructions
     int* table = reinterpret_cast<int*>(smem + NS * STAGE + 1024);   // [NTAB][32][4]: xoff, vmask, dyoff, -
+    const unsigned lds0 = (unsigned)(size_t)(wd_lds_void*)smem;      // LDS byte address of the staging area
+    const unsigned dummy_off = lds0 + NS * STAGE;                    // 1 KB sink of the padding instructions
 
     const hc_wgrad_desc& d = a.d;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -76,65 +94,85 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const Args a) {
     if (s_end > a.total_steps) s_end = a.total_steps;
     const int nsteps = s_end - s_begin;
 
-    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(d.x, (unsigned)d.N * d.IH * d.IW * d.Cin * 2u);
-    const __amdgpu_buffer_rsrc_t rsy = make_rsrc(d.dy, (unsigned)d.N * d.OH * d.OW * d.Cout * 2u);
+    const u32x4 rsx = raw_rsrc(d.x, (unsigned)d.N * d.IH * d.IW * d.Cin * 2u);
+    const u32x4 rsy = raw_rsrc(d.dy, (unsigned)d.N * d.OH * d.OW * d.Cout * 2u);
 
-    // ---- pixel table of one k-step (lanes 0..31 of wave 0) ---------------------------------------------
-    auto make_table = [&](int step) {   // step relative to s_begin; steps past the range are all-invalid
-        const int j = lane;
-        const int m = (s_begin + step) * 32 + j;
+    // ---- pixel table of one k-step: lanes 0..31 of wave 0 walk the pixels 32 at a time (no divisions in the loop) ----
+    int tn = 0, toh = 0, tow = 0, tstep = 0;         // (n, oh, ow) of this lane's pixel at table step `tstep`
+    {
+        const int m = s_begin * 32 + (lane & 31);
+        const int hw = d.OH * d.OW;
+        tn = m / hw;
+        const int r = m - tn * hw;
+        toh = r / d.OW;
+        tow = r - toh * d.OW;
+    }
+    auto make_table = [&]() {                        // writes table(tstep), then advances by 32 pixels
+        const int m = (s_begin + tstep) * 32 + lane;
         int xoff = 0, vmask = 0;
         unsigned dyoff = HC_OOB;
-        if (step < nsteps && m < a.M) {
-            const int hw = d.OH * d.OW;
-            const int n = m / hw;
-            const int r = m - n * hw;
-            const int oh = r / d.OW, ow = r - oh * d.OW;
-            const int ih = oh * d.stride + kh - d.pad, iw0 = ow * d.stride - d.pad;
+        if (tstep < nsteps && m < a.M) {
+            const int ih = toh * d.stride + kh - d.pad, iw0 = tow * d.stride - d.pad;
             if ((unsigned)ih < (unsigned)d.IH) {
 #pragma unroll
                 for (int t = 0; t < TG; ++t)
                     if ((unsigned)(iw0 + t) < (unsigned)d.IW) vmask |= 1 << t;
             }
-            xoff = ((n * d.IH + ih) * d.IW + iw0) * d.Cin * 2;     // may wrap below zero for iw0 = -1: fine
+            xoff = ((tn * d.IH + ih) * d.IW + iw0) * d.Cin * 2;     // may wrap below zero for iw0 = -1: fine
             dyoff = (unsigned)m * (unsigned)d.Cout * 2u;
         }
-        int* e = table + ((step % NTAB) * 32 + j) * 4;
+        int* e = table + ((tstep % NTAB) * 32 + lane) * 4;
         e[0] = xoff;
         e[1] = vmask;
         e[2] = (int)dyoff;
+        ++tstep;
+        tow += a.adv_ow;  toh += a.adv_oh;  tn += a.adv_n;          // 32 = adv_n * OH*OW + adv_oh * OW + adv_ow
+        if (tow >= d.OW) { tow -= d.OW; ++toh; }
+        if (toh >= d.OH) { toh -= d.OH; ++tn; }
     };
 
-    // ---- DMA of one stage --------------------------------------------------------------------------
+    // ---- DMA of one stage: everything that does not depend on the step is a per-lane constant ----------------
     const int prow = lane >> 3;                       // pixel row inside a 1 KB DMA slab (8 rows of 128 B)
     const int pchunk = lane & 7;                      // physical 16-byte chunk inside the row
+    int i_tab[CEILI];                                 // table index (ints) of the pixel this lane stages
+    unsigned i_cof[CEILI];                            // channel (+ tap) byte offset, HC_OOB when the channel is out of range
+#pragma unroll
+    for (int ii = 0; ii < CEILI; ++ii) {
+        const int i = wid + ii * NW;
+        const int sub = i >> 2, q = i & 3;
+        const int p = 8 * q + prow;
+        const int lc = pchunk ^ (((p >> 1) & 1) << 2);             // source-side swizzle
+        i_tab[ii] = p * 4;
+        if (sub < SUBA) {
+            const int ch = co0 + sub * 64 + lc * 8;
+            i_cof[ii] = ch < d.Cout ? (unsigned)ch * 2u : HC_OOB;
+        } else {
+            const int sb = sub - SUBA;
+            const int t = sb / WN, w = sb - t * WN;
+            const int ch = ci0 + w * 64 + lc * 8;
+            i_cof[ii] = ch < d.Cin ? (unsigned)((t * d.Cin + ch) * 2) : HC_OOB;
+        }
+    }
     auto issue = [&](int step) {
-        char* st = smem + (step % NS) * STAGE;
+        const unsigned st = lds0 + (unsigned)(step % NS) * STAGE;
         const int* tb = table + (step % NTAB) * 32 * 4;
 #pragma unroll
         for (int ii = 0; ii < CEILI; ++ii) {
             const int i = wid + ii * NW;              // wave-uniform
             if (i < NI) {
                 const int sub = i >> 2, q = i & 3;
-                const int p = 8 * q + prow;
-                const int lc = pchunk ^ (((p >> 1) & 1) << 2);     // source-side swizzle
-                const int* e = tb + p * 4;
-                unsigned voff;
+                const int e0 = tb[i_tab[ii]], e1 = tb[i_tab[ii] + 1], e2 = tb[i_tab[ii] + 2];
+                const unsigned dst = __builtin_amdgcn_readfirstlane(st + (unsigned)(sub * SUB + q * 1024));
                 if (sub < SUBA) {
-                    const int ch = co0 + sub * 64 + lc * 8;
-                    const unsigned dyo = (unsigned)e[2];
-                    voff = (dyo != HC_OOB && ch < d.Cout) ? dyo + (unsigned)ch * 2u : HC_OOB;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsy, (wd_lds_void*)(st + sub * SUB + q * 1024), 16, voff, 0, 0, 0);
+                    const bool ok = ((unsigned)e2 != HC_OOB) & (i_cof[ii] != HC_OOB);
+                    dma16(rsy, dst, ok ? (unsigned)e2 + i_cof[ii] : HC_OOB);
                 } else {
-                    const int sb = sub - SUBA;
-                    const int t = sb / WN, w = sb - t * WN;
-                    const int ch = ci0 + w * 64 + lc * 8;
-                    const bool ok = ((e[1] >> t) & 1) && ch < d.Cin;
-                    voff = ok ? (unsigned)e[0] + (unsigned)((t * d.Cin + ch) * 2) : HC_OOB;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (wd_lds_void*)(st + sub * SUB + q * 1024), 16, voff, 0, 0, 0);
+                    const int t = (sub - SUBA) / WN;
+                    const bool ok = (((e1 >> t) & 1) != 0) & (i_cof[ii] != HC_OOB);
+                    dma16(rsx, dst, ok ? (unsigned)e0 + i_cof[ii] : HC_OOB);
                 }
             } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (wd_lds_void*)dummy, 16, HC_OOB, 0, 0, 0);
+                dma16(rsx, __builtin_amdgcn_readfirstlane(dummy_off), HC_OOB);
             }
         }
     };
@@ -175,7 +213,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const Args a) {
     };
 
     // ---- pipeline ------------------------------------------------------------------------------------
-    if (wid == 0 && lane < 32) { make_table(0); make_table(1); make_table(2); }
+    if (wid == 0 && lane < 32) { make_table(); make_table(); make_table(); }
     __syncthreads();
     issue(0);
     issue(1);
@@ -191,7 +229,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const Args a) {
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __syncthreads();                 // stage s visible to all, compute(s-1) finished, table(s+2) visible
         issue(s + 2);                    // into the buffer compute(s-1) just released
-        if (wid == 0 && lane < 32) make_table(s + 3);
+        if (wid == 0 && lane < 32) make_table();     // table(s+3)
         compute(s);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the zero-fill tail before the workgroup retires
@@ -249,6 +287,10 @@ inline Plan make_plan(const hc_wgrad_desc& d) {
     a.n_co_tiles = d.Cout / (64 * WM);
     a.n_ci_tiles = d.Cin / (64 * WN);
     a.n_tg = T / pl.TG;
+    const int hw = d.OH * d.OW;
+    a.adv_n = 32 / hw;
+    a.adv_oh = (32 - a.adv_n * hw) / d.OW;
+    a.adv_ow = 32 - a.adv_n * hw - a.adv_oh * d.OW;
     pl.ok = true;
     return pl;
 }
