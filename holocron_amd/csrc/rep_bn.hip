@@ -437,24 +437,56 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_apply_kernel(const u32x
 }
 
 // ---------------------------------------------------------------- global average pool
-__global__ void gap_fwd_kernel(const u32x4* __restrict__ x, float* __restrict__ y, int N, int HW, int C) {
+// y[n][c] += mean over an HW slice: grid (slices, N); R = 256 / cg threads share a channel group and are combined in LDS,
+// one atomicAdd per (block, channel) into the zeroed output (the squeeze-excite pools of ReXNet read 100+ MB each)
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const u32x4* __restrict__ x, float* __restrict__ y, int N, int HW, int C,
+                                                      int rows_per_block) {
+    __shared__ float sh[256 * 9];
     const int cg = C / 8;
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long)N * cg) return;
-    const int n = (int)(t / cg), g = (int)(t % cg);
-    float s[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s[i] = 0.f;
-    const u32x4* p = x + (long)n * HW * cg + g;
-    for (int h = 0; h < HW; ++h) {
-        float f[8];
-        unpack8(p[(long)h * cg], f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s[i] += f[i];
-    }
+    const int n = blockIdx.y;
+    const int h0 = blockIdx.x * rows_per_block;
+    int h1 = h0 + rows_per_block;
+    if (h1 > HW) h1 = HW;
     const float inv = 1.f / (float)HW;
+    const u32x4* p = x + (long)n * HW * cg;
+    if (cg <= 256) {
+        const int R = 256 / cg;                   // threads per channel group
+        const int g = threadIdx.x % cg, r0 = threadIdx.x / cg;
+        float s[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) y[(long)n * C + g * 8 + i] = s[i] * inv;
+        for (int i = 0; i < 8; ++i) s[i] = 0.f;
+        if (r0 < R) {
+            for (int h = h0 + r0; h < h1; h += R) {
+                float f[8];
+                unpack8(p[(long)h * cg + g], f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s[i] += f[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sh[threadIdx.x * 9 + i] = s[i];
+        __syncthreads();
+        for (int o = threadIdx.x; o < C; o += 256) {
+            const int gg = o >> 3, e = o & 7;
+            float acc = 0.f;
+            for (int r = 0; r < R; ++r) acc += sh[(r * cg + gg) * 9 + e];
+            atomicAdd(y + (long)n * C + o, acc * inv);
+        }
+    } else {
+        for (int g = threadIdx.x; g < cg; g += 256) {
+            float s[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] = 0.f;
+            for (int h = h0; h < h1; ++h) {
+                float f[8];
+                unpack8(p[(long)h * cg + g], f);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s[i] += f[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) atomicAdd(y + (long)n * C + g * 8 + i, s[i] * inv);
+        }
+    }
 }
 __global__ void gap_bwd_kernel(const float* __restrict__ dy, u32x4* __restrict__ dx, int N, int HW, int C) {
     const int cg = C / 8;
@@ -725,8 +757,15 @@ int hc_bn_act_bwd_apply(const void* g, int32_t g_ld, const void* y, const float*
 }
 int hc_gap_fwd(const void* x, float* y, int32_t N, int32_t HW, int32_t C, hc_stream_t stream) {
     if (x == nullptr || y == nullptr || (C % 8) != 0) return HC_ERR_ARG;
-    const long t = (long)N * (C / 8);
-    hipLaunchKernelGGL(gap_fwd_kernel, dim3((t + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, y, N, HW, C);
+    if (N <= 0 || HW <= 0 || N > 65535) return (N == 0 || HW == 0) ? HC_OK : HC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)N * C, st) != hipSuccess) return HC_ERR_LAUNCH;
+    const int cg = C / 8;
+    const int R = cg <= 256 ? 256 / cg : 1;
+    // enough workgroups to fill the chip, at least 4 rows per thread
+    int rows = R * 4;
+    while ((long)N * ((HW + rows - 1) / rows) > 8192 && rows < HW) rows *= 2;
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3((HW + rows - 1) / rows, N), dim3(256), 0, st, (const u32x4*)x, y, N, HW, C, rows);
     return hc_launch_status();
 }
 int hc_gap_bwd(const float* dy, void* dx, int32_t N, int32_t HW, int32_t C, hc_stream_t stream) {

@@ -416,7 +416,14 @@ class _GapFn(torch.autograd.Function):
 
 def global_avg_pool2d(x: Tensor) -> Tensor:
     """Mean over H*W of an NHWC-bf16 activation -> fp32 [N, C]."""
-    from ..ops.conv import to_cl_bf16
-    if x.shape[1] % 8 != 0:
-        return x.float().flatten(2).mean(2)
-    return _GapFn.apply(to_cl_bf16(x))
+    from ..ops.conv import is_cl_bf16, to_cl_bf16
+    _lib.require_gpu(x)
+    if not is_cl_bf16(x):
+        if x.shape[1] % 8 != 0:
+            from .mbconv_op import _PadChannelsFn, ceil16
+            return _GapFn.apply(_PadChannelsFn.apply(x, ceil16(x.shape[1])))[:, :x.shape[1]]
+        # layout / dtype change through autograd-aware torch ops when a gradient has to flow back
+        x = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if x.requires_grad else to_cl_bf16(x)
+        if x.stride(1) != 1:
+            x = to_cl_bf16(x.detach()) if not x.requires_grad else x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return _GapFn.apply(x)

@@ -167,6 +167,22 @@ def test_dropblock_batched_masks_equal_per_call_masks():
         off += n * h * w
 
 
+def test_global_avg_pool_matches_adaptive_avg_pool():
+    """tests/test_nn_downsample.py:37-50 of the reference: GlobalAvgPool2d == AdaptiveAvgPool2d(1), plus gradients."""
+    import holocron_amd as h
+    g = torch.Generator().manual_seed(9)
+    for (n, c, hh, ww) in [(2, 16, 7, 7), (3, 240, 28, 28), (2, 2056, 5, 4), (5, 1280, 1, 1), (4, 48, 56, 56)]:
+        x = torch.randn((n, c, hh, ww), generator=g).to(torch.bfloat16).float()
+        xg = x.cuda().requires_grad_(True)
+        y = h.nn.GlobalAvgPool2d(flatten=True)(xg)
+        ref = x.mean(dim=(2, 3))
+        assert y.shape == (n, c) and torch.allclose(y.float().cpu(), ref, rtol=1e-5, atol=1e-6)
+        r = torch.randn((n, c), generator=g)
+        (y.float() * r.cuda()).sum().backward()
+        assert torch.allclose(xg.grad.float().cpu(), (r / (hh * ww)).view(n, c, 1, 1).expand(n, c, hh, ww), rtol=1e-2, atol=1e-6)
+    assert h.nn.GlobalAvgPool2d(flatten=False)(torch.rand(2, 8, 4, 4).cuda()).shape == (2, 8, 1, 1)
+
+
 def test_adabelief_matches_reference(golden):
     import holocron_amd as h
     for c in golden("optim.pt")["adabelief"]:
