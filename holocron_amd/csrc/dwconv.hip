@@ -29,6 +29,9 @@ inline int dw_blocks(long items, int cg, int per_thread) {
     while (b) { int t = a % b; a = b; b = t; }
     const int unit = cg / a;
     long want = items / ((long)DW_THREADS * per_thread);
+    long floor_blocks = items / DW_THREADS;      // mid-size tensors: fill the chip before batching work per thread
+    if (floor_blocks > 1024) floor_blocks = 1024;
+    if (want < floor_blocks) want = floor_blocks;
     if (want > 4096) want = 4096;
     if (want < 1) want = 1;
     const long k = (want + unit - 1) / unit;

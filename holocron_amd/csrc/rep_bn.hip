@@ -25,6 +25,11 @@ inline int ew_blocks(long nchunks, int cg, int cpt_default = 8) {
     // reduction (their tail costs as much as streaming a few MB, measured with scripts/bench_ew.py)
     const int cpt = cpt_default;
     long want = nchunks / (EW_THREADS * cpt);
+    // mid-size tensors: fill the chip (at least ~4 workgroups per CU) as long as every thread still has 2 chunks
+    static const long fl = getenv("HC_EW_FLOOR") ? atol(getenv("HC_EW_FLOOR")) : 1024;
+    long floor_blocks = nchunks / (EW_THREADS * 2);
+    if (floor_blocks > fl) floor_blocks = fl;
+    if (want < floor_blocks) want = floor_blocks;
     if (want > 2048) want = 2048;
     if (want < 1) want = 1;
     long k = (want + unit - 1) / unit;
