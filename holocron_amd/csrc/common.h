@@ -36,6 +36,30 @@ __device__ __forceinline__ float bf16hi(unsigned int w) { return __builtin_bit_c
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
+// Direct-to-LDS DMA of 16 bytes per lane (buffer_load_dwordx4 ... lds) issued through inline assembly.  The compiler's
+// wait-count insertion treats the builtin as an LDS store that later LDS reads and barriers must wait for with
+// vmcnt(0), which defeats multi-stage pipelines; with the asm form the kernels own the ordering (explicit
+// `s_waitcnt vmcnt(n)` + barrier).  lds_off: wave-uniform LDS byte address (lane i lands at +16 i).
+typedef __attribute__((address_space(3))) void hc_lds_void;
+__device__ __forceinline__ void hc_dma16(const u32x4 rsrc, unsigned lds_off, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_off), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ u32x4 hc_raw_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    u32x4 r;
+    r[0] = (unsigned)a;
+    r[1] = (unsigned)(a >> 32) & 0xffffu;
+    r[2] = bytes;
+    r[3] = 0x00020000u;
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void hc_wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ unsigned hc_lds_addr(const void* p) { return (unsigned)(size_t)(hc_lds_void*)p; }
+
 __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned int voff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
 }
