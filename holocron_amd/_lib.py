@@ -28,7 +28,8 @@ class ConvDesc(C.Structure):
                 ("stats", c_void_p), ("bias", c_void_p), ("act", c_int32),
                 ("N", c_int32), ("IH", c_int32), ("IW", c_int32), ("srcC", c_int32),
                 ("OH", c_int32), ("OW", c_int32), ("Cout", c_int32), ("T", c_int32), ("nclass", c_int32),
-                ("cls", ConvClass * 4), ("pix_scale", c_void_p), ("pix_shift", c_void_p), ("ch_coef", c_void_p)]
+                ("cls", ConvClass * 4), ("pix_scale", c_void_p), ("pix_shift", c_void_p), ("ch_coef", c_void_p),
+                ("ch_mult", c_void_p)]
 
 
 class ConvSmallDesc(C.Structure):
@@ -161,6 +162,8 @@ SIGNATURES = {
                                          c_int64, c_int32, c_void_p]),
     "hc_patch_stats": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p] + [c_int32] * 8 + [c_float, c_void_p]),
     "hc_normconv_bwd_scale": (c_int32, [c_void_p] * 5 + [c_int64, c_int32, c_void_p]),
+    "hc_quantize_fp8": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_float, c_void_p]),
+    "hc_gap_fp8": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "hc_version": (C.c_char_p, []),
 }
 

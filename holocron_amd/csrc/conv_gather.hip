@@ -25,8 +25,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
-template <int MR, int NR, int WM, int WN, int BK>
+// FP8: inference-only variant on OCP e4m3 bytes (config C5, reparametrised RepVGG).  A k-step of 64 fp8 channels has the
+// byte geometry of a 32-element bf16 k-step, so staging, swizzle and DMA are shared (the host passes srcC / 2); the
+// fragments are 32 bytes per lane (row = lane & 31, k = 32 * (lane >> 5) + [0, 32), probed in scripts/probes/mx_fp8_probe.hip)
+// and one v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 0x7f) replaces two bf16 MFMAs at twice the rate;
+// the epilogue applies the per-channel dequant * requant factor and bias, ReLU, and stores fp8.
+typedef __attribute__((ext_vector_type(8))) int hc_i32x8;
+template <int MR, int NR, int WM, int WN, int BK, bool FP8>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_conv_desc d) {
+    static_assert(!FP8 || BK == 32, "fp8: 64 one-byte channels per k-step");
     constexpr int NT = 64 * WM * WN;
     constexpr int BC = 32 * MR * WM;  // output-channel tile (A rows)
     constexpr int BP = 32 * NR * WN;  // output-pixel tile (B cols)
@@ -132,8 +139,32 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) frag_off[kk] = lds_off<BK>(lane & 31, kk * 2 + (lane >> 5));
     const int a_row0 = wm * MR * 32 * BK * 2, b_row0 = WBYTES + wn * NR * 32 * BK * 2;
+    const int f8_off0 = lds_off<BK>(lane & 31, 2 * (lane >> 5)), f8_off1 = lds_off<BK>(lane & 31, 2 * (lane >> 5) + 1);
     auto compute = [&](int stage) {
         const char* st = smem + stage * STAGE;
+        if (FP8) {
+            hc_i32x8 a[MR], b[NR];
+            const char* pa = st + a_row0;
+            const char* pb = st + b_row0;
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+                const u32x4 lo = *reinterpret_cast<const u32x4*>(pa + mr * 32 * BK * 2 + f8_off0);
+                const u32x4 hi = *reinterpret_cast<const u32x4*>(pa + mr * 32 * BK * 2 + f8_off1);
+                a[mr] = hc_i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            }
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const u32x4 lo = *reinterpret_cast<const u32x4*>(pb + nr * 32 * BK * 2 + f8_off0);
+                const u32x4 hi = *reinterpret_cast<const u32x4*>(pb + nr * 32 * BK * 2 + f8_off1);
+                b[nr] = hc_i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            }
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    acc[mr][nr] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[mr], b[nr], acc[mr][nr], 0, 0, 0, 0x7f, 0, 0x7f);
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8 a[MR], b[NR];
@@ -224,6 +255,39 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
         }
     }
 
+    if (FP8) {
+        // out = fp8(act(acc * ch_mult[co] + bias[co])): 4 consecutive channels of a pixel = one 32-bit store
+        unsigned char* dst8 = reinterpret_cast<unsigned char*>(d.dst);
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int m = pbase + (wn * NR + nr) * 32 + lr;
+            if (m >= M) continue;
+            const int n = m / (OHg * OWg);
+            const int rem = m - n * (OHg * OWg);
+            const int oi = rem / OWg, oj = rem - oi * OWg;
+            const long pix = ((long)n * d.OH + (oi * cl.ostep + cl.oy0)) * d.OW + (oj * cl.ostep + cl.ox0);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = cbase + (wm * MR + mr) * 32 + 8 * q + 4 * lh;
+                    if (co >= Cout) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[mr][nr][4 * q + e] * d.ch_mult[co + e] + (d.bias != nullptr ? d.bias[co + e] : 0.f);
+                        if (d.act != 0) t = apply_act(t, d.act);
+                        v[e] = fminf(fmaxf(t, -448.f), 448.f);       // e4m3fn has no inf: saturate
+                    }
+                    int pk = 0;
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], pk, false);
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+                    *reinterpret_cast<int*>(dst8 + pix * Cout + co) = pk;
+                }
+            }
+        }
+        return;
+    }
     bf16_t* dst = reinterpret_cast<bf16_t*>(d.dst);
     const bf16_t* resid = reinterpret_cast<const bf16_t*>(d.resid);
 #pragma unroll
@@ -284,7 +348,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
     }
 }
 
-template <int MR, int NR, int WM, int WN, int BK>
+template <int MR, int NR, int WM, int WN, int BK, bool FP8 = false>
 int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
     constexpr int BC = 32 * MR * WM, BP = 32 * NR * WN;
     constexpr int smem = 2 * (BC + BP) * BK * 2;
@@ -295,7 +359,7 @@ int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
     }
     if (maxM == 0) return HC_OK;
     dim3 grid((maxM + BP - 1) / BP, (d.Cout + BC - 1) / BC, d.nclass);
-    auto kern = conv_gather_kernel<MR, NR, WM, WN, BK>;
+    auto kern = conv_gather_kernel<MR, NR, WM, WN, BK, FP8>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -316,6 +380,18 @@ int launch_bk(const hc_conv_desc& d, hipStream_t st) {
     return launch_cfg<2, 2, 2, 2, BK>(d, st);
 }
 
+// fp8 inference: the descriptor arrives with srcC in channels (= bytes); the kernel sees it in 2-byte units
+int launch_fp8(const hc_conv_desc& din, hipStream_t st) {
+    hc_conv_desc d = din;
+    d.srcC = din.srcC / 2;
+    const int C = d.Cout;
+    if (C <= 64) return launch_cfg<1, 2, 2, 2, 32, true>(d, st);
+    if (C <= 96) return launch_cfg<3, 1, 1, 4, 32, true>(d, st);
+    const int w128 = ((C + 127) / 128) * 128 - C, w192 = ((C + 191) / 192) * 192 - C;
+    if (w192 <= w128) return launch_cfg<3, 2, 2, 2, 32, true>(d, st);
+    return launch_cfg<2, 2, 2, 2, 32, true>(d, st);
+}
+
 }  // namespace
 
 extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
@@ -331,6 +407,11 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
             if (((d.cls[c].tap[t] >> 16) & 0xff) != 0 && d.src1 == nullptr) return HC_ERR_ARG;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d.ch_mult != nullptr) {   // fp8 inference path
+        if ((d.srcC % 64) != 0 || (d.Cout % 4) != 0 || d.stats != nullptr || d.resid != nullptr || d.pix_scale != nullptr) return HC_ERR_ARG;
+        if ((double)d.N * d.IH * d.IW * d.srcC >= 4294967280.0) return HC_ERR_ARG;
+        return launch_fp8(d, st);
+    }
     if (d.srcC % 64 == 0) return launch_bk<64>(d, st);
     if (d.srcC % 32 == 0) return launch_bk<32>(d, st);
     return launch_bk<16>(d, st);

@@ -244,6 +244,42 @@ __global__ void slim_fold_bwd_apply_kernel(const bf16_t* __restrict__ l, int lld
     }
 }
 
+// ---------------------------------------------------------------- fp8 (OCP e4m3) helpers of the inference path
+__global__ void quantize_fp8_kernel(const bf16_t* __restrict__ src, int sld, unsigned char* __restrict__ dst, int dld, long npix, int C,
+                                    float inv_scale) {
+    const int q4 = dld / 4;   // 4 output bytes per thread
+    const long total = npix * q4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / q4;
+        const int c = (int)(i - p * q4) * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = (c + e < C) ? bf16_to_f32(src[p * sld + c + e]) * inv_scale : 0.f;
+            v[e] = fminf(fmaxf(t, -448.f), 448.f);
+        }
+        int pk = 0;
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], pk, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+        *reinterpret_cast<int*>(dst + p * dld + c) = pk;
+    }
+}
+__device__ __forceinline__ float fp8_e4m3_to_f32(unsigned int b) {   // OCP e4m3fn byte -> fp32 (no NaN handling needed here)
+    const unsigned int s = (b & 0x80u) << 24, e = (b >> 3) & 15u, m = b & 7u;
+    if (e == 0) return __builtin_bit_cast(float, s) + (s ? -1.f : 1.f) * (float)m * 0.001953125f;   // m * 2^-9
+    return __builtin_bit_cast(float, s | ((e + 120u) << 23) | (m << 20));
+}
+__global__ __launch_bounds__(256) void gap_fp8_kernel(const unsigned char* __restrict__ x, float* __restrict__ y, int HW, int ld, int C,
+                                                      float scale) {
+    const long n = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const unsigned char* p = x + n * HW * ld + c;
+    float s = 0.f;
+    for (int h = 0; h < HW; ++h) s += fp8_e4m3_to_f32(p[(long)h * ld]);
+    y[n * C + c] = s * scale / (float)HW;
+}
+
 }  // namespace
 
 extern "C" {
@@ -328,6 +364,22 @@ int hc_slim_fold_bwd_apply(const void* gate_logits, int32_t l_ld, const void* gt
     hipLaunchKernelGGL(slim_fold_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)gate_logits, l_ld, (const bf16_t*)gtop, (const bf16_t*)gbot, out_ld, dpool, dpool_ld, (bf16_t*)dx,
                        x_ld, (long)N, (long)HW, C);
+    return hc_launch_status();
+}
+
+int hc_quantize_fp8(const void* src_bf16, int32_t src_ld, void* dst_fp8, int32_t dst_ld, int64_t npix, int32_t C, float inv_scale,
+                    hc_stream_t stream) {
+    if (src_bf16 == nullptr || dst_fp8 == nullptr || C <= 0 || src_ld < C || dst_ld < C || (dst_ld % 4) != 0) return HC_ERR_ARG;
+    if (npix == 0) return HC_OK;
+    hipLaunchKernelGGL(quantize_fp8_kernel, dim3(grid_for((long)npix * (dst_ld / 4))), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src_bf16, src_ld, (unsigned char*)dst_fp8, dst_ld, (long)npix, C, inv_scale);
+    return hc_launch_status();
+}
+int hc_gap_fp8(const void* x_fp8, float* y, int32_t N, int32_t HW, int32_t ld, int32_t C, float scale, hc_stream_t stream) {
+    if (x_fp8 == nullptr || y == nullptr || C <= 0 || ld < C || N < 0 || N > 65535) return HC_ERR_ARG;
+    if (N == 0 || HW == 0) return HC_OK;
+    hipLaunchKernelGGL(gap_fp8_kernel, dim3((C + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x_fp8, y, HW, ld,
+                       C, scale);
     return hc_launch_status();
 }
 

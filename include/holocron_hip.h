@@ -58,6 +58,11 @@ typedef struct {
     const float* pix_scale;  /* fp32 [N*OH*OW]: rsqrt(var + eps) of each unfolded patch */
     const float* pix_shift;  /* fp32 [N*OH*OW]: mean of each unfolded patch */
     const float* ch_coef;    /* fp32 [Cout]: sum over (ci, kh, kw) of the (bf16-rounded) weights */
+    /* fp8 inference (BASELINE config C5, reparametrised RepVGG: repvgg.py:75-107 + one conv + ReLU per block): when
+     * ch_mult != NULL the sources, packed weights and dst hold OCP e4m3 bytes (srcC % 64 == 0, Cout % 4 == 0), the MFMA is
+     * v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales and dst = fp8(act(acc * ch_mult[co] + bias[co])), i.e.
+     * ch_mult = weight_scale[co] * input_scale / output_scale and bias is pre-divided by the output scale. */
+    const float* ch_mult;    /* fp32 [Cout] */
 } hc_conv_desc;
 int hc_conv_gather(const hc_conv_desc* d, hc_stream_t stream);
 
@@ -411,6 +416,12 @@ int hc_patch_stats(const void* x, int32_t x_ld, float* mean, float* rstd, int32_
                    int32_t KW, int32_t stride, int32_t pad, float eps, hc_stream_t stream);
 int hc_normconv_bwd_scale(const void* g, const float* mean, const float* rstd, void* gs, float* red, int64_t npix, int32_t C,
                           hc_stream_t stream);
+
+/* fp8 helpers of the C5 inference path: quantize NHWC bf16 -> e4m3 bytes (out = fp8(clamp(x * inv_scale))), with optional
+ * channel padding dst_ld >= C (zeros); global average pool of an fp8 NHWC tensor -> fp32 [N][C] (times `scale`). */
+int hc_quantize_fp8(const void* src_bf16, int32_t src_ld, void* dst_fp8, int32_t dst_ld, int64_t npix, int32_t C, float inv_scale,
+                    hc_stream_t stream);
+int hc_gap_fp8(const void* x_fp8, float* y, int32_t N, int32_t HW, int32_t ld, int32_t C, float scale, hc_stream_t stream);
 
 const char* hc_version(void);
 

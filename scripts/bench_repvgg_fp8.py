@@ -1,0 +1,55 @@
+"""Secondary measurement: repvgg_a2 re-parametrised fp8 (OCP e4m3) inference, synthetic 224 x 224,
+batch 1024 on one MI355X; also times the bf16 re-parametrised path of the same model.  Prints one JSON line.
+
+    python scripts/bench_repvgg_fp8.py --batch 1024 --steps 20 --warmup 5
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: E402
+
+import holocron_amd as h  # noqa: E402
+from holocron_amd.models.classification.repvgg_fp8 import Fp8RepVGG  # noqa: E402
+
+INFER_GFLOP_PER_IMG = 14.465   # 2 x 7.2326 GMAC, re-parametrised repvgg_a2
+
+
+def timeit(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    m = h.models.repvgg_a2(num_classes=1000).cuda().eval()
+    m.reparametrize()
+    x = torch.rand((a.batch, 3, 224, 224), device="cuda")
+    q = Fp8RepVGG(m, x[:64])
+    with torch.no_grad():
+        t_bf16 = timeit(lambda: m(x), max(3, a.steps // 4), 2)
+        t_fp8 = timeit(lambda: q(x), a.steps, a.warmup)
+        agree = float((q(x[:256]).argmax(1) == m(x[:256]).float().argmax(1)).float().mean())
+    print(json.dumps({"metric": "images/sec inference, repvgg_a2 re-parametrised fp8 e4m3, 224^2", "value": a.batch / t_fp8, "unit": "img/s",
+                      "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": t_fp8 * 1e3, "dtype": "fp8 e4m3 (fp32 accumulate)",
+                      "data": "synthetic", "config": {"workload": f"repvgg_a2 reparam fp8 inference 224^2 bs{a.batch}"},
+                      "tflops": INFER_GFLOP_PER_IMG * a.batch / t_fp8 / 1e3, "frac_of_5PF": INFER_GFLOP_PER_IMG * 1e9 * a.batch / t_fp8 / 5e15,
+                      "bf16_img_s": a.batch / t_bf16, "bf16_ms": t_bf16 * 1e3, "top1_agreement_with_bf16": agree}))
+
+
+if __name__ == "__main__":
+    main()
