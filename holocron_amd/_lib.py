@@ -162,6 +162,7 @@ SIGNATURES = {
                                          c_int64, c_int32, c_void_p]),
     "hc_patch_stats": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p] + [c_int32] * 8 + [c_float, c_void_p]),
     "hc_normconv_bwd_scale": (c_int32, [c_void_p] * 5 + [c_int64, c_int32, c_void_p]),
+    "hc_im2col_small_fp8": (c_int32, [c_void_p, c_void_p] + [c_int32] * 11 + [c_float, c_void_p]),
     "hc_quantize_fp8": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_float, c_void_p]),
     "hc_gap_fp8": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "hc_version": (C.c_char_p, []),

@@ -619,6 +619,42 @@ __global__ void im2col_small_kernel(const float* __restrict__ x, bf16_t* __restr
         reinterpret_cast<u32x4*>(col)[q] = pack8(f);
     }
 }
+// same gather, quantised straight to OCP e4m3 bytes (fp8 inference stem): col [N][OH][OW][Kpad] uint8 = fp8(x * inv_scale)
+__global__ void im2col_small_fp8_kernel(const float* __restrict__ x, unsigned char* __restrict__ col, int N, int Cin, int H, int W,
+                                        int OH, int OW, int KH, int KW, int stride, int pad, int Kpad, float inv_scale) {
+    const long total = (long)N * OH * OW * (Kpad / 8);
+    const int K = Cin * KH * KW;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+        const int kc = (int)(q % (Kpad / 8));
+        const long p = q / (Kpad / 8);
+        const int ox = (int)(p % OW);
+        const long r = p / OW;
+        const int oy = (int)(r % OH);
+        const int n = (int)(r / OH);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kc * 8 + e;
+            float v = 0.f;
+            if (k < K) {
+                const int ci = k % Cin, t = k / Cin;
+                const int kh = t / KW, kw = t % KW;
+                const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[(((long)n * Cin + ci) * H + iy) * W + ix];
+            }
+            f[e] = fminf(fmaxf(v * inv_scale, -448.f), 448.f);
+        }
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        u32x2 pk;
+        pk[0] = (unsigned)lo;
+        pk[1] = (unsigned)hi;
+        reinterpret_cast<u32x2*>(col)[q] = pk;
+    }
+}
 // dwcol fp32 [Cout][Kpad] (k = (kh*KW+kw)*Cin+ci) -> dw OIHW
 __global__ void unpack_im2col_grad_kernel(const float* __restrict__ dwcol, float* __restrict__ dw, int Cout, int Cin, int KH, int KW,
                                           int Kpad, int beta) {
@@ -817,6 +853,14 @@ int hc_im2col_small(const float* x, void* col, int32_t N, int32_t Cin, int32_t H
     const long total = (long)N * OH * OW * (Kpad / 8);
     hipLaunchKernelGGL(im2col_small_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)col, N,
                        Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad);
+    return hc_launch_status();
+}
+int hc_im2col_small_fp8(const float* x, void* col, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t KH,
+                        int32_t KW, int32_t stride, int32_t pad, int32_t Kpad, float inv_scale, hc_stream_t stream) {
+    if (x == nullptr || col == nullptr || (Kpad % 8) != 0 || Cin * KH * KW > Kpad) return HC_ERR_ARG;
+    const long total = (long)N * OH * OW * (Kpad / 8);
+    hipLaunchKernelGGL(im2col_small_fp8_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x,
+                       (unsigned char*)col, N, Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad, inv_scale);
     return hc_launch_status();
 }
 int hc_unpack_im2col_grad(const float* dwcol, float* dw, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t Kpad,

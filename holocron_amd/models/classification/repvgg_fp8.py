@@ -8,8 +8,8 @@ repvgg.py:75-107,168-171): one 3x3 conv + bias + ReLU per block.  This executor 
 * activations quantised per tensor with static scales from a calibration batch:  Xq = fp8(X / sx),
 * convolutions on ``v_mfma_scale_f32_32x32x64_f8f6f4`` (unit block scales) with fp32 accumulation, and the epilogue
   ``out_q = fp8(relu(acc * (sw[co] * sx_in / sx_out) + bias[co] / sx_out))`` (hc_conv_gather, ``ch_mult`` mode),
-* channel counts padded to multiples of 64 in the fp8 layout (zeros), the stem (3 input channels) through a bf16
-  im2col that is quantised to a 64-wide fp8 k-step,
+* channel counts padded to multiples of 64 in the fp8 layout (zeros), the stem (3 input channels) through an im2col
+  that quantises straight to a 64-wide fp8 k-step,
 * global average pool on the fp8 tensor, fp32 linear head.
 """
 from typing import List
@@ -122,11 +122,12 @@ class Fp8RepVGG(nn.Module):
         N = x.shape[0]
         L0 = self.layers[0]
         k, pad = self._conv_meta[0]
-        col = cv.im2col_small(x, k, k, L0.stride, pad, L0.im2col_k)                 # bf16 [N, Kpad, OH, OW] (NHWC)
-        OH, OW = col.shape[2], col.shape[3]
+        xc = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+        H0, W0 = xc.shape[2], xc.shape[3]
+        OH, OW = cv.conv_out_size(H0, k, L0.stride, pad), cv.conv_out_size(W0, k, L0.stride, pad)
         h = torch.empty((N, OH, OW, 64), dtype=torch.uint8, device=x.device)
-        check(lib.hc_quantize_fp8(ptr(col), L0.im2col_k, ptr(h), 64, N * OH * OW, L0.im2col_k, 1.0 / self.input_scale, stream()),
-              "hc_quantize_fp8")
+        check(lib.hc_im2col_small_fp8(ptr(xc), ptr(h), N, xc.shape[1], H0, W0, OH, OW, k, k, L0.stride, pad, 64, 1.0 / self.input_scale,
+                                      stream()), "hc_im2col_small_fp8")
         H, W = OH, OW
         for i, L in enumerate(self.layers):
             h = self._conv(L, i, h, N, H, W)

@@ -419,6 +419,9 @@ int hc_normconv_bwd_scale(const void* g, const float* mean, const float* rstd, v
 
 /* fp8 helpers of the C5 inference path: quantize NHWC bf16 -> e4m3 bytes (out = fp8(clamp(x * inv_scale))), with optional
  * channel padding dst_ld >= C (zeros); global average pool of an fp8 NHWC tensor -> fp32 [N][C] (times `scale`). */
+/* im2col of a tiny-Cin input straight to fp8: col uint8 [N][OH][OW][Kpad] = fp8(clamp(x * inv_scale)) (fp8 inference stem). */
+int hc_im2col_small_fp8(const float* x, void* col, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t KH,
+                        int32_t KW, int32_t stride, int32_t pad, int32_t Kpad, float inv_scale, hc_stream_t stream);
 int hc_quantize_fp8(const void* src_bf16, int32_t src_ld, void* dst_fp8, int32_t dst_ld, int64_t npix, int32_t C, float inv_scale,
                     hc_stream_t stream);
 int hc_gap_fp8(const void* x_fp8, float* y, int32_t N, int32_t HW, int32_t ld, int32_t C, float scale, hc_stream_t stream);

@@ -221,7 +221,7 @@ def fp8r(t):
 
 def forward_fp8_emulated(convs, head_w, head_b, x, input_scale, act_scales):
     """convs: list of (weight OIHW, bias, stride) of the re-parametrised blocks.  Returns the logits."""
-    h = fp8r(bf16r(x) / input_scale)                       # the stem input passes through a bf16 im2col first
+    h = fp8r(x / input_scale)
     sx_in = input_scale
     for (w, b, stride), sx_out in zip(convs, act_scales):
         sw = (w.abs().amax(dim=(1, 2, 3)).clamp(min=1e-12) / FP8_MAX).float()
