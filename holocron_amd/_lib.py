@@ -84,6 +84,11 @@ class DropItem(C.Structure):
                 ("pad_", c_int32)]
 
 
+class AdamxGroup(C.Structure):
+    _fields_ = [("lr", c_double), ("beta1", c_double), ("beta2", c_double), ("beta3", c_double), ("alpha", c_double),
+                ("eps", c_double), ("weight_decay", c_double), ("delta", c_double), ("step", c_int32), ("amsgrad", c_int32)]
+
+
 def tap(dy, dx, src, wt):
     """HC_TAP of the header."""
     u = (dy & 0xff) | ((dx & 0xff) << 8) | ((src & 0xff) << 16) | ((wt & 0xff) << 24)
@@ -120,6 +125,8 @@ SIGNATURES = {
     "hc_gap_fwd": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "hc_gap_bwd": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "hc_adabelief_step": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
+    "hc_ademamix_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p]),
+    "hc_adamp_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "hc_lars_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     "hc_hard_mish_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "hc_hard_mish_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -114,6 +114,86 @@ __global__ __launch_bounds__(256) void lars_update_kernel(const hc_mt_chunk* __r
     }
 }
 
+// ---------------------------------------------------------------- AdEMAMix (holocron/optim/ademamix.py:158-200)
+// chunk fields: m = exp_avg, s = exp_avg_sq, smax = exp_avg_slow
+__global__ __launch_bounds__(256) void ademamix_kernel(const hc_mt_chunk* __restrict__ chunks, const hc_adamx_group* __restrict__ groups) {
+    const hc_mt_chunk ck = chunks[blockIdx.x];
+    const hc_adamx_group gr = groups[ck.group];
+    const double bc1 = 1.0 - pow(gr.beta1, (double)gr.step), bc2 = 1.0 - pow(gr.beta2, (double)gr.step);
+    const float b1 = (float)gr.beta1, b2 = (float)gr.beta2, b3 = (float)gr.beta3;
+    const float o1 = (float)(1.0 - gr.beta1), o2 = (float)(1.0 - gr.beta2), o3 = (float)(1.0 - gr.beta3);
+    const float sqrt_bc2 = (float)sqrt(bc2), fbc1 = (float)bc1, eps = (float)gr.eps, alpha = (float)gr.alpha;
+    const float neg_lr = (float)(-gr.lr), wd = (float)gr.weight_decay;
+    for (int i = threadIdx.x; i < ck.n; i += 256) {
+        float p = ck.p[i], g = ck.g[i];
+        if (wd != 0.f) g = g + wd * p;
+        const float m1 = ck.m[i] * b1 + o1 * g;
+        const float nu = ck.s[i] * b2 + o2 * (g * g);
+        const float m2 = ck.smax[i] * b3 + o3 * g;
+        ck.m[i] = m1; ck.s[i] = nu; ck.smax[i] = m2;
+        const float den = sqrtf(nu) / sqrt_bc2 + eps;
+        ck.p[i] = p + neg_lr * ((m1 / fbc1 + alpha * m2) / den);
+    }
+}
+
+// ---------------------------------------------------------------- AdamP (holocron/optim/adamp.py:142-200)
+// pass 1: moments (in place) and the four per-tensor sums the projection test needs: p.g, p.p, g.g, p.pt
+__device__ __forceinline__ float adamp_pt(float m, float s, float fbc1, float sqrt_bc2, float eps) {
+    return (m / fbc1) / (sqrtf(s) / sqrt_bc2 + eps);
+}
+__global__ __launch_bounds__(256) void adamp_moments_kernel(const hc_mt_chunk* __restrict__ chunks, const hc_adamx_group* __restrict__ groups,
+                                                            float* __restrict__ sums) {
+    const hc_mt_chunk ck = chunks[blockIdx.x];
+    const hc_adamx_group gr = groups[ck.group];
+    const double bc1 = 1.0 - pow(gr.beta1, (double)gr.step), bc2 = 1.0 - pow(gr.beta2, (double)gr.step);
+    const float b1 = (float)gr.beta1, b2 = (float)gr.beta2, o1 = (float)(1.0 - gr.beta1), o2 = (float)(1.0 - gr.beta2);
+    const float sqrt_bc2 = (float)sqrt(bc2), fbc1 = (float)bc1, eps = (float)gr.eps, wd = (float)gr.weight_decay;
+    const bool ams = gr.amsgrad != 0 && ck.smax != nullptr;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < ck.n; i += 256) {
+        const float p = ck.p[i];
+        float g = ck.g[i];
+        if (wd != 0.f) g = g + wd * p;
+        const float m = ck.m[i] * b1 + o1 * g;
+        float s = ck.s[i] * b2 + o2 * (g * g);
+        ck.m[i] = m; ck.s[i] = s;
+        if (ams) { s = fmaxf(ck.smax[i], s); ck.smax[i] = s; }
+        const float pt = adamp_pt(m, s, fbc1, sqrt_bc2, eps);
+        acc[0] += p * g; acc[1] += p * p; acc[2] += g * g; acc[3] += p * pt;
+    }
+    __shared__ float sh[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float v = wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(sums + 4 * ck.tensor + threadIdx.x, sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+// pass 2: pt recomputed from the updated moments; projection onto the tangent space of p when
+// cos(p, g) < delta / sqrt(numel) (the reference's host-side `if`, adamp.py:196, decided on the device)
+__global__ __launch_bounds__(256) void adamp_update_kernel(const hc_mt_chunk* __restrict__ chunks, const hc_adamx_group* __restrict__ groups,
+                                                           const float* __restrict__ sums, const int* __restrict__ numel) {
+    const hc_mt_chunk ck = chunks[blockIdx.x];
+    const hc_adamx_group gr = groups[ck.group];
+    const double bc1 = 1.0 - pow(gr.beta1, (double)gr.step), bc2 = 1.0 - pow(gr.beta2, (double)gr.step);
+    const float sqrt_bc2 = (float)sqrt(bc2), fbc1 = (float)bc1, eps = (float)gr.eps, neg_lr = (float)(-gr.lr);
+    const bool ams = gr.amsgrad != 0 && ck.smax != nullptr;
+    const float pg = sums[4 * ck.tensor], pp = sums[4 * ck.tensor + 1], gg = sums[4 * ck.tensor + 2], ppt = sums[4 * ck.tensor + 3];
+    // F.cosine_similarity(x1, x2, eps=1e-8): x1.x2 / sqrt(max(|x1|^2 |x2|^2, eps^2))
+    const float cosv = pg / sqrtf(fmaxf(pp * gg, 1e-16f));
+    const bool project = cosv < (float)gr.delta / sqrtf((float)numel[ck.tensor]);
+    const float pn = sqrtf(pp) + eps;                 // param.norm().add_(eps)
+    const float coef = project ? (ppt / pn) / pn : 0.f;   // pt -= (sum(p/pn * pt)) * p/pn
+    for (int i = threadIdx.x; i < ck.n; i += 256) {
+        const float p = ck.p[i];
+        const float s = ams ? ck.smax[i] : ck.s[i];
+        float pt = adamp_pt(ck.m[i], s, fbc1, sqrt_bc2, eps);
+        pt = pt - coef * p;
+        ck.p[i] = p + neg_lr * pt;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -137,6 +217,23 @@ int hc_lars_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_lars_group
     if (hipMemsetAsync(norms, 0, sizeof(float) * 2 * ntensors, st) != hipSuccess) return HC_ERR_LAUNCH;
     hipLaunchKernelGGL(lars_norm_kernel, dim3(nchunks), dim3(256), 0, st, chunks, norms);
     hipLaunchKernelGGL(lars_update_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups, norms);
+    return hc_launch_status();
+}
+
+int hc_ademamix_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_adamx_group* groups, hc_stream_t stream) {
+    if (chunks == nullptr || groups == nullptr || nchunks < 0) return HC_ERR_ARG;
+    if (nchunks == 0) return HC_OK;
+    hipLaunchKernelGGL(ademamix_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, chunks, groups);
+    return hc_launch_status();
+}
+int hc_adamp_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_adamx_group* groups, float* sums, const int32_t* numel,
+                  int32_t ntensors, hc_stream_t stream) {
+    if (chunks == nullptr || groups == nullptr || sums == nullptr || numel == nullptr || nchunks < 0 || ntensors < 0) return HC_ERR_ARG;
+    if (nchunks == 0) return HC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, sizeof(float) * 4 * (size_t)ntensors, st) != hipSuccess) return HC_ERR_LAUNCH;
+    hipLaunchKernelGGL(adamp_moments_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups, sums);
+    hipLaunchKernelGGL(adamp_update_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups, sums, (const int*)numel);
     return hc_launch_status();
 }
 

@@ -1,2 +1,3 @@
 from .adabelief import *  # noqa: F401,F403
 from .lars import *  # noqa: F401,F403
+from .adamp import *  # noqa: F401,F403

@@ -265,6 +265,20 @@ typedef struct {
 int hc_lars_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_lars_group* groups, float* norms,
                  int32_t ntensors, hc_stream_t stream);
 
+/* AdamP / AdEMAMix (holocron/optim/adamp.py:142-200, holocron/optim/ademamix.py:158-200; the optimizers
+ * references/classification/train.py:33,206-213 imports next to AdaBelief).  `step` is the count after the increment.
+ * AdEMAMix: chunk.m = exp_avg, chunk.s = exp_avg_sq, chunk.smax = exp_avg_slow.
+ * AdamP: two passes (moments + per-tensor sums, then the update with the tangent-space projection decided on the device
+ * instead of the reference's host-side `if cosine_similarity(...) < delta / sqrt(numel)`); sums fp32 [ntensors][4] scratch,
+ * numel int32 [ntensors]. */
+typedef struct {
+    double lr, beta1, beta2, beta3, alpha, eps, weight_decay, delta;
+    int32_t step, amsgrad;
+} hc_adamx_group;
+int hc_ademamix_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_adamx_group* groups, hc_stream_t stream);
+int hc_adamp_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_adamx_group* groups, float* sums, const int32_t* numel,
+                  int32_t ntensors, hc_stream_t stream);
+
 /* ---- pointwise / losses / boxes ---- */
 /* hard_mish: 0.5*x*clamp(x+2,0,2) (holocron/nn/functional.py:30-41), fp32, y may alias x. */
 int hc_hard_mish_fwd(const float* x, float* y, int64_t n, hc_stream_t stream);

@@ -16,6 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import _refshim  # noqa: E402
 
+from _inputs import optim2_inputs  # noqa: E402
+
 ref = _refshim.load_reference()
 torch.set_num_threads(4)
 
@@ -473,6 +475,44 @@ def gen_convs():
     save("convs.pt", {"slim": slim, "norm": norm})
 
 
+def gen_optim2():
+    """AdamP (with tensors on both sides of the projection test) and AdEMAMix trajectories of the reference; parameters and
+    gradients come from `optim2_inputs` seeds, only the results are stored."""
+    out = {"adamp": [], "ademamix": []}
+    adamp_cfgs = [dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, delta=0.1),
+                  dict(lr=5e-3, betas=(0.8, 0.99), eps=1e-6, weight_decay=1e-2, amsgrad=True, delta=0.3)]
+    for case, kw in enumerate(adamp_cfgs):
+        shapes = [(16, 8, 3, 3), (40,), (70000,) if case == 0 else (300,), (24, 24)]
+        params = [torch.nn.Parameter(optim2_inputs(case, -1, k, sh)) for k, sh in enumerate(shapes)]
+        opt = ref.optim.AdamP(params, **kw)
+        proj, mid = [], None
+        for it in range(3):
+            gs = [optim2_inputs(case, it, k, p.shape, p.data, adamp=True) for k, p in enumerate(params)]
+            for p, gr in zip(params, gs):
+                p.grad = gr.clone()
+            proj.append([bool(torch.nn.functional.cosine_similarity(p.data.view(1, -1), (gr + kw["weight_decay"] * p.data).view(1, -1)).max()
+                              < kw["delta"] / p.numel() ** 0.5) for p, gr in zip(params, gs)])
+            opt.step()
+            if it == 0:
+                mid = [p.data.clone() for p in params if p.numel() < 5000]
+        out["adamp"].append({"kw": kw, "shapes": shapes, "projected": proj, "after_first_small": mid,
+                             "final": [p.data.clone() for p in params],
+                             "exp_avg_sq": [opt.state[p]["exp_avg_sq"].clone() for p in params if p.numel() < 5000]})
+    mix_cfgs = [dict(lr=1e-2, betas=(0.9, 0.999, 0.9999), alpha=5.0, eps=1e-8, weight_decay=0.0),
+                dict(lr=3e-3, betas=(0.8, 0.95, 0.99), alpha=2.0, eps=1e-6, weight_decay=5e-2)]
+    for case, kw in enumerate(mix_cfgs):
+        shapes = [(8, 4, 3, 3), (33,), (66000,) if case == 0 else (500,)]
+        params = [torch.nn.Parameter(optim2_inputs(10 + case, -1, k, sh)) for k, sh in enumerate(shapes)]
+        opt = ref.optim.AdEMAMix(params, **kw)
+        for it in range(3):
+            for k, p in enumerate(params):
+                p.grad = optim2_inputs(10 + case, it, k, p.shape)
+            opt.step()
+        out["ademamix"].append({"kw": kw, "shapes": shapes, "final": [p.data.clone() for p in params],
+                                "exp_avg_slow": [opt.state[p]["exp_avg_slow"].clone() for p in params if p.numel() < 5000]})
+    save("optim2.pt", out)
+
+
 def gen_nms():
     """torchvision.ops.nms is absent: these vectors come from the restated algorithm (oracle/tv_ops.py),
     plus the two situations the reference's own tests pin (tests/test_models_detection.py:158-163: disjoint
@@ -496,6 +536,6 @@ def gen_nms():
 
 if __name__ == "__main__":
     gens = {"boxes": gen_boxes, "functional": gen_functional, "optim": gen_optim, "repblock": gen_repblock,
-            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "convs": gen_convs, "nms": gen_nms}
+            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "convs": gen_convs, "optim2": gen_optim2, "nms": gen_nms}
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()

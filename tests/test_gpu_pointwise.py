@@ -183,6 +183,40 @@ def test_global_avg_pool_matches_adaptive_avg_pool():
     assert h.nn.GlobalAvgPool2d(flatten=False)(torch.rand(2, 8, 4, 4).cuda()).shape == (2, 8, 1, 1)
 
 
+def test_adamp_and_ademamix_match_reference(golden):
+    import holocron_amd as h
+    from _inputs import optim2_inputs
+    g = golden("optim2.pt")
+    for case, c in enumerate(g["adamp"]):
+        params = [torch.nn.Parameter(optim2_inputs(case, -1, k, sh).cuda()) for k, sh in enumerate(c["shapes"])]
+        opt = h.optim.AdamP(params, **c["kw"])
+        for it in range(3):
+            for k, p in enumerate(params):
+                p.grad = optim2_inputs(case, it, k, p.shape, p.detach().cpu(), adamp=True).cuda()
+            opt.step()
+            if it == 0:
+                small = [p for p in params if p.numel() < 5000]
+                for p, r in zip(small, c["after_first_small"]):
+                    assert torch.allclose(p.detach().cpu(), r, rtol=2e-5, atol=1e-6)
+        for p, f in zip(params, c["final"]):
+            assert torch.allclose(p.detach().cpu(), f, rtol=1e-4, atol=2e-6), (case, p.shape)
+        st = opt.state[params[0]]
+        assert st["step"] == 3 and set(st) >= {"exp_avg", "exp_avg_sq"}
+        assert torch.allclose(st["exp_avg_sq"].cpu(), c["exp_avg_sq"][0], rtol=1e-5, atol=1e-9)
+    for case, c in enumerate(g["ademamix"]):
+        params = [torch.nn.Parameter(optim2_inputs(10 + case, -1, k, sh).cuda()) for k, sh in enumerate(c["shapes"])]
+        opt = h.optim.AdEMAMix(params, **c["kw"])
+        for it in range(3):
+            for k, p in enumerate(params):
+                p.grad = optim2_inputs(10 + case, it, k, p.shape).cuda()
+            opt.step()
+        for p, f in zip(params, c["final"]):
+            assert torch.allclose(p.detach().cpu(), f, rtol=2e-5, atol=1e-6), (case, p.shape)
+        assert torch.allclose(opt.state[params[0]]["exp_avg_slow"].cpu(), c["exp_avg_slow"][0], rtol=1e-5, atol=1e-8)
+    with pytest.raises(ValueError):
+        h.optim.AdEMAMix([torch.nn.Parameter(torch.zeros(1))], betas=(0.9, 0.999, 1.0))      # ademamix.py:68-70
+
+
 def test_adabelief_matches_reference(golden):
     import holocron_amd as h
     for c in golden("optim.pt")["adabelief"]:

@@ -206,6 +206,34 @@ def test_slim_and_norm_conv_oracles_match_reference(golden):
         assert rel_l2(dw, c["dw"]) < 1e-4 and rel_l2(db, c["db"]) < 1e-5
 
 
+def test_adamp_ademamix_oracles_match_reference(golden):
+    from _inputs import optim2_inputs
+    g = golden("optim2.pt")
+    for case, c in enumerate(g["adamp"]):
+        kw = c["kw"]
+        ps = [optim2_inputs(case, -1, k, sh) for k, sh in enumerate(c["shapes"])]
+        ms, ss = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+        mx = [torch.zeros_like(p) if kw["amsgrad"] else None for p in ps]
+        for it in range(3):
+            gs = [optim2_inputs(case, it, k, p.shape, p, adamp=True) for k, p in enumerate(ps)]
+            for k, p in enumerate(ps):
+                oo.adamp_step(p, gs[k], ms[k], ss[k], it + 1, kw["lr"], kw["betas"][0], kw["betas"][1], kw["eps"], kw["weight_decay"],
+                              kw["delta"], mx[k])
+        assert any(any(r) for r in c["projected"]) and not all(all(r) for r in c["projected"])
+        for p, f in zip(ps, c["final"]):
+            assert torch.allclose(p, f, rtol=1e-6, atol=1e-7)
+    for case, c in enumerate(g["ademamix"]):
+        kw = c["kw"]
+        ps = [optim2_inputs(10 + case, -1, k, sh) for k, sh in enumerate(c["shapes"])]
+        m1, m2, nu = ([torch.zeros_like(p) for p in ps] for _ in range(3))
+        for it in range(3):
+            for k, p in enumerate(ps):
+                oo.ademamix_step(p, optim2_inputs(10 + case, it, k, p.shape), m1[k], m2[k], nu[k], it + 1, kw["lr"], *kw["betas"], kw["alpha"],
+                                 kw["eps"], kw["weight_decay"])
+        for p, f in zip(ps, c["final"]):
+            assert torch.equal(p, f)
+
+
 def test_optim_match_reference(golden):
     g = golden("optim.pt")
     for c in g["adabelief"]:
