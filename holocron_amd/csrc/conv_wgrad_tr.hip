@@ -345,7 +345,7 @@ inline Plan make_plan_seg(const hc_wgrad_desc& d, int NR, int nseg) {
 // fewest column segments whose halo-extended x rows fit the staging registers / LDS
 inline Plan make_plan_nr(const hc_wgrad_desc& d, int NR) {
     const int seg0 = (d.OW + 127) / 128;
-    for (int nseg = seg0; nseg <= seg0 + 6 && (d.OW + nseg - 1) / nseg >= 16; ++nseg) {
+    for (int nseg = seg0; nseg <= seg0 + 6 && (nseg == seg0 || (d.OW + nseg - 1) / nseg >= 16); ++nseg) {
         const Plan pl = make_plan_seg(d, NR, nseg);
         if (pl.ok) return pl;
     }
