@@ -279,6 +279,9 @@ class DropPlan:
         if not self.ready:
             self.entries, self.recording = [], True
             return
+        if any(bs > 13 for (_, _, _, _, bs) in self.entries):     # the batched kernel tiles with a 6-pixel halo at most
+            self.recording = False
+            return
         self.recording = False
         import ctypes as C
         import numpy as np
