@@ -169,16 +169,26 @@ def main():
         step()
         torch.cuda.synchronize()
         fam = {}
-        for name, flops, e0, e1 in cv.PROFILE:
-            f = fam.setdefault(name, [0.0, 0.0, 0])
+        for name, flops, e0, e1, nbytes in cv.PROFILE:
+            f = fam.setdefault(name, [0.0, 0.0, 0, 0.0])
             f[0] += flops
             f[1] += e0.elapsed_time(e1) * 1e-3
             f[2] += 1
+            f[3] += nbytes
         cv.PROFILE = None
         dom = max(fam, key=lambda k: fam[k][1])
-        fl, sec, n = fam[dom]
+        fl, sec, n, alg_bytes = fam[dom]
+        # HBM bytes per launch from the PMC passes over this same command (scripts/pmc_step.sh; the counters cannot be read
+        # from inside the process), committed next to the kernel-trace summary
+        traffic = None
+        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_step_traffic.json")
+        if args.batch == 256 and os.path.exists(pmc_file):
+            with open(pmc_file) as fh:
+                traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
         roof = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
-                "unit": "TFLOP/s", "frac": fl / sec / MFMA_BF16_PEAK, "traffic": None,
+                "unit": "TFLOP/s", "frac": fl / sec / MFMA_BF16_PEAK, "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_step_traffic.json)",
+                "algorithmic_bytes_per_launch": alg_bytes / n,
                 "launches_per_step": n, "avg_launch_ms": sec / n * 1e3,
                 "families": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] * 1e3, "launches": v[2]}
                              for k, v in fam.items()}}

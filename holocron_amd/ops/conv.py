@@ -113,7 +113,7 @@ def dgrad_desc(N, Cin, H, W, Cout, branches, stride):
     return d
 
 
-PROFILE = None  # bench.py sets this to a list: (family, algorithmic flops, start event, end event)
+PROFILE = None  # bench.py sets this to a list: (family, algorithmic flops, start event, end event, algorithmic bytes)
 
 
 def _desc_flops(d):
@@ -132,7 +132,8 @@ def launch_conv(d, src0, wpk, dst, src1=None, resid=None, stats=None, bias=None,
         e0.record()
         check(_lib.load().hc_conv_gather(C.byref(d), stream()), "hc_conv_gather")
         e1.record()
-        PROFILE.append(("conv_gather", _desc_flops(d) if flops is None else flops, e0, e1))
+        nbytes = sum(t.numel() * t.element_size() for t in (src0, src1, wpk, dst, resid) if t is not None)
+        PROFILE.append(("conv_gather", _desc_flops(d) if flops is None else flops, e0, e1, nbytes))
         return
     check(_lib.load().hc_conv_gather(C.byref(d), stream()), "hc_conv_gather")
 
@@ -198,7 +199,8 @@ def conv_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, out=None, accumulate=False
         e0.record()
         check(lib.hc_conv_wgrad(C.byref(d), stream()), "hc_conv_wgrad")
         e1.record()
-        PROFILE.append(("conv_wgrad", 2.0 * N * OH * OW * Cout * KH * KW * Cin if flops is None else flops, e0, e1))
+        nbytes = sum(t.numel() * t.element_size() for t in (x, dy, out))
+        PROFILE.append(("conv_wgrad", 2.0 * N * OH * OW * Cout * KH * KW * Cin if flops is None else flops, e0, e1, nbytes))
         return out
     check(lib.hc_conv_wgrad(C.byref(d), stream()), "hc_conv_wgrad")
     return out
@@ -273,6 +275,6 @@ def _launch_small(d, flops):
         e0.record()
         check(_lib.load().hc_conv_small(C.byref(d), stream()), "hc_conv_small")
         e1.record()
-        PROFILE.append(("conv_small", flops, e0, e1))
+        PROFILE.append(("conv_small", flops, e0, e1, 0))
         return
     check(_lib.load().hc_conv_small(C.byref(d), stream()), "hc_conv_small")
