@@ -89,6 +89,27 @@ class AdamxGroup(C.Structure):
                 ("eps", c_double), ("weight_decay", c_double), ("delta", c_double), ("step", c_int32), ("amsgrad", c_int32)]
 
 
+HC_MSBN_MAX_BRANCHES = 6
+
+
+class MsbnBranch(C.Structure):
+    _fields_ = [("stats", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p),
+                ("num_batches_tracked", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("stats_ld", c_int32),
+                ("eps", c_float), ("momentum", c_float), ("pad_", c_int32)]
+
+
+class MsbnDesc(C.Structure):
+    _fields_ = [("br", MsbnBranch * HC_MSBN_MAX_BRANCHES), ("coef", c_void_p), ("save", c_void_p), ("red", c_void_p),
+                ("bcoef", c_void_p), ("count", c_int64), ("B", c_int32), ("C", c_int32), ("c_valid", c_int32),
+                ("training", c_int32), ("accumulate", c_int32), ("pad_", c_int32)]
+
+
+class MsbnIo(C.Structure):
+    _fields_ = [("y", c_void_p * HC_MSBN_MAX_BRANCHES), ("dy", c_void_p * HC_MSBN_MAX_BRANCHES),
+                ("ld", c_int32 * HC_MSBN_MAX_BRANCHES), ("dld", c_int32 * HC_MSBN_MAX_BRANCHES), ("npix", c_int64),
+                ("B", c_int32), ("C", c_int32)]
+
+
 def tap(dy, dx, src, wt):
     """HC_TAP of the header."""
     u = (dy & 0xff) | ((dx & 0xff) << 8) | ((src & 0xff) << 16) | ((wt & 0xff) << 24)
@@ -97,6 +118,12 @@ def tap(dy, dx, src, wt):
 
 # name -> (restype, argtypes); every symbol include/holocron_hip.h declares
 SIGNATURES = {
+    "hc_msbn_finalize": (c_int32, [C.POINTER(MsbnDesc), c_void_p]),
+    "hc_msbn_bwd_finalize": (c_int32, [C.POINTER(MsbnDesc), c_void_p]),
+    "hc_msbn_apply": (c_int32, [C.POINTER(MsbnIo), c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "hc_msbn_bwd_reduce": (c_int32, [C.POINTER(MsbnIo), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+    "hc_msbn_bwd_apply": (c_int32, [C.POINTER(MsbnIo), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+    "hc_dwrep_dgrad": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
     "hc_conv_gather": (c_int32, [C.POINTER(ConvDesc), c_void_p]),
     "hc_conv_small": (c_int32, [C.POINTER(ConvSmallDesc), c_void_p]),
     "hc_conv_small_supported": (c_int32, [C.POINTER(ConvSmallDesc)]),

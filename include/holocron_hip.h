@@ -440,6 +440,66 @@ int hc_quantize_fp8(const void* src_bf16, int32_t src_ld, void* dst_fp8, int32_t
                     hc_stream_t stream);
 int hc_gap_fp8(const void* x_fp8, float* y, int32_t N, int32_t HW, int32_t ld, int32_t C, float scale, hc_stream_t stream);
 
+/* ---- MobileOne over-parameterised blocks, training form (holocron/models/classification/mobileone.py:31-176):
+ * out = act(sum_b BN_b(y_b)) over B <= HC_MSBN_MAX_BRANCHES parallel branch outputs y_b (NHWC bf16, y_b[p][c] at
+ * y[b] + p * ld[b] + c), every branch with its own BatchNorm2d.  DepthConvBlock.forward (:66-67): the branches are K depthwise
+ * 3x3 + one depthwise 1x1 (hc_dw3x3_fwd planes) + the input; PointConvBlock.forward (:120-121): K dense 1x1 (one stacked
+ * hc_conv_gather) + the input.  act: 0 none | 1 ReLU.
+ *   hc_msbn_finalize      per-branch statistics ([HC_STAT_REPLICAS][2][stats_ld] sums) -> coef [B][2][C] (scale, shift),
+ *                         save [B][2][C] (mean, rstd); updates running statistics like nn.BatchNorm2d (training) or uses
+ *                         them (eval).  Channels >= c_valid are layout padding (scale = shift = 0).
+ *   hc_msbn_apply         out[p][c] = act(sum_b scale_b y_b + shift_b); out dense [npix][C]; optional out_stats
+ *                         [HC_STAT_REPLICAS][2][C] (zeroed by the caller) += sum / sum of squares of the stored output.
+ *   hc_msbn_bwd_reduce    red [HC_STAT_REPLICAS][B + 1][C] (zeroed by the caller) += sum gz, sum gz y_b with
+ *                         gz = g * act'(out)
+ *   hc_msbn_bwd_finalize  red -> dgamma_b, dbeta_b (= or +=), bcoef [B][3][C]: dy_b = k1 gz + k2 y_b + k3
+ *   hc_msbn_bwd_apply     writes dy_b to dy[b] + p * dld[b] + c for every branch with dy[b] != NULL
+ *   hc_dwrep_dgrad        DepthConvBlock data gradient: dx = sum_b dwconv3x3^T(dy_b, wpk_b) (+ extra, stride 1 only: the
+ *                         identity branch's gradient); wpk_b forward tap-major fp32 [9][C] from hc_dw3x3_pack ---- */
+#define HC_MSBN_MAX_BRANCHES 6
+typedef struct {
+    const float* stats;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    int64_t* num_batches_tracked;
+    float* dgamma;
+    float* dbeta;
+    int32_t stats_ld;
+    float eps, momentum;
+    int32_t pad_;
+} hc_msbn_branch;
+typedef struct {
+    hc_msbn_branch br[HC_MSBN_MAX_BRANCHES];
+    float* coef;
+    float* save;
+    const float* red;
+    float* bcoef;
+    int64_t count;             /* N*H*W */
+    int32_t B, C, c_valid;
+    int32_t training;          /* 0: running statistics (eval) */
+    int32_t accumulate;        /* bwd_finalize: dgamma / dbeta += */
+    int32_t pad_;
+} hc_msbn_desc;
+typedef struct {
+    const void* y[HC_MSBN_MAX_BRANCHES];
+    void* dy[HC_MSBN_MAX_BRANCHES];
+    int32_t ld[HC_MSBN_MAX_BRANCHES];
+    int32_t dld[HC_MSBN_MAX_BRANCHES];
+    int64_t npix;
+    int32_t B, C;
+} hc_msbn_io;
+int hc_msbn_finalize(const hc_msbn_desc* d, hc_stream_t stream);
+int hc_msbn_bwd_finalize(const hc_msbn_desc* d, hc_stream_t stream);
+int hc_msbn_apply(const hc_msbn_io* io, const float* coef, void* out, float* out_stats, int32_t act, hc_stream_t stream);
+int hc_msbn_bwd_reduce(const hc_msbn_io* io, const void* g, int32_t g_ld, const void* out, float* red, int32_t act,
+                       hc_stream_t stream);
+int hc_msbn_bwd_apply(const hc_msbn_io* io, const void* g, int32_t g_ld, const void* out, const float* bcoef, int32_t act,
+                      hc_stream_t stream);
+int hc_dwrep_dgrad(const void* const* dy, const float* const* wpk, int32_t nplanes, const void* extra, void* dx, int32_t N,
+                   int32_t H, int32_t W, int32_t C, int32_t stride, hc_stream_t stream);
+
 const char* hc_version(void);
 
 #ifdef __cplusplus

@@ -436,6 +436,70 @@ def gen_rexnet():
                                              if k.endswith("running_mean") or k.endswith("running_var")}}})
 
 
+def gen_mobileone():
+    """Reference MobileOneBlocks (stem-like 3 channels, both identities, stride 2 with channel change, single branch), in
+    training mode (outputs, gradients, running statistics), eval mode and re-parametrised; one training step and the
+    re-parametrised inference of mobileone_s0 (weights reproducible from the seed)."""
+    import importlib
+    mo = importlib.import_module("ref_holocron.models.classification.mobileone")
+    g = torch.Generator().manual_seed(71)
+    blocks = []
+    for (cin, cout, K, stride, hw) in [(3, 48, 4, 2, 16), (48, 48, 4, 1, 9), (48, 128, 2, 2, 10), (32, 32, 1, 1, 7)]:
+        torch.manual_seed(cin + cout + K)
+        blk = mo.MobileOneBlock(cin, cout, K, stride)
+        ref.nn.init.init_module(blk, "relu")
+        _randomize_bn(blk, g)
+        for p in blk.parameters():
+            if p.dim() == 4 and p.shape[1] != 1:
+                p.data = bf16r(p.data)
+        sd0 = {k: v.clone() for k, v in blk.state_dict().items()}
+        x = bf16r(torch.randn((3, cin, hw, hw), generator=g)).requires_grad_(True)
+        blk.train()
+        out = blk(x)
+        r = bf16r(torch.randn(out.shape, generator=g))
+        names = [n for n, _ in blk.named_parameters()]
+        grads = torch.autograd.grad((out * r).sum(), [x] + list(blk.parameters()))
+        after = {k: v.clone() for k, v in blk.state_dict().items() if "running" in k or "tracked" in k}
+        blk.load_state_dict(sd0)
+        blk.eval()
+        with torch.no_grad():
+            out_eval = blk(x.detach())
+            blk.reparametrize()
+            out_rep = blk(x.detach())
+        blocks.append({"cfg": (cin, cout, K, stride), "state": sd0, "x": x.detach(), "r": r, "out": out.detach(), "dx": grads[0],
+                       "dparams": dict(zip(names, grads[1:])), "state_after": after, "out_eval": out_eval,
+                       "rep_state": {k: v.clone() for k, v in blk.state_dict().items()}, "out_rep": out_rep})
+    torch.manual_seed(61)
+    m = mo.mobileone_s0(num_classes=10)
+    x = bf16r(torch.rand((4, 3, 64, 64), generator=g))
+    t = torch.randint(0, 10, (4,), generator=g)
+    m.train()
+    stage_means = {}
+    hooks = [m.features[i].register_forward_hook(lambda mod, inp, out, i=i: stage_means.__setitem__(i, out.detach().mean((2, 3))))
+             for i in (0, 1, 2)]
+    logits = m(x)
+    for hk in hooks:
+        hk.remove()
+    loss = torch.nn.functional.cross_entropy(logits, t)
+    loss.backward()
+    params = dict(m.named_parameters())
+    keep = ["features.0.0.0.0.weight", "features.0.0.1.0.weight", "features.0.2.0.0.weight", "features.1.1.0.0.weight",
+            "features.1.1.0.3.0.weight", "features.2.3.2.0.weight", "features.2.3.2.2.0.weight", "features.3.9.0.1.0.weight",
+            "features.4.0.0.2.0.weight", "head.weight", "head.bias"]
+    running = {k: v.clone() for k, v in m.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+    m.eval()
+    with torch.no_grad():
+        logits_eval = m(x)
+        m.reparametrize()
+        logits_rep = m(x)
+    save("mobileone.pt", {"blocks": blocks,
+                          "model": {"seed": 61, "num_classes": 10, "x": x, "target": t, "logits": logits.detach(), "loss": loss.detach(),
+                                    "grads": {n: params[n].grad.clone() for n in keep},
+                                    "grad_norms": {n: float(p.grad.norm()) for n, p in params.items()},
+                                    "running_sample": {k: running[k] for k in list(running)[:24]}, "stage_means": stage_means,
+                                    "logits_eval": logits_eval, "logits_rep": logits_rep}})
+
+
 def gen_convs():
     """SlimConv2d and NormConv2d of the reference (holocron/nn/modules/conv.py:55-147,262-370)."""
     g = torch.Generator().manual_seed(61)
@@ -536,6 +600,6 @@ def gen_nms():
 
 if __name__ == "__main__":
     gens = {"boxes": gen_boxes, "functional": gen_functional, "optim": gen_optim, "repblock": gen_repblock,
-            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "convs": gen_convs, "optim2": gen_optim2, "nms": gen_nms}
+            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "convs": gen_convs, "optim2": gen_optim2, "nms": gen_nms, "mobileone": gen_mobileone}
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()

@@ -180,6 +180,67 @@ def test_rexnet_oracle_matches_reference(golden):
         assert rel_l2(gg, gm["grads"][n]) < 5e-3, (n, rel_l2(gg, gm["grads"][n]))
 
 
+def test_mobileone_oracle_matches_reference(golden):
+    from oracle import mobileone as omo
+    g = golden("mobileone.pt")
+    for c in g["blocks"]:
+        cin, cout, K, stride = c["cfg"]
+        sd = {"b." + k: v.clone() for k, v in c["state"].items()}
+        names = list(c["dparams"])
+        leaves = [sd["b." + n].requires_grad_(True) for n in names]
+        x = c["x"].clone().requires_grad_(True)
+        out = omo.block(x, sd, "b", stride, True)
+        assert torch.allclose(out, c["out"], rtol=1e-4, atol=1e-5), c["cfg"]
+        grads = torch.autograd.grad((out * c["r"]).sum(), [x] + leaves)
+        assert rel_l2(grads[0], c["dx"]) < 1e-4
+        for n, gg in zip(names, grads[1:]):
+            # a depth-wise 1x1 in front of BatchNorm is a per-channel scale BatchNorm removes: its gradient is zero up to
+            # eps and round-off, so only its magnitude is comparable
+            scale_only = gg.dim() == 4 and gg.shape[1:] == (1, 1, 1)
+            assert rel_l2(gg, c["dparams"][n]) < (1e-2 if scale_only else 2e-4) or float(c["dparams"][n].abs().max()) < 1e-6, (c["cfg"], n)
+        for k, v in c["state_after"].items():
+            assert torch.allclose(sd["b." + k].detach().float(), v.float(), rtol=1e-4, atol=1e-6), k
+        sd = {"b." + k: v.clone() for k, v in c["state"].items()}
+        assert torch.allclose(omo.block(c["x"], sd, "b", stride, False), c["out_eval"], rtol=1e-4, atol=1e-5)
+        sd = {"b." + k: v.clone() for k, v in c["rep_state"].items()}
+        assert torch.allclose(omo.block(c["x"], sd, "b", stride, False), c["out_rep"], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(c["out_rep"], c["out_eval"], rtol=1e-3, atol=1e-3)
+        # the mirror's own fold (host arithmetic on the parameters) gives the reference's folded parameters
+        import holocron_amd as h
+        blk = h.models.MobileOneBlock(cin, cout, K, stride)
+        assert list(blk.state_dict()) == list(c["state"])
+        blk.load_state_dict(c["state"])
+        blk.eval().reparametrize()
+        assert list(blk.state_dict()) == list(c["rep_state"])
+        for k, v in c["rep_state"].items():
+            assert torch.allclose(blk.state_dict()[k], v, rtol=1e-5, atol=1e-6), k
+    gm = g["model"]
+    torch.manual_seed(gm["seed"])
+    m = h.models.mobileone_s0(num_classes=gm["num_classes"])
+    assert [n for n, _ in m.named_parameters()] == list(gm["grad_norms"])
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    leaves = {n: sd[n].requires_grad_(True) for n in gm["grads"]}
+    logits = omo.forward(sd, gm["x"], training=True)
+    assert torch.allclose(logits, gm["logits"], rtol=1e-3, atol=1e-4)
+    loss = torch.nn.functional.cross_entropy(logits, gm["target"])
+    grads = torch.autograd.grad(loss, list(leaves.values()))
+    for (n, _), gg in zip(leaves.items(), grads):
+        # 23 blocks of batch-statistics BatchNorm down to 2x2 maps of 4 images amplify fp32 summation-order differences
+        # to the percent level at the first layers; the block cases above are the sharp check
+        assert rel_l2(gg, gm["grads"][n]) < 8e-2, (n, rel_l2(gg, gm["grads"][n]))
+    for k, v in gm["running_sample"].items():
+        assert torch.allclose(sd[k].detach(), v, rtol=1e-3, atol=1e-5), k
+    # the mirror's host-side re-parametrisation against the reference's folded model
+    with torch.no_grad():
+        sd_eval = {k: v.detach().clone() for k, v in sd.items()}
+        assert torch.allclose(omo.forward(sd_eval, gm["x"]), gm["logits_eval"], rtol=1e-3, atol=1e-3)
+        m.load_state_dict({k: v.detach() for k, v in sd.items()})
+        m.reparametrize()
+        assert not any(isinstance(mod, torch.nn.BatchNorm2d) for mod in m.modules())
+        rep = omo.forward({k: v.clone() for k, v in m.state_dict().items()}, gm["x"])
+        assert torch.allclose(rep, gm["logits_rep"], rtol=1e-3, atol=1e-3)
+
+
 def test_slim_and_norm_conv_oracles_match_reference(golden):
     import torch.nn.functional as F
     g = golden("convs.pt")
