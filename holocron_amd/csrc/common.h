@@ -80,6 +80,32 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Zero-fill as a kernel launch.  hipMemsetAsync nodes of a captured stream did not stay ordered against the kernels around
+// them when the graph was replayed (a workspace zeroed, accumulated into with atomics and reduced several times per step came
+// back with stale contents from the second replay on), so everything that may run under hipGraph capture clears its scratch
+// with this kernel instead.
+static __global__ void hc_zero_kernel(unsigned char* __restrict__ p, size_t bytes) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    if ((((size_t)p | bytes) & 15) == 0) {
+        u32x4* q = reinterpret_cast<u32x4*>(p);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (size_t i = tid; i < bytes / 16; i += nth) q[i] = z;
+    } else if ((((size_t)p | bytes) & 3) == 0) {
+        unsigned int* q = reinterpret_cast<unsigned int*>(p);
+        for (size_t i = tid; i < bytes / 4; i += nth) q[i] = 0u;
+    } else {
+        for (size_t i = tid; i < bytes; i += nth) p[i] = 0;
+    }
+}
+static inline hipError_t hc_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    size_t blocks = (bytes / 16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(hc_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned char*)p, bytes);
+    return hipGetLastError();
+}
+
 static inline int hc_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? HC_OK : HC_ERR_LAUNCH;

@@ -38,25 +38,34 @@ inline int dw_blocks(long items, int cg, int per_thread) {
     return (int)(k * unit);
 }
 
-// per-workgroup reduction of v[S][8] over the threads that share a channel group, then one atomic per (k, c)
-template <int S>
+// per-workgroup reduction of v[S][8] over the threads that share a channel group, then one atomic per (k, c).  The rows go
+// through LDS CH at a time (256 x (8 CH + 1) floats): a 9- or 7-row reduction in one piece would take 58-75 KB of LDS and
+// leave two workgroups per CU on these HBM-bound kernels.  lds: DW_THREADS * (8 * CH + 1) floats.
+template <int S, int CH = (S < 3 ? S : 3)>
 __device__ __forceinline__ void block_reduce_flush(const float (&v)[S][8], int cg, int C, float* __restrict__ dst, float* __restrict__ lds) {
-    constexpr int STR = S * 8 + 1;
+    constexpr int STR = CH * 8 + 1;
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < S; ++k)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) lds[tid * STR + k * 8 + e] = v[k][e];
-    __syncthreads();
     const int blockbase = (int)(((long)blockIdx.x * DW_THREADS) % cg);
-    for (int o = tid; o < S * C; o += DW_THREADS) {
-        const int k = o / C, c = o - k * C;
-        const int g = c >> 3, e = c & 7;
-        int first = g - blockbase;
-        if (first < 0) first += cg;
-        float sum = 0.f;
-        for (int t = first; t < DW_THREADS; t += cg) sum += lds[t * STR + k * 8 + e];
-        atomicAdd(dst + (size_t)k * C + c, sum);
+#pragma unroll
+    for (int k0 = 0; k0 < S; k0 += CH) {
+        if (k0) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (k0 + k < S) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lds[tid * STR + k * 8 + e] = v[k0 + k][e];
+            }
+        __syncthreads();
+        const int rows = (S - k0) < CH ? (S - k0) : CH;
+        for (int o = tid; o < rows * C; o += DW_THREADS) {
+            const int k = o / C, c = o - k * C;
+            const int g = c >> 3, e = c & 7;
+            int first = g - blockbase;
+            if (first < 0) first += cg;
+            float sum = 0.f;
+            for (int t = first; t < DW_THREADS; t += cg) sum += lds[t * STR + k * 8 + e];
+            atomicAdd(dst + (size_t)(k0 + k) * C + c, sum);
+        }
     }
 }
 
@@ -237,14 +246,21 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_wgrad_kernel(const u32x4* __
     block_reduce_flush<9>(acc, cg, C, dw + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 9 * C, sred);
 }
 
-// dw OIHW fp32 [C][1][3][3] = sum over replicas of slab [R][9][Cpad]
-__global__ void dw3x3_wgrad_finish_kernel(const float* __restrict__ slab, float* __restrict__ dw, int C, int Cpad, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C * 9) return;
-    const int c = i / 9, t = i - c * 9;
+// dw OIHW fp32 [C][1][3][3] = sum over replicas of slab [R][9][Cpad]; 8 lanes per element (c fastest: coalesced slab reads),
+// each summing 16 replicas
+__global__ __launch_bounds__(256) void dw3x3_wgrad_finish_kernel(const float* __restrict__ slab, float* __restrict__ dw, int C, int Cpad,
+                                                                 int accumulate) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    const bool live = i < C * 9;
+    const int t = live ? i / C : 0, c = live ? i - t * C : 0;
     float s = 0.f;
-    for (int r = 0; r < HC_STAT_REPLICAS; ++r) s += slab[((size_t)r * 9 + t) * Cpad + c];
-    dw[i] = accumulate ? dw[i] + s : s;
+    if (live)
+        for (int r = sub; r < HC_STAT_REPLICAS; r += 8) s += slab[((size_t)r * 9 + t) * Cpad + c];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if (live && sub == 0) dw[c * 9 + t] = accumulate ? dw[c * 9 + t] + s : s;
 }
 // w OIHW fp32 [C][1][3][3] -> tap-major fp32 [9][Cpad] (zero padded), optionally flipped (stride-1 data gradient)
 __global__ void dw3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int C, int Cpad, int flip) {
@@ -482,11 +498,11 @@ int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N
         (stride != 1 && stride != 2))
         return HC_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, (size_t)hc_dw3x3_wgrad_ws_bytes(C), st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(ws, (size_t)hc_dw3x3_wgrad_ws_bytes(C), st) != hipSuccess) return HC_ERR_LAUNCH;
     const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
     const int cg = C / 8;
     if ((long)N * OH * OW > 0) {
-        const size_t lds = (size_t)DW_THREADS * 73 * sizeof(float);
+        const size_t lds = (size_t)DW_THREADS * 25 * sizeof(float);
         if (stride == 1) {
             constexpr int TW = 4;
             const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
@@ -499,7 +515,7 @@ int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N
                                (const u32x4*)dy, (float*)ws, N, H, W, OH, OW, C);
         }
     }
-    hipLaunchKernelGGL(dw3x3_wgrad_finish_kernel, dim3((Creal * 9 + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, Creal, C,
+    hipLaunchKernelGGL(dw3x3_wgrad_finish_kernel, dim3((Creal * 9 * 8 + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, Creal, C,
                        accumulate);
     return hc_launch_status();
 }
@@ -540,7 +556,7 @@ int hc_se_scale_bwd_gate(const void* g, const void* z, const void* gate_logits, 
         return HC_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if ((long)N * C == 0) return HC_OK;
-    if (hipMemsetAsync(dgate, 0, sizeof(float) * (size_t)N * C, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(dgate, sizeof(float) * (size_t)N * C, st) != hipSuccess) return HC_ERR_LAUNCH;
     const int cg = C / 8;
     if (HW > 0) {
         int bx = dw_blocks((long)HW * cg, cg, 8);

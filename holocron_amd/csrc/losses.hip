@@ -305,7 +305,7 @@ int hc_poly_loss_soft_bwd(const float* x, const float* target, const float* weig
 int hc_dice_sums(const float* x, const float* target, float* sums, int32_t N, int32_t K, int64_t S, hc_stream_t stream) {
     if (x == nullptr || target == nullptr || sums == nullptr || K <= 0 || N < 0 || S < 0) return HC_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, sizeof(float) * 3 * K, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(sums, sizeof(float) * 3 * K, st) != hipSuccess) return HC_ERR_LAUNCH;
     if ((long)N * S == 0) return HC_OK;
     int bx = grid_for((long)N * S, 256, 1024);
     if ((long)bx * K > 16384) bx = (int)(16384 / K > 0 ? 16384 / K : 1);
@@ -324,7 +324,7 @@ int hc_dropblock_mask(const float* noise, float* keep, float* count, int32_t N, 
                       float gamma, hc_stream_t stream) {
     if (noise == nullptr || keep == nullptr || count == nullptr || block_size < 1 || (block_size & 1) == 0) return HC_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(count, 0, sizeof(float), st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(count, sizeof(float), st) != hipSuccess) return HC_ERR_LAUNCH;
     if ((long)N * H * W == 0) return HC_OK;
     hipLaunchKernelGGL(dropblock_mask_kernel, dim3(grid_for((long)N * H * W, 256, 2048)), dim3(256), 0, st, noise, keep, count, N,
                        H, W, block_size, gamma);
@@ -349,7 +349,7 @@ int hc_dropblock_mask_batched(const hc_drop_item* items, int32_t nitems, int64_t
     if (nitems < 0 || (nitems > 0 && (items == nullptr || noise == nullptr || keep == nullptr || counts == nullptr))) return HC_ERR_ARG;
     if (nitems == 0) return HC_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(counts, 0, sizeof(float) * (size_t)nitems, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(counts, sizeof(float) * (size_t)nitems, st) != hipSuccess) return HC_ERR_LAUNCH;
     int bx = (int)((max_pixels + 1023) / 1024);          // 32 x 32 tiles; a workgroup walks several
     if (bx > 512) bx = 512;
     if (bx < 1) bx = 1;

@@ -51,43 +51,68 @@ inline int mb_blocks(long items, int cg, int per_thread) {
     return (int)(k * unit);
 }
 
-// per-workgroup reduction of v[S][8] over the threads that share a channel group, then one atomic per (k, c)
-template <int S>
+// per-workgroup reduction of v[S][8] over the threads that share a channel group, then one atomic per (k, c).  The rows go
+// through LDS CH at a time (256 x (8 CH + 1) floats): a 9- or 7-row reduction in one piece would take 58-75 KB of LDS and
+// leave two workgroups per CU on these HBM-bound kernels.  lds: MB_THREADS * (8 * CH + 1) floats.
+template <int S, int CH = (S < 3 ? S : 3)>
 __device__ __forceinline__ void block_reduce_flush(const float (&v)[S][8], int cg, int C, float* __restrict__ dst, float* __restrict__ lds) {
-    constexpr int STR = S * 8 + 1;
+    constexpr int STR = CH * 8 + 1;
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < S; ++k)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) lds[tid * STR + k * 8 + e] = v[k][e];
-    __syncthreads();
     const int blockbase = (int)(((long)blockIdx.x * MB_THREADS) % cg);
-    for (int o = tid; o < S * C; o += MB_THREADS) {
-        const int k = o / C, c = o - k * C;
-        const int g = c >> 3, e = c & 7;
-        int first = g - blockbase;
-        if (first < 0) first += cg;
-        float sum = 0.f;
-        for (int t = first; t < MB_THREADS; t += cg) sum += lds[t * STR + k * 8 + e];
-        atomicAdd(dst + (size_t)k * C + c, sum);
+#pragma unroll
+    for (int k0 = 0; k0 < S; k0 += CH) {
+        if (k0) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (k0 + k < S) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lds[tid * STR + k * 8 + e] = v[k0 + k][e];
+            }
+        __syncthreads();
+        const int rows = (S - k0) < CH ? (S - k0) : CH;
+        for (int o = tid; o < rows * C; o += MB_THREADS) {
+            const int k = o / C, c = o - k * C;
+            const int g = c >> 3, e = c & 7;
+            int first = g - blockbase;
+            if (first < 0) first += cg;
+            float sum = 0.f;
+            for (int t = first; t < MB_THREADS; t += cg) sum += lds[t * STR + k * 8 + e];
+            atomicAdd(dst + (size_t)(k0 + k) * C + c, sum);
+        }
     }
 }
 
 // ---------------------------------------------------------------- statistics -> affine
-__global__ void msbn_finalize_kernel(const hc_msbn_desc d) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.B * d.C) return;
-    const int b = i / d.C, c = i - b * d.C;
+// 8 lanes per (branch, channel): each sums 16 of the HC_STAT_REPLICAS partial sums, a butterfly combines them
+constexpr int FIN_SUB = 8;
+__device__ __forceinline__ float sub_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void msbn_finalize_kernel(const hc_msbn_desc d) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) / FIN_SUB;
+    const int sub = threadIdx.x & (FIN_SUB - 1);
+    const bool live = i < d.B * d.C;
+    const int b = live ? i / d.C : 0, c = live ? i - b * d.C : 0;
     const hc_msbn_branch br = d.br[b];
+    const bool valid = live && c < d.c_valid;
+    float s = 0.f, q = 0.f;
+    if (valid && d.training) {
+        for (int r = sub; r < HC_STAT_REPLICAS; r += FIN_SUB) {
+            s += br.stats[((size_t)r * 2 + 0) * br.stats_ld + c];
+            q += br.stats[((size_t)r * 2 + 1) * br.stats_ld + c];
+        }
+    }
+    s = sub_sum(s);
+    q = sub_sum(q);
+    if (!live || sub != 0) return;
     float scale = 0.f, shift = 0.f, mean = 0.f, rstd = 0.f;
-    if (c < d.c_valid) {
+    if (valid) {
         float var;
         if (d.training) {
-            float s = 0.f, q = 0.f;
-            for (int r = 0; r < HC_STAT_REPLICAS; ++r) {
-                s += br.stats[((size_t)r * 2 + 0) * br.stats_ld + c];
-                q += br.stats[((size_t)r * 2 + 1) * br.stats_ld + c];
-            }
             const float n = (float)d.count;
             mean = s / n;
             var = fmaxf(q / n - mean * mean, 0.f);
@@ -112,18 +137,25 @@ __global__ void msbn_finalize_kernel(const hc_msbn_desc d) {
 }
 
 // red: [HC_STAT_REPLICAS][B + 1][C]; k = 0: sum gz, k = 1 + b: sum gz * y_b
-__global__ void msbn_bwd_finalize_kernel(const hc_msbn_desc d) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.B * d.C) return;
-    const int b = i / d.C, c = i - b * d.C;
+__global__ __launch_bounds__(256) void msbn_bwd_finalize_kernel(const hc_msbn_desc d) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) / FIN_SUB;
+    const int sub = threadIdx.x & (FIN_SUB - 1);
+    const bool live = i < d.B * d.C;
+    const int b = live ? i / d.C : 0, c = live ? i - b * d.C : 0;
     const hc_msbn_branch br = d.br[b];
-    float k1 = 0.f, k2 = 0.f, k3 = 0.f;
-    if (c < d.c_valid) {
-        float sg = 0.f, sgy = 0.f;
-        for (int r = 0; r < HC_STAT_REPLICAS; ++r) {
+    const bool valid = live && c < d.c_valid;
+    float sg = 0.f, sgy = 0.f;
+    if (valid) {
+        for (int r = sub; r < HC_STAT_REPLICAS; r += FIN_SUB) {
             sg += d.red[((size_t)r * (d.B + 1) + 0) * d.C + c];
             sgy += d.red[((size_t)r * (d.B + 1) + 1 + b) * d.C + c];
         }
+    }
+    sg = sub_sum(sg);
+    sgy = sub_sum(sgy);
+    if (!live || sub != 0) return;
+    float k1 = 0.f, k2 = 0.f, k3 = 0.f;
+    if (valid) {
         const float mean = d.save[((size_t)b * 2 + 0) * d.C + c], rstd = d.save[((size_t)b * 2 + 1) * d.C + c];
         const float dgam = rstd * (sgy - mean * sg);
         const float A = br.gamma[c] * rstd;
@@ -425,7 +457,7 @@ int hc_msbn_finalize(const hc_msbn_desc* d, hc_stream_t stream) {
             return HC_ERR_ARG;
         if ((br.running_mean == nullptr) != (br.running_var == nullptr)) return HC_ERR_ARG;
     }
-    const int n = d->B * d->C;
+    const int n = d->B * d->C * FIN_SUB;
     hipLaunchKernelGGL(msbn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d);
     return hc_launch_status();
 }
@@ -434,7 +466,7 @@ int hc_msbn_bwd_finalize(const hc_msbn_desc* d, hc_stream_t stream) {
     if (!desc_ok(d) || d->red == nullptr || d->save == nullptr || d->bcoef == nullptr) return HC_ERR_ARG;
     for (int b = 0; b < d->B; ++b)
         if (d->br[b].gamma == nullptr) return HC_ERR_ARG;
-    const int n = d->B * d->C;
+    const int n = d->B * d->C * FIN_SUB;
     hipLaunchKernelGGL(msbn_bwd_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d);
     return hc_launch_status();
 }
@@ -472,7 +504,7 @@ int hc_msbn_bwd_reduce(const hc_msbn_io* io, const void* g, int32_t g_ld, const 
     const long npix = (long)io->npix;
     const int C = io->C;
     MSBN_DISPATCH(io->B, hipLaunchKernelGGL((msbn_bwd_reduce_kernel<BB>), dim3(blocks), dim3(MB_THREADS),
-                                            (size_t)MB_THREADS * ((BB + 1) * 8 + 1) * sizeof(float), st, s, (const u32x4*)g, g_ld / 8,
+                                            (size_t)MB_THREADS * 25 * sizeof(float), st, s, (const u32x4*)g, g_ld / 8,
                                             (const u32x4*)out, red, npix, C, act));
     return hc_launch_status();
 }

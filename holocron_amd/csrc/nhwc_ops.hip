@@ -349,7 +349,7 @@ int hc_slim_fold_bwd_gate(const void* x, int32_t x_ld, const void* gate_logits, 
         return HC_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if ((long)N * l_ld == 0) return HC_OK;
-    if (hipMemsetAsync(dlogits, 0, (size_t)N * l_ld * 2, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(dlogits, (size_t)N * l_ld * 2, st) != hipSuccess) return HC_ERR_LAUNCH;
     hipLaunchKernelGGL(slim_fold_bwd_gate_kernel, dim3(C, (unsigned)N), dim3(256), 0, st, (const bf16_t*)x, x_ld,
                        (const bf16_t*)gate_logits, l_ld, (const bf16_t*)gtop, (const bf16_t*)gbot, out_ld, (bf16_t*)dlogits, (long)HW, C);
     return hc_launch_status();

@@ -214,7 +214,7 @@ int hc_lars_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_lars_group
     if (chunks == nullptr || groups == nullptr || norms == nullptr || nchunks < 0) return HC_ERR_ARG;
     if (nchunks == 0) return HC_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(norms, 0, sizeof(float) * 2 * ntensors, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(norms, sizeof(float) * 2 * ntensors, st) != hipSuccess) return HC_ERR_LAUNCH;
     hipLaunchKernelGGL(lars_norm_kernel, dim3(nchunks), dim3(256), 0, st, chunks, norms);
     hipLaunchKernelGGL(lars_update_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups, norms);
     return hc_launch_status();
@@ -231,7 +231,7 @@ int hc_adamp_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_adamx_gro
     if (chunks == nullptr || groups == nullptr || sums == nullptr || numel == nullptr || nchunks < 0 || ntensors < 0) return HC_ERR_ARG;
     if (nchunks == 0) return HC_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, sizeof(float) * 4 * (size_t)ntensors, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(sums, sizeof(float) * 4 * (size_t)ntensors, st) != hipSuccess) return HC_ERR_LAUNCH;
     hipLaunchKernelGGL(adamp_moments_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups, sums);
     hipLaunchKernelGGL(adamp_update_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups, sums, (const int*)numel);
     return hc_launch_status();

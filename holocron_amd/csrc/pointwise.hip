@@ -285,7 +285,7 @@ int hc_nms_sorted(const float* boxes, int32_t n, float iou_thr, void* ws, int32_
     if (n < 0 || nkeep == nullptr) return HC_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
-        if (hipMemsetAsync(nkeep, 0, sizeof(int32_t), st) != hipSuccess) return HC_ERR_LAUNCH;
+        if (hc_zero_async(nkeep, sizeof(int32_t), st) != hipSuccess) return HC_ERR_LAUNCH;
         return HC_OK;
     }
     if (boxes == nullptr || ws == nullptr || keep == nullptr) return HC_ERR_ARG;

@@ -800,7 +800,7 @@ int hc_gap_fwd(const void* x, float* y, int32_t N, int32_t HW, int32_t C, hc_str
     if (x == nullptr || y == nullptr || (C % 8) != 0) return HC_ERR_ARG;
     if (N <= 0 || HW <= 0 || N > 65535) return (N == 0 || HW == 0) ? HC_OK : HC_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)N * C, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(y, sizeof(float) * (size_t)N * C, st) != hipSuccess) return HC_ERR_LAUNCH;
     const int cg = C / 8;
     const int R = cg <= 256 ? 256 / cg : 1;
     // enough workgroups to fill the chip, at least 4 rows per thread

@@ -290,8 +290,8 @@ int hc_yolo_assign(const float* gt_boxes, const int32_t* gt_img, int32_t G, cons
     if (obj_mask == nullptr || cell_gt == nullptr || anchors == nullptr || G < 0 || A <= 0) return HC_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const size_t cells = (size_t)N * H * W;
-    if (hipMemsetAsync(obj_mask, 0, cells * A, st) != hipSuccess) return HC_ERR_LAUNCH;
-    if (hipMemsetAsync(cell_gt, 0, cells, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(obj_mask, cells * A, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(cell_gt, cells, st) != hipSuccess) return HC_ERR_LAUNCH;
     if (G == 0) return HC_OK;
     if (gt_boxes == nullptr || gt_img == nullptr) return HC_ERR_ARG;
     hipLaunchKernelGGL(yolo_assign_kernel, dim3((G + 127) / 128), dim3(128), 0, st, gt_boxes, gt_img, G, anchors, H, W, A, obj_mask,
@@ -306,7 +306,7 @@ int hc_yolo_loss_fwd(const void* logits, int32_t dtype, int64_t sn, int64_t sc, 
         (dtype != 0 && dtype != 1) || A <= 0)
         return HC_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, 4 * sizeof(float), st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(sums, 4 * sizeof(float), st) != hipSuccess) return HC_ERR_LAUNCH;
     const long total = (long)N * H * W * A;
     if (total == 0) return HC_OK;
     const Logits x = {logits, dtype, (long)sn, (long)sc, (long)sp};

@@ -65,10 +65,9 @@ def _io(srcs, lds, npix, Cp):
     return io
 
 
-def _msbn_backward(ctx, lib, g, io, B, gammas, Cp, c_valid, npix, dy_ptrs, dy_lds, dev):
+def _msbn_backward(ctx, lib, g, out, save, io, B, gammas, Cp, c_valid, npix, dy_ptrs, dy_lds, dev):
     """reduce -> finalize -> apply; returns the per-branch [B, 2, c_valid] parameter gradients."""
     g, g_ld = as_cl_view(g)
-    out, save = ctx.out_save
     red = ctx.red
     ctx.red = None
     if red is None:
@@ -156,10 +155,8 @@ class DepthRepFn(torch.autograd.Function):
         ctx.act, ctx.training = act, training
         ctx.geom = (N, Cp, H, W, OH, OW, P, B)
         ctx.red = POOL.take((R, B + 1, Cp), dev) if any(t.requires_grad for t in params) or x.requires_grad else None
-        ctx.out_save = (out, save)
-        ctx.planes = planes
-        ctx.gammas = gammas
-        ctx.save_for_backward(x, *ws)
+        ctx.nb = (P, B)
+        ctx.save_for_backward(x, out, save, planes, *gammas, *ws)
         return out
 
     @staticmethod
@@ -168,34 +165,37 @@ class DepthRepFn(torch.autograd.Function):
         st = ctx.st
         stride, has_id, infos, training, act, Cc = ctx.meta
         N, Cp, H, W, OH, OW, P, B = ctx.geom
-        x = ctx.saved_tensors[0]
-        ws = ctx.saved_tensors[1:]
+        x, out, save, planes = ctx.saved_tensors[:4]
+        gammas = ctx.saved_tensors[4:4 + B]
+        ws = ctx.saved_tensors[4 + B:]
         dev = g.device
         npix = N * OH * OW
-        planes = ctx.planes
         psz = npix * Cp * 2
         srcs = [planes.data_ptr() + b * psz for b in range(P)] + ([x.data_ptr()] if has_id else [])
         io = _io(srcs, [Cp] * B, npix, Cp)
         dplanes = torch.empty_like(planes)
         did = cv.empty_cl(N, Cp, H, W, dev) if has_id else None
         dy_ptrs = [dplanes.data_ptr() + b * psz for b in range(P)] + ([did.data_ptr()] if has_id else [])
-        pgrad = _msbn_backward(ctx, lib, g, io, B, ctx.gammas, Cp, Cc, npix, dy_ptrs, [Cp] * B, dev)
+        pgrad = _msbn_backward(ctx, lib, g, out, save, io, B, gammas, Cp, Cc, npix, dy_ptrs, [Cp] * B, dev)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = cv.empty_cl(N, Cp, H, W, dev)
             dyarr = (C.c_void_p * P)(*dy_ptrs[:P])
             warr = (C.c_void_p * P)(*[st.pw[b].data_ptr() for b in range(P)])
             check(lib.hc_dwrep_dgrad(dyarr, warr, P, ptr(did), ptr(dx), N, H, W, Cp, stride, stream()), "hc_dwrep_dgrad")
-        wsb = torch.empty((lib.hc_dw3x3_wgrad_ws_bytes(Cp) // 4,), dtype=torch.float32, device=dev)
+        # one workspace slice per plane: successive memset + atomics rounds on ONE buffer came back corrupted from hipGraph
+        # replays (the memset nodes of a captured stream are not kept ordered against the kernels between them)
+        wsn = lib.hc_dw3x3_wgrad_ws_bytes(Cp) // 4
+        wsb = torch.empty((P, wsn), dtype=torch.float32, device=dev)
         grads = []
         if has_id:
             grads += [pgrad[B - 1, 0, :Cc], pgrad[B - 1, 1, :Cc]]
         for b, w in enumerate(ws):
             dw3 = torch.empty((Cc, 1, 3, 3), dtype=torch.float32, device=dev)
-            check(lib.hc_dw3x3_wgrad(ptr(x), dy_ptrs[b], ptr(wsb), ptr(dw3), N, H, W, Cp, Cc, stride, 0, stream()), "hc_dw3x3_wgrad")
+            check(lib.hc_dw3x3_wgrad(ptr(x), dy_ptrs[b], wsb.data_ptr() + b * wsn * 4, ptr(dw3), N, H, W, Cp, Cc, stride, 0, stream()),
+                  "hc_dw3x3_wgrad")
             dw = dw3 if w.shape[-1] == 3 else dw3[:, :, 1:2, 1:2].contiguous()
             grads += [dw, pgrad[b, 0, :Cc], pgrad[b, 1, :Cc]]
-        ctx.planes = None
         return (dx, None, None, *grads)
 
 
@@ -275,10 +275,7 @@ class PointRepFn(torch.autograd.Function):
         ctx.act, ctx.training = act, training
         ctx.geom = (N, H, W, Cin_p, Cout_p, K, B)
         ctx.red = POOL.take((R, B + 1, Cout_p), dev) if any(t.requires_grad for t in params) or x.requires_grad else None
-        ctx.out_save = (out, save)
-        ctx.Y = Y
-        ctx.gammas = gammas
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(x, out, save, Y, *gammas)
         return out
 
     @staticmethod
@@ -287,11 +284,11 @@ class PointRepFn(torch.autograd.Function):
         st = ctx.st
         has_id, infos, training, act, Cin, Cout = ctx.meta
         N, H, W, Cin_p, Cout_p, K, B = ctx.geom
-        (x,) = ctx.saved_tensors
+        x, out, save, Y = ctx.saved_tensors[:4]
+        gammas = ctx.saved_tensors[4:]
         dev = g.device
         npix = N * H * W
         KC = K * Cout_p
-        Y = ctx.Y
         srcs = [Y.data_ptr() + b * Cout_p * 2 for b in range(K)] + ([x.data_ptr()] if has_id else [])
         lds = [KC] * K + ([Cin_p] if has_id else [])
         io = _io(srcs, lds, npix, Cout_p)
@@ -299,7 +296,7 @@ class PointRepFn(torch.autograd.Function):
         did = cv.empty_cl(N, Cin_p, H, W, dev) if has_id else None
         dy_ptrs = [dY.data_ptr() + b * Cout_p * 2 for b in range(K)] + ([did.data_ptr()] if has_id else [])
         dy_lds = [KC] * K + ([Cin_p] if has_id else [])
-        pgrad = _msbn_backward(ctx, lib, g, io, B, ctx.gammas, Cout_p, Cout, npix, dy_ptrs, dy_lds, dev)
+        pgrad = _msbn_backward(ctx, lib, g, out, save, io, B, gammas, Cout_p, Cout, npix, dy_ptrs, dy_lds, dev)
         dx = None
         if ctx.needs_input_grad[0]:
             dkey = ("d", N, H, W)
@@ -313,7 +310,6 @@ class PointRepFn(torch.autograd.Function):
             grads += [pgrad[B - 1, 0, :Cout], pgrad[B - 1, 1, :Cout]]
         for b in range(K):
             grads += [dwp[b * Cout_p:b * Cout_p + Cout, :Cin].contiguous(), pgrad[b, 0, :Cout], pgrad[b, 1, :Cout]]
-        ctx.Y = None
         return (dx, None, None, *grads)
 
 
