@@ -110,6 +110,11 @@ class MsbnIo(C.Structure):
                 ("B", c_int32), ("C", c_int32)]
 
 
+class LambGroup(C.Structure):
+    _fields_ = [("lr", c_double), ("beta1", c_double), ("beta2", c_double), ("eps", c_double), ("weight_decay", c_double),
+                ("clip_lo", c_double), ("clip_hi", c_double), ("rect", c_double), ("step", c_int32), ("mode", c_int32)]
+
+
 def tap(dy, dx, src, wt):
     """HC_TAP of the header."""
     u = (dy & 0xff) | ((dx & 0xff) << 8) | ((src & 0xff) << 16) | ((wt & 0xff) << 24)
@@ -118,6 +123,10 @@ def tap(dy, dx, src, wt):
 
 # name -> (restype, argtypes); every symbol include/holocron_hip.h declares
 SIGNATURES = {
+    "hc_lamb_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "hc_tadam_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "hc_adan_step": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "hc_lookahead_sync": (c_int32, [c_void_p, c_int32, c_float, c_void_p]),
     "hc_msbn_finalize": (c_int32, [C.POINTER(MsbnDesc), c_void_p]),
     "hc_msbn_bwd_finalize": (c_int32, [C.POINTER(MsbnDesc), c_void_p]),
     "hc_msbn_apply": (c_int32, [C.POINTER(MsbnIo), c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),

@@ -194,6 +194,175 @@ __global__ __launch_bounds__(256) void adamp_update_kernel(const hc_mt_chunk* __
     }
 }
 
+// block-wide sum of K per-thread partials -> atomicAdd into dst[0..K)
+template <int K>
+__device__ __forceinline__ void block_sums_to(const float (&acc)[K], float* __restrict__ dst) {
+    __shared__ float sh[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float v = wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) atomicAdd(dst + threadIdx.x, sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+// ---------------------------------------------------------------- LAMB / RaLars (holocron/optim/lamb.py:84-137, ralars.py:66-140)
+// update direction from the (already updated) moments; mode 0: LAMB (no bias correction, lamb.py:121-123), 1: rectified
+// adaptive momentum (ralars.py:108-115), 2: adaptive momentum without rectification (:117-121), 3: plain momentum (:123-124)
+struct LambCoef {
+    float b1, b2, o1, o2, eps, wd, bc1, bc2, rect;
+    int mode;
+};
+__device__ __forceinline__ LambCoef lamb_coef(const hc_lamb_group& gr) {
+    LambCoef c;
+    c.b1 = (float)gr.beta1; c.b2 = (float)gr.beta2; c.o1 = (float)(1.0 - gr.beta1); c.o2 = (float)(1.0 - gr.beta2);
+    c.eps = (float)gr.eps; c.wd = (float)gr.weight_decay; c.rect = (float)gr.rect; c.mode = gr.mode;
+    c.bc1 = (float)(1.0 - pow(gr.beta1, (double)gr.step));
+    c.bc2 = (float)(1.0 - pow(gr.beta2, (double)gr.step));
+    return c;
+}
+__device__ __forceinline__ float lamb_dir(const LambCoef& c, float p, float m, float v) {
+    float u;
+    if (c.mode == 0) u = m / (sqrtf(v) + c.eps);
+    else if (c.mode == 1) u = c.rect * ((m / c.bc1) / (sqrtf(v / c.bc2) + c.eps));
+    else if (c.mode == 2) u = (m / c.bc1) / (sqrtf(v / c.bc2) + c.eps);
+    else u = m / c.bc1;
+    if (c.wd != 0.f) u = u + c.wd * p;
+    return u;
+}
+// pass 1: moments in place, per-tensor sum p^2 and sum u^2
+__global__ __launch_bounds__(256) void lamb_moments_kernel(const hc_mt_chunk* __restrict__ chunks, const hc_lamb_group* __restrict__ groups,
+                                                           float* __restrict__ norms) {
+    const hc_mt_chunk ck = chunks[blockIdx.x];
+    const LambCoef c = lamb_coef(groups[ck.group]);
+    float acc[2] = {0.f, 0.f};
+    for (int i = threadIdx.x; i < ck.n; i += 256) {
+        const float p = ck.p[i], g = ck.g[i];
+        const float m = ck.m[i] * c.b1 + c.o1 * g;
+        const float v = ck.s[i] * c.b2 + c.o2 * (g * g);
+        ck.m[i] = m; ck.s[i] = v;
+        const float u = lamb_dir(c, p, m, v);
+        acc[0] += p * p; acc[1] += u * u;
+    }
+    block_sums_to<2>(acc, norms + 2 * ck.tensor);
+}
+// pass 2: local_lr = 1 if phi(|p|) == 0 or |u| == 0 else phi(|p|) / |u|;  p -= lr * local_lr * u
+__global__ __launch_bounds__(256) void lamb_update_kernel(const hc_mt_chunk* __restrict__ chunks, const hc_lamb_group* __restrict__ groups,
+                                                          const float* __restrict__ norms, float* __restrict__ local_lr) {
+    const hc_mt_chunk ck = chunks[blockIdx.x];
+    const hc_lamb_group gr = groups[ck.group];
+    const LambCoef c = lamb_coef(gr);
+    const float pn = sqrtf(norms[2 * ck.tensor]), un = sqrtf(norms[2 * ck.tensor + 1]);
+    const float phi = fminf(fmaxf(pn, (float)gr.clip_lo), (float)gr.clip_hi);
+    const float loc = (phi == 0.f || un == 0.f) ? 1.f : phi / un;
+    if (threadIdx.x == 0) local_lr[ck.tensor] = loc;      // every chunk of the tensor writes the same value
+    const float neg = (float)(-gr.lr) * loc;
+    for (int i = threadIdx.x; i < ck.n; i += 256) {
+        const float p = ck.p[i];
+        ck.p[i] = p + neg * lamb_dir(c, p, ck.m[i], ck.s[i]);
+    }
+}
+
+// ---------------------------------------------------------------- TAdam (holocron/optim/tadam.py:157-212)
+// pass 1: per-tensor sum of (g - m)^2 / (v + eps) over the OLD moments (g includes the weight decay term)
+__global__ __launch_bounds__(256) void tadam_sum_kernel(const hc_mt_chunk* __restrict__ chunks, const hc_adamx_group* __restrict__ groups,
+                                                        float* __restrict__ sums) {
+    const hc_mt_chunk ck = chunks[blockIdx.x];
+    const hc_adamx_group gr = groups[ck.group];
+    const float eps = (float)gr.eps, wd = (float)gr.weight_decay;
+    float acc[1] = {0.f};
+    for (int i = threadIdx.x; i < ck.n; i += 256) {
+        float g = ck.g[i];
+        if (wd != 0.f) g = g + wd * ck.p[i];
+        const float d = g - ck.m[i];
+        acc[0] += (d * d) / (ck.s[i] + eps);
+    }
+    block_sums_to<1>(acc, sums + ck.tensor);
+}
+// per tensor: w_t = (dof + numel) / (sum + dof); wts[t] = (W_t, w_t) for the update pass; W_t <- W_t (2 beta1 - 1) / beta1 + w_t
+__global__ void tadam_scalar_kernel(const float* __restrict__ sums, const float* __restrict__ dof, const int* __restrict__ numel,
+                                    float* const* __restrict__ W, const int* __restrict__ tgroup,
+                                    const hc_adamx_group* __restrict__ groups, float* __restrict__ wts, int ntensors) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntensors) return;
+    const float b1 = (float)groups[tgroup[t]].beta1;
+    const float w = (dof[t] + (float)numel[t]) / (sums[t] + dof[t]);
+    const float Wold = *W[t];
+    wts[2 * t] = Wold;
+    wts[2 * t + 1] = w;
+    *W[t] = Wold * ((2.f * b1 - 1.f) / b1) + w;
+}
+// pass 2: m = m W/(W+w) + w g/(W+w); v = beta2 v + (1 - beta2) g^2; p -= lr/bc1 * m / (sqrt(v [max])/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void tadam_update_kernel(const hc_mt_chunk* __restrict__ chunks, const hc_adamx_group* __restrict__ groups,
+                                                           const float* __restrict__ wts) {
+    const hc_mt_chunk ck = chunks[blockIdx.x];
+    const hc_adamx_group gr = groups[ck.group];
+    const double bc1 = 1.0 - pow(gr.beta1, (double)gr.step), bc2 = 1.0 - pow(gr.beta2, (double)gr.step);
+    const float b2 = (float)gr.beta2, o2 = (float)(1.0 - gr.beta2), eps = (float)gr.eps, wd = (float)gr.weight_decay;
+    const float sqrt_bc2 = (float)sqrt(bc2), neg_step = (float)(-(gr.lr / bc1));
+    const bool ams = gr.amsgrad != 0 && ck.smax != nullptr;
+    const float W = wts[2 * ck.tensor], w = wts[2 * ck.tensor + 1];
+    const float km = W / (W + w), kg = w / (W + w);
+    for (int i = threadIdx.x; i < ck.n; i += 256) {
+        const float p = ck.p[i];
+        float g = ck.g[i];
+        if (wd != 0.f) g = g + wd * p;
+        const float m = ck.m[i] * km + kg * g;
+        float v = ck.s[i] * b2 + o2 * (g * g);
+        ck.m[i] = m; ck.s[i] = v;
+        if (ams) { v = fmaxf(ck.smax[i], v); ck.smax[i] = v; }
+        ck.p[i] = p + neg_step * (m / (sqrtf(v) / sqrt_bc2 + eps));
+    }
+}
+
+// ---------------------------------------------------------------- Adan (holocron/optim/adan.py:146-199)
+// chunk.m = exp_avg, chunk.s = exp_avg_sq (EMA of the gradient difference), chunk.smax = exp_avg_delta;
+// extra[chunk].m = max_exp_avg_delta (amsgrad), extra[chunk].s = prev_grad (read only: the reference never writes it)
+__global__ __launch_bounds__(256) void adan_kernel(const hc_mt_chunk* __restrict__ chunks, const hc_mt_chunk* __restrict__ extra,
+                                                   const hc_adamx_group* __restrict__ groups) {
+    const hc_mt_chunk ck = chunks[blockIdx.x], ex = extra[blockIdx.x];
+    const hc_adamx_group gr = groups[ck.group];
+    const float bc1 = (float)(1.0 - pow(gr.beta1, (double)gr.step)), bc2 = (float)(1.0 - pow(gr.beta2, (double)gr.step));
+    const float sqrt_bc3 = (float)sqrt(1.0 - pow(gr.beta3, (double)gr.step));
+    const float b1 = (float)gr.beta1, b2 = (float)gr.beta2, b3 = (float)gr.beta3;
+    const float o1 = (float)(1.0 - gr.beta1), o2 = (float)(1.0 - gr.beta2), o3 = (float)(1.0 - gr.beta3);
+    const float eps = (float)gr.eps, wd = (float)gr.weight_decay, neg_lr = (float)(-gr.lr);
+    const float shrink = (float)(1.0 + gr.weight_decay * gr.lr);
+    const bool ams = gr.amsgrad != 0 && ex.m != nullptr;
+    for (int i = threadIdx.x; i < ck.n; i += 256) {
+        float p = ck.p[i];
+        float g = ck.g[i];
+        if (wd != 0.f) g = g + wd * p;
+        const float m = ck.m[i] * b1 + o1 * g;
+        const float dg = g - (ex.s != nullptr ? ex.s[i] : 0.f);
+        const float v = ck.s[i] * b2 + o2 * dg;
+        const float t = g + b2 * dg;
+        float n = ck.smax[i] * b3 + o3 * (t * t);
+        ck.m[i] = m; ck.s[i] = v; ck.smax[i] = n;
+        if (ams) { n = fmaxf(ex.m[i], n); ex.m[i] = n; }
+        const float den = sqrtf(n) / sqrt_bc3 + eps;
+        p = p + neg_lr * ((m / bc1 + b2 * v / bc2) / den);
+        if (wd != 0.f) p = p / shrink;
+        ck.p[i] = p;
+    }
+}
+
+// ---------------------------------------------------------------- Lookahead / Scout synchronisation (holocron/optim/wrapper.py:121-134)
+// chunk.p = fast weights, chunk.m = slow weights: slow += rate (fast - slow) [rate > 0]; fast = slow
+__global__ __launch_bounds__(256) void lookahead_sync_kernel(const hc_mt_chunk* __restrict__ chunks, float rate) {
+    const hc_mt_chunk ck = chunks[blockIdx.x];
+    for (int i = threadIdx.x; i < ck.n; i += 256) {
+        float sl = ck.m[i];
+        if (rate > 0.f) {
+            const float d = ck.p[i] - sl;
+            sl = sl + rate * d;
+            ck.m[i] = sl;
+        }
+        ck.p[i] = sl;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -234,6 +403,45 @@ int hc_adamp_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_adamx_gro
     if (hc_zero_async(sums, sizeof(float) * 4 * (size_t)ntensors, st) != hipSuccess) return HC_ERR_LAUNCH;
     hipLaunchKernelGGL(adamp_moments_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups, sums);
     hipLaunchKernelGGL(adamp_update_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups, sums, (const int*)numel);
+    return hc_launch_status();
+}
+
+int hc_lamb_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_lamb_group* groups, float* norms, float* local_lr,
+                 int32_t ntensors, hc_stream_t stream) {
+    if (chunks == nullptr || groups == nullptr || norms == nullptr || local_lr == nullptr || nchunks < 0 || ntensors < 0) return HC_ERR_ARG;
+    if (nchunks == 0) return HC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hc_zero_async(norms, sizeof(float) * 2 * (size_t)ntensors, st) != hipSuccess) return HC_ERR_LAUNCH;
+    hipLaunchKernelGGL(lamb_moments_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups, norms);
+    hipLaunchKernelGGL(lamb_update_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups, (const float*)norms, local_lr);
+    return hc_launch_status();
+}
+int hc_tadam_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_adamx_group* groups, float* scratch, const float* dof,
+                  const int32_t* numel, const int32_t* tensor_group, float* const* W_t, int32_t ntensors, hc_stream_t stream) {
+    if (chunks == nullptr || groups == nullptr || scratch == nullptr || dof == nullptr || numel == nullptr || tensor_group == nullptr ||
+        W_t == nullptr || nchunks < 0 || ntensors < 0)
+        return HC_ERR_ARG;
+    if (nchunks == 0) return HC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    float* sums = scratch;                       // [ntensors]
+    float* wts = scratch + ntensors;             // [ntensors][2]
+    if (hc_zero_async(sums, sizeof(float) * (size_t)ntensors, st) != hipSuccess) return HC_ERR_LAUNCH;
+    hipLaunchKernelGGL(tadam_sum_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups, sums);
+    hipLaunchKernelGGL(tadam_scalar_kernel, dim3((ntensors + 63) / 64), dim3(64), 0, st, (const float*)sums, dof, (const int*)numel, W_t,
+                       (const int*)tensor_group, groups, wts, ntensors);
+    hipLaunchKernelGGL(tadam_update_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups, (const float*)wts);
+    return hc_launch_status();
+}
+int hc_adan_step(const hc_mt_chunk* chunks, const hc_mt_chunk* extra, int32_t nchunks, const hc_adamx_group* groups, hc_stream_t stream) {
+    if (chunks == nullptr || extra == nullptr || groups == nullptr || nchunks < 0) return HC_ERR_ARG;
+    if (nchunks == 0) return HC_OK;
+    hipLaunchKernelGGL(adan_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, chunks, extra, groups);
+    return hc_launch_status();
+}
+int hc_lookahead_sync(const hc_mt_chunk* chunks, int32_t nchunks, float sync_rate, hc_stream_t stream) {
+    if (chunks == nullptr || nchunks < 0 || !(sync_rate >= 0.f && sync_rate <= 1.f)) return HC_ERR_ARG;
+    if (nchunks == 0) return HC_OK;
+    hipLaunchKernelGGL(lookahead_sync_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, chunks, sync_rate);
     return hc_launch_status();
 }
 

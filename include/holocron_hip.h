@@ -279,6 +279,31 @@ int hc_ademamix_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_adamx_
 int hc_adamp_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_adamx_group* groups, float* sums, const int32_t* numel,
                   int32_t ntensors, hc_stream_t stream);
 
+/* LAMB / RaLars (holocron/optim/lamb.py:84-137, holocron/optim/ralars.py:66-140): Adam-style moments + a per-tensor trust
+ * ratio.  mode 0: LAMB, u = m / (sqrt(v) + eps); 1: rectified adaptive momentum, u = rect * (m / bc1) / (sqrt(v / bc2) + eps);
+ * 2: the same without rectification (force_adaptive_momentum); 3: u = m / bc1.  u += weight_decay * p;
+ * local_lr = 1 if clamp(|p|, clip_lo, clip_hi) == 0 or |u| == 0 else clamp(|p|) / |u|;  p -= lr * local_lr * u.
+ * norms: fp32 [ntensors][2] scratch (zeroed by the callee); local_lr: fp32 [ntensors] out. */
+typedef struct {
+    double lr, beta1, beta2, eps, weight_decay, clip_lo, clip_hi, rect;
+    int32_t step, mode;
+} hc_lamb_group;
+int hc_lamb_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_lamb_group* groups, float* norms, float* local_lr,
+                 int32_t ntensors, hc_stream_t stream);
+/* TAdam (holocron/optim/tadam.py:157-212): per tensor w_t = (dof + numel) / (sum((g - m)^2 / (v + eps)) + dof),
+ * m = m W/(W + w_t) + w_t g/(W + w_t), W <- W (2 beta1 - 1)/beta1 + w_t (W_t: device array of pointers to the per-parameter
+ * one-element state tensors), then the Adam step.  scratch: fp32 [3 * ntensors]; dof fp32 [ntensors] (numel when the
+ * group's dof is None); numel / tensor_group int32 [ntensors]. */
+int hc_tadam_step(const hc_mt_chunk* chunks, int32_t nchunks, const hc_adamx_group* groups, float* scratch, const float* dof,
+                  const int32_t* numel, const int32_t* tensor_group, float* const* W_t, int32_t ntensors, hc_stream_t stream);
+/* Adan (holocron/optim/adan.py:146-199): chunk.m = exp_avg, chunk.s = exp_avg_sq, chunk.smax = exp_avg_delta;
+ * extra[i].m = max_exp_avg_delta (amsgrad) and extra[i].s = prev_grad (read only, like the reference) of the same chunk. */
+int hc_adan_step(const hc_mt_chunk* chunks, const hc_mt_chunk* extra, int32_t nchunks, const hc_adamx_group* groups,
+                 hc_stream_t stream);
+/* Lookahead / Scout synchronisation (holocron/optim/wrapper.py:121-134): chunk.p = fast, chunk.m = slow weights;
+ * slow += sync_rate * (fast - slow) when sync_rate > 0, then fast = slow. */
+int hc_lookahead_sync(const hc_mt_chunk* chunks, int32_t nchunks, float sync_rate, hc_stream_t stream);
+
 /* ---- pointwise / losses / boxes ---- */
 /* hard_mish: 0.5*x*clamp(x+2,0,2) (holocron/nn/functional.py:30-41), fp32, y may alias x. */
 int hc_hard_mish_fwd(const float* x, float* y, int64_t n, hc_stream_t stream);

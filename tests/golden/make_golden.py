@@ -577,6 +577,50 @@ def gen_optim2():
     save("optim2.pt", out)
 
 
+def gen_optim3():
+    """LAMB, RaLars (through the step where the rectification switches on, and with force_adaptive_momentum), TAdam, Adan and
+    the Lookahead / Scout wrappers of the reference; parameters and gradients come from `optim2_inputs` seeds."""
+    out = {}
+
+    def run(cls, case, kw, shapes, iters, extra_state=()):
+        params = [torch.nn.Parameter(optim2_inputs(case, -1, k, sh) * (0.0 if (k == 1 and case % 2 == 1) else 1.0)) for k, sh in enumerate(shapes)]
+        opt = cls(params, **kw)
+        traj = []
+        for it in range(iters):
+            for k, p in enumerate(params):
+                p.grad = optim2_inputs(case, it, k, p.shape)
+            opt.step()
+            traj.append([p.data[..., :4].flatten()[:4].clone() for p in params])
+        st = {name: [opt.state[p][name].clone() if torch.is_tensor(opt.state[p][name]) else torch.tensor(float(opt.state[p][name]))
+                     for p in params if p.numel() < 5000 or name in ("local_lr", "W_t")] for name in extra_state}
+        return {"kw": kw, "shapes": shapes, "iters": iters, "traj": traj, "final": [p.data.clone() for p in params if p.numel() < 5000],
+                "final_sum": [float(p.data.double().sum()) for p in params], "state": st}
+
+    out["lamb"] = [run(ref.optim.LAMB, 20, dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0), [(16, 8, 3, 3), (40,), (70000,)], 3, ("local_lr", "exp_avg_sq")),
+                   run(ref.optim.LAMB, 21, dict(lr=5e-3, betas=(0.8, 0.99), eps=1e-6, weight_decay=1e-2, scale_clip=(0.5, 2.0)), [(8, 8), (24,), (300,)], 3, ("local_lr", "exp_avg"))]
+    out["ralars"] = [run(ref.optim.RaLars, 22, dict(lr=1e-2, betas=(0.9, 0.9), eps=1e-8, weight_decay=0.0), [(16, 8, 3, 3), (40,), (66000,)], 8, ("local_lr", "exp_avg_sq")),
+                     run(ref.optim.RaLars, 23, dict(lr=5e-3, betas=(0.8, 0.99), eps=1e-6, weight_decay=1e-2, force_adaptive_momentum=True, scale_clip=(0.1, 5.0)), [(8, 8), (24,), (300,)], 3, ("local_lr", "exp_avg"))]
+    out["tadam"] = [run(ref.optim.TAdam, 24, dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0), [(16, 8, 3, 3), (40,), (70000,)], 3, ("W_t", "exp_avg")),
+                    run(ref.optim.TAdam, 25, dict(lr=5e-3, betas=(0.8, 0.99), eps=1e-6, weight_decay=1e-2, amsgrad=True, dof=3.0), [(8, 8), (24,), (300,)], 3, ("W_t", "max_exp_avg_sq"))]
+    out["adan"] = [run(ref.optim.Adan, 26, dict(lr=1e-2), [(16, 8, 3, 3), (40,), (70000,)], 3, ("exp_avg_sq", "exp_avg_delta", "prev_grad")),
+                   run(ref.optim.Adan, 27, dict(lr=5e-3, betas=(0.9, 0.8, 0.95), eps=1e-6, weight_decay=1e-2, amsgrad=True), [(8, 8), (24,), (300,)], 3, ("max_exp_avg_delta",))]
+    wrap = []
+    for case, (wcls, kw) in enumerate([(ref.optim.wrapper.Lookahead, dict(sync_rate=0.5, sync_period=3)), (ref.optim.wrapper.Scout, dict(sync_rate=0.3, sync_period=2))]):
+        shapes = [(8, 4, 3, 3), (33,), (500,)]
+        params = [torch.nn.Parameter(optim2_inputs(30 + case, -1, k, sh)) for k, sh in enumerate(shapes)]
+        opt = wcls(torch.optim.SGD(params, lr=0.1), **kw)
+        traj = []
+        for it in range(7):
+            for k, p in enumerate(params):
+                p.grad = optim2_inputs(30 + case, it, k, p.shape)
+            opt.step()
+            traj.append([p.data.clone() for p in params])
+        wrap.append({"cls": wcls.__name__, "kw": kw, "shapes": shapes, "traj": traj,
+                     "slow": [p.data.clone() for g_ in opt.param_groups for p in g_["params"]]})
+    out["wrapper"] = wrap
+    save("optim3.pt", out)
+
+
 def gen_nms():
     """torchvision.ops.nms is absent: these vectors come from the restated algorithm (oracle/tv_ops.py),
     plus the two situations the reference's own tests pin (tests/test_models_detection.py:158-163: disjoint
@@ -600,6 +644,6 @@ def gen_nms():
 
 if __name__ == "__main__":
     gens = {"boxes": gen_boxes, "functional": gen_functional, "optim": gen_optim, "repblock": gen_repblock,
-            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "convs": gen_convs, "optim2": gen_optim2, "nms": gen_nms, "mobileone": gen_mobileone}
+            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "convs": gen_convs, "optim2": gen_optim2, "nms": gen_nms, "mobileone": gen_mobileone, "optim3": gen_optim3}
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()

@@ -217,6 +217,62 @@ def test_adamp_and_ademamix_match_reference(golden):
         h.optim.AdEMAMix([torch.nn.Parameter(torch.zeros(1))], betas=(0.9, 0.999, 1.0))      # ademamix.py:68-70
 
 
+def test_lamb_ralars_tadam_adan_match_reference(golden):
+    import holocron_amd as h
+    from _inputs import optim2_inputs
+    g = golden("optim3.pt")
+    specs = [("lamb", h.optim.LAMB, (20, 21), ("local_lr",)), ("ralars", h.optim.RaLars, (22, 23), ("local_lr",)),
+             ("tadam", h.optim.TAdam, (24, 25), ("W_t",)), ("adan", h.optim.Adan, (26, 27), ())]
+    for name, cls, cases, snames in specs:
+        for case, c in zip(cases, g[name]):
+            params = [torch.nn.Parameter((optim2_inputs(case, -1, k, sh) * (0.0 if (k == 1 and case % 2 == 1) else 1.0)).cuda())
+                      for k, sh in enumerate(c["shapes"])]
+            opt = cls(params, **c["kw"])
+            for it in range(c["iters"]):
+                for k, p in enumerate(params):
+                    p.grad = optim2_inputs(case, it, k, p.shape).cuda()
+                opt.step()
+                for p, f in zip(params, c["traj"][it]):
+                    assert torch.allclose(p.data[..., :4].flatten()[:4].cpu(), f, rtol=2e-5, atol=1e-6), (name, case, it)
+            small = [p for p in params if p.numel() < 5000]
+            for p, f in zip(small, c["final"]):
+                assert torch.allclose(p.data.cpu(), f, rtol=2e-5, atol=1e-6), (name, case, float((p.data.cpu() - f).abs().max()))
+            for p, fs in zip(params, c["final_sum"]):
+                assert abs(float(p.data.double().sum()) - fs) < 2e-3 * max(1.0, abs(fs)) + 1e-2, (name, case)
+            for sn in snames:
+                for p, f in zip(params, c["state"][sn]):
+                    v = opt.state[p][sn]
+                    assert torch.allclose(torch.as_tensor(v).float().cpu().flatten(), f.flatten().float(), rtol=1e-4, atol=1e-6), (name, case, sn)
+            for sn, vals in c["state"].items():
+                if sn in snames:
+                    continue
+                for p, f in zip(small, vals):
+                    assert torch.allclose(opt.state[p][sn].cpu(), f, rtol=1e-4, atol=1e-7), (name, case, sn)
+            assert set(opt.state[params[0]].keys()) >= set(c["state"].keys()) | {"step"}
+
+
+def test_lookahead_and_scout_match_reference(golden):
+    import holocron_amd as h
+    from _inputs import optim2_inputs
+    for case, c in enumerate(golden("optim3.pt")["wrapper"]):
+        params = [torch.nn.Parameter(optim2_inputs(30 + case, -1, k, sh).cuda()) for k, sh in enumerate(c["shapes"])]
+        wcls = getattr(h.optim.wrapper, c["cls"])
+        opt = wcls(torch.optim.SGD(params, lr=0.1), **c["kw"])
+        for it in range(len(c["traj"])):
+            for k, p in enumerate(params):
+                p.grad = optim2_inputs(30 + case, it, k, p.shape).cuda()
+            opt.step()
+            for p, f in zip(params, c["traj"][it]):
+                assert torch.allclose(p.data.cpu(), f, rtol=1e-5, atol=1e-6), (c["cls"], it)
+        slow = [p for g_ in opt.param_groups for p in g_["params"]]
+        for p, f in zip(slow, c["slow"]):
+            assert torch.allclose(p.data.cpu(), f, rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        h.optim.Lookahead(torch.optim.SGD(params, lr=0.1), sync_rate=1.5)
+    with pytest.raises(ValueError):
+        h.optim.Scout(torch.optim.SGD(params, lr=0.1), sync_period=0)
+
+
 def test_adabelief_matches_reference(golden):
     import holocron_amd as h
     for c in golden("optim.pt")["adabelief"]:

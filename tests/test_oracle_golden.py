@@ -295,6 +295,80 @@ def test_adamp_ademamix_oracles_match_reference(golden):
             assert torch.equal(p, f)
 
 
+def _optim3_params(case, shapes):
+    from _inputs import optim2_inputs
+    return [optim2_inputs(case, -1, k, sh) * (0.0 if (k == 1 and case % 2 == 1) else 1.0) for k, sh in enumerate(shapes)]
+
+
+def test_lamb_ralars_tadam_adan_wrappers_oracles_match_reference(golden):
+    from _inputs import optim2_inputs
+    g = golden("optim3.pt")
+
+    def check(c, ps, state, tol=1e-6):
+        small = [p for p in ps if p.numel() < 5000]
+        for p, f in zip(small, c["final"]):
+            assert torch.allclose(p, f, rtol=tol, atol=tol * 0.1), float((p - f).abs().max())
+        for p, fs in zip(ps, c["final_sum"]):
+            assert abs(float(p.double().sum()) - fs) < 1e-4 * max(1.0, abs(fs))
+        for name, vals in state.items():
+            for v, f in zip(vals, c["state"][name]):
+                assert torch.allclose(torch.as_tensor(v, dtype=torch.float32).flatten(), f.flatten().float(), rtol=1e-5, atol=1e-7), name
+
+    for case, c in zip((20, 21), g["lamb"]):
+        kw = c["kw"]
+        ps = _optim3_params(case, c["shapes"])
+        ms, ss = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+        for it in range(c["iters"]):
+            loc = [oo.lamb_step(p, optim2_inputs(case, it, k, p.shape), ms[k], ss[k], kw["lr"], *kw["betas"], kw["eps"], kw["weight_decay"],
+                                kw.get("scale_clip", (0.0, 10.0))) for k, p in enumerate(ps)]
+        check(c, ps, {"local_lr": loc})
+    for case, c in zip((22, 23), g["ralars"]):
+        kw = c["kw"]
+        ps = _optim3_params(case, c["shapes"])
+        ms, ss = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+        for it in range(c["iters"]):
+            loc = [oo.ralars_step(p, optim2_inputs(case, it, k, p.shape), ms[k], ss[k], it + 1, kw["lr"], *kw["betas"], kw["eps"],
+                                  kw["weight_decay"], kw.get("force_adaptive_momentum", False), kw.get("scale_clip", (0, 10)))
+                   for k, p in enumerate(ps)]
+        check(c, ps, {"local_lr": loc})
+    for case, c in zip((24, 25), g["tadam"]):
+        kw = c["kw"]
+        ps = _optim3_params(case, c["shapes"])
+        ms, ss = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+        mx = [torch.zeros_like(p) if kw.get("amsgrad") else None for p in ps]
+        Ws = [kw["betas"][0] / (1 - kw["betas"][0]) * torch.ones(1) for _ in ps]
+        for it in range(c["iters"]):
+            for k, p in enumerate(ps):
+                oo.tadam_step(p, optim2_inputs(case, it, k, p.shape), ms[k], ss[k], Ws[k], it + 1, kw["lr"], *kw["betas"], kw["eps"],
+                              kw["weight_decay"], kw.get("dof"), mx[k])
+        check(c, ps, {"W_t": Ws})
+    for case, c in zip((26, 27), g["adan"]):
+        kw = c["kw"]
+        betas = kw.get("betas", (0.98, 0.92, 0.99))
+        ps = _optim3_params(case, c["shapes"])
+        ms, vs, ns, pg = ([torch.zeros_like(p) for p in ps] for _ in range(4))
+        mx = [torch.zeros_like(p) if kw.get("amsgrad") else None for p in ps]
+        for it in range(c["iters"]):
+            for k, p in enumerate(ps):
+                oo.adan_step(p, optim2_inputs(case, it, k, p.shape), pg[k], ms[k], vs[k], ns[k], it + 1, kw["lr"], *betas, kw.get("eps", 1e-8),
+                             kw.get("weight_decay", 0.0), mx[k])
+        check(c, ps, {})
+        if "prev_grad" in c["state"]:
+            assert all(float(t.abs().max()) == 0.0 for t in c["state"]["prev_grad"])      # the reference never writes it
+    # Lookahead over plain SGD: slow / fast trajectories with the oracle's sync rule
+    c = g["wrapper"][0]
+    ps = [optim2_inputs(30, -1, k, sh) for k, sh in enumerate(c["shapes"])]
+    slow = [p.clone() for p in ps]
+    for it in range(len(c["traj"])):
+        for k, p in enumerate(ps):
+            p.add_(optim2_inputs(30, it, k, p.shape), alpha=-0.1)
+        if (it + 1) % c["kw"]["sync_period"] == 0:
+            for p, sl in zip(ps, slow):
+                oo.lookahead_sync(p, sl, c["kw"]["sync_rate"])
+        for p, f in zip(ps, c["traj"][it]):
+            assert torch.allclose(p, f, rtol=1e-6, atol=1e-7)
+
+
 def test_optim_match_reference(golden):
     g = golden("optim.pt")
     for c in g["adabelief"]:
