@@ -123,6 +123,13 @@ def tap(dy, dx, src, wt):
 
 # name -> (restype, argtypes); every symbol include/holocron_hip.h declares
 SIGNATURES = {
+    "hc_maxpool2_fwd": (c_int32, [c_void_p] * 3 + [c_int32] * 4 + [c_void_p]),
+    "hc_maxpool2_bwd": (c_int32, [c_void_p] * 3 + [c_int32] * 4 + [c_void_p]),
+    "hc_space_to_depth": (c_int32, [c_void_p] * 2 + [c_int32] * 8 + [c_void_p]),
+    "hc_leaky_bwd": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "hc_yolo1_loss_fwd": (c_int32, [c_void_p] * 3 + [c_int32] * 8 + [c_void_p] * 4 + [c_int32] + [c_void_p] * 4),
+    "hc_yolo1_loss_bwd": (c_int32, [c_void_p] * 3 + [c_int32] * 8 + [c_void_p] * 4 + [c_int32] + [c_void_p] * 7),
+    "hc_yolo1_decode": (c_int32, [c_void_p] * 3 + [c_int32] * 7 + [c_void_p] * 4),
     "hc_lamb_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "hc_tadam_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "hc_adan_step": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),

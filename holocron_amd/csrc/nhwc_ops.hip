@@ -280,6 +280,104 @@ __global__ __launch_bounds__(256) void gap_fp8_kernel(const unsigned char* __res
     y[n * C + c] = s * scale / (float)HW;
 }
 
+// ---------------------------------------------------------------- nn.MaxPool2d(2) of the DarkNet-19 / 24 bodies (darknet.py:83, darknetv2.py:94)
+// out[n][oh][ow] = max over the 2 x 2 window (floor mode: a trailing odd row / column is dropped); idx: 2 bits per channel
+// (8 channels -> one uint16 per 16-byte chunk), the first maximum in row-major order like torch's max_pool2d
+__global__ void maxpool2_fwd_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out, unsigned short* __restrict__ idx, int N, int H,
+                                    int W, int OH, int OW, int c8) {
+    const long total = (long)N * OH * OW * c8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / c8;
+        const int c = (int)(i - p * c8);
+        const int ow = (int)(p % OW);
+        const int oh = (int)((p / OW) % OH);
+        const long n = p / ((long)OW * OH);
+        float best[8];
+        unsigned code = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long sp = (n * H + 2 * oh + (k >> 1)) * W + 2 * ow + (k & 1);
+            const u32x4 v = x[sp * c8 + c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = bf16lo(v[e]), hi = bf16hi(v[e]);
+                if (k == 0 || lo > best[2 * e]) { best[2 * e] = lo; code = (code & ~(3u << (4 * e))) | ((unsigned)k << (4 * e)); }
+                if (k == 0 || hi > best[2 * e + 1]) { best[2 * e + 1] = hi; code = (code & ~(3u << (4 * e + 2))) | ((unsigned)k << (4 * e + 2)); }
+            }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(best[2 * e], best[2 * e + 1]);
+        out[i] = o;
+        idx[i] = (unsigned short)code;
+    }
+}
+__global__ void maxpool2_bwd_kernel(const u32x4* __restrict__ g, const unsigned short* __restrict__ idx, u32x4* __restrict__ dx, int N, int H,
+                                    int W, int OH, int OW, int c8) {
+    const long total = (long)N * H * W * c8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / c8;
+        const int c = (int)(i - p * c8);
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        const long n = p / ((long)W * H);
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if ((h >> 1) < OH && (w >> 1) < OW) {
+            const long q = ((n * OH + (h >> 1)) * OW + (w >> 1)) * c8 + c;
+            const u32x4 gv = g[q];
+            const unsigned code = idx[q], k = (unsigned)((h & 1) * 2 + (w & 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned lo = ((code >> (4 * e)) & 3u) == k ? (gv[e] & 0xffffu) : 0u;
+                const unsigned hi = ((code >> (4 * e + 2)) & 3u) == k ? (gv[e] & 0xffff0000u) : 0u;
+                o[e] = lo | hi;
+            }
+        }
+        dx[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------- concat_downsample2d (holocron/nn/functional.py:116-136)
+// dst[n][oh][ow][dc0 + (a*s + b)*C + c] = src[n][oh*s + a][ow*s + b][c]   (and its gradient: the inverse scatter)
+template <bool BWD>
+__global__ void space_to_depth_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int dld8, int dc8, int N, int OH, int OW, int c8,
+                                      int s) {
+    const long total = (long)N * OH * OW * s * s * c8;
+    const int H = OH * s, W = OW * s;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c8);
+        long r = i / c8;
+        const int ab = (int)(r % (s * s));
+        r /= s * s;
+        const int ow = (int)(r % OW);
+        const int oh = (int)((r / OW) % OH);
+        const long n = r / ((long)OW * OH);
+        const long big = ((n * H + oh * s + ab / s) * W + ow * s + ab % s) * c8 + c;               // dense [N][H][W][C]
+        const long small = ((n * OH + oh) * OW + ow) * (long)dld8 + dc8 + (long)ab * c8 + c;         // [N][OH][OW][ld]
+        if (BWD) dst[big] = src[small];
+        else dst[small] = src[big];
+    }
+}
+
+// dy = g * (out > 0 ? 1 : slope): gradient through ReLU / LeakyReLU from the stored OUTPUT (same sign as the pre-activation)
+__global__ void leaky_bwd_kernel(const u32x4* __restrict__ g, int gld8, const u32x4* __restrict__ out, u32x4* __restrict__ dy, long npix,
+                                 int c8, float slope) {
+    const long total = npix * c8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / c8;
+        const int c = (int)(i - p * c8);
+        const u32x4 gv = g[p * gld8 + c], ov = out[i];
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = bf16lo(gv[e]) * (bf16lo(ov[e]) > 0.f ? 1.f : slope);
+            const float b = bf16hi(gv[e]) * (bf16hi(ov[e]) > 0.f ? 1.f : slope);
+            o[e] = pack_bf16x2(a, b);
+        }
+        dy[i] = o;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -380,6 +478,42 @@ int hc_gap_fp8(const void* x_fp8, float* y, int32_t N, int32_t HW, int32_t ld, i
     if (N == 0 || HW == 0) return HC_OK;
     hipLaunchKernelGGL(gap_fp8_kernel, dim3((C + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x_fp8, y, HW, ld,
                        C, scale);
+    return hc_launch_status();
+}
+
+int hc_maxpool2_fwd(const void* x, void* out, void* idx, int32_t N, int32_t H, int32_t W, int32_t C, hc_stream_t stream) {
+    if (x == nullptr || out == nullptr || idx == nullptr || C <= 0 || (C & 7) || H < 0 || W < 0) return HC_ERR_ARG;
+    const int OH = H / 2, OW = W / 2;
+    if ((long)N * OH * OW == 0) return HC_OK;
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for((long)N * OH * OW * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x,
+                       (u32x4*)out, (unsigned short*)idx, N, H, W, OH, OW, C / 8);
+    return hc_launch_status();
+}
+int hc_maxpool2_bwd(const void* g, const void* idx, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, hc_stream_t stream) {
+    if (g == nullptr || dx == nullptr || idx == nullptr || C <= 0 || (C & 7) || H < 0 || W < 0) return HC_ERR_ARG;
+    if ((long)N * H * W == 0) return HC_OK;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const u32x4*)g,
+                       (const unsigned short*)idx, (u32x4*)dx, N, H, W, H / 2, W / 2, C / 8);
+    return hc_launch_status();
+}
+int hc_space_to_depth(const void* src, void* dst, int32_t ld, int32_t c0, int32_t N, int32_t OH, int32_t OW, int32_t C, int32_t scale,
+                      int32_t backward, hc_stream_t stream) {
+    if (src == nullptr || dst == nullptr || C <= 0 || ((C | ld | c0) & 7) || scale < 1 || c0 + scale * scale * C > ld) return HC_ERR_ARG;
+    const long total = (long)N * OH * OW * scale * scale * (C / 8);
+    if (total == 0) return HC_OK;
+    if (backward)
+        hipLaunchKernelGGL((space_to_depth_kernel<true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst,
+                           ld / 8, c0 / 8, N, OH, OW, C / 8, scale);
+    else
+        hipLaunchKernelGGL((space_to_depth_kernel<false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst,
+                           ld / 8, c0 / 8, N, OH, OW, C / 8, scale);
+    return hc_launch_status();
+}
+int hc_leaky_bwd(const void* g, int32_t g_ld, const void* out, void* dy, int64_t npix, int32_t C, float slope, hc_stream_t stream) {
+    if (g == nullptr || out == nullptr || dy == nullptr || C <= 0 || ((C | g_ld) & 7) || g_ld < C || npix < 0) return HC_ERR_ARG;
+    if (npix == 0) return HC_OK;
+    hipLaunchKernelGGL(leaky_bwd_kernel, dim3(grid_for((long)npix * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const u32x4*)g, g_ld / 8,
+                       (const u32x4*)out, (u32x4*)dy, (long)npix, C / 8, slope);
     return hc_launch_status();
 }
 

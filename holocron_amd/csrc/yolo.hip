@@ -260,6 +260,167 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(Logits x, Grads dx, int 
     }
 }
 
+
+// ================================================================ YOLOv1 / YOLOv2 (holocron/models/detection/yolo.py:48-215)
+// Already formatted predictions (fp32, contiguous): boxes [N][H][W][A][4] (xc, yc, w, h), objectness [N][H][W][A], class
+// probabilities [N][H][W][As][nc] with As = 1 (YOLOv1: one distribution per cell) or A.  cell_rel != 0: the centre is relative to
+// the cell (YOLOv1.to_isoboxes, yolo.py:140-163), else it is absolute (YOLOv2.to_isoboxes, yolov2.py:157-173).
+__device__ __forceinline__ Box isobox(const float* __restrict__ b, int cx, int cy, int W, int H, int cell_rel) {
+    const float X = cell_rel ? (b[0] + (float)cx) / (float)W : b[0];
+    const float Y = cell_rel ? (b[1] + (float)cy) / (float)H : b[1];
+    const float hw = b[2] / 2.f, hh = b[3] / 2.f;
+    return Box{X - hw, Y - hh, X + hw, Y + hh};
+}
+
+// one thread per ground-truth box: the responsible anchor of its cell (highest IoU, first on ties) -> assign[g] = (cell * A + a),
+// iou_out[g]; mark[n][cell][a] = 1 (yolo.py:97-103)
+__global__ void yolo1_assign_kernel(const float* __restrict__ pb, const float* __restrict__ gt, const int* __restrict__ gt_img, int G, int H,
+                                    int W, int A, int cell_rel, int* __restrict__ assign, float* __restrict__ iou_out,
+                                    unsigned char* __restrict__ mark) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const Box gb = {gt[4 * g], gt[4 * g + 1], gt[4 * g + 2], gt[4 * g + 3]};
+    const int n = gt_img[g];
+    int cx = (int)(((gb.x1 + gb.x2) / 2.f) * (float)W), cy = (int)(((gb.y1 + gb.y2) / 2.f) * (float)H);
+    cx = cx < 0 ? 0 : (cx >= W ? W - 1 : cx);
+    cy = cy < 0 ? 0 : (cy >= H ? H - 1 : cy);
+    const long cell = ((long)n * H + cy) * W + cx;
+    float best = -1.f;
+    int abest = 0;
+    for (int a = 0; a < A; ++a) {
+        const float v = iou_of(gb, isobox(pb + (cell * A + a) * 4, cx, cy, W, H, cell_rel));
+        if (v > best) { best = v; abest = a; }
+    }
+    assign[g] = (int)(cell * A + abest);
+    iou_out[g] = best;
+    mark[cell * A + abest] = 1;
+}
+
+// ground-truth terms, one thread per box (yolo.py:104-121).  sums: obj, noobj, bbox, clf.  BWD: gradients (scaled by
+// gc[0..3]) are accumulated with atomics (several boxes may share a cell / anchor); the buffers are zeroed by the caller.
+template <bool BWD>
+__global__ void yolo1_gt_kernel(const float* __restrict__ pb, const float* __restrict__ po, const float* __restrict__ ps,
+                                const float* __restrict__ gt, const long* __restrict__ gt_label, const int* __restrict__ gt_img,
+                                const int* __restrict__ gt_off, int G, int H, int W, int A, int As, int nc, int cell_rel,
+                                const int* __restrict__ assign, const float* __restrict__ gc, float* __restrict__ sums,
+                                float* __restrict__ dpb, float* __restrict__ dpo, float* __restrict__ dps) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const Box gb = {gt[4 * g], gt[4 * g + 1], gt[4 * g + 2], gt[4 * g + 3]};
+    const int n = gt_img[g];
+    const int slot = assign[g];                     // cell * A + a
+    const long cell = slot / A;
+    const int cx = (int)(cell % W), cy = (int)((cell / W) % H);
+    const float* b = pb + (long)slot * 4;
+    const Box pbx = isobox(b, cx, cy, W, H, cell_rel);
+    const float iou = iou_of(gb, pbx);
+    const float o = po[slot];
+    // classification: (one_hot - p)^2 over the As distributions of the cell
+    const long lab = gt_label[g];
+    float clf = 0.f;
+    for (int sidx = 0; sidx < As; ++sidx)
+        for (int c = 0; c < nc; ++c) {
+            const long q = (cell * As + sidx) * nc + c;
+            const float d = (c == lab ? 1.f : 0.f) - ps[q];
+            clf += d * d;
+            if (BWD) atomicAdd(dps + q, gc[3] * (-2.f * d));
+        }
+    // box centre against the prediction's centre; sqrt(w), sqrt(h) of EVERY box of the image against the prediction's
+    // (yolo.py:115-120: `gt_wh.sqrt()` is not indexed by the box)
+    const float X = (pbx.x1 + pbx.x2) / 2.f, Y = (pbx.y1 + pbx.y2) / 2.f;
+    const float gx = (gb.x1 + gb.x2) / 2.f, gy = (gb.y1 + gb.y2) / 2.f;
+    float bbox = (gx - X) * (gx - X) + (gy - Y) * (gy - Y);
+    const float sw = sqrtf(b[2]), sh = sqrtf(b[3]);
+    float dsw = 0.f, dsh = 0.f;
+    for (int k = gt_off[n]; k < gt_off[n + 1]; ++k) {
+        const float a = sqrtf(gt[4 * k + 2] - gt[4 * k]) - sw, c = sqrtf(gt[4 * k + 3] - gt[4 * k + 1]) - sh;
+        bbox += a * a + c * c;
+        dsw += -2.f * a;
+        dsh += -2.f * c;
+    }
+    const float diff = iou - o;
+    if (!BWD) {
+        atomicAdd(sums + 0, diff * diff);
+        atomicAdd(sums + 2, bbox);
+        atomicAdd(sums + 3, clf);
+    } else {
+        atomicAdd(dpo + slot, gc[0] * (-2.f * diff));
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+        iou_grad(pbx, gb, gc[0] * 2.f * diff, d);             // the objectness target is the differentiable IoU
+        float dX = d[0] + d[2], dY = d[1] + d[3];
+        float dw = 0.5f * (d[2] - d[0]), dh = 0.5f * (d[3] - d[1]);
+        dX += gc[2] * (-2.f * (gx - X));
+        dY += gc[2] * (-2.f * (gy - Y));
+        dw += gc[2] * dsw * (0.5f / sw);
+        dh += gc[2] * dsh * (0.5f / sh);
+        atomicAdd(dpb + (long)slot * 4 + 0, cell_rel ? dX / (float)W : dX);
+        atomicAdd(dpb + (long)slot * 4 + 1, cell_rel ? dY / (float)H : dY);
+        atomicAdd(dpb + (long)slot * 4 + 2, dw);
+        atomicAdd(dpb + (long)slot * 4 + 3, dh);
+    }
+}
+
+// no-object term over every (cell, anchor) without a box, optionally skipping predictions whose best IoU with a box of the
+// image reaches 0.5 (yolo.py:123-128)
+template <bool BWD>
+__global__ __launch_bounds__(256) void yolo1_noobj_kernel(const float* __restrict__ pb, const float* __restrict__ po,
+                                                          const float* __restrict__ gt, const int* __restrict__ gt_off, int N, int H, int W,
+                                                          int A, int cell_rel, int ignore_high_iou,
+                                                          const unsigned char* __restrict__ mark, const float* __restrict__ gc,
+                                                          float* __restrict__ sums, float* __restrict__ dpo) {
+    const long total = (long)N * H * W * A;
+    float acc = 0.f;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        if (mark[t]) continue;
+        const long cell = t / A;
+        const int cx = (int)(cell % W), cy = (int)((cell / W) % H);
+        const int n = (int)(cell / ((long)W * H));
+        if (ignore_high_iou) {
+            const Box bx = isobox(pb + t * 4, cx, cy, W, H, cell_rel);
+            float best = -1.f;
+            for (int k = gt_off[n]; k < gt_off[n + 1]; ++k)
+                best = fmaxf(best, iou_of(bx, Box{gt[4 * k], gt[4 * k + 1], gt[4 * k + 2], gt[4 * k + 3]}));
+            if (best >= 0.5f) continue;
+        }
+        const float o = po[t];
+        if (BWD) atomicAdd(dpo + t, gc[1] * 2.f * o);
+        else acc += o * o;
+    }
+    if (!BWD) {
+        __shared__ float sh[4];
+        const float v = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sums + 1, sh[0] + sh[1] + sh[2] + sh[3]);
+    }
+}
+
+// to_isoboxes (+ clamp) and the eval-time score of post_process (yolo.py:165-215): score = max_c p_c * objectness
+__global__ void yolo1_decode_kernel(const float* __restrict__ pb, const float* __restrict__ po, const float* __restrict__ ps, long total,
+                                    int H, int W, int A, int nc, int cell_rel, int clamp01, float* __restrict__ boxes,
+                                    float* __restrict__ score, long* __restrict__ label) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long cell = t / A;
+        const int cx = (int)(cell % W), cy = (int)((cell / W) % H);
+        Box b = isobox(pb + t * 4, cx, cy, W, H, cell_rel);
+        if (clamp01) {
+            b.x1 = fminf(fmaxf(b.x1, 0.f), 1.f); b.y1 = fminf(fmaxf(b.y1, 0.f), 1.f);
+            b.x2 = fminf(fmaxf(b.x2, 0.f), 1.f); b.y2 = fminf(fmaxf(b.y2, 0.f), 1.f);
+        }
+        boxes[4 * t] = b.x1; boxes[4 * t + 1] = b.y1; boxes[4 * t + 2] = b.x2; boxes[4 * t + 3] = b.y2;
+        if (score != nullptr) {
+            float best = ps[t * nc];
+            long bi = 0;
+            for (int c = 1; c < nc; ++c) {
+                const float v = ps[t * nc + c];
+                if (v > best) { best = v; bi = c; }
+            }
+            score[t] = best * po[t];
+            label[t] = bi;
+        }
+    }
+}
+
 inline int grid_for(long total, int threads = 256, int cap = 4096) {
     long b = (total + threads - 1) / threads;
     if (b > cap) b = cap;
@@ -330,6 +491,70 @@ int hc_yolo_loss_bwd(const void* logits, int32_t dtype, int64_t sn, int64_t sc, 
     hipLaunchKernelGGL((yolo_loss_kernel<true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dx, N, H, W, A,
                        num_classes, anchors, scale_xy, gt_boxes, (const long*)gt_labels, gt_off, obj_mask, cell_gt, (float*)nullptr,
                        gcoef);
+    return hc_launch_status();
+}
+
+int hc_yolo1_loss_fwd(const float* pred_boxes, const float* pred_o, const float* pred_scores, int32_t N, int32_t H, int32_t W, int32_t A,
+                      int32_t As, int32_t nc, int32_t cell_rel, int32_t ignore_high_iou, const float* gt_boxes, const int64_t* gt_labels,
+                      const int32_t* gt_img, const int32_t* gt_off, int32_t G, int32_t* assign, uint8_t* mark, float* sums,
+                      hc_stream_t stream) {
+    if (pred_boxes == nullptr || pred_o == nullptr || pred_scores == nullptr || gt_off == nullptr || mark == nullptr || sums == nullptr ||
+        N < 0 || H <= 0 || W <= 0 || A <= 0 || (As != 1 && As != A) || nc <= 0 || G < 0)
+        return HC_ERR_ARG;
+    if (G > 0 && (gt_boxes == nullptr || gt_labels == nullptr || gt_img == nullptr || assign == nullptr)) return HC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * H * W * A;
+    if (hc_zero_async(mark, (size_t)total, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(sums, 4 * sizeof(float), st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (G > 0) {
+        // the IoU of the assignment is recomputed by the loss kernel; iou_out reuses the tail of `assign` ([2 * G] ints)
+        hipLaunchKernelGGL(yolo1_assign_kernel, dim3((G + 63) / 64), dim3(64), 0, st, pred_boxes, gt_boxes, (const int*)gt_img, G, H, W, A,
+                           cell_rel, (int*)assign, reinterpret_cast<float*>(assign + G), (unsigned char*)mark);
+        hipLaunchKernelGGL((yolo1_gt_kernel<false>), dim3((G + 63) / 64), dim3(64), 0, st, pred_boxes, pred_o, pred_scores, gt_boxes,
+                           (const long*)gt_labels, (const int*)gt_img, (const int*)gt_off, G, H, W, A, As, nc, cell_rel, (const int*)assign,
+                           (const float*)nullptr, sums, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+    }
+    if (total > 0)
+        hipLaunchKernelGGL((yolo1_noobj_kernel<false>), dim3(grid_for(total)), dim3(256), 0, st, pred_boxes, pred_o, gt_boxes,
+                           (const int*)gt_off, N, H, W, A, cell_rel, ignore_high_iou, (const unsigned char*)mark, (const float*)nullptr, sums,
+                           (float*)nullptr);
+    return hc_launch_status();
+}
+
+int hc_yolo1_loss_bwd(const float* pred_boxes, const float* pred_o, const float* pred_scores, int32_t N, int32_t H, int32_t W, int32_t A,
+                      int32_t As, int32_t nc, int32_t cell_rel, int32_t ignore_high_iou, const float* gt_boxes, const int64_t* gt_labels,
+                      const int32_t* gt_img, const int32_t* gt_off, int32_t G, const int32_t* assign, const uint8_t* mark,
+                      const float* grad_sums, float* d_boxes, float* d_o, float* d_scores, hc_stream_t stream) {
+    if (pred_boxes == nullptr || pred_o == nullptr || pred_scores == nullptr || gt_off == nullptr || mark == nullptr ||
+        grad_sums == nullptr || d_boxes == nullptr || d_o == nullptr || d_scores == nullptr || N < 0 || H <= 0 || W <= 0 || A <= 0 ||
+        (As != 1 && As != A) || nc <= 0 || G < 0)
+        return HC_ERR_ARG;
+    if (G > 0 && (gt_boxes == nullptr || gt_labels == nullptr || gt_img == nullptr || assign == nullptr)) return HC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * H * W * A;
+    if (hc_zero_async(d_boxes, sizeof(float) * 4 * (size_t)total, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(d_o, sizeof(float) * (size_t)total, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (hc_zero_async(d_scores, sizeof(float) * (size_t)N * H * W * As * nc, st) != hipSuccess) return HC_ERR_LAUNCH;
+    if (G > 0)
+        hipLaunchKernelGGL((yolo1_gt_kernel<true>), dim3((G + 63) / 64), dim3(64), 0, st, pred_boxes, pred_o, pred_scores, gt_boxes,
+                           (const long*)gt_labels, (const int*)gt_img, (const int*)gt_off, G, H, W, A, As, nc, cell_rel, (const int*)assign,
+                           grad_sums, (float*)nullptr, d_boxes, d_o, d_scores);
+    if (total > 0)
+        hipLaunchKernelGGL((yolo1_noobj_kernel<true>), dim3(grid_for(total)), dim3(256), 0, st, pred_boxes, pred_o, gt_boxes,
+                           (const int*)gt_off, N, H, W, A, cell_rel, ignore_high_iou, (const unsigned char*)mark, grad_sums, (float*)nullptr,
+                           d_o);
+    return hc_launch_status();
+}
+
+int hc_yolo1_decode(const float* b_coords, const float* b_o, const float* b_scores, int32_t N, int32_t H, int32_t W, int32_t A, int32_t nc,
+                    int32_t cell_rel, int32_t clamp01, float* boxes, float* score, int64_t* label, hc_stream_t stream) {
+    if (b_coords == nullptr || boxes == nullptr || N < 0 || H <= 0 || W <= 0 || A <= 0) return HC_ERR_ARG;
+    if ((score == nullptr) != (label == nullptr)) return HC_ERR_ARG;
+    if (score != nullptr && (b_o == nullptr || b_scores == nullptr || nc <= 0)) return HC_ERR_ARG;
+    const long total = (long)N * H * W * A;
+    if (total == 0) return HC_OK;
+    hipLaunchKernelGGL(yolo1_decode_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, b_coords, b_o, b_scores, total, H, W, A,
+                       nc, cell_rel, clamp01, boxes, score, (long*)label);
     return hc_launch_status();
 }
 

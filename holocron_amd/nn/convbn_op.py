@@ -263,6 +263,105 @@ class ConvBiasFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class ConvBiasActFn(torch.autograd.Function):
+    """act(conv(x) + bias) with act in {none, ReLU, LeakyReLU}, no normalisation: the conv_sequence unit of a model built with
+    ``norm_layer=None`` (YOLOv1's default, yolo.py:233-296).  Bias and activation ride in the gather-conv epilogue; the backward
+    pass rebuilds the activation mask from the stored output.  Cin % 16 != 0 (a 3-channel stem) goes through the im2col
+    column tensor like the BatchNorm units."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, st, meta):
+        stride, pad, act, slope = meta
+        Cout, Cin, KH, KW = w.shape
+        N, _, H, W = x.shape
+        dev = x.device
+        if Cout % 16:
+            raise NotImplementedError("conv+bias+act on the HIP path needs Cout % 16 == 0")
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            raise RuntimeError("conv_bias_act (HIP) expects contiguous fp32 conv weights")
+        im2col = (Cin % 16) != 0
+        if im2col:
+            K = Cin * KH * KW
+            Kpad = (K + 15) // 16 * 16
+            src = cv.im2col_small(x, KH, KW, stride, pad, Kpad)
+            wpk = st.fwd_cache.get((w,), lambda: cv.pack_weight_im2col(w, Kpad))
+            key = ("cb", N, src.shape[2], src.shape[3], Kpad, Cout)
+            if key not in st.desc:
+                st.desc[key] = cv.fwd_desc(N, Kpad, src.shape[2], src.shape[3], Cout, 1, 1, 1, 0)
+        else:
+            src = cv.to_cl_bf16(x)
+            wpk = st.fwd_cache.get((w,), lambda: cv.pack_weight(w, 0))
+            key = ("fba", N, Cin, H, W, Cout, KH, KW, stride, pad)
+            if key not in st.desc:
+                st.desc[key] = cv.fwd_desc(N, Cin, H, W, Cout, KH, KW, stride, pad)
+        fd = st.desc[key]
+        bkey = None if bias is None else (bias.data_ptr(), bias._version, cv.weights_epoch())
+        if getattr(st, "bias_key", ()) != bkey or getattr(st, "bias_f", None) is None or st.bias_f.device != dev:
+            st.bias_f = torch.zeros((Cout,), dtype=torch.float32, device=dev) if bias is None else bias.detach().float().contiguous()
+            st.bias_key = bkey
+        out = cv.empty_cl(N, Cout, fd.OH, fd.OW, dev)
+        cv.launch_conv(fd, src, wpk, out, bias=st.bias_f, act=act, flops=2.0 * N * fd.OH * fd.OW * Cout * Cin * KH * KW)
+        if act == 3 and slope != 0.1:
+            raise NotImplementedError("the gather-conv epilogue fuses LeakyReLU(0.1) only")
+        ctx.st, ctx.meta2 = st, (stride, pad, act, slope, im2col, bias is not None)
+        ctx.geom = (N, Cin, H, W, Cout, KH, KW, fd.OH, fd.OW)
+        ctx.save_for_backward(src, w, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        src, w, out = ctx.saved_tensors
+        st = ctx.st
+        stride, pad, act, slope, im2col, has_bias = ctx.meta2
+        N, Cin, H, W, Cout, KH, KW, OH, OW = ctx.geom
+        dev = g.device
+        lib = _lib.load()
+        g, g_ld = as_cl_view(g)
+        npix = N * OH * OW
+        if act == 0:
+            dy = g if g_ld == Cout else g.contiguous(memory_format=torch.channels_last)
+        else:
+            dy = torch.empty_like(out)
+            check(lib.hc_leaky_bwd(ptr(g), g_ld, ptr(out), ptr(dy), npix, Cout, slope if act == 3 else 0.0, stream()), "hc_leaky_bwd")
+        db = None
+        if has_bias:
+            stats = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Cout), dtype=torch.float32, device=dev)
+            check(lib.hc_channel_stats(ptr(dy), ptr(stats), npix, Cout, stream()), "hc_channel_stats")
+            db = stats[:, 0].sum(0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if im2col:
+                raise NotImplementedError("input gradient of the im2col (Cin % 16 != 0) path")
+            key = ("dba", N, Cin, H, W, Cout, KH, KW, stride, pad)
+            if key not in st.desc:
+                st.desc[key] = cv.dgrad_desc(N, Cin, H, W, Cout, [(KH, KW, pad, 0, 0)], stride)
+            wpd = st.bwd_cache.get((w,), lambda: cv.pack_weight(w, 1))
+            dx = cv.empty_cl(N, Cin, H, W, dev)
+            cv.launch_conv(st.desc[key], dy, wpd, dx)
+        if im2col:
+            Kpad = src.shape[1]
+            dwc = cv.conv_wgrad(src, dy, Kpad, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * Cin * KH * KW)
+            dw = torch.empty_like(w, dtype=torch.float32)
+            check(lib.hc_unpack_im2col_grad(ptr(dwc), ptr(dw), Cout, Cin, KH, KW, Kpad, 0, stream()), "hc_unpack_im2col_grad")
+        else:
+            dw = cv.conv_wgrad(src, dy, Cin, Cout, KH, KW, stride, pad)
+        return dx, dw, db, None, None
+
+
+def conv_bias_act(x, conv, act):
+    """``act(conv(x))`` for a bias-carrying nn.Conv2d followed directly by ReLU / LeakyReLU(0.1) (no BatchNorm)."""
+    st = getattr(conv, "_hc", None)
+    if st is None:
+        st = conv._hc = ConvState()
+    code = act_code(act)
+    if not (type(conv) is nn.Conv2d and conv.groups == 1 and conv.dilation == (1, 1) and conv.padding_mode == "zeros"
+            and conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2)
+            and conv.padding[0] == conv.padding[1] and code is not None and code[0] in (0, 1, 3)
+            and (conv.in_channels % 16 != 0 or conv.kernel_size[0] * conv.kernel_size[1] <= _lib.HC_MAX_TAPS)):
+        raise NotImplementedError(f"conv+bias+act unit outside the HIP path: {conv}, {act}")
+    return ConvBiasActFn.apply(x, conv.weight, conv.bias, st, (conv.stride[0], conv.padding[0], code[0], code[1]))
+
+
 def conv_bias(x, conv):
     """``conv(x)`` for a bias-carrying nn.Conv2d with no BN / activation after it, as an NHWC bf16 tensor whose
     channel count is rounded up to a multiple of 16 (the extra channels are exact zeros)."""
@@ -281,7 +380,7 @@ def fusable(conv, bn, act):
             and conv.groups == 1 and conv.dilation == (1, 1) and conv.bias is None
             and conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1]
             and conv.padding[0] == conv.padding[1] and conv.stride[0] in (1, 2)
-            and conv.kernel_size[0] * conv.kernel_size[1] <= _lib.HC_MAX_TAPS and conv.padding_mode == "zeros"
+            and (conv.in_channels % 16 != 0 or conv.kernel_size[0] * conv.kernel_size[1] <= _lib.HC_MAX_TAPS) and conv.padding_mode == "zeros"
             and conv.out_channels % 16 == 0 and act_code(act) is not None)
 
 
@@ -332,11 +431,20 @@ def plan_conv_sequence(seq):
                 i = j
                 continue
             if m.bias is not None:
+                if i + 1 < n and _is_act(mods[i + 1]) and m.out_channels % 16 == 0:
+                    units.append(("convbiasact", m, mods[i + 1]))
+                    i += 2
+                    continue
                 units.append(("convbias", m))
                 i += 1
                 continue
             raise NotImplementedError(f"bias-free convolution without BatchNorm is outside the HIP path: {m}")
-        if isinstance(m, SPP):
+        if isinstance(m, nn.MaxPool2d):
+            if not (m.kernel_size in (2, (2, 2)) and m.stride in (2, (2, 2)) and m.padding in (0, (0, 0)) and not m.ceil_mode
+                    and m.dilation in (1, (1, 1))):
+                raise NotImplementedError(f"only MaxPool2d(2) has a HIP path: {m}")
+            units.append(("maxpool2", m))
+        elif isinstance(m, SPP):
             units.append(("spp", m))
         elif isinstance(m, DropBlock2d):
             units.append(("drop", m))
@@ -372,6 +480,11 @@ def run_conv_sequence(seq, x, residual=None, out=None, padded_out=False):
             x = conv_bias(x, u[1])
             if x.shape[1] != u[1].out_channels and not (padded_out and k == last):
                 x = x[:, :u[1].out_channels]
+        elif kind == "convbiasact":
+            x = conv_bias_act(x, u[1], u[2])
+        elif kind == "maxpool2":
+            from ..ops.nhwc import maxpool2_cl
+            x = maxpool2_cl(x)
         elif kind == "spp":
             x = u[1](x)
         elif kind == "drop":

@@ -11,7 +11,7 @@ from torch import Tensor
 from .. import _lib
 from .._lib import check, ptr, stream
 
-__all__ = ["hard_mish", "focal_loss", "dice_loss", "poly_loss", "dropblock2d", "global_avg_pool2d"]
+__all__ = ["hard_mish", "focal_loss", "dice_loss", "poly_loss", "dropblock2d", "global_avg_pool2d", "concat_downsample2d"]
 
 
 class _HardMishFn(torch.autograd.Function):
@@ -430,3 +430,20 @@ def global_avg_pool2d(x: Tensor) -> Tensor:
         if x.stride(1) != 1:
             x = to_cl_bf16(x.detach()) if not x.requires_grad else x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
     return _GapFn.apply(x)
+
+
+def concat_downsample2d(x: Tensor, scale_factor: int) -> Tensor:
+    """``[N, C, H, W] -> [N, s*s*C, H/s, W/s]`` with output channel ``(a*s + b)*C + c`` = input pixel ``(h*s + a, w*s + b)``
+    (holocron/nn/functional.py:116-136).  Channel counts that are not multiples of 8 are padded for the kernel and sliced back."""
+    from ..ops.nhwc import concat_downsample2d_cl
+    _lib.require_gpu(x)
+    if (x.shape[2] % scale_factor != 0) or (x.shape[3] % scale_factor != 0):
+        raise AssertionError("Spatial size of input tensor must be multiples of `scale_factor`")
+    c = x.shape[1]
+    if c % 8 == 0:
+        return concat_downsample2d_cl(x, scale_factor)
+    from .mbconv_op import _PadChannelsFn, ceil16
+    cp = ceil16(c)
+    out = concat_downsample2d_cl(_PadChannelsFn.apply(x, cp), scale_factor)
+    s2 = scale_factor * scale_factor
+    return torch.cat([out[:, k * cp:k * cp + c] for k in range(s2)], dim=1)

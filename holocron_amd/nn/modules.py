@@ -6,7 +6,7 @@ from torch import Tensor, nn
 
 from . import functional as F
 
-__all__ = ["HardMish", "GlobalAvgPool2d", "FocalLoss", "DiceLoss", "PolyLoss", "DropBlock2d", "SPP", "FReLU", "SlimConv2d", "NormConv2d"]
+__all__ = ["HardMish", "GlobalAvgPool2d", "FocalLoss", "DiceLoss", "PolyLoss", "DropBlock2d", "SPP", "FReLU", "SlimConv2d", "NormConv2d", "ConcatDownsample2d"]
 
 
 class HardMish(nn.Module):
@@ -132,6 +132,21 @@ class SPP(nn.ModuleList):
         if self.kernel_sizes != [5, 9, 13]:
             raise NotImplementedError("the HIP SPP kernel implements the (5, 9, 13) pyramid only")
         return spp_cl(x)
+
+
+class ConcatDownsample2d(nn.Module):
+    """Loss-less downsampling by stacking the ``scale_factor`` x ``scale_factor`` neighbours on the channel axis
+    (holocron/nn/modules/downsample.py:26-39, the YOLOv2 passthrough)."""
+
+    def __init__(self, scale_factor: int) -> None:
+        super().__init__()
+        self.scale_factor = scale_factor
+
+    def forward(self, x: Tensor) -> Tensor:
+        return F.concat_downsample2d(x, self.scale_factor)
+
+    def forward_hip(self, x: Tensor) -> Tensor:       # unit protocol of run_conv_sequence
+        return self.forward(x)
 
 
 class FReLU(nn.Module):

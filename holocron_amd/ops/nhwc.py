@@ -185,3 +185,66 @@ def spp_cl(x: torch.Tensor) -> torch.Tensor:
     if x.shape[1] % 8:
         raise _lib.HipError("spp_cl: channel count must be a multiple of 8")
     return _SppFn.apply(x)
+
+
+class _MaxPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x if (_ld(x) == x.shape[1]) else to_cl_bf16(x).contiguous(memory_format=torch.channels_last)
+        N, Cc, H, W = x.shape
+        out = empty_cl(N, Cc, H // 2, W // 2, x.device)
+        idx = torch.empty((N, H // 2, W // 2, Cc // 8), dtype=torch.int16, device=x.device)
+        check(_lib.load().hc_maxpool2_fwd(ptr(x), ptr(out), ptr(idx), N, H, W, Cc, stream()), "hc_maxpool2_fwd")
+        ctx.geom = (N, Cc, H, W)
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, Cc, H, W = ctx.geom
+        (idx,) = ctx.saved_tensors
+        g = g if (_ld(g) == Cc) else to_cl_bf16(g).contiguous(memory_format=torch.channels_last)
+        dx = empty_cl(N, Cc, H, W, g.device)
+        check(_lib.load().hc_maxpool2_bwd(ptr(g), ptr(idx), ptr(dx), N, H, W, Cc, stream()), "hc_maxpool2_bwd")
+        return dx
+
+
+def maxpool2_cl(x: torch.Tensor) -> torch.Tensor:
+    """``nn.MaxPool2d(2)`` on an NHWC bf16 activation (darknet.py:83, darknetv2.py:94)."""
+    _lib.require_gpu(x)
+    if x.shape[1] % 8:
+        raise _lib.HipError("maxpool2_cl: channel count must be a multiple of 8")
+    return _MaxPool2Fn.apply(x)
+
+
+class _SpaceToDepthFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s, holder):
+        x = x if (_ld(x) == x.shape[1]) else to_cl_bf16(x).contiguous(memory_format=torch.channels_last)
+        N, Cc, H, W = x.shape
+        OH, OW = H // s, W // s
+        out = holder[0] if holder is not None else empty_cl(N, Cc * s * s, OH, OW, x.device)
+        if tuple(out.shape) != (N, Cc * s * s, OH, OW) or _ld(out) is None:
+            raise _lib.HipError("concat_downsample2d: bad `out` view")
+        check(_lib.load().hc_space_to_depth(ptr(x), ptr(out), _ld(out), 0, N, OH, OW, Cc, s, 0, stream()), "hc_space_to_depth")
+        ctx.geom = (N, Cc, H, W, s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, Cc, H, W, s = ctx.geom
+        if _ld(g) is None:
+            g = to_cl_bf16(g)
+        dx = empty_cl(N, Cc, H, W, g.device)
+        check(_lib.load().hc_space_to_depth(ptr(g), ptr(dx), _ld(g), 0, N, H // s, W // s, Cc, s, 1, stream()), "hc_space_to_depth")
+        return dx, None, None
+
+
+def concat_downsample2d_cl(x: torch.Tensor, scale_factor: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``concat_downsample2d`` (nn/functional.py:116-136), optionally written straight into a concat slice."""
+    _lib.require_gpu(x)
+    if (x.shape[2] % scale_factor != 0) or (x.shape[3] % scale_factor != 0):
+        raise AssertionError("Spatial size of input tensor must be multiples of `scale_factor`")
+    if x.shape[1] % 8:
+        raise _lib.HipError("concat_downsample2d: channel count must be a multiple of 8")
+    return _SpaceToDepthFn.apply(x, int(scale_factor), None if out is None else [out])

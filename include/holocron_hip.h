@@ -403,6 +403,44 @@ int hc_yolo_loss_bwd(const void* logits, int32_t dtype, int64_t sn, int64_t sc, 
                      const int64_t* gt_labels, const int32_t* gt_off, const uint8_t* obj_mask, const uint8_t* cell_gt,
                      const float* gcoef, void* dlogits, hc_stream_t stream);
 
+/* ---- YOLOv1 / YOLOv2 (holocron/models/detection/yolo.py:48-215): _YOLO._compute_losses, to_isoboxes, post_process on the
+ * formatted predictions (fp32, contiguous): pred_boxes [N][H][W][A][4] (xc, yc, w, h), pred_o [N][H][W][A], pred_scores
+ * [N][H][W][As][nc] with As = 1 (YOLOv1) or A.  cell_rel != 0: box centres are relative to their cell (YOLOv1.to_isoboxes,
+ * yolo.py:140-163), else absolute (YOLOv2.to_isoboxes, yolov2.py:157-173).  Targets: gt_boxes [G][4] xyxy in [0, 1],
+ * gt_labels int64 [G], gt_img int32 [G] (image of each box), gt_off int32 [N + 1].
+ * loss_fwd: sums[4] = obj, noobj, bbox, clf (before the lambda / N scaling); assign: int32 [2 * G] scratch kept for the
+ * backward pass, mark: uint8 [N*H*W*A] (1 where a box was assigned).  The objectness target is the differentiable IoU and the
+ * sqrt(w), sqrt(h) term runs over every box of the image, like the reference (yolo.py:111-120).
+ * loss_bwd: grad_sums[4] (device) -> d_boxes, d_o, d_scores (same shapes as the predictions, overwritten).
+ * decode: boxes [N*H*W*A][4] xyxy (clamped to [0, 1] when clamp01); optional score = max_c p_c * objectness and its label
+ * (b_scores [N*H*W*A][nc], already repeated per anchor as in YOLOv1.forward, yolo.py:366-367). ---- */
+int hc_yolo1_loss_fwd(const float* pred_boxes, const float* pred_o, const float* pred_scores, int32_t N, int32_t H, int32_t W,
+                      int32_t A, int32_t As, int32_t nc, int32_t cell_rel, int32_t ignore_high_iou, const float* gt_boxes,
+                      const int64_t* gt_labels, const int32_t* gt_img, const int32_t* gt_off, int32_t G, int32_t* assign,
+                      uint8_t* mark, float* sums, hc_stream_t stream);
+int hc_yolo1_loss_bwd(const float* pred_boxes, const float* pred_o, const float* pred_scores, int32_t N, int32_t H, int32_t W,
+                      int32_t A, int32_t As, int32_t nc, int32_t cell_rel, int32_t ignore_high_iou, const float* gt_boxes,
+                      const int64_t* gt_labels, const int32_t* gt_img, const int32_t* gt_off, int32_t G, const int32_t* assign,
+                      const uint8_t* mark, const float* grad_sums, float* d_boxes, float* d_o, float* d_scores,
+                      hc_stream_t stream);
+int hc_yolo1_decode(const float* b_coords, const float* b_o, const float* b_scores, int32_t N, int32_t H, int32_t W, int32_t A,
+                    int32_t nc, int32_t cell_rel, int32_t clamp01, float* boxes, float* score, int64_t* label,
+                    hc_stream_t stream);
+
+/* ---- DarkNet-19 / 24 bodies and the YOLOv2 passthrough (darknet.py:83, darknetv2.py:94, nn/functional.py:116-136), NHWC bf16,
+ * C % 8 == 0.
+ * maxpool2: nn.MaxPool2d(2) (floor mode); idx uint16 [N][H/2][W/2][C/8]: 2 bits per channel, the first maximum in row-major
+ *           order; bwd routes each gradient to that position (dx dense [N][H][W][C], zero elsewhere).
+ * space_to_depth: concat_downsample2d.  forward: src dense [N][OH*s][OW*s][C] -> dst[n][oh][ow][c0 + (a*s + b)*C + c] with `ld`
+ *           channels per pixel (a concat buffer); backward != 0: src is that [N][OH][OW][ld] gradient, dst the dense one.
+ * leaky_bwd: dy = g * (out > 0 ? 1 : slope), the gradient of ReLU (slope 0) / LeakyReLU from the stored output. ---- */
+int hc_maxpool2_fwd(const void* x, void* out, void* idx, int32_t N, int32_t H, int32_t W, int32_t C, hc_stream_t stream);
+int hc_maxpool2_bwd(const void* g, const void* idx, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, hc_stream_t stream);
+int hc_space_to_depth(const void* src, void* dst, int32_t ld, int32_t c0, int32_t N, int32_t OH, int32_t OW, int32_t C,
+                      int32_t scale, int32_t backward, hc_stream_t stream);
+int hc_leaky_bwd(const void* g, int32_t g_ld, const void* out, void* dy, int64_t npix, int32_t C, float slope,
+                 hc_stream_t stream);
+
 /* ---- depthwise 3x3 convolution, pad 1, stride 1 | 2, NHWC bf16 (ReXBlock, rexnet.py:111-124; FReLU,
  * nn/modules/activation.py:58-82).  C % 8 == 0 (pad channels carry zero weights).  wpk: fp32 tap-major [9][C] from
  * hc_dw3x3_pack (flip = 1 gives the taps of the stride-1 data gradient).  fwd optionally accumulates the BatchNorm

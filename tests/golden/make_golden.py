@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import _refshim  # noqa: E402
 
-from _inputs import optim2_inputs  # noqa: E402
+from _inputs import optim2_inputs, yolo12_image  # noqa: E402
 
 ref = _refshim.load_reference()
 torch.set_num_threads(4)
@@ -621,6 +621,107 @@ def gen_optim3():
     save("optim3.pt", out)
 
 
+def gen_yolo_v1():
+    """The reference's own known-answer cases for YOLOv1 / YOLOv2 (tests/test_models_detection.py:95-233) and random
+    predictions / targets through the reference `_compute_losses` (values + gradients), `post_process` and
+    `_format_outputs`; one small training step and eval pass of each detector (weights reproducible from the seed)."""
+    import importlib
+    y1 = importlib.import_module("ref_holocron.models.detection.yolo")
+    y2 = importlib.import_module("ref_holocron.models.detection.yolov2")
+    g = torch.Generator().manual_seed(91)
+    torch.manual_seed(5)
+    m1 = y1.yolov1(num_classes=10, pretrained_backbone=False)
+    torch.manual_seed(6)
+    m2 = y2.yolov2(num_classes=10, pretrained_backbone=False)
+    out = {"kat": [], "rand": [], "post": [], "fmt": {}}
+    # ---- known-answer cases (values asserted by the reference tests)
+    for tag, m, (h, w), A in (("v1", m1, (7, 7), 2), ("v2", m2, (13, 13), 5)):
+        nc = 10
+        if tag == "v1":
+            target = [{"boxes": torch.tensor([[0, 0, 1 / 7, 1 / 7]], dtype=torch.float32), "labels": torch.zeros((1,), dtype=torch.long)}]
+            pb = torch.zeros((1, h, w, A, 4)); pb[..., :2] = 0.5; pb[..., 2:] = 1 / 7; pb[0, 0, 0, 1, 0] = 0.8
+            po = torch.zeros((1, h, w, A)); po[0, 0, 0, 0] = 0.5; po[0, -1, -1, 0] = 0.5
+            ps = torch.zeros((1, h, w, 1, nc)); ps[0, 0, 0, 0, 0] = 0.5; ps[0, 0, 0, 0, 1:] = 0.5 / (nc - 1)
+        else:
+            target = [{"boxes": torch.tensor([[0, 0, 1, 1]], dtype=torch.float32), "labels": torch.zeros((1,), dtype=torch.long)}]
+            pb = torch.zeros((1, h, w, A, 4)); pb[..., :2] = 0.5; pb[..., 2:] = 1
+            pb[0, -1, -1, 0, 0] = (w - 1) / w; pb[0, -1, -1, 0, 1] = (h - 1) / h; pb[0, -1, -1, 0, 2] = 1 / w; pb[0, -1, -1, 0, 3] = 1 / h
+            po = torch.zeros((1, h, w, A)); po[0, h // 2, w // 2, 0] = 0.5; po[0, -1, -1, 0] = 0.5
+            ps = torch.zeros((1, h, w, 1, nc)); ps[0, h // 2, w // 2, 0, 0] = 0.5; ps[0, h // 2, w // 2, 0, 1:] = 0.5 / (nc - 1)
+        with torch.no_grad():
+            ld = m._compute_losses(pb, po, ps, target, ignore_high_iou=True)
+        out["kat"].append({"tag": tag, "pb": pb, "po": po, "ps": ps, "target": target, "losses": {k: v.clone() for k, v in ld.items()},
+                           "lambdas": (m.lambda_obj, m.lambda_noobj, m.lambda_coords, m.lambda_class)})
+        n = 2
+        bc = torch.zeros((n, h * w * A, 4)); bc[..., :2] = 0.5; bc[..., 2:] = (1 / h if tag == "v1" else 1)
+        bo = torch.zeros((n, h * w * A)); bo[:, ::2] = 0.5
+        bs = torch.zeros((n, h * w * A, nc)); bs[..., 0] = 0.5; bs[..., 1:] = 0.5 / (nc - 1)
+        with torch.no_grad():
+            dets = m.post_process(bc, bo, bs, (h, w))
+        out["post"].append({"tag": tag, "bc": bc, "bo": bo, "bs": bs, "grid": (h, w), "A": A, "dets": dets, "kat": True})
+    # ---- random predictions and targets: values and gradients
+    for tag, m, (h, w), A, As in (("v1", m1, (7, 7), 2, 1), ("v2", m2, (13, 13), 5, 5), ("v2", m2, (5, 6), 3, 3)):
+        nc = 10 if (h, w) != (5, 6) else 4
+        N = 3
+        for ignore in (False, True):
+            pb = torch.rand((N, h, w, A, 4), generator=g)
+            if tag == "v2":
+                pb[..., 0] = (pb[..., 0] + torch.arange(w).view(1, 1, -1, 1)) / w
+                pb[..., 1] = (pb[..., 1] + torch.arange(h).view(1, -1, 1, 1)) / h
+            pb[..., 2:] = pb[..., 2:] * 0.5 + 0.05
+            po = torch.rand((N, h, w, A), generator=g)
+            ps = torch.softmax(torch.randn((N, h, w, As, nc), generator=g), -1)
+            target = []
+            for i, k in enumerate((3, 1, 5) if ignore else (3, 0, 5)):      # the reference cannot take an empty image with ignore_high_iou
+                xy = torch.rand((k, 2), generator=g) * 0.55
+                wh = torch.rand((k, 2), generator=g) * 0.4 + 0.04
+                bx = torch.cat([xy, xy + wh], 1)
+                if k == 5:
+                    bx[4] = bx[3] + 0.004          # two boxes in one cell (and, with two anchors, often one anchor)
+                target.append({"boxes": bx, "labels": torch.randint(0, nc, (k,), generator=g)})
+            pb.requires_grad_(True); po.requires_grad_(True); ps.requires_grad_(True)
+            ld = m._compute_losses(pb, po, ps, target, ignore_high_iou=ignore)
+            wts = {"obj_loss": 1.0, "noobj_loss": 0.7, "bbox_loss": 1.3, "clf_loss": 0.9}
+            total = sum(wts[k] * v.sum() for k, v in ld.items())
+            grads = torch.autograd.grad(total, [pb, po, ps])
+            out["rand"].append({"tag": tag, "ignore": ignore, "pb": pb.detach(), "po": po.detach(), "ps": ps.detach(), "target": target,
+                                "weights": wts, "losses": {k: v.detach().clone() for k, v in ld.items()},
+                                "grads": [t.clone() for t in grads],
+                                "lambdas": (m.lambda_obj, m.lambda_noobj, m.lambda_coords, m.lambda_class)})
+        bc = pb.detach().reshape(N, -1, 4)
+        bo = po.detach().reshape(N, -1)
+        bs = (ps.detach().repeat_interleave(A, dim=3) if As == 1 else ps.detach()).contiguous().reshape(N, -1, nc)
+        if (h, w) == (5, 6):
+            m2nc = y2.yolov2(num_classes=4, pretrained_backbone=False, anchors=torch.rand((3, 2), generator=g))
+            dets = m2nc.post_process(bc, bo, bs, (h, w))
+        else:
+            with torch.no_grad():
+                dets = m.post_process(bc, bo, bs, (h, w))
+        out["post"].append({"tag": tag, "bc": bc, "bo": bo, "bs": bs, "grid": (h, w), "A": A, "dets": dets, "kat": False})
+    # ---- _format_outputs
+    x1 = torch.randn((2, 7 * 7 * (2 * 5 + 10)), generator=g)
+    x2 = torch.randn((2, 5 * 15, 13, 13), generator=g)
+    out["fmt"] = {"x1": x1, "v1": [t.clone() for t in m1._format_outputs(x1)], "x2": x2, "v2": [t.clone() for t in m2._format_outputs(x2)],
+                  "anchors": m2.anchors.clone()}
+    # ---- one training-mode forward / backward and one eval pass of each detector (weights reproducible from the seeds 5 / 6)
+    out["model"] = {}
+    for tag, m in (("v1", m1), ("v2", m2)):
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0                       # the draw cannot be replayed on another device
+        x = yolo12_image(tag)
+        target = [{"boxes": torch.tensor([[0.1, 0.2, 0.5, 0.7], [0.55, 0.5, 0.95, 0.9]]), "labels": torch.tensor([1, 3])},
+                  {"boxes": torch.tensor([[0.3, 0.3, 0.8, 0.6]]), "labels": torch.tensor([7])}]
+        m.train()
+        raw = m._forward(x)
+        ld = m._compute_losses(*m._format_outputs(raw), target)
+        sum(v.sum() for v in ld.values()).backward()
+        params = dict(m.named_parameters())
+        out["model"][tag] = {"target": target, "raw": raw.detach().clone(), "losses": {k: v.detach().clone() for k, v in ld.items()},
+                             "grad_norms": {n: float(p.grad.norm()) for n, p in params.items() if p.grad is not None}}
+    save("yolo_v1.pt", out)
+
+
 def gen_nms():
     """torchvision.ops.nms is absent: these vectors come from the restated algorithm (oracle/tv_ops.py),
     plus the two situations the reference's own tests pin (tests/test_models_detection.py:158-163: disjoint
@@ -644,6 +745,6 @@ def gen_nms():
 
 if __name__ == "__main__":
     gens = {"boxes": gen_boxes, "functional": gen_functional, "optim": gen_optim, "repblock": gen_repblock,
-            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "convs": gen_convs, "optim2": gen_optim2, "nms": gen_nms, "mobileone": gen_mobileone, "optim3": gen_optim3}
+            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "convs": gen_convs, "optim2": gen_optim2, "nms": gen_nms, "mobileone": gen_mobileone, "optim3": gen_optim3, "yolo_v1": gen_yolo_v1}
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()

@@ -241,6 +241,46 @@ def test_mobileone_oracle_matches_reference(golden):
         assert torch.allclose(rep, gm["logits_rep"], rtol=1e-3, atol=1e-3)
 
 
+def test_yolo_v1_v2_oracle_matches_reference(golden):
+    from oracle import yolo_v1 as oy
+    g = golden("yolo_v1.pt")
+    for c in g["kat"]:
+        rel = c["tag"] == "v1"
+        ld = oy.compute_losses(c["pb"], c["po"], c["ps"], c["target"], c["lambdas"], True, rel)
+        for k, v in c["losses"].items():
+            assert torch.equal(ld[k], v), (c["tag"], k)
+        # the values the reference's own tests assert (tests/test_models_detection.py:141-151,207-217)
+        lam = c["lambdas"]
+        assert ld["obj_loss"].item() == lam[0] * 0.5 ** 2 and ld["noobj_loss"].item() == lam[1] * 0.5 ** 2 and ld["bbox_loss"].item() == 0
+        assert abs(ld["clf_loss"].item() - lam[3] * (0.5 ** 2 + 9 * (0.5 / 9) ** 2)) < 1e-7
+    for c in g["rand"]:
+        rel = c["tag"] == "v1"
+        pb, po, ps = (c[k].clone().requires_grad_(True) for k in ("pb", "po", "ps"))
+        ld = oy.compute_losses(pb, po, ps, c["target"], c["lambdas"], c["ignore"], rel)
+        for k, v in c["losses"].items():
+            assert torch.allclose(ld[k], v, rtol=1e-6, atol=1e-7), (c["tag"], k)
+        grads = torch.autograd.grad(sum(c["weights"][k] * v.sum() for k, v in ld.items()), [pb, po, ps])
+        for a, b in zip(grads, c["grads"]):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    for c in g["post"]:
+        dets = oy.post_process(c["bc"], c["bo"], c["bs"], c["grid"], c["A"], cell_relative=c["tag"] == "v1")
+        for d, r in zip(dets, c["dets"]):
+            assert torch.equal(d["boxes"], r["boxes"]) and torch.equal(d["scores"], r["scores"]) and torch.equal(d["labels"], r["labels"])
+        if c["kat"]:      # tests/test_models_detection.py:163-169,229-233
+            assert torch.all(dets[0]["labels"] == 0) and torch.all(dets[0]["scores"] == 0.25)
+            assert dets[0]["labels"].shape[0] == (c["bo"].shape[1] // 2 if c["tag"] == "v1" else 1)
+    f = g["fmt"]
+    for a, b in zip(oy.format_outputs_v1(f["x1"], 2, 10), f["v1"]):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    for a, b in zip(oy.format_outputs_v2(f["x2"], f["anchors"], 10), f["v2"]):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    # module tree / constructor parity of the mirrors (parameter names in the reference's order)
+    import holocron_amd as h
+    for tag, fn in (("v1", h.models.detection.yolov1), ("v2", h.models.detection.yolov2)):
+        m = fn(num_classes=10)
+        assert [n for n, p in m.named_parameters() if n in g["model"][tag]["grad_norms"]] == list(g["model"][tag]["grad_norms"])
+
+
 def test_slim_and_norm_conv_oracles_match_reference(golden):
     import torch.nn.functional as F
     g = golden("convs.pt")
