@@ -123,6 +123,9 @@ def tap(dy, dx, src, wt):
 
 # name -> (restype, argtypes); every symbol include/holocron_hip.h declares
 SIGNATURES = {
+    "hc_mixup": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_float, c_void_p]),
+    "hc_mixup_onehot": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "hc_topk_hits": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "hc_maxpool2_fwd": (c_int32, [c_void_p] * 3 + [c_int32] * 4 + [c_void_p]),
     "hc_maxpool2_bwd": (c_int32, [c_void_p] * 3 + [c_int32] * 4 + [c_void_p]),
     "hc_space_to_depth": (c_int32, [c_void_p] * 2 + [c_int32] * 8 + [c_void_p]),

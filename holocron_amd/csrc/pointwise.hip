@@ -251,6 +251,64 @@ __global__ void ce_fwd_bwd_kernel(const float* __restrict__ logits, const long* 
     }
 }
 
+
+// ---------------------------------------------------------------- input side of the training step
+// Mixup (holocron/utils/data/collate.py:39-64): out[i] = lam x[i] + (1 - lam) x[perm[i]] over rows of D elements
+template <typename T>
+__global__ void mixup_kernel(const T* __restrict__ x, const long* __restrict__ perm, T* __restrict__ out, long D, float lam);
+template <>
+__global__ void mixup_kernel<float>(const float* __restrict__ x, const long* __restrict__ perm, float* __restrict__ out, long D, float lam) {
+    const long i = blockIdx.y, j = perm[i];
+    const float* a = x + i * D;
+    const float* b = x + j * D;
+    float* o = out + i * D;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < D; k += (long)gridDim.x * blockDim.x) o[k] = lam * a[k] + (1.f - lam) * b[k];
+}
+template <>
+__global__ void mixup_kernel<bf16_t>(const bf16_t* __restrict__ x, const long* __restrict__ perm, bf16_t* __restrict__ out, long D, float lam) {
+    const long i = blockIdx.y, j = perm[i];
+    const bf16_t* a = x + i * D;
+    const bf16_t* b = x + j * D;
+    bf16_t* o = out + i * D;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < D; k += (long)gridDim.x * blockDim.x)
+        o[k] = f32_to_bf16(lam * bf16_to_f32(a[k]) + (1.f - lam) * bf16_to_f32(b[k]));
+}
+// class indices -> mixed one-hot rows: out[i][c] = lam [t[i] == c] + (1 - lam) [t[perm[i]] == c]
+__global__ void mixup_onehot_kernel(const long* __restrict__ t, const long* __restrict__ perm, float* __restrict__ out, long N, int C, float lam) {
+    const long total = N * C;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+        const long i = q / C;
+        const int c = (int)(q - i * C);
+        out[q] = (t[i] == c ? lam : 0.f) + (t[perm[i]] == c ? 1.f - lam : 0.f);
+    }
+}
+// top-1 / top-k hits of a batch accumulated on the device (trainer/classification.py:60-66 without the per-batch .item()):
+// one wave per row; rank of the target = number of classes that beat it (ties broken towards the lower index)
+__global__ __launch_bounds__(256) void topk_hits_kernel(const float* __restrict__ logits, const long* __restrict__ target, long N, int C, int k,
+                                                        float* __restrict__ counters) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* l = logits + row * C;
+    const long t = target[row];
+    float beat = 0.f;
+    if (t >= 0 && t < C) {
+        const float tv = l[t];
+        for (int c = lane; c < C; c += 64) {
+            const float v = l[c];
+            if (v > tv || (v == tv && c < t)) beat += 1.f;
+        }
+    } else {
+        beat = lane == 0 ? (float)C : 0.f;
+    }
+    beat = wave_sum(beat);
+    if (lane == 0) {
+        if (beat < 1.f) atomicAdd(counters + 0, 1.f);
+        if (k > 1 && beat < (float)k) atomicAdd(counters + 1, 1.f);
+        atomicAdd(counters + 2, 1.f);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -318,6 +376,34 @@ int hc_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss_el, fl
     if (logits == nullptr || target == nullptr || loss_el == nullptr || N <= 0 || K <= 0) return HC_ERR_ARG;
     hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, logits, (const long*)target,
                        loss_el, dlogits, N, K, label_smoothing);
+    return hc_launch_status();
+}
+
+int hc_mixup(const void* x, const int64_t* perm, void* out, int64_t N, int64_t D, int32_t dtype, float lam, hc_stream_t stream) {
+    if (x == nullptr || perm == nullptr || out == nullptr || N < 0 || D < 0 || N > 65535 || (dtype != 0 && dtype != 1)) return HC_ERR_ARG;
+    if (N == 0 || D == 0) return HC_OK;
+    long bx = (D + 1023) / 1024;
+    if (bx > 1024) bx = 1024;
+    if (dtype == 0)
+        hipLaunchKernelGGL(mixup_kernel<float>, dim3((unsigned)bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const long*)perm,
+                           (float*)out, (long)D, lam);
+    else
+        hipLaunchKernelGGL(mixup_kernel<bf16_t>, dim3((unsigned)bx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           (const long*)perm, (bf16_t*)out, (long)D, lam);
+    return hc_launch_status();
+}
+int hc_mixup_onehot(const int64_t* target, const int64_t* perm, float* out, int64_t N, int32_t C, float lam, hc_stream_t stream) {
+    if (target == nullptr || perm == nullptr || out == nullptr || N < 0 || C <= 0) return HC_ERR_ARG;
+    if (N == 0) return HC_OK;
+    hipLaunchKernelGGL(mixup_onehot_kernel, dim3(grid_for(N * C)), dim3(256), 0, (hipStream_t)stream, (const long*)target, (const long*)perm, out,
+                       (long)N, C, lam);
+    return hc_launch_status();
+}
+int hc_topk_hits(const float* logits, const int64_t* target, int64_t N, int32_t C, int32_t k, float* counters, hc_stream_t stream) {
+    if (logits == nullptr || target == nullptr || counters == nullptr || N < 0 || C <= 0 || k < 1) return HC_ERR_ARG;
+    if (N == 0) return HC_OK;
+    hipLaunchKernelGGL(topk_hits_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, (const long*)target, (long)N, C, k,
+                       counters);
     return hc_launch_status();
 }
 

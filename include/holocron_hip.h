@@ -563,6 +563,15 @@ int hc_msbn_bwd_apply(const hc_msbn_io* io, const void* g, int32_t g_ld, const v
 int hc_dwrep_dgrad(const void* const* dy, const float* const* wpk, int32_t nplanes, const void* extra, void* dx, int32_t N,
                    int32_t H, int32_t W, int32_t C, int32_t stride, hc_stream_t stream);
 
+/* ---- the steps either side of the training step.
+ * mixup (holocron/utils/data/collate.py:39-64): out[i] = lam x[i] + (1 - lam) x[perm[i]] over N rows of D elements (dtype 0 fp32,
+ *   1 bf16; out must not alias x); mixup_onehot: class indices -> out fp32 [N][C] = lam onehot(t[i]) + (1 - lam) onehot(t[perm[i]]).
+ * topk_hits (holocron/trainer/classification.py:60-66 without the per-batch .item() synchronisations): counters[0] += rows whose
+ *   target has the highest logit, counters[1] += rows whose target is among the k highest (k > 1), counters[2] += N. ---- */
+int hc_mixup(const void* x, const int64_t* perm, void* out, int64_t N, int64_t D, int32_t dtype, float lam, hc_stream_t stream);
+int hc_mixup_onehot(const int64_t* target, const int64_t* perm, float* out, int64_t N, int32_t C, float lam, hc_stream_t stream);
+int hc_topk_hits(const float* logits, const int64_t* target, int64_t N, int32_t C, int32_t k, float* counters, hc_stream_t stream);
+
 const char* hc_version(void);
 
 #ifdef __cplusplus

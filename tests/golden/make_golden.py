@@ -722,6 +722,34 @@ def gen_yolo_v1():
     save("yolo_v1.pt", out)
 
 
+def gen_mixup():
+    """Reference Mixup (holocron/utils/data/collate.py) under fixed host seeds: index targets, dense targets, the binary case and
+    alpha = 0; and the top-1 / top-5 accuracy arithmetic of ClassificationTrainer.evaluate (trainer/classification.py:60-66)."""
+    import importlib
+    col = importlib.import_module("ref_holocron.utils.data.collate")
+    out = {"cases": []}
+    g = torch.Generator().manual_seed(77)
+    for seed, (nc, alpha, shape, tkind) in enumerate([(10, 0.4, (6, 3, 8, 8), "index"), (5, 1.0, (4, 2, 5, 5), "dense"), (1, 0.3, (5, 3, 4, 4), "binary"),
+                                                      (7, 0.0, (3, 1, 4, 4), "index")]):
+        x = torch.rand(shape, generator=g)
+        if tkind == "index":
+            t = torch.randint(0, nc, (shape[0],), generator=g)
+        elif tkind == "dense":
+            t = torch.rand((shape[0], nc), generator=g)
+        else:
+            t = torch.randint(0, 2, (shape[0],), generator=g).float()
+        torch.manual_seed(1000 + seed)
+        mx, mt = col.Mixup(nc, alpha)(x.clone(), t.clone())
+        out["cases"].append({"nc": nc, "alpha": alpha, "x": x, "t": t, "seed": 1000 + seed, "mx": mx, "mt": mt})
+    logits = torch.randn((64, 12), generator=g)
+    logits[5, 3] = logits[5, 7]
+    target = torch.randint(0, 12, (64,), generator=g)
+    pred = logits.topk(5, dim=1)[1]
+    correct = pred.eq(target.view(-1, 1).expand_as(pred))
+    out["topk"] = {"logits": logits, "target": target, "top1": int(correct[:, 0].sum()), "top5": int(correct.any(dim=1).sum())}
+    save("mixup.pt", out)
+
+
 def gen_nms():
     """torchvision.ops.nms is absent: these vectors come from the restated algorithm (oracle/tv_ops.py),
     plus the two situations the reference's own tests pin (tests/test_models_detection.py:158-163: disjoint
@@ -745,6 +773,6 @@ def gen_nms():
 
 if __name__ == "__main__":
     gens = {"boxes": gen_boxes, "functional": gen_functional, "optim": gen_optim, "repblock": gen_repblock,
-            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "convs": gen_convs, "optim2": gen_optim2, "nms": gen_nms, "mobileone": gen_mobileone, "optim3": gen_optim3, "yolo_v1": gen_yolo_v1}
+            "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "convs": gen_convs, "optim2": gen_optim2, "nms": gen_nms, "mobileone": gen_mobileone, "optim3": gen_optim3, "yolo_v1": gen_yolo_v1, "mixup": gen_mixup}
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()

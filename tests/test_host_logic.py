@@ -150,3 +150,17 @@ def test_chunk_table():
     assert [c.n for c in arr] == [_lib.HC_MT_CHUNK] * 3 + [5]
     assert arr[1].p == p.data_ptr() + 4 * _lib.HC_MT_CHUNK and arr[3].group == 2 and arr[3].tensor == 7
     assert arr[0].smax is None
+
+
+def test_mixup_and_metrics_host_contract():
+    """holocron/utils/data/collate.py:31-37: negative alpha is rejected; the device ops refuse CPU tensors loudly."""
+    import holocron_amd as h
+    with pytest.raises(ValueError):
+        h.utils.data.Mixup(10, -0.5)
+    m = h.utils.data.Mixup(10, 0.2)
+    assert m.num_classes == 10 and m.alpha == 0.2
+    with pytest.raises(_lib.HipError):
+        m(torch.rand(2, 3, 4, 4), torch.tensor([1, 2]))
+    with pytest.raises(_lib.HipError):
+        h.utils.metrics.TopKAccuracy().update(torch.rand(2, 10), torch.tensor([1, 2]))
+    assert h.utils.metrics.TopKAccuracy().compute() == (0.0, 0.0, 0)
