@@ -557,37 +557,76 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
         }
     }
 }
-// all conv weights of a model in one launch: blockIdx.y = item.  Threads walk the OUTPUT (packed)
-// order so the 2-byte stores coalesce; the strided fp32 reads are served by L2/MALL.
-__global__ void pack_weight_multi_kernel(const hc_pack_item* __restrict__ items) {
+// all conv weights of a model in one launch: blockIdx.y = item.  The fp32 OIHW source is read in runs along its fastest axes
+// (ci, tap) and the bf16 destination is written in runs along ITS fastest axis (ci for the forward image, co for the
+// data-gradient image) through an LDS tile: a thread-per-output-element walk reads the data-gradient image with a stride of
+// Cin * KK floats (one cache line per lane), which made this kernel 20x slower than its traffic.
+constexpr int PK_MAXKK = 9;
+constexpr int PK_TILE = 16 * 64 * PK_MAXKK;      // floats: 16 x 64 (co x ci or ci x co) x taps
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const hc_pack_item* __restrict__ items) {
+    __shared__ float tile[PK_TILE + 64];
     const hc_pack_item it = items[blockIdx.y];
     const int KK = it.KH * it.KW;
-    const long total = (long)it.Cout * it.Cin * KK;
     bf16_t* wpk = reinterpret_cast<bf16_t*>(it.dst);
-    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
-        int co, ci, t;
-        long dst;
-        if (it.mode == 0) {          // [co][tap][ci], rows of ld >= Cin elements (zero padding left untouched)
-            ci = (int)(o % it.Cin);
-            const long r = o / it.Cin;
-            t = (int)(r % KK);
-            co = (int)(r / KK);
-            dst = ((long)co * it.T + it.tap0 + t) * (it.ld > 0 ? it.ld : it.Cin) + ci;
-        } else if (it.mode == 1) {   // [ci][flipped tap][co]
-            co = (int)(o % it.Cout);
-            const long r = o / it.Cout;
-            const int tf = (int)(r % KK);
-            ci = (int)(r / KK);
-            t = KK - 1 - tf;         // flip both kh and kw
-            dst = ((long)ci * it.T + it.tap0 + tf) * (it.ld > 0 ? it.ld : it.Cout) + co;
-        } else {                     // [co][tap0 + tap*Cin + ci]
-            ci = (int)(o % it.Cin);
-            const long r = o / it.Cin;
-            t = (int)(r % KK);
-            co = (int)(r / KK);
-            dst = (long)co * it.T + it.tap0 + t * it.Cin + ci;
+    if (it.mode == 2 || KK > PK_MAXKK) {            // im2col order / large kernels: element-wise walk
+        const long total = (long)it.Cout * it.Cin * KK;
+        for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+            int co, ci, t;
+            long dst;
+            if (it.mode == 0) {
+                ci = (int)(o % it.Cin);
+                const long r = o / it.Cin;
+                t = (int)(r % KK);
+                co = (int)(r / KK);
+                dst = ((long)co * it.T + it.tap0 + t) * (it.ld > 0 ? it.ld : it.Cin) + ci;
+            } else if (it.mode == 1) {
+                co = (int)(o % it.Cout);
+                const long r = o / it.Cout;
+                const int tf = (int)(r % KK);
+                ci = (int)(r / KK);
+                t = KK - 1 - tf;
+                dst = ((long)ci * it.T + it.tap0 + tf) * (it.ld > 0 ? it.ld : it.Cout) + co;
+            } else {                     // [co][tap0 + tap*Cin + ci]
+                ci = (int)(o % it.Cin);
+                const long r = o / it.Cin;
+                t = (int)(r % KK);
+                co = (int)(r / KK);
+                dst = (long)co * it.T + it.tap0 + t * it.Cin + ci;
+            }
+            wpk[dst] = f32_to_bf16(it.w[((long)co * it.Cin + ci) * KK + t]);
         }
-        wpk[dst] = f32_to_bf16(it.w[((long)co * it.Cin + ci) * KK + t]);
+        return;
+    }
+    // mode 0: tiles of 16 co x 64 ci, written [co][tap][ci] (rows of ld >= Cin; the padding is left untouched)
+    // mode 1: tiles of 64 co x 16 ci, written [ci][flipped tap][co]
+    const int TCO = it.mode == 0 ? 16 : 64, TCI = it.mode == 0 ? 64 : 16;
+    const int nco = (it.Cout + TCO - 1) / TCO, nci = (it.Cin + TCI - 1) / TCI;
+    const int run = TCI * KK;                       // contiguous source floats per co row of a tile
+    const int lrun = run + 1;                       // LDS row stride (odd: the transposing reads spread over the banks)
+    for (int tl = blockIdx.x; tl < nco * nci; tl += gridDim.x) {
+        const int co0 = (tl / nci) * TCO, ci0 = (tl % nci) * TCI;
+        const int cw = min(TCI, it.Cin - ci0) * KK;   // valid floats of a row
+        __syncthreads();
+        for (int e = threadIdx.x; e < TCO * run; e += 256) {
+            const int r = e / run, c = e - r * run;
+            if (co0 + r < it.Cout && c < cw) tile[r * lrun + c] = it.w[((long)(co0 + r) * it.Cin + ci0) * KK + c];
+        }
+        __syncthreads();
+        if (it.mode == 0) {
+            const int ld = it.ld > 0 ? it.ld : it.Cin;
+            for (int e = threadIdx.x; e < TCO * KK * TCI; e += 256) {
+                const int ci = e % TCI, t = (e / TCI) % KK, r = e / (TCI * KK);
+                if (co0 + r < it.Cout && ci0 + ci < it.Cin)
+                    wpk[((long)(co0 + r) * it.T + it.tap0 + t) * ld + ci0 + ci] = f32_to_bf16(tile[r * lrun + ci * KK + t]);
+            }
+        } else {
+            const int ld = it.ld > 0 ? it.ld : it.Cout;
+            for (int e = threadIdx.x; e < TCI * KK * TCO; e += 256) {
+                const int r = e % TCO, tf = (e / TCO) % KK, ci = e / (TCO * KK);
+                if (co0 + r < it.Cout && ci0 + ci < it.Cin)
+                    wpk[((long)(ci0 + ci) * it.T + it.tap0 + tf) * ld + co0 + r] = f32_to_bf16(tile[r * lrun + ci * KK + (KK - 1 - tf)]);
+            }
+        }
     }
 }
 
@@ -841,8 +880,8 @@ int hc_pack_conv_weight(const float* w, void* wpk, int32_t Cout, int32_t Cin, in
 int hc_pack_conv_weights_multi(const hc_pack_item* items, int32_t nitems, int64_t max_elems, hc_stream_t stream) {
     if (items == nullptr || nitems < 0) return HC_ERR_ARG;
     if (nitems == 0) return HC_OK;
-    int bx = (int)((max_elems + 1023) / 1024);
-    if (bx > 2048) bx = 2048;
+    int bx = (int)((max_elems + 1024 * PK_MAXKK - 1) / (1024 * PK_MAXKK));      // one 16 x 64 x taps tile per workgroup round
+    if (bx > 512) bx = 512;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(bx, nitems), dim3(256), 0, (hipStream_t)stream, items);
     return hc_launch_status();
