@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libholocron_hip.so")
 
 HC_MAX_TAPS = 12
-HC_MT_CHUNK = 65536
+HC_MT_CHUNK = 8192
 HC_STAT_REPLICAS = 128
 
 c_void_p, c_int32, c_int64, c_float, c_double = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double

@@ -233,7 +233,7 @@ int hc_unpack_im2col_grad(const float* dwcol, float* dw, int32_t Cout, int32_t C
 /* ---- optimizers (multi-tensor; holocron/optim/adabelief.py:121-167, lars.py:90-135) ---- */
 /* One entry per CHUNK of a parameter tensor (the host splits tensors into chunks of at most
  * HC_MT_CHUNK elements so that one workgroup handles one entry). */
-#define HC_MT_CHUNK 65536
+#define HC_MT_CHUNK 8192
 typedef struct {
     float* p;
     float* g;          /* LARS adds weight decay into g in place (lars.py:113-114) */
