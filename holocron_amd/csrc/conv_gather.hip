@@ -8,10 +8,13 @@
 // (cols = output pixels), so every lane ends up with 4 consecutive output channels of one
 // pixel per accumulator quad -> 8-byte NHWC stores.  Zero padding and ragged tiles come from
 // buffer-descriptor range checks (out-of-range voffset reads 0), not from branches.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/holocron_hip.h"
 
 namespace {
+
+
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
@@ -45,9 +48,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
     const hc_conv_class& cl = d.cls[blockIdx.z];
     const int OHg = cl.OHg, OWg = cl.OWg;
     const int M = d.N * OHg * OWg;
-    const int pbase = blockIdx.x * BP;
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), so a plain
+    // (pixel tile, channel tile) grid puts every channel tile that is in flight on every XCD and the weight tiles thrash the
+    // 4 MB L2s.  Give XCD k the k-th contiguous run of the channel-tile-major list instead: the workgroups that share an L2 share
+    // one weight tile and walk neighbouring pixel tiles.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int gx = gridDim.x, T = gx * gridDim.y, L = by * gx + bx;
+        const int q = T >> 3, r = T & 7, xcd = L & 7, j = L >> 3;
+        const int tile = xcd * q + (xcd < r ? xcd : r) + j;
+        by = tile / gx;
+        bx = tile - by * gx;
+    }
+    const int pbase = bx * BP;
     if (pbase >= M) return;
-    const int cbase = blockIdx.y * BC;
+    const int cbase = by * BC;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int IH = d.IH, IW = d.IW, srcC = d.srcC, T = d.T, Cout = d.Cout;
@@ -189,7 +204,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage s has landed
         __syncthreads();                                     // ... everybody's has, and compute(s-1) is over
         if (s + 1 < S) {
-            if (++ck == kcb) { ck = 0; ++tap; }
+            // taps inner, channel blocks outer: consecutive steps read the same pixels shifted by one tap, so the x rows are
+            // still in L2 (one step of the co-resident workgroups apart) instead of a whole channel sweep apart (+6 % on the
+            // 1280-channel layers, neutral elsewhere)
+            if (++tap == cl.ntaps) { tap = 0; ++ck; }
             issue((s + 1) & 1, tap, ck);
         }
         compute(s & 1);

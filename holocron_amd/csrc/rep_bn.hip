@@ -880,7 +880,7 @@ int hc_pack_conv_weight(const float* w, void* wpk, int32_t Cout, int32_t Cin, in
 int hc_pack_conv_weights_multi(const hc_pack_item* items, int32_t nitems, int64_t max_elems, hc_stream_t stream) {
     if (items == nullptr || nitems < 0) return HC_ERR_ARG;
     if (nitems == 0) return HC_OK;
-    int bx = (int)((max_elems + 1024 * PK_MAXKK - 1) / (1024 * PK_MAXKK));      // one 16 x 64 x taps tile per workgroup round
+    int bx = (int)((max_elems + 1023) / 1024);      // a 1x1 tile is 16 x 64 elements; workgroups beyond an item's tile count exit
     if (bx > 512) bx = 512;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(bx, nitems), dim3(256), 0, (hipStream_t)stream, items);
