@@ -205,27 +205,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// dw[co][ci][t] = beta*dw + sum_split ws[split][co][t][ci].  One workgroup per (co, 64-wide ci tile):
-// thread (t, c) sums its element over the splits with reads coalesced along ci, the tile is turned
-// through LDS and written as one contiguous run of 64*T floats of the OIHW gradient.
+// dw[co][ci][t] = beta*dw + sum_split ws[split][co][t][ci].  One workgroup per (co, 64-wide ci tile, chunk of splits):
+// thread (t, c) sums its element over the chunk's splits with reads coalesced along ci, the tile is turned
+// through LDS and written as one contiguous run of 64*T floats of the OIHW gradient.  Few-channel layers have few
+// (co, ci tile) pairs and hundreds of splits: blockIdx.z spreads the splits over more workgroups, which then combine with
+// atomics (dw zeroed by the launcher when beta == 0).
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int Cout, int T, int Cin,
-                                    int beta) {
+                                    int beta, int chunk) {
     extern __shared__ float sm[];  // [T][64]
     const int co = blockIdx.x, ci0 = blockIdx.y * 64;
     const int t = threadIdx.x / 64, c = threadIdx.x % 64;
     const long slab = (long)Cout * T * Cin;
+    const int k0 = blockIdx.z * chunk, k1 = min(nsplit, k0 + chunk);
     float s = 0.f;
     if (ci0 + c < Cin) {
         const float* p = ws + ((long)co * T + t) * Cin + ci0 + c;
-        int k = 0;
-        for (; k + 8 <= nsplit; k += 8) {   // 8 independent loads in flight
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {   // 8 independent loads in flight
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = p[(long)(k + u) * slab];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; k < nsplit; ++k) s += p[(long)k * slab];
+        for (; k < k1; ++k) s += p[(long)k * slab];
     }
     sm[t * 64 + c] = s;
     __syncthreads();
@@ -234,8 +237,29 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     if (ci0 + cl < Cin) {
         float* o = dw + ((long)co * Cin + ci0 + cl) * T + tt;
         const float v = sm[tt * 64 + cl];
-        *o = beta ? *o + v : v;
+        if (gridDim.z > 1) atomicAdd(o, v);
+        else *o = beta ? *o + v : v;
     }
+}
+
+// the split range goes over several workgroups when the (co, ci tile) grid alone cannot fill the chip
+static inline int launch_wgrad_reduce(const hc_wgrad_desc& d, int nsplit, hipStream_t st) {
+    const int T = d.KH * d.KW;
+    const int base = d.Cout * ((d.Cin + 63) / 64);
+    int nz = 1;
+    if (base < 512 && nsplit >= 64) {
+        nz = (512 + base - 1) / base;
+        if (nz > nsplit / 16) nz = nsplit / 16;
+        if (nz < 1) nz = 1;
+    }
+    const int chunk = (nsplit + nz - 1) / nz;
+    nz = (nsplit + chunk - 1) / chunk;
+    if (nz > 1 && !d.beta) {
+        if (hc_zero_async(d.dw, sizeof(float) * (size_t)d.Cout * d.Cin * T, st) != hipSuccess) return HC_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d.Cout, (d.Cin + 63) / 64, nz), dim3(64 * T), 64 * T * sizeof(float), st,
+                       reinterpret_cast<const float*>(d.ws), d.dw, nsplit, d.Cout, T, d.Cin, d.beta, chunk);
+    return hc_launch_status();
 }
 
 // plan_only: size the split count (workspace query) without launching
@@ -270,9 +294,7 @@ int launch_wgrad(const hc_wgrad_desc& d, hipStream_t st, bool plan_only, int* ns
     if (plan_only) return HC_OK;
     dim3 grid(a.n_ci_tiles * T, n_co_tiles, nsplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d.Cout, (d.Cin + 63) / 64), dim3(64 * T), 64 * T * sizeof(float), st,
-                       reinterpret_cast<const float*>(d.ws), d.dw, nsplit, d.Cout, T, d.Cin, d.beta);
-    return hc_launch_status();
+    return launch_wgrad_reduce(d, nsplit, st);
 }
 
 // tile shape (MR, NR) -> ci tile 64*MR, co tile 64*NR: least padded work, then fewest tiles
@@ -322,10 +344,7 @@ extern "C" int hc_conv_wgrad(const hc_wgrad_desc* dp, hc_stream_t stream) {
     if (rc < 0) rc = wgrad_tr_launch(d, st, &ns);
     if (rc >= 0) {
         if (rc != HC_OK) return rc;
-        const int T = d.KH * d.KW;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d.Cout, (d.Cin + 63) / 64), dim3(64 * T), 64 * T * sizeof(float), st,
-                           reinterpret_cast<const float*>(d.ws), d.dw, ns, d.Cout, T, d.Cin, d.beta);
-        return hc_launch_status();
+        return launch_wgrad_reduce(d, ns, st);
     }
     return generic_dispatch(d, st, false, &ns);
 }
