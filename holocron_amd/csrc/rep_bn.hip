@@ -563,6 +563,43 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
 // Cin * KK floats (one cache line per lane), which made this kernel 20x slower than its traffic.
 constexpr int PK_MAXKK = 9;
 constexpr int PK_TILE = 16 * 64 * PK_MAXKK;      // floats: 16 x 64 (co x ci or ci x co) x taps
+// mode 0: tiles of 16 co x 64 ci, written [co][tap][ci] (rows of ld >= Cin; the padding is left untouched)
+// mode 1: tiles of 64 co x 16 ci, written [ci][flipped tap][co]
+// KKC: compile-time tap count (1 | 9; 0 = run time) - the index arithmetic is all divisions, which must be by constants
+template <int MODE, int KKC>
+__device__ __forceinline__ void pack_tiles(const hc_pack_item& it, bf16_t* __restrict__ wpk, float* __restrict__ tile) {
+    const int KK = KKC ? KKC : it.KH * it.KW;
+    constexpr int TCO = MODE == 0 ? 16 : 64, TCI = MODE == 0 ? 64 : 16;
+    const int nco = (it.Cout + TCO - 1) / TCO, nci = (it.Cin + TCI - 1) / TCI;
+    const int run = TCI * KK;                       // contiguous source floats per co row of a tile
+    const int lrun = run + 1;                       // LDS row stride (odd: the transposing reads spread over the banks)
+    for (int tl = blockIdx.x; tl < nco * nci; tl += gridDim.x) {
+        const int co0 = (tl / nci) * TCO, ci0 = (tl % nci) * TCI;
+        const int cw = min(TCI, it.Cin - ci0) * KK;   // valid floats of a row
+        __syncthreads();
+        for (int e = threadIdx.x; e < TCO * run; e += 256) {
+            const int r = e / run, c = e - r * run;
+            if (co0 + r < it.Cout && c < cw) tile[r * lrun + c] = it.w[((long)(co0 + r) * it.Cin + ci0) * KK + c];
+        }
+        __syncthreads();
+        if (MODE == 0) {
+            const int ld = it.ld > 0 ? it.ld : it.Cin;
+            for (int e = threadIdx.x; e < TCO * KK * TCI; e += 256) {
+                const int ci = e % TCI, q = e / TCI, t = q % KK, r = q / KK;
+                if (co0 + r < it.Cout && ci0 + ci < it.Cin)
+                    wpk[((long)(co0 + r) * it.T + it.tap0 + t) * ld + ci0 + ci] = f32_to_bf16(tile[r * lrun + ci * KK + t]);
+            }
+        } else {
+            const int ld = it.ld > 0 ? it.ld : it.Cout;
+            for (int e = threadIdx.x; e < TCI * KK * TCO; e += 256) {
+                const int r = e % TCO, q = e / TCO, tf = q % KK, ci = q / KK;
+                if (co0 + r < it.Cout && ci0 + ci < it.Cin)
+                    wpk[((long)(ci0 + ci) * it.T + it.tap0 + tf) * ld + co0 + r] = f32_to_bf16(tile[r * lrun + ci * KK + (KK - 1 - tf)]);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const hc_pack_item* __restrict__ items) {
     __shared__ float tile[PK_TILE + 64];
     const hc_pack_item it = items[blockIdx.y];
@@ -597,47 +634,29 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const hc_pack_it
         }
         return;
     }
-    // mode 0: tiles of 16 co x 64 ci, written [co][tap][ci] (rows of ld >= Cin; the padding is left untouched)
-    // mode 1: tiles of 64 co x 16 ci, written [ci][flipped tap][co]
-    const int TCO = it.mode == 0 ? 16 : 64, TCI = it.mode == 0 ? 64 : 16;
-    const int nco = (it.Cout + TCO - 1) / TCO, nci = (it.Cin + TCI - 1) / TCI;
-    const int run = TCI * KK;                       // contiguous source floats per co row of a tile
-    const int lrun = run + 1;                       // LDS row stride (odd: the transposing reads spread over the banks)
-    for (int tl = blockIdx.x; tl < nco * nci; tl += gridDim.x) {
-        const int co0 = (tl / nci) * TCO, ci0 = (tl % nci) * TCI;
-        const int cw = min(TCI, it.Cin - ci0) * KK;   // valid floats of a row
-        __syncthreads();
-        for (int e = threadIdx.x; e < TCO * run; e += 256) {
-            const int r = e / run, c = e - r * run;
-            if (co0 + r < it.Cout && c < cw) tile[r * lrun + c] = it.w[((long)(co0 + r) * it.Cin + ci0) * KK + c];
-        }
-        __syncthreads();
-        if (it.mode == 0) {
-            const int ld = it.ld > 0 ? it.ld : it.Cin;
-            for (int e = threadIdx.x; e < TCO * KK * TCI; e += 256) {
-                const int ci = e % TCI, t = (e / TCI) % KK, r = e / (TCI * KK);
-                if (co0 + r < it.Cout && ci0 + ci < it.Cin)
-                    wpk[((long)(co0 + r) * it.T + it.tap0 + t) * ld + ci0 + ci] = f32_to_bf16(tile[r * lrun + ci * KK + t]);
-            }
-        } else {
-            const int ld = it.ld > 0 ? it.ld : it.Cout;
-            for (int e = threadIdx.x; e < TCI * KK * TCO; e += 256) {
-                const int r = e % TCO, tf = (e / TCO) % KK, ci = e / (TCO * KK);
-                if (co0 + r < it.Cout && ci0 + ci < it.Cin)
-                    wpk[((long)(ci0 + ci) * it.T + it.tap0 + tf) * ld + co0 + r] = f32_to_bf16(tile[r * lrun + ci * KK + (KK - 1 - tf)]);
-            }
-        }
+    if (it.mode == 0) {
+        if (KK == 9) pack_tiles<0, 9>(it, wpk, tile);
+        else if (KK == 1) pack_tiles<0, 1>(it, wpk, tile);
+        else pack_tiles<0, 0>(it, wpk, tile);
+    } else {
+        if (KK == 9) pack_tiles<1, 9>(it, wpk, tile);
+        else if (KK == 1) pack_tiles<1, 1>(it, wpk, tile);
+        else pack_tiles<1, 0>(it, wpk, tile);
     }
 }
 
 // im2col for tiny Cin (stem): x NCHW fp32 -> col [N][OH][OW][Kpad] bf16, k = (kh*KW+kw)*Cin+ci
-__global__ void im2col_small_kernel(const float* __restrict__ x, bf16_t* __restrict__ col, int N, int Cin, int H, int W, int OH,
-                                    int OW, int KH, int KW, int stride, int pad, int Kpad) {
-    const long total = (long)N * OH * OW * (Kpad / 8);
+// CINC / KSC: compile-time channel count and (square) kernel size, 0 = run time: the index arithmetic is all div / mod
+template <int CINC, int KSC>
+__global__ void im2col_small_kernel(const float* __restrict__ x, bf16_t* __restrict__ col, int N, int Cin_, int H, int W, int OH,
+                                    int OW, int KH_, int KW_, int stride, int pad, int Kpad) {
+    const int Cin = CINC ? CINC : Cin_, KH = KSC ? KSC : KH_, KW = KSC ? KSC : KW_;
+    const int kchunks = Kpad / 8;
+    const long total = (long)N * OH * OW * kchunks;
     const int K = Cin * KH * KW;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
-        const int kc = (int)(q % (Kpad / 8));
-        const long p = q / (Kpad / 8);
+        const int kc = (int)(q % kchunks);
+        const long p = q / kchunks;
         const int ox = (int)(p % OW);
         const long r = p / OW;
         const int oy = (int)(r % OH);
@@ -890,8 +909,12 @@ int hc_im2col_small(const float* x, void* col, int32_t N, int32_t Cin, int32_t H
                     int32_t KW, int32_t stride, int32_t pad, int32_t Kpad, hc_stream_t stream) {
     if (x == nullptr || col == nullptr || (Kpad % 8) != 0 || Cin * KH * KW > Kpad) return HC_ERR_ARG;
     const long total = (long)N * OH * OW * (Kpad / 8);
-    hipLaunchKernelGGL(im2col_small_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)col, N,
-                       Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad);
+    if (Cin == 3 && KH == 3 && KW == 3)
+        hipLaunchKernelGGL((im2col_small_kernel<3, 3>), dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)col,
+                           N, Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad);
+    else
+        hipLaunchKernelGGL((im2col_small_kernel<0, 0>), dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)col,
+                           N, Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad);
     return hc_launch_status();
 }
 int hc_im2col_small_fp8(const float* x, void* col, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t KH,
