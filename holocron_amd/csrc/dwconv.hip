@@ -95,10 +95,11 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_fwd_kernel(const u32x4* __re
     for (int e = 0; e < 8; ++e) sv[0][e] = sv[1][e] = 0.f;
     constexpr int IWN = (TW - 1) * STRIDE + 3;   // input columns a strip touches
     for (long s = gtid / cg; s < nstrips; s += nthreads / cg) {
-        const int sw = (int)(s % strips_w);
-        const long r = s / strips_w;
-        const int oh = (int)(r % OH);
-        const long n = r / OH;
+        const unsigned su = (unsigned)s, ru = su / (unsigned)strips_w;   // 32-bit: the launcher bounds the strip count
+        const int sw = (int)(su - ru * (unsigned)strips_w);
+        const unsigned nu = ru / (unsigned)OH;
+        const int oh = (int)(ru - nu * (unsigned)OH);
+        const long n = nu;
         const int ow0 = sw * TW;
         float acc[TW][8];
 #pragma unroll
@@ -157,9 +158,11 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_dgrad_s2_kernel(const u32x4*
     }
     const long npix = (long)N * H * W;
     for (long p = gtid / cg; p < npix; p += nthreads / cg) {
-        const int iw = (int)(p % W);
-        const int ih = (int)((p / W) % H);
-        const long n = p / ((long)W * H);
+        const unsigned pu = (unsigned)p, qu = pu / (unsigned)W;   // 32-bit: the launcher bounds the pixel count
+        const int iw = (int)(pu - qu * (unsigned)W);
+        const unsigned nu = qu / (unsigned)H;
+        const int ih = (int)(qu - nu * (unsigned)H);
+        const long n = nu;
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -206,10 +209,11 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_wgrad_kernel(const u32x4* __
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
     for (long s = gtid / cg; s < nstrips; s += nthreads / cg) {
-        const int sw = (int)(s % strips_w);
-        const long r = s / strips_w;
-        const int oh = (int)(r % OH);
-        const long n = r / OH;
+        const unsigned su = (unsigned)s, ru = su / (unsigned)strips_w;   // 32-bit: the launcher bounds the strip count
+        const int sw = (int)(su - ru * (unsigned)strips_w);
+        const unsigned nu = ru / (unsigned)OH;
+        const int oh = (int)(ru - nu * (unsigned)OH);
+        const long n = nu;
         const int ow0 = sw * TW;
         float g[TW][8];
         const u32x4* grow = dy + ((n * OH + oh) * (long)OW + ow0) * cg + cgi;
@@ -454,6 +458,7 @@ int hc_dw3x3_pack(const float* w, float* out, int32_t C, int32_t Cpad, int32_t f
 
 int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t N, int32_t H, int32_t W, int32_t C, int32_t stride,
                  hc_stream_t stream) {
+    if ((long)N * H * W >= (1L << 31)) return HC_ERR_ARG;   // the kernels decode pixel indices in 32 bits
     if (x == nullptr || wpk == nullptr || y == nullptr || C <= 0 || (C % 8) != 0 || (stride != 1 && stride != 2)) return HC_ERR_ARG;
     const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
     if ((long)N * OH * OW == 0) return HC_OK;
@@ -477,6 +482,7 @@ int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t
 int hc_dw3x3_dgrad(const void* dy, const float* wpk, const float* wpk_flipped, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                    int32_t stride, hc_stream_t stream) {
     if (dy == nullptr || dx == nullptr || C <= 0 || (C % 8) != 0 || (stride != 1 && stride != 2)) return HC_ERR_ARG;
+    if ((long)N * H * W >= (1L << 31)) return HC_ERR_ARG;
     if ((long)N * H * W == 0) return HC_OK;
     if (stride == 1) {   // correlation of dy with the flipped taps
         if (wpk_flipped == nullptr) return HC_ERR_ARG;
@@ -495,7 +501,7 @@ int64_t hc_dw3x3_wgrad_ws_bytes(int32_t C) { return (int64_t)HC_STAT_REPLICAS * 
 int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Creal,
                    int32_t stride, int32_t accumulate, hc_stream_t stream) {
     if (x == nullptr || dy == nullptr || ws == nullptr || dw == nullptr || C <= 0 || (C % 8) != 0 || Creal <= 0 || Creal > C ||
-        (stride != 1 && stride != 2))
+        (stride != 1 && stride != 2) || (long)N * H * W >= (1L << 31))
         return HC_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (hc_zero_async(ws, (size_t)hc_dw3x3_wgrad_ws_bytes(C), st) != hipSuccess) return HC_ERR_LAUNCH;

@@ -322,10 +322,11 @@ __global__ __launch_bounds__(MB_THREADS) void dwrep_dgrad_s1_kernel(const Planes
     const int strips_w = (W + TW - 1) / TW;
     const long nstrips = (long)N * H * strips_w;
     for (long s = gtid / cg; s < nstrips; s += nthreads / cg) {
-        const int sw = (int)(s % strips_w);
-        const long r = s / strips_w;
-        const int h = (int)(r % H);
-        const long n = r / H;
+        const unsigned su = (unsigned)s, ru = su / (unsigned)strips_w;   // 32-bit: the launcher bounds the strip count
+        const int sw = (int)(su - ru * (unsigned)strips_w);
+        const unsigned nu = ru / (unsigned)H;
+        const int h = (int)(ru - nu * (unsigned)H);
+        const long n = nu;
         const int w0 = sw * TW;
         float acc[TW][8];
 #pragma unroll
@@ -379,9 +380,11 @@ __global__ __launch_bounds__(MB_THREADS) void dwrep_dgrad_s2_kernel(const Planes
     const int cgi = (int)(gtid % cg);
     const long npix = (long)N * H * W;
     for (long p = gtid / cg; p < npix; p += nthreads / cg) {
-        const int iw = (int)(p % W);
-        const int ih = (int)((p / W) % H);
-        const long n = p / ((long)W * H);
+        const unsigned pu = (unsigned)p, qu = pu / (unsigned)W;   // 32-bit: the launcher bounds the pixel count
+        const int iw = (int)(pu - qu * (unsigned)W);
+        const unsigned nu = qu / (unsigned)H;
+        const int ih = (int)(qu - nu * (unsigned)H);
+        const long n = nu;
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -529,7 +532,7 @@ int hc_msbn_bwd_apply(const hc_msbn_io* io, const void* g, int32_t g_ld, const v
 int hc_dwrep_dgrad(const void* const* dy, const float* const* wpk, int32_t nplanes, const void* extra, void* dx, int32_t N, int32_t H,
                    int32_t W, int32_t C, int32_t stride, hc_stream_t stream) {
     if (dy == nullptr || wpk == nullptr || dx == nullptr || nplanes < 1 || nplanes > MAXB || C <= 0 || (C % 8) != 0 ||
-        (stride != 1 && stride != 2) || (stride == 2 && extra != nullptr))
+        (stride != 1 && stride != 2) || (stride == 2 && extra != nullptr) || (long)N * H * W >= (1L << 31))
         return HC_ERR_ARG;
     Planes pl;
     for (int b = 0; b < MAXB; ++b) { pl.dy[b] = nullptr; pl.w[b] = nullptr; }
