@@ -18,33 +18,51 @@ from ._multi_tensor import build_chunks
 __all__ = ["Lookahead", "Scout"]
 
 
+def _check_sync_args(sync_rate: float, sync_period: int) -> None:
+    if not 0 <= sync_rate <= 1:
+        raise ValueError(f"expected positive float lower than 1 as sync_rate, received: {sync_rate}")
+    if not (isinstance(sync_period, int) and sync_period >= 1):
+        raise ValueError(f"expected positive integer as sync_period, received: {sync_period}")
+
+
 class Lookahead(Optimizer):
-    """k steps forward, 1 step back (wrapper.py:18-134)."""
+    """k steps forward, 1 step back (wrapper.py:18-134).  ``param_groups`` hold the slow weights (detached copies of the base
+    optimizer's parameters), ``fast_steps`` counts base steps, every ``sync_period``-th step synchronises."""
 
     def __init__(self, base_optimizer: torch.optim.Optimizer, sync_rate: float = 0.5, sync_period: int = 6) -> None:
-        if sync_rate < 0 or sync_rate > 1:
-            raise ValueError(f"expected positive float lower than 1 as sync_rate, received: {sync_rate}")
-        if not isinstance(sync_period, int) or sync_period < 1:
-            raise ValueError(f"expected positive integer as sync_period, received: {sync_period}")
-        self.defaults = {"sync_rate": sync_rate, "sync_period": sync_period}
-        self.state = defaultdict(dict)
+        _check_sync_args(sync_rate, sync_period)
+        # like the reference, torch's Optimizer.__init__ is not run: the wrapper owns no hyper-parameters of its own
         self.base_optimizer = base_optimizer
+        self.defaults = dict(sync_rate=sync_rate, sync_period=sync_period)
+        self.state = defaultdict(dict)
         self.fast_steps = 0
         self.param_groups = []
-        for group in self.base_optimizer.param_groups:
-            self._add_param_group(group)
+        for fast_group in base_optimizer.param_groups:
+            self._add_param_group(fast_group)
+
+    # ---- bookkeeping -------------------------------------------------------------------------------------------------
+    def _add_param_group(self, param_group: Dict[str, Any]) -> None:
+        """Slow twin of one base group: detached clones of its parameters, same learning rate entry."""
+        slow = [fast.detach().clone() for fast in param_group["params"]]
+        for t in slow:
+            t.requires_grad = False
+        self.param_groups.append({"params": slow, "lr": param_group["lr"]})
+
+    def add_param_group(self, param_group: Dict[str, Any]) -> None:
+        """New group for the base optimizer (fast weights) plus its slow twin."""
+        self.base_optimizer.add_param_group(param_group)
+        self._add_param_group(self.base_optimizer.param_groups[-1])
 
     def __getstate__(self) -> Dict[str, Any]:
-        return {
-            "defaults": self.defaults,
-            "state": self.state,
-            "base_state": self.base_optimizer.__getstate__(),
-            "fast_steps": self.fast_steps,
-            "param_groups": self.param_groups,
-        }
+        keys = ("defaults", "state", "fast_steps", "param_groups")
+        out = {k: getattr(self, k) for k in keys}
+        out["base_state"] = self.base_optimizer.__getstate__()
+        return out
 
     def state_dict(self) -> Dict[str, Any]:
-        return dict(**super().state_dict(), base_state_dict=self.base_optimizer.state_dict())
+        own = super().state_dict()
+        own["base_state_dict"] = self.base_optimizer.state_dict()
+        return own
 
     def load_state_dict(self, state_dict: Dict[str, Any]) -> None:
         self.base_optimizer.load_state_dict(state_dict["base_state_dict"])
@@ -54,6 +72,12 @@ class Lookahead(Optimizer):
     def zero_grad(self, set_to_none: bool = True) -> None:
         self.base_optimizer.zero_grad(set_to_none)
 
+    def __repr__(self) -> str:
+        inner = repr(self.base_optimizer).replace("\n", "\n\t")
+        lines = [f"{type(self).__name__} (", f"base_optimizer={inner},"] + [f"{k}={v}," for k, v in self.defaults.items()] + [")"]
+        return "\n".join(lines)
+
+    # ---- optimisation ------------------------------------------------------------------------------------------------
     def step(self, closure: Optional[Callable[[], float]] = None) -> Optional[float]:  # type: ignore[override]
         loss = self.base_optimizer.step(closure)
         self.fast_steps += 1
@@ -61,29 +85,9 @@ class Lookahead(Optimizer):
             self.sync_params(self.defaults["sync_rate"])
         return loss
 
-    def __repr__(self) -> str:
-        format_string = self.__class__.__name__ + " ("
-        optimizer_repr = self.base_optimizer.__repr__().replace("\n", "\n\t")
-        format_string += f"\nbase_optimizer={optimizer_repr},"
-        for arg, val in self.defaults.items():
-            format_string += f"\n{arg}={val},"
-        format_string += "\n)"
-        return format_string
-
-    def _add_param_group(self, param_group: Dict[str, Any]) -> None:
-        """Adds a new slow parameter group (a detached copy of the fast weights)."""
-        group = {"params": [p.clone().detach() for p in param_group["params"]], "lr": param_group["lr"]}
-        for p in group["params"]:
-            p.requires_grad = False
-        self.param_groups.append(group)
-
-    def add_param_group(self, param_group: Dict[str, Any]) -> None:
-        """Adds a parameter group to the base optimizer (fast weights) and its slow counterpart."""
-        self.base_optimizer.add_param_group(param_group)
-        self._add_param_group(self.base_optimizer.param_groups[-1])
-
     def sync_params(self, sync_rate: float = 0.0) -> None:
-        """slow_param <- slow_param + sync_rate * (fast_param - slow_param); fast_param <- slow_param (wrapper.py:121-134)."""
+        """slow <- slow + sync_rate * (fast - slow) when sync_rate > 0, then fast <- slow (wrapper.py:121-134): one multi-tensor
+        launch over every parameter."""
         entries = []
         for fast_group, slow_group in zip(self.base_optimizer.param_groups, self.param_groups):
             for fast_p, slow_p in zip(fast_group["params"], slow_group["params"]):
