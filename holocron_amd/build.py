@@ -18,6 +18,7 @@ ARCH = "gfx950"
 SOURCES = {
     "conv_gather.hip": [],
     "conv_small.hip": [],
+    "conv_resident.hip": [],
     "conv_wgrad.hip": [],
     "conv_wgrad_tr.hip": [],
     "conv_wgrad_dma.hip": [],

@@ -1,0 +1,292 @@
+// Stride-1 3x3 (+ 1x1) convolution with the IMAGE RESIDENT in LDS, for mid-size channel counts on small maps - the
+// 192-channel 14x14 RepVGG stage (reference: RepBlock.forward, holocron/models/classification/repvgg.py:71-73, and its data
+// gradient).  Same contract as the small-channel kernel (hc_conv_small_desc):
+//   mode 0 (forward) : out3 = W3 (*) A, out1 = W1 . A (+ BN statistics of both)
+//   mode 1 (dgrad)   : out3 = W3 (*) A + W1 . B + resid      (A = dy3, B = dy1, weights flipped by the packer)
+//
+// The gather-conv re-stages the input tile for every tap and every 128-pixel tile re-reads the weight tensor from L2:
+// ~1.7 MB of L2 -> LDS traffic per image for a 14x14x192 layer.  Here one workgroup owns one image: the whole (H+2)x(W+2) window
+// (zero halo, natural NHWC, 75 KB of payload) is staged once and every tap reads it at a shifted address; only the weights
+// stream through a double-buffered 24 KB tile (663 KB per image, shared through L2 by the 256 co-resident workgroups).  The 1x1
+// branch (forward) or the second source (data gradient) reuses the resident window / the same accumulators.
+//
+// MFMA v_mfma_f32_32x32x16_bf16, D[co][pix]: A = weights (rows = out channels), B = pixels.  8 waves: wave (cw, pw) owns the
+// channel half cw (MR 32-row tiles) x two of the eight 32-pixel tiles.  Pixel stride in LDS = 2 C + 16 bytes (== 144 mod 256
+// for C = 192): the 16-lane groups of ds_read_b128 land in 16 distinct bank slots.
+#include "common.h"
+#include "../../include/holocron_hip.h"
+
+namespace crs {
+
+constexpr int NT = 512, NW = 8, BK = 64, NR = 2;
+
+struct Args {
+    hc_conv_small_desc d;
+    int PS;            // bytes per window pixel
+    int win_bytes;     // (H+2)*(W+2)*PS
+    int wtile_bytes;   // Cout * 128
+};
+
+template <int KCB, int MR>   // C = 64 KCB input channels, Cout = 64 MR output channels
+__global__ __launch_bounds__(NT, 1) void conv_resident_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const hc_conv_small_desc& d = a.d;
+    constexpr int C = 64 * KCB, Cout = 64 * MR, CP = C / 8;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int cw = wid & 1, pw = wid >> 1;
+    const int H = d.H, W = d.W, HW = H * W, WW = W + 2, PS = a.PS;
+    const int n = blockIdx.x;
+    char* win = smem;
+    char* wst = smem + a.win_bytes;                 // two weight stages
+    const bool dgrad = (d.mode & 1) == 1;
+
+    // ---- per-lane constants ----------------------------------------------------------------------------------------
+    // B operand: this lane's pixel of each of the wave's two tiles -> window byte address of its centre tap
+    // Maps up to 16 x 16: a 32-pixel tile is two image rows x 16 columns, so each 16-lane group of a ds_read_b128 walks 16
+    // consecutive window slots (16 distinct bank slots at the 2 C + 16 byte pitch); 32 linear pixels would wrap an image row
+    // inside the group and collide with its own start.  Larger maps fall back to linear pixels.
+    int b_base[NR], b_pix[NR];
+    bool b_ok[NR];
+    const bool rowpair = (W <= 16 && H <= 16);
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int tile = pw * NR + nr;
+        int oh, ow;
+        if (rowpair) {
+            oh = 2 * tile + ((lane >> 4) & 1);
+            ow = lane & 15;
+            b_ok[nr] = oh < H && ow < W;
+        } else {
+            const int p = tile * 32 + (lane & 31);
+            b_ok[nr] = p < HW;
+            oh = (b_ok[nr] ? p : 0) / W;
+            ow = (b_ok[nr] ? p : 0) - oh * W;
+        }
+        if (oh >= H) oh = 0;                         // keep the reads of idle lanes inside the window
+        b_pix[nr] = oh * W + (ow < W ? ow : 0);
+        b_base[nr] = ((oh + 1) * WW + ow + 1) * PS + (lane >> 5) * 16;
+    }
+    // A operand: conflict-free swizzled tile [Cout][64] (lds_off), rows of this wave's channel half
+    int frag_off[BK / 16];
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) frag_off[kk] = lds_off<BK>(lane & 31, kk * 2 + (lane >> 5));
+    const int a_row0 = cw * MR * 32 * BK * 2;
+    // weight DMA: instruction i = wid + 8 j moves rows 8 i .. 8 i + 7 (64 lanes x 16 B); swizzle on the source side
+    constexpr int WQ = Cout / 8, WJ = (WQ + NW - 1) / NW;
+    int w_row[WJ], w_lc[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int row = (wid + j * NW) * 8 + (lane >> 3);
+        w_row[j] = row;
+        w_lc[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 16;
+    }
+
+    f32x16 acc[MR][NR];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int b = 0; b < NR; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][b][r] = 0.f;
+    };
+
+    // ---- window staging: (H+2) x (W+2) slots of PS bytes, zero halo and zero pad chunk -------------------------------------
+    auto stage_window = [&](const void* srcp) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(srcp) + (size_t)n * HW * CP;
+        const int nchunks = (H + 2) * WW * (CP + 1);
+        for (int j = tid; j < nchunks; j += NT) {
+            const int slot = j / (CP + 1), c = j - slot * (CP + 1);
+            const int ih = slot / WW - 1, iw = slot - (ih + 1) * WW - 1;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (c < CP && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = src[(ih * W + iw) * CP + c];
+            *reinterpret_cast<u32x4*>(win + slot * PS + c * 16) = v;
+        }
+    };
+
+    // ---- k loop over (tap, channel block): weights double buffered by DMA, the window read in place ----------------------------
+    // wbase: packed rows [Cout][taps][C] with `rstride` elements per row; tap_lo..tap_hi index the 3x3 taps (4 = centre)
+    auto run_taps = [&](const void* wbase, int rstride, int wtap0, int tap_lo, int tap_hi) {
+        const __amdgpu_buffer_rsrc_t rsw = make_rsrc(wbase, (unsigned)Cout * rstride * 2u);
+        const int ntaps = tap_hi - tap_lo, S = ntaps * KCB;
+        auto issue = [&](int stage, int t, int ck) {
+            char* sw = wst + stage * a.wtile_bytes;
+            const unsigned wk = (unsigned)((wtap0 + t) * C + ck * BK) * 2u;
+#pragma unroll
+            for (int j = 0; j < WJ; ++j) {
+                if (WQ % NW == 0 || wid + j * NW < WQ) {
+                    const unsigned voff = (unsigned)w_row[j] * (unsigned)rstride * 2u + wk + (unsigned)w_lc[j];
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_void*)(sw + (wid + j * NW) * 1024), 16, voff, 0, 0, 0);
+                }
+            }
+        };
+        issue(0, 0, 0);
+        int t = 0, ck = 0;
+        for (int s = 0; s < S; ++s) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int tc = t, cc = ck;
+            if (s + 1 < S) {
+                if (++t == ntaps) { t = 0; ++ck; }
+                issue((s + 1) & 1, t, ck);
+            }
+            const char* sw = wst + (s & 1) * a.wtile_bytes + a_row0;
+            const int tap = tap_lo + tc;
+            const int tofs = ((tap / 3 - 1) * WW + (tap % 3 - 1)) * PS + cc * (BK * 2);
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                bf16x8 af[MR], bfr[NR];
+#pragma unroll
+                for (int m = 0; m < MR; ++m) af[m] = *reinterpret_cast<const bf16x8*>(sw + frag_off[kk] + m * 32 * BK * 2);
+#pragma unroll
+                for (int b = 0; b < NR; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(win + b_base[b] + tofs + kk * 32);
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+#pragma unroll
+                    for (int b = 0; b < NR; ++b) acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[b], acc[m][b], 0, 0, 0);
+            }
+        }
+        __syncthreads();          // the weight stages are free again
+    };
+
+    // ---- epilogue: optional BN statistics of the fp32 result, then bf16 NHWC stores (+ residual) ---------------------------
+    const int lr = lane & 31, lh = lane >> 5;
+    auto epilogue = [&](void* outp, float* stats, const void* residp) {
+        if (stats != nullptr) {
+            float* sred = reinterpret_cast<float*>(wst);     // [2][Cout], the weight stages are dead here
+            for (int i = tid; i < 2 * Cout; i += NT) sred[i] = 0.f;
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                float s1[16], s2[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                    for (int b = 0; b < NR; ++b) {
+                        const float v = b_ok[b] ? acc[m][b][r] : 0.f;
+                        a1 += v;
+                        a2 += v * v;
+                    }
+                    s1[r] = a1;
+                    s2[r] = a2;
+                }
+#pragma unroll
+                for (int w = 8, o = 16; w >= 1; w >>= 1, o >>= 1) {       // butterfly over the 32 pixel lanes of each half wave
+                    const bool up = (lane & o) != 0;
+#pragma unroll
+                    for (int i = 0; i < w; ++i) {
+                        const float k1 = up ? s1[i + w] : s1[i], g1 = up ? s1[i] : s1[i + w];
+                        const float k2 = up ? s2[i + w] : s2[i], g2 = up ? s2[i] : s2[i + w];
+                        s1[i] = k1 + __shfl_xor(g1, o);
+                        s2[i] = k2 + __shfl_xor(g2, o);
+                    }
+                }
+                s1[0] += __shfl_xor(s1[0], 1);
+                s2[0] += __shfl_xor(s2[0], 1);
+                if ((lane & 1) == 0) {
+                    const int r = 8 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 1) & 1);
+                    const int co = (cw * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    atomicAdd(&sred[co], s1[0]);
+                    atomicAdd(&sred[Cout + co], s2[0]);
+                }
+            }
+            __syncthreads();
+            float* rep = stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * Cout;
+            for (int i = tid; i < 2 * Cout; i += NT) atomicAdd(rep + i, sred[i]);
+            __syncthreads();
+        }
+        bf16_t* dst = reinterpret_cast<bf16_t*>(outp) + (size_t)n * HW * Cout;
+        const bf16_t* resid = residp != nullptr ? reinterpret_cast<const bf16_t*>(residp) + (size_t)n * HW * Cout : nullptr;
+#pragma unroll
+        for (int b = 0; b < NR; ++b) {
+            if (!b_ok[b]) continue;
+            const int p = b_pix[b];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = (cw * MR + m) * 32 + 8 * q + 4 * lh;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[m][b][4 * q + e];
+                    if (resid != nullptr) {
+                        const u32x2 rv = *reinterpret_cast<const u32x2*>(resid + (size_t)p * Cout + co);
+                        v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]); v[2] += bf16lo(rv[1]); v[3] += bf16hi(rv[1]);
+                    }
+                    u32x2 o;
+                    o[0] = pack_bf16x2(v[0], v[1]);
+                    o[1] = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(dst + (size_t)p * Cout + co) = o;
+                }
+            }
+        }
+    };
+
+    // ---- the block -------------------------------------------------------------------------------------------------
+    stage_window(d.srcA);
+    zero_acc();
+    __syncthreads();
+    run_taps(d.w3, d.w3_rstride, 0, 0, 9);
+    if (!dgrad) {
+        epilogue(d.out3, d.stats3, nullptr);
+        zero_acc();
+        __syncthreads();
+        run_taps(d.w1, d.w1_rstride, 0, 4, 5);         // 1x1 branch: the centre tap of the same window
+        epilogue(d.out1, d.stats1, nullptr);
+    } else {
+        stage_window(d.srcB);                           // second source (dy1) through the same window, same accumulators
+        __syncthreads();
+        run_taps(d.w1, d.w1_rstride, 0, 4, 5);
+        epilogue(d.out3, nullptr, d.resid);
+    }
+}
+
+inline bool make_args(const hc_conv_small_desc& d, Args& a, int& smem) {
+    if (d.C != d.Cout || d.C < 64 || d.C > 256 || (d.C % 64) != 0) return false;
+    if (d.H < 1 || d.W < 1 || d.N < 1) return false;
+    if (!((d.W <= 16 && d.H <= 16) || d.H * d.W <= 8 * 32)) return false;     // eight 32-pixel tiles (row pairs or linear)
+    a.d = d;
+    a.PS = d.C * 2 + 16;
+    a.win_bytes = (d.H + 2) * (d.W + 2) * a.PS;
+    a.wtile_bytes = d.Cout * BK * 2;
+    smem = a.win_bytes + 2 * a.wtile_bytes;
+    if (smem < a.win_bytes + 2 * d.Cout * (int)sizeof(float)) smem = a.win_bytes + 2 * d.Cout * (int)sizeof(float);
+    return smem <= 160 * 1024;
+}
+
+template <int K>
+void launch(const Args& a, int smem, hipStream_t st) {
+    auto kern = conv_resident_kernel<K, K>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.d.N), dim3(NT), smem, st, a);
+}
+
+}  // namespace crs
+
+// called by hc_conv_small / hc_conv_small_supported (conv_small.hip) for the channel counts this kernel covers
+bool hc_conv_resident_supported(const hc_conv_small_desc& d) {
+    crs::Args a;
+    int smem = 0;
+    return (d.mode == 0 || d.mode == 1) && crs::make_args(d, a, smem);
+}
+int hc_conv_resident_launch(const hc_conv_small_desc& d, hipStream_t st) {
+    crs::Args a;
+    int smem = 0;
+    if (!crs::make_args(d, a, smem)) return HC_ERR_ARG;
+    if (d.srcA == nullptr || d.w3 == nullptr || d.w1 == nullptr || d.out3 == nullptr) return HC_ERR_ARG;
+    if (d.mode == 0 && d.out1 == nullptr) return HC_ERR_ARG;
+    if (d.mode == 1 && d.srcB == nullptr) return HC_ERR_ARG;
+    switch (d.C / 64) {
+        case 1: crs::launch<1>(a, smem, st); break;
+        case 2: crs::launch<2>(a, smem, st); break;
+        case 3: crs::launch<3>(a, smem, st); break;
+        default: crs::launch<4>(a, smem, st); break;
+    }
+    return hc_launch_status();
+}

@@ -16,6 +16,7 @@
 // pixels (4 waves x 32).  LDS strides are == 112 (mod 256) so that the 16-lane groups of
 // ds_read_b128 hit 16 distinct 16-byte bank slots (rows r*112 mod 256 are all different for the
 // group row sets {0-3,12-15,20-27} / {4-11,16-19,28-31}).
+#include <cstdlib>
 #include "common.h"
 #include "../../include/holocron_hip.h"
 
@@ -370,9 +371,22 @@ void launch(const Args& a, int grid, int smem, hipStream_t st) {
 
 }  // namespace csm
 
+// image-resident variant for 64 .. 256 channels on small maps (conv_resident.hip); HC_CONV_RESIDENT=0 routes those shapes back to
+// the gather-conv
+bool hc_conv_resident_supported(const hc_conv_small_desc& d);
+int hc_conv_resident_launch(const hc_conv_small_desc& d, hipStream_t st);
+static bool resident_enabled() {
+    static const bool on = [] { const char* e = getenv("HC_CONV_RESIDENT"); return e == nullptr || atoi(e) != 0; }();
+    return on;
+}
+
 extern "C" int hc_conv_small(const hc_conv_small_desc* dp, hc_stream_t stream) {
     if (dp == nullptr) return HC_ERR_ARG;
     const hc_conv_small_desc& d = *dp;
+    if (d.C >= 64) {
+        if (!resident_enabled() || !hc_conv_resident_supported(d)) return HC_ERR_ARG;
+        return hc_conv_resident_launch(d, reinterpret_cast<hipStream_t>(stream));
+    }
     if (d.srcA == nullptr || d.w3 == nullptr || d.w1 == nullptr || d.out3 == nullptr) return HC_ERR_ARG;
     if ((d.mode & 1) == 1 && d.srcB == nullptr) return HC_ERR_ARG;
     if ((d.mode & 1) == 0 && d.out1 == nullptr) return HC_ERR_ARG;
@@ -390,6 +404,7 @@ extern "C" int hc_conv_small(const hc_conv_small_desc* dp, hc_stream_t stream) {
 
 extern "C" int hc_conv_small_supported(const hc_conv_small_desc* dp) {
     if (dp == nullptr) return 0;
+    if (dp->C >= 64) return (resident_enabled() && hc_conv_resident_supported(*dp)) ? 1 : 0;
     csm::Args a;
     int smem = 0;
     return csm::make_args(*dp, a, smem) ? 1 : 0;
