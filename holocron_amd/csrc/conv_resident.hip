@@ -134,17 +134,27 @@ __global__ __launch_bounds__(NT, 1) void conv_resident_kernel(const Args a) {
             const char* sw = wst + (s & 1) * a.wtile_bytes + a_row0;
             const int tap = tap_lo + tc;
             const int tofs = ((tap / 3 - 1) * WW + (tap % 3 - 1)) * PS + cc * (BK * 2);
+            // fragments of k-chunk kk + 1 are requested before the MFMAs of chunk kk are issued (and the scheduler is told not
+            // to hoist every read to the top): the two waves of a SIMD then alternate LDS and MFMA phases instead of both
+            // reading, then both multiplying
+            bf16x8 af[2][MR], bfr[2][NR];
+            auto load_frags = [&](int kk, int buf) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) af[buf][m] = *reinterpret_cast<const bf16x8*>(sw + frag_off[kk] + m * 32 * BK * 2);
+#pragma unroll
+                for (int b = 0; b < NR; ++b) bfr[buf][b] = *reinterpret_cast<const bf16x8*>(win + b_base[b] + tofs + kk * 32);
+            };
+            load_frags(0, 0);
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
-                bf16x8 af[MR], bfr[NR];
-#pragma unroll
-                for (int m = 0; m < MR; ++m) af[m] = *reinterpret_cast<const bf16x8*>(sw + frag_off[kk] + m * 32 * BK * 2);
-#pragma unroll
-                for (int b = 0; b < NR; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(win + b_base[b] + tofs + kk * 32);
+                if (kk + 1 < BK / 16) load_frags(kk + 1, (kk + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
-                    for (int b = 0; b < NR; ++b) acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[b], acc[m][b], 0, 0, 0);
+                    for (int b = 0; b < NR; ++b)
+                        acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][m], bfr[kk & 1][b], acc[m][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();          // the weight stages are free again

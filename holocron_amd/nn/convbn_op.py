@@ -277,6 +277,8 @@ class ConvBiasActFn(torch.autograd.Function):
         dev = x.device
         if Cout % 16:
             raise NotImplementedError("conv+bias+act on the HIP path needs Cout % 16 == 0")
+        if act == 3 and abs(slope - 0.1) > 1e-9:
+            raise NotImplementedError("the gather-conv epilogue fuses LeakyReLU(0.1) only")
         if w.dtype != torch.float32 or not w.is_contiguous():
             raise RuntimeError("conv_bias_act (HIP) expects contiguous fp32 conv weights")
         im2col = (Cin % 16) != 0
@@ -301,8 +303,6 @@ class ConvBiasActFn(torch.autograd.Function):
             st.bias_key = bkey
         out = cv.empty_cl(N, Cout, fd.OH, fd.OW, dev)
         cv.launch_conv(fd, src, wpk, out, bias=st.bias_f, act=act, flops=2.0 * N * fd.OH * fd.OW * Cout * Cin * KH * KW)
-        if act == 3 and slope != 0.1:
-            raise NotImplementedError("the gather-conv epilogue fuses LeakyReLU(0.1) only")
         ctx.st, ctx.meta2 = st, (stride, pad, act, slope, im2col, bias is not None)
         ctx.geom = (N, Cin, H, W, Cout, KH, KW, fd.OH, fd.OW)
         ctx.save_for_backward(src, w, out)
