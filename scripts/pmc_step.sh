@@ -10,7 +10,7 @@ timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_step -o 
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_step -o w --output-format csv -- $CMD > gpurun_out/pmc_step/run_w.log 2>&1
 python - <<'PY'
 import csv, glob, collections, json
-fam = lambda k: ("conv_gather" if "conv_gather_kernel" in k else "conv_small" if "conv_small" in k else
+fam = lambda k: ("conv_gather" if "conv_gather_kernel" in k else "conv_small" if ("conv_small" in k or "conv_resident" in k) else
                  "conv_wgrad" if ("wgrad" in k and "reduce" not in k and "dw3x3" not in k) else None)
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in sorted(glob.glob("gpurun_out/pmc_step/**/*counter_collection.csv", recursive=True)):
