@@ -43,78 +43,180 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> N
 
 
 class _Bucket:
-    def __init__(self, params: List[torch.nn.Parameter], dtype: torch.dtype):
+    def __init__(self, params: List[torch.nn.Parameter], flat: torch.Tensor):
         self.params = params
         self.numel = sum(p.numel() for p in params)
-        self.flat = torch.empty(self.numel, dtype=dtype, device=params[0].device)
+        self.flat = flat                      # a contiguous slice of the reducer's communication buffer
         self.views = []
         off = 0
         for p in params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.pending = len(params)
+        self.ready = False
         self.work = None
 
 
-class GradReducer:
-    """Bucketed, overlapped gradient averaging.
+def _copy_all(dst: List[torch.Tensor], src: List[torch.Tensor]) -> None:
+    """dst[i] <- src[i] (casting) in as few launches as the tensors allow."""
+    if not dst:
+        return
+    try:
+        torch._foreach_copy_(dst, src)
+    except (RuntimeError, AttributeError):    # mixed layouts the fused path refuses
+        for d, s in zip(dst, src):
+            d.copy_(s)
 
-    ``comm_dtype=torch.bfloat16`` halves the bytes on the links (gradients are averaged in bf16,
-    parameters and optimizer state stay fp32)."""
+
+class GradReducer:
+    """Bucketed gradient averaging over one flat communication buffer.
+
+    Two ways to drive it:
+
+    * overlapped (default): post-accumulate hooks count a bucket's gradients; when the last one
+      arrives the bucket is packed (one fused cast-copy) and its all-reduce is issued from the autograd
+      thread, so it runs behind the rest of backward.  ``finalize()`` waits, unpacks and scales.
+    * deferred (``overlap=False``): no hooks.  ``pack()`` / ``reduce()`` / ``unpack()`` are three
+      separate calls so that a training step replayed from hipGraphs can keep ``pack`` at the end of
+      the captured backward and ``unpack`` in front of the captured optimizer step, with the single
+      whole-buffer collective issued eagerly between the two replays (RCCL stays outside the
+      graphs).  ``finalize()`` runs the three in order.
+
+    ``comm_dtype=torch.bfloat16`` halves the bytes on the links (gradients are summed in bf16,
+    parameters and optimizer state stay fp32).  ``force=True`` builds the buckets even for a group of
+    one rank (used to exercise the path on a single GPU)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0,
-                 comm_dtype: torch.dtype = torch.float32, group=None) -> None:
+                 comm_dtype: torch.dtype = torch.float32, group=None, overlap: bool = True,
+                 force: bool = False) -> None:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
         self.comm_dtype = comm_dtype
+        self.overlap = overlap
+        self.active = (self.world > 1 or force) and dist.is_initialized() and len(self.params) > 0
         self.buckets: List[_Bucket] = []
+        self.flat: Optional[torch.Tensor] = None
         self._of = {}
         self._hooks = []
-        if self.world > 1:
+        self._next = 0                       # first bucket whose collective has not been issued yet
+        if self.active:
             self._build(bucket_mb)
 
     def _build(self, bucket_mb: float) -> None:
         cap = int(bucket_mb * 1024 * 1024 / torch.empty((), dtype=self.comm_dtype).element_size())
+        groups: List[List[torch.nn.Parameter]] = []
         cur: List[torch.nn.Parameter] = []
         size = 0
         for p in reversed(self.params):      # backward produces the last layers' gradients first
             if cur and size + p.numel() > cap:
-                self.buckets.append(_Bucket(cur, self.comm_dtype))
+                groups.append(cur)
                 cur, size = [], 0
             cur.append(p)
             size += p.numel()
         if cur:
-            self.buckets.append(_Bucket(cur, self.comm_dtype))
+            groups.append(cur)
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=self.comm_dtype, device=self.params[0].device)
+        off = 0
+        for g in groups:
+            n = sum(p.numel() for p in g)
+            self.buckets.append(_Bucket(g, self.flat[off:off + n]))
+            off += n
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 self._of[p] = (b, i)
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        if self.overlap:
+            self.set_overlap(True)
+
+    def set_overlap(self, overlap: bool) -> None:
+        """Switch between the hook-driven (overlapped) and the deferred mode."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self.overlap = overlap
+        if overlap and self.active:
+            self._next = 0
+            for b in self.buckets:
+                b.pending, b.ready = len(b.params), False
+                for p in b.params:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # ---- bucket-level pieces ----------------------------------------------------------------
+    @staticmethod
+    def _pack_bucket(b: _Bucket) -> None:
+        dst, src = [], []
+        for v, p in zip(b.views, b.params):
+            if p.grad is None:               # no gradient this step: contributes zeros
+                v.zero_()
+            else:
+                dst.append(v)
+                src.append(p.grad)
+        _copy_all(dst, src)
+
+    def _unpack_bucket(self, b: _Bucket) -> None:
+        for p in b.params:
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+        grads = [p.grad for p in b.params]
+        _copy_all(grads, b.views)
+        torch._foreach_mul_(grads, 1.0 / self.world)
+
+    def _launch(self, b: _Bucket) -> None:
+        self._pack_bucket(b)
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
-        b, i = self._of[p]
-        b.views[i].copy_(p.grad)
+        b, _ = self._of[p]
         b.pending -= 1
         if b.pending == 0:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b.ready = True
+            # collectives are issued strictly in bucket order: ranks whose graphs produce gradients
+            # in different orders (or not at all for some parameters) still pair the same buffers
+            while self._next < len(self.buckets) and self.buckets[self._next].ready:
+                self._launch(self.buckets[self._next])
+                self._next += 1
 
+    # ---- deferred mode ------------------------------------------------------------------------
+    @torch.no_grad()
+    def pack(self) -> None:
+        """Gradients -> communication buffer (capturable: plain device copies)."""
+        if self.active:
+            for b in self.buckets:
+                self._pack_bucket(b)
+
+    def reduce(self) -> None:
+        """One all-reduce over the whole buffer, ordered after the current stream's work; the
+        current stream waits for it (no host synchronisation)."""
+        if self.active:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    @torch.no_grad()
+    def unpack(self) -> None:
+        """Communication buffer / world -> gradients (capturable)."""
+        if self.active:
+            for b in self.buckets:
+                self._unpack_bucket(b)
+
+    # ---- one-call form ----------------------------------------------------------------------------
+    @torch.no_grad()
     def finalize(self) -> None:
-        """Wait for the collectives and write the averaged gradients back into ``p.grad``."""
-        if self.world <= 1:
+        """Make every ``p.grad`` the average over ranks (call between backward and the optimizer)."""
+        if not self.active:
             return
-        inv = 1.0 / self.world
+        if not self.overlap:
+            self.pack()
+            self.reduce()
+            self.unpack()
+            return
+        for b in self.buckets[self._next:]:   # buckets some of whose parameters received no gradient
+            self._launch(b)
+        self._next = 0
         for b in self.buckets:
-            if b.pending != 0:   # parameters that received no gradient this step: reduce what we have
-                for v, p in zip(b.views, b.params):
-                    if p.grad is None:
-                        v.zero_()
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             b.work.wait()
-            for v, p in zip(b.views, b.params):
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
-                p.grad.copy_(v).mul_(inv) if p.grad.dtype == v.dtype else p.grad.copy_(v.to(p.grad.dtype) * inv)
+            self._unpack_bucket(b)
             b.pending = len(b.params)
+            b.ready = False
             b.work = None
 
     def remove(self) -> None:

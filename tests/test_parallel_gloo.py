@@ -16,15 +16,19 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, bucket_mb, comm_dtype, out):
+def _worker(rank, world, port, bucket_mb, comm_dtype, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from holocron_amd.parallel import GradReducer, broadcast_parameters
     torch.manual_seed(100 + rank)                      # different init per rank on purpose
     model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
     broadcast_parameters(model, 0)
-    red = GradReducer(model.parameters(), bucket_mb=bucket_mb, comm_dtype=comm_dtype)
+    red = GradReducer(model.parameters(), bucket_mb=bucket_mb, comm_dtype=comm_dtype, overlap=(mode == "overlap"))
     assert len(red.buckets) >= 1
+    # one communication buffer, the buckets are contiguous slices of it
+    assert red.flat.numel() == sum(p.numel() for p in model.parameters())
+    assert sum(b.flat.numel() for b in red.buckets) == red.flat.numel()
+    assert (len(red._hooks) > 0) == (mode == "overlap")
     torch.manual_seed(7)
     data = torch.randn(2 * world, 8)
     target = torch.randn(2 * world, 4)
@@ -34,7 +38,12 @@ def _worker(rank, world, port, bucket_mb, comm_dtype, out):
             p.grad = None
         loss = ((model(x) - t) ** 2).sum()
         loss.backward()
-        red.finalize()
+        if mode == "split":          # the three pieces a graph-replayed step calls separately
+            red.pack()
+            red.reduce()
+            red.unpack()
+        else:
+            red.finalize()
         with torch.no_grad():
             for p in model.parameters():
                 p -= 0.01 * p.grad
@@ -59,9 +68,9 @@ def _worker(rank, world, port, bucket_mb, comm_dtype, out):
     dist.destroy_process_group()
 
 
-def _run(bucket_mb, comm_dtype):
+def _run(bucket_mb, comm_dtype, mode="overlap"):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, bucket_mb, comm_dtype, None), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, bucket_mb, comm_dtype, mode), nprocs=2, join=True)
 
 
 def test_grad_reducer_world2_single_bucket():
@@ -74,3 +83,59 @@ def test_grad_reducer_world2_many_small_buckets():
 
 def test_grad_reducer_world2_bf16_comm():
     _run(0.0002, torch.bfloat16)
+
+
+def test_grad_reducer_world2_deferred_finalize():
+    _run(0.0001, torch.float32, "deferred")
+
+
+def test_grad_reducer_world2_deferred_pack_reduce_unpack():
+    _run(32.0, torch.bfloat16, "split")
+
+
+def _worker_unused(rank, world, port, overlap):
+    """A parameter that receives no gradient on any rank: its bucket is still reduced (zeros) and
+    the other gradients are averaged; a parameter used on one rank only gets grad / world."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from holocron_amd.parallel import GradReducer
+    a = torch.nn.Parameter(torch.ones(5))
+    b = torch.nn.Parameter(torch.ones(3))          # never used
+    c = torch.nn.Parameter(torch.ones(4))          # used on rank 0 only
+    red = GradReducer([a, b, c], bucket_mb=1e-5, overlap=overlap)
+    assert len(red.buckets) == 3
+    for it in range(2):
+        for p in (a, b, c):
+            p.grad = None
+        loss = (a * (rank + 1)).sum() + (c.sum() * 3 if rank == 0 else 0)
+        loss.backward()
+        red.finalize()
+        assert torch.allclose(a.grad, torch.full((5,), 1.5)), a.grad
+        assert torch.equal(b.grad, torch.zeros(3))
+        assert torch.allclose(c.grad, torch.full((4,), 1.5)), c.grad
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_missing_gradients():
+    for overlap in (True, False):
+        mp.spawn(_worker_unused, args=(2, _free_port(), overlap), nprocs=2, join=True)
+
+
+def _worker_single(rank, world, port):
+    """force=True on a group of one rank: same code path, gradients unchanged (sum of one / 1)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from holocron_amd.parallel import GradReducer
+    lin = torch.nn.Linear(6, 3)
+    assert not GradReducer(lin.parameters()).active
+    red = GradReducer(lin.parameters(), force=True, overlap=False)
+    assert red.active
+    lin(torch.ones(2, 6)).sum().backward()
+    want = [p.grad.clone() for p in lin.parameters()]
+    red.finalize()
+    assert all(torch.equal(p.grad, w) for p, w in zip(lin.parameters(), want))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_forced_world1():
+    mp.spawn(_worker_single, args=(1, _free_port()), nprocs=1, join=True)
