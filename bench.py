@@ -74,31 +74,42 @@ def main():
     from holocron_amd import parallel
     from holocron_amd.ops import conv as cv
 
-    distributed = world > 1
-    if distributed:
+    # HC_FORCE_DIST=1 drives the multi-GPU code path (process group, reducer, two-graph step) on one rank:
+    # the 8-GPU runs are the driver's, this is how that path is exercised on a 1-GPU box
+    force_dist = os.environ.get("HC_FORCE_DIST", "0") == "1"
+    distributed = world > 1 or force_dist
+    if world > 1:
         parallel.init_process_group_from_env("nccl")
+    elif force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1)
 
     torch.manual_seed(0)
     model = h.models.repvgg_a0(num_classes=10).to(dev).train()
     if distributed:
         parallel.broadcast_parameters(model)
     opt = h.optim.AdaBelief(model.parameters(), lr=1e-3, betas=(0.95, 0.99), eps=1e-6, weight_decay=0.0)
-    reducer = parallel.GradReducer(model.parameters(), bucket_mb=32.0, comm_dtype=torch.bfloat16) if distributed else None
+    reducer = (parallel.GradReducer(model.parameters(), bucket_mb=32.0, comm_dtype=torch.bfloat16, force=force_dist)
+               if distributed else None)
 
     g = torch.Generator(device=dev).manual_seed(rank)
     x = torch.rand((args.batch, 3, 224, 224), device=dev, generator=g)
     t = torch.randint(0, 10, (args.batch,), device=dev, generator=g)
     loss_buf = torch.zeros((), device=dev)
 
-    def step():
+    def fwd_bwd():
         opt.zero_grad(set_to_none=True)
         logits = model(x)
         loss = torch.nn.functional.cross_entropy(logits, t, label_smoothing=0.1)
         loss.backward()
+        loss_buf.copy_(loss.detach())
+
+    def step():          # eager: per-bucket all-reduces issued from the autograd hooks, overlapped with backward
+        fwd_bwd()
         if reducer is not None:
             reducer.finalize()
         opt.step()
-        loss_buf.copy_(loss.detach())
 
     # ---- warm-up (eager) ----------------------------------------------------------------------
     n_eager_warm = max(2, args.warmup) if not args.no_graph else args.warmup
@@ -106,39 +117,44 @@ def main():
         step()
     torch.cuda.synchronize()
 
-    # ---- optional hipGraph capture of the whole step --------------------------------------------
-    graph = None
-    graph_note = "eager"
-    if not args.no_graph and not distributed:
+    # ---- hipGraph capture of the whole step (one graph; two around the all-reduce when distributed) ----
+    gstep = None
+    graph_note = "eager" + (", bucketed all-reduce overlapped with backward" if distributed else "")
+    if not args.no_graph:
+        ok, why = 1, ""
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            gph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gph):
-                step()
-            torch.cuda.synchronize()
+            if distributed:
+                time.sleep(0.5)      # let RCCL's watchdog retire the warm-up collectives before a capture starts
+            gstep = parallel.GraphedStep(fwd_bwd, opt, reducer)
+            gstep.capture()
             # replay must keep training: loss finite and parameters moving
             before = model.head.weight.detach().clone()
-            opt.advance_for_replay()
-            gph.replay()
+            gstep.run()
             torch.cuda.synchronize()
             if not torch.isfinite(loss_buf).item() or torch.equal(before, model.head.weight.detach()):
                 raise RuntimeError("graph replay did not train")
-            graph = gph
-            graph_note = "hipGraph replay of the full step"
         except Exception as e:  # noqa: BLE001
-            graph = None
-            graph_note = f"eager (graph capture failed: {type(e).__name__}: {str(e)[:80]})"
+            ok, why = 0, f"{type(e).__name__}: {str(e)[:80]}"
             torch.cuda.synchronize()
+        if distributed:          # every rank replays or none does (the two modes issue different collectives)
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if ok and not int(flag.item()):
+                ok, why = 0, "capture failed on another rank"
+        if ok:
+            graph_note = ("hipGraph replay of the full step" if not distributed else
+                          "hipGraph replay (fwd+bwd+pack | one eager RCCL all-reduce of the flat bf16 gradient | unpack+AdaBelief)")
+        else:
+            if gstep is not None:
+                gstep.release()
+            gstep = None
+            if reducer is not None:
+                reducer.set_overlap(True)
+            graph_note += f" (graph capture failed: {why})"
 
     def run_step():
-        if graph is not None:
-            opt.advance_for_replay()
-            graph.replay()
+        if gstep is not None:
+            gstep.run()
         else:
             step()
 
@@ -164,9 +180,12 @@ def main():
 
     # ---- roofline: instrumented eager step, HIP events on the launch stream -----------------------
     roof = None
+    if reducer is not None:
+        reducer.set_overlap(False)   # the instrumented step below runs on rank 0 only: no collectives, no hooks
     if rank == 0:
         cv.PROFILE = []
-        step()
+        fwd_bwd()
+        opt.step()
         torch.cuda.synchronize()
         fam = {}
         for name, flops, e0, e1, nbytes in cv.PROFILE:

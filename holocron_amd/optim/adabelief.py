@@ -119,3 +119,14 @@ class AdaBelief(Adam):
         if plist:
             self._sync_groups(plist[0][0].device, hyper, steps)
         bump_weights_epoch()
+
+    def rewind_after_capture(self) -> None:
+        """``step()`` under stream capture advanced the host-side counters, but the launch was only
+        recorded: take the host back by one so that it agrees with the device again."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and p.grad is not None:
+                    st["step"] -= 1
+        if getattr(self, "_hc_gsteps", None) is not None:
+            self._hc_gsteps = [s - 1 for s in self._hc_gsteps]
