@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK = 2.5e15   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+WGRAD_STREAM_DEFAULT = "0"
 TRAIN_GFLOP_PER_IMG = 16.88  # conv fwd+dgrad+wgrad (stem dgrad excluded), 2*MAC
 
 
@@ -118,6 +119,8 @@ def main():
     torch.cuda.synchronize()
 
     # ---- hipGraph capture of the whole step (one graph; two around the all-reduce when distributed) ----
+    # weight gradients on a second stream (parallel branch of the captured graph): HC_WGRAD_STREAM=0/1
+    wgrad_side = os.environ.get("HC_WGRAD_STREAM", WGRAD_STREAM_DEFAULT) == "1" and not args.no_graph
     gstep = None
     graph_note = "eager" + (", bucketed all-reduce overlapped with backward" if distributed else "")
     if not args.no_graph:
@@ -125,6 +128,7 @@ def main():
         try:
             if distributed:
                 time.sleep(0.5)      # let RCCL's watchdog retire the warm-up collectives before a capture starts
+            cv.set_wgrad_side_stream(wgrad_side)
             gstep = parallel.GraphedStep(fwd_bwd, opt, reducer)
             gstep.capture()
             # replay must keep training: loss finite and parameters moving
@@ -142,12 +146,13 @@ def main():
             if ok and not int(flag.item()):
                 ok, why = 0, "capture failed on another rank"
         if ok:
-            graph_note = ("hipGraph replay of the full step" if not distributed else
+            graph_note = ("weight gradients on a second stream; " if wgrad_side else "") + ("hipGraph replay of the full step" if not distributed else
                           "hipGraph replay (fwd+bwd+pack | one eager RCCL all-reduce of the flat bf16 gradient | unpack+AdaBelief)")
         else:
             if gstep is not None:
                 gstep.release()
             gstep = None
+            cv.set_wgrad_side_stream(False)
             if reducer is not None:
                 reducer.set_overlap(True)
             graph_note += f" (graph capture failed: {why})"
@@ -180,6 +185,7 @@ def main():
 
     # ---- roofline: instrumented eager step, HIP events on the launch stream -----------------------
     roof = None
+    cv.set_wgrad_side_stream(False)
     if reducer is not None:
         reducer.set_overlap(False)   # the instrumented step below runs on rank 0 only: no collectives, no hooks
     if rank == 0:

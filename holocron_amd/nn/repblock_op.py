@@ -269,16 +269,18 @@ class RepBlockFn(torch.autograd.Function):
             else:
                 cv.launch_conv(dg, dy3, wpd, dx, src1=dy1, resid=dxid)
 
-        if ctx.stem:
-            K = STEM_KPAD
-            dwc3 = cv.conv_wgrad(src, dy3, K, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * 9 * Cin)
-            dwc1 = cv.conv_wgrad(src, dy1, K, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * Cin)
-            dw3 = torch.empty_like(w3, dtype=torch.float32)
-            check(lib.hc_unpack_im2col_grad(ptr(dwc3), ptr(dw3), Cout, Cin, 3, 3, K, 0, stream()), "hc_unpack_im2col_grad")
-            dw1 = dwc1.view(Cout, K)[:, 4 * Cin:5 * Cin].reshape(Cout, Cin, 1, 1).contiguous()
-        else:
-            dw3 = cv.conv_wgrad(src, dy3, Cin, Cout, 3, 3, st.stride, 1)
-            dw1 = cv.conv_wgrad(src, dy1, Cin, Cout, 1, 1, st.stride, 0)
+        with cv.side_stream_for_wgrad((w3, w1), (src, dy3, dy1)) as side:
+            if ctx.stem:
+                K = STEM_KPAD
+                dwc3 = cv.conv_wgrad(src, dy3, K, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * 9 * Cin)
+                dwc1 = cv.conv_wgrad(src, dy1, K, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * Cin)
+                dw3 = torch.empty_like(w3, dtype=torch.float32)
+                check(lib.hc_unpack_im2col_grad(ptr(dwc3), ptr(dw3), Cout, Cin, 3, 3, K, 0, stream()), "hc_unpack_im2col_grad")
+                dw1 = dwc1.view(Cout, K)[:, 4 * Cin:5 * Cin].reshape(Cout, Cin, 1, 1).contiguous()
+            else:
+                dw3 = cv.conv_wgrad(src, dy3, Cin, Cout, 3, 3, st.stride, 1)
+                dw1 = cv.conv_wgrad(src, dy1, Cin, Cout, 1, 1, st.stride, 0)
+            side.produced(dw3, dw1)
         return (dx, dw3, dw1, dgam[0], dbet[0], dgam[1], dbet[1],
                 dgam[2] if st.identity else None, dbet[2] if st.identity else None, None, None)
 

@@ -180,6 +180,93 @@ class PackCache:
 
 
 # ------------------------------------------------------------------ weight gradient
+class _WgradSide:
+    """Weight gradients on a second HIP stream (opt-in: ``set_wgrad_side_stream(True)``).
+
+    In backward a block's weight gradients feed nothing but the optimizer, while its data gradient is on
+    the critical path to the previous block.  With the side stream on, ``side_stream_for_wgrad`` forks a
+    second stream after the block's dy tensors exist, the weight-gradient kernels (and their split-K
+    reductions) are issued there and run next to the main chain's BN passes and data gradients; one autograd
+    final callback per backward joins the side stream back into the caller's stream, so everything after
+    ``backward()`` (reducer, optimizer, clipping) sees finished gradients.  Captured in a hipGraph the fork /
+    join become a parallel branch of the graph.
+
+    Safe by construction rather than by luck: it is used only when the parameters have no ``.grad`` yet
+    (autograd then adopts the returned tensor without launching anything on the main stream), and the join
+    callback checks that this adoption really happened and raises otherwise.  Inputs are
+    ``record_stream``-ed so that the allocator does not hand their memory out while the side stream reads it."""
+
+    def __init__(self):
+        self.on = False
+        self.streams = {}
+        self.pending = False
+        self.adopted = []      # (parameter, data_ptr of the gradient computed on the side stream)
+
+    def stream_of(self, device):
+        s = self.streams.get(device.index)
+        if s is None:
+            s = self.streams[device.index] = torch.cuda.Stream(device)
+        return s
+
+    def join(self):
+        self.pending = False
+        adopted, self.adopted = self.adopted, []
+        for idx, s in self.streams.items():
+            torch.cuda.current_stream(idx).wait_stream(s)
+        for p, dptr in adopted:
+            if p.grad is None or p.grad.data_ptr() != dptr:
+                raise RuntimeError("weight gradient computed on the side stream was copied or accumulated by autograd "
+                                   "on the main stream before the join (unsynchronised read); call "
+                                   "holocron_amd.ops.conv.set_wgrad_side_stream(False) for this training loop")
+
+
+_SIDE = _WgradSide()
+
+
+def set_wgrad_side_stream(on: bool) -> None:
+    _SIDE.on = bool(on)
+
+
+def wgrad_side_stream_enabled() -> bool:
+    return _SIDE.on
+
+
+class side_stream_for_wgrad:
+    """Context manager around the weight-gradient launches of one backward node.  ``params`` are the
+    parameters whose gradients are produced inside, ``inputs`` the tensors the kernels read."""
+
+    def __init__(self, params, inputs):
+        self.params = params
+        self.inputs = [t for t in inputs if t is not None]
+        self.ctx = None
+
+    def __enter__(self):
+        if not _SIDE.on or PROFILE is not None or any(p.grad is not None for p in self.params):
+            return self
+        cur = torch.cuda.current_stream()
+        side = _SIDE.stream_of(self.inputs[0].device)
+        side.wait_stream(cur)
+        for t in self.inputs:
+            t.record_stream(side)
+        if not _SIDE.pending:
+            _SIDE.pending = True
+            torch.autograd.Variable._execution_engine.queue_callback(_SIDE.join)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def produced(self, *grads):
+        """Tell the join which tensors autograd is expected to adopt as ``p.grad``."""
+        if self.ctx is not None:
+            for p, g in zip(self.params, grads):
+                _SIDE.adopted.append((p, g.data_ptr()))
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def conv_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, out=None, accumulate=False, flops=None):
     """dW (fp32 OIHW) of a conv from NHWC-bf16 ``x`` [N,Cin,H,W] and ``dy`` [N,Cout,OH,OW]."""
     N, _, H, W = x.shape

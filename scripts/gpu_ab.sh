@@ -1,0 +1,15 @@
+#!/bin/bash
+# One GPU-box call: targeted tests of the new paths, then same-box A/B of the bench modes.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out/ab
+O=gpurun_out/ab
+timeout 400 python -m pytest tests/test_gpu_graph.py tests/test_gpu_zz_dp_graph.py -x -q > $O/tests.log 2>&1; echo "tests rc=$?" | tee -a $O/tests.log
+run() { name=$1; shift; ( "$@" timeout 240 python bench.py --no-cpu-baseline $EXTRA > $O/$name.json 2> $O/$name.err ); echo "$name rc=$? $(cut -c1-160 $O/$name.json)"; }
+run base env
+run side env HC_WGRAD_STREAM=1
+run dist env HC_FORCE_DIST=1
+run dist_side env HC_FORCE_DIST=1 HC_WGRAD_STREAM=1
+EXTRA=--no-graph run dist_eager env HC_FORCE_DIST=1
+run base2 env
+run side2 env HC_WGRAD_STREAM=1
+tail -5 $O/tests.log

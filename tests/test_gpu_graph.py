@@ -52,3 +52,62 @@ def test_graph_replay_equals_eager():
                 # a replay that read a stale workspace is wrong at the O(1) level
                 e = float((got[k] - v).norm() / (v.norm() + 1e-12))
                 assert e < 2e-2, (name, "replay", it, k, e)
+
+
+def test_wgrad_side_stream_matches_main_stream():
+    """Weight gradients issued on the second stream (holocron_amd.ops.conv.set_wgrad_side_stream) must equal the ones of the
+    single-stream step, eagerly and from a hipGraph replay (fork / join captured as a parallel branch), and autograd must
+    have adopted the side-stream tensors as .grad (the join callback raises if it copied them on the main stream)."""
+    import holocron_amd as h
+    from holocron_amd.ops import conv as cv
+    dev = torch.device("cuda:0")
+    cfg = dict(num_blocks=[1, 2, 2, 1, 1], planes=[16, 16, 32, 64, 64], width_multiplier=1, final_width_multiplier=1)
+    torch.manual_seed(0)
+    m = h.models.RepVGG(**cfg).to(dev).train()
+    x = torch.rand((8, 3, 64, 64), device=dev)
+    t = torch.randint(0, 10, (8,), device=dev)
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        torch.nn.functional.cross_entropy(m(x), t).backward()
+
+    def grads():
+        return {n: p.grad.float().clone() for n, p in m.named_parameters()}
+
+    def compare(ref, got, what):
+        for k, v in ref.items():
+            e = float((got[k] - v).norm() / (v.norm() + 1e-12))
+            assert e < 2e-2, (what, k, e)
+
+    assert not cv.wgrad_side_stream_enabled()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    # BatchNorm running statistics move every step but do not enter the training-mode gradients: same x, same weights
+    ref = grads()
+    cv.set_wgrad_side_stream(True)
+    try:
+        for it in range(2):
+            step()
+            torch.cuda.synchronize()
+            compare(ref, grads(), f"eager side stream {it}")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        torch.cuda.synchronize()
+        for it in range(3):
+            for p in m.parameters():      # a replay that skipped the side branch would leave these zeros behind
+                p.grad.zero_()
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            compare(ref, grads(), f"replay side stream {it}")
+    finally:
+        cv.set_wgrad_side_stream(False)
