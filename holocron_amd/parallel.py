@@ -247,10 +247,16 @@ class GraphedStep:
     """
 
     def __init__(self, fwd_bwd, optimizer, reducer: Optional["GradReducer"] = None,
-                 capture_error_mode: str = "global") -> None:
+                 capture_error_mode: Optional[str] = None) -> None:
         self.fwd_bwd = fwd_bwd
         self.optimizer = optimizer
         self.reducer = reducer if (reducer is not None and reducer.active) else None
+        # With a process group alive, its watchdog thread polls the events of outstanding collectives
+        # (hipEventQuery); under a "global"-mode capture that call is illegal from ANY thread and takes the
+        # process down (seen on the MI355X box).  A thread-local capture restricts only the capturing thread,
+        # and _quiesce() additionally lets the watchdog retire finished collectives before a capture begins.
+        if capture_error_mode is None:
+            capture_error_mode = "thread_local" if dist.is_initialized() else "global"
         self.capture_error_mode = capture_error_mode
         self.graphs: List[torch.cuda.CUDAGraph] = []
         if self.reducer is not None:
@@ -262,6 +268,13 @@ class GraphedStep:
             self.reducer.finalize()
         self.optimizer.step()
 
+    @staticmethod
+    def _quiesce() -> None:
+        torch.cuda.synchronize()
+        if dist.is_initialized():
+            import time
+            time.sleep(0.3)              # > the watchdog's 100 ms polling period
+
     def capture(self) -> None:
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -269,7 +282,7 @@ class GraphedStep:
         with torch.cuda.stream(side):
             self.eager()
         cur.wait_stream(side)
-        torch.cuda.synchronize()
+        self._quiesce()
         ga = torch.cuda.CUDAGraph()
         if self.reducer is None:
             with torch.cuda.graph(ga, capture_error_mode=self.capture_error_mode):
@@ -281,6 +294,7 @@ class GraphedStep:
                 self.fwd_bwd()
                 self.reducer.pack()
             self.reducer.reduce()        # keeps the ranks' collective sequences identical
+            self._quiesce()
             gb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=self.capture_error_mode):
                 self.reducer.unpack()
