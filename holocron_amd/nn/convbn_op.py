@@ -188,13 +188,15 @@ class ConvBnActFn(torch.autograd.Function):
             wpd = st.bwd_cache.get((w,), lambda: cv.pack_weight(w, 1))
             dx = cv.empty_cl(N, Cin, H, W, dev)
             cv.launch_conv(st.desc[key], dy, wpd, dx)
-        if im2col:
-            Kpad = src.shape[1]
-            dwc = cv.conv_wgrad(src, dy, Kpad, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * Cin * KH * KW)
-            dw = torch.empty_like(w, dtype=torch.float32)
-            check(lib.hc_unpack_im2col_grad(ptr(dwc), ptr(dw), Cout, Cin, KH, KW, Kpad, 0, stream()), "hc_unpack_im2col_grad")
-        else:
-            dw = cv.conv_wgrad(src, dy, Cin, Cout, KH, KW, stride, pad)
+        with cv.side_stream_for_wgrad((w,), (src, dy)) as side:
+            if im2col:
+                Kpad = src.shape[1]
+                dwc = cv.conv_wgrad(src, dy, Kpad, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * Cin * KH * KW)
+                dw = torch.empty_like(w, dtype=torch.float32)
+                check(lib.hc_unpack_im2col_grad(ptr(dwc), ptr(dw), Cout, Cin, KH, KW, Kpad, 0, stream()), "hc_unpack_im2col_grad")
+            else:
+                dw = cv.conv_wgrad(src, dy, Cin, Cout, KH, KW, stride, pad)
+            side.produced(dw)
         return dx, dw, dgam, dbet, (g if ctx.has_res else None), None, None, None
 
 
@@ -338,13 +340,15 @@ class ConvBiasActFn(torch.autograd.Function):
             wpd = st.bwd_cache.get((w,), lambda: cv.pack_weight(w, 1))
             dx = cv.empty_cl(N, Cin, H, W, dev)
             cv.launch_conv(st.desc[key], dy, wpd, dx)
-        if im2col:
-            Kpad = src.shape[1]
-            dwc = cv.conv_wgrad(src, dy, Kpad, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * Cin * KH * KW)
-            dw = torch.empty_like(w, dtype=torch.float32)
-            check(lib.hc_unpack_im2col_grad(ptr(dwc), ptr(dw), Cout, Cin, KH, KW, Kpad, 0, stream()), "hc_unpack_im2col_grad")
-        else:
-            dw = cv.conv_wgrad(src, dy, Cin, Cout, KH, KW, stride, pad)
+        with cv.side_stream_for_wgrad((w,), (src, dy)) as side:
+            if im2col:
+                Kpad = src.shape[1]
+                dwc = cv.conv_wgrad(src, dy, Kpad, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * Cin * KH * KW)
+                dw = torch.empty_like(w, dtype=torch.float32)
+                check(lib.hc_unpack_im2col_grad(ptr(dwc), ptr(dw), Cout, Cin, KH, KW, Kpad, 0, stream()), "hc_unpack_im2col_grad")
+            else:
+                dw = cv.conv_wgrad(src, dy, Cin, Cout, KH, KW, stride, pad)
+            side.produced(dw)
         return dx, dw, db, None, None
 
 

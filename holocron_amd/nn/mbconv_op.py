@@ -192,8 +192,10 @@ class PadConvBnActFn(torch.autograd.Function):
                     st.desc[key] = cv.dgrad_desc(N, Cin_p, H, W, Cout_p, [(KH, KW, pad, 0, 0)], stride)
                 dx = cv.empty_cl(N, Cin_p, H, W, dev)
                 cv.launch_conv(st.desc[key], dy, wb, dx)
-            dwp = cv.conv_wgrad(x, dy, Cin_p, Cout_p, KH, KW, stride, pad, flops=2.0 * npix * Cout * Cin * KH * KW)
-            dw = dwp if (Cin_p == Cin and Cout_p == Cout) else dwp[:Cout, :Cin].contiguous()
+            with cv.side_stream_for_wgrad((w,), (x, dy)) as side:
+                dwp = cv.conv_wgrad(x, dy, Cin_p, Cout_p, KH, KW, stride, pad, flops=2.0 * npix * Cout * Cin * KH * KW)
+                dw = dwp if (Cin_p == Cin and Cout_p == Cout) else dwp[:Cout, :Cin].contiguous()
+                side.produced(dw)
         gres = None
         if res_C:
             gres = g if res_C == Cout_p and g_ld == Cout_p else g[:, :res_C]
@@ -357,8 +359,10 @@ class PadConvBiasFn(torch.autograd.Function):
                 st.desc[key] = cv.dgrad_desc(N, Cin_p, H, W, Cout_p, [(KH, KW, pad, 0, 0)], stride)
             dx = cv.empty_cl(N, Cin_p, H, W, dev)
             cv.launch_conv(st.desc[key], dy, st.pw[1], dx)
-        dwp = cv.conv_wgrad(x, dy, Cin_p, Cout_p, KH, KW, stride, pad, flops=2.0 * N * OH * OW * Cout * Cin * KH * KW)
-        dw = dwp if (Cin_p == Cin and Cout_p == Cout) else dwp[:Cout, :Cin].contiguous()
+        with cv.side_stream_for_wgrad((w,), (x, dy)) as side:
+            dwp = cv.conv_wgrad(x, dy, Cin_p, Cout_p, KH, KW, stride, pad, flops=2.0 * N * OH * OW * Cout * Cin * KH * KW)
+            dw = dwp if (Cin_p == Cin and Cout_p == Cout) else dwp[:Cout, :Cin].contiguous()
+            side.produced(dw)
         return dx, dw, db, None, None
 
 

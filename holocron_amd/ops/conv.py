@@ -6,6 +6,7 @@ surface (reference ``state_dict`` layout, SURVEY.md §5 checkpoint row) and are 
 kernel layout lazily (cached on parameter version + optimizer epoch).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -221,6 +222,7 @@ class _WgradSide:
 
 
 _SIDE = _WgradSide()
+_SIDE.on = os.environ.get("HC_WGRAD_SIDE_STREAM", "0") == "1"   # process-wide opt-in; see set_wgrad_side_stream
 
 
 def set_wgrad_side_stream(on: bool) -> None:
@@ -241,7 +243,17 @@ class side_stream_for_wgrad:
         self.ctx = None
 
     def __enter__(self):
-        if not _SIDE.on or PROFILE is not None or any(p.grad is not None for p in self.params):
+        if not _SIDE.on or PROFILE is not None:
+            return self
+        if any(p.grad is not None for p in self.params):
+            # autograd will accumulate into .grad on this stream.  If that .grad was itself produced on the side
+            # stream earlier in this backward (a weight shared by two nodes), order the accumulation after it.
+            mine = [i for i, (q, _) in enumerate(_SIDE.adopted) if any(q is p for p in self.params)]
+            if mine:
+                for idx, s in _SIDE.streams.items():
+                    torch.cuda.current_stream(idx).wait_stream(s)
+                for i in reversed(mine):
+                    del _SIDE.adopted[i]
             return self
         cur = torch.cuda.current_stream()
         side = _SIDE.stream_of(self.inputs[0].device)

@@ -80,7 +80,8 @@ def test_wgrad_side_stream_matches_main_stream():
             e = float((got[k] - v).norm() / (v.norm() + 1e-12))
             assert e < 2e-2, (what, k, e)
 
-    assert not cv.wgrad_side_stream_enabled()
+    was_on = cv.wgrad_side_stream_enabled()
+    cv.set_wgrad_side_stream(False)
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -110,4 +111,4 @@ def test_wgrad_side_stream_matches_main_stream():
             torch.cuda.synchronize()
             compare(ref, grads(), f"replay side stream {it}")
     finally:
-        cv.set_wgrad_side_stream(False)
+        cv.set_wgrad_side_stream(was_on)
