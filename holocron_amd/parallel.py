@@ -15,7 +15,7 @@ from typing import Iterable, List, Optional
 import torch
 import torch.distributed as dist
 
-__all__ = ["GradReducer", "GraphedStep", "init_process_group_from_env", "broadcast_parameters"]
+__all__ = ["GradReducer", "GraphedStep", "BackwardCut", "init_process_group_from_env", "broadcast_parameters"]
 
 
 def init_process_group_from_env(backend: Optional[str] = None) -> bool:
@@ -88,7 +88,7 @@ class GradReducer:
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0,
                  comm_dtype: torch.dtype = torch.float32, group=None, overlap: bool = True,
-                 force: bool = False) -> None:
+                 force: bool = False, new_bucket_at: Optional[Iterable[torch.nn.Parameter]] = None) -> None:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
@@ -100,6 +100,9 @@ class GradReducer:
         self._of = {}
         self._hooks = []
         self._next = 0                       # first bucket whose collective has not been issued yet
+        # parameters (walking in reverse registration order) at which a new bucket must begin: lets a bucket
+        # end exactly where a backward segment ends (BackwardCut / GraphedStep)
+        self._starts = {id(p) for p in (new_bucket_at or ())}
         if self.active:
             self._build(bucket_mb)
 
@@ -109,7 +112,7 @@ class GradReducer:
         cur: List[torch.nn.Parameter] = []
         size = 0
         for p in reversed(self.params):      # backward produces the last layers' gradients first
-            if cur and size + p.numel() > cap:
+            if cur and (size + p.numel() > cap or id(p) in self._starts):
                 groups.append(cur)
                 cur, size = [], 0
             cur.append(p)
@@ -177,6 +180,30 @@ class GradReducer:
                 self._launch(self.buckets[self._next])
                 self._next += 1
 
+    # ---- segment-wise use (GraphedStep) --------------------------------------------------------
+    def buckets_with_all_grads(self, exclude=()) -> List[int]:
+        """Indices of the buckets (not in ``exclude``) all of whose parameters hold a gradient right now."""
+        return [i for i, b in enumerate(self.buckets)
+                if i not in exclude and all(p.grad is not None for p in b.params)]
+
+    def spans(self, indices: Iterable[int]) -> List[torch.Tensor]:
+        """The buckets ``indices`` as maximal contiguous slices of the communication buffer."""
+        out: List[torch.Tensor] = []
+        offs = [0]
+        for b in self.buckets:
+            offs.append(offs[-1] + b.numel)
+        run = None
+        for i in sorted(indices):
+            if run is not None and run[1] == i:
+                run[1] = i + 1
+            else:
+                if run is not None:
+                    out.append(self.flat[offs[run[0]]:offs[run[1]]])
+                run = [i, i + 1]
+        if run is not None:
+            out.append(self.flat[offs[run[0]]:offs[run[1]]])
+        return out
+
     # ---- deferred mode ------------------------------------------------------------------------
     @torch.no_grad()
     def pack(self) -> None:
@@ -225,30 +252,69 @@ class GradReducer:
         self._hooks = []
 
 
+class BackwardCut:
+    """Cuts the autograd graph at the input of ``module`` so that backward can run in two pieces.
+
+    A forward pre-hook replaces the module's input ``h`` by ``h.detach().requires_grad_()``.  ``loss.backward()``
+    then stops there (gradients of ``module`` and everything after it, plus d loss / d h);
+    ``continue_backward()`` pushes that gradient through the part of the network in front of ``module``.
+    Between the two calls the gradients of the rear part are complete: a GraphedStep uses the gap to start
+    their all-reduce while the front part's backward is still to run (RepVGG-A0: the last block and the
+    head hold 66 % of the parameters and their gradients are the first ones backward produces)."""
+
+    def __init__(self, module: torch.nn.Module) -> None:
+        self.pair = None
+        self._handle = module.register_forward_pre_hook(self._pre)
+
+    def _pre(self, module, args):
+        h = args[0]
+        if not (torch.is_grad_enabled() and isinstance(h, torch.Tensor) and h.requires_grad):
+            self.pair = None
+            return None
+        hd = h.detach().requires_grad_(True)
+        for attr in ("_hc_stats",):           # side information the fused blocks hand to their consumer
+            if hasattr(h, attr):
+                setattr(hd, attr, getattr(h, attr))
+        self.pair = (h, hd)
+        return (hd,) + tuple(args[1:])
+
+    def continue_backward(self) -> None:
+        if self.pair is None:
+            return
+        h, hd = self.pair
+        self.pair = None
+        if hd.grad is not None:
+            h.backward(hd.grad)
+
+    def remove(self) -> None:
+        self._handle.remove()
+
+
 class GraphedStep:
     """A whole training step replayed from hipGraphs, with the gradient all-reduce kept outside them.
 
     A RepVGG-A0 step is ~600 kernel launches of 5-100 us each: issued one by one the host is the
     bottleneck, replayed from a graph it is not.  On one rank the step is one graph
-    (``fwd_bwd`` + ``optimizer.step``).  With an active ``GradReducer`` it is two graphs around one
-    eager collective::
+    (``fwd_bwd`` + ``optimizer.step``).  With an active ``GradReducer`` the collectives run eagerly
+    between graphs, so that RCCL never executes under stream capture::
 
-        graph A:  zero_grad, forward, loss, backward, reducer.pack()      (gradients -> flat buffer)
-        eager  :  reducer.reduce()                                        (one RCCL all-reduce; RCCL's stream is
-                                                                           ordered against ours by events, no host wait)
+        graph 0:  zero_grad, forward, loss, backward [up to a BackwardCut], pack the complete buckets
+        eager  :  async all-reduce of those buckets (RCCL's stream, ordered against ours by events)
+        graph 1:  [rest of backward], pack the remaining buckets        <- runs while RCCL reduces the first ones
+        eager  :  all-reduce of the remaining buckets; our stream waits for all of them (no host wait)
         graph B:  reducer.unpack(), optimizer.step()
 
-    so that RCCL never runs under stream capture.  The price is that the collective is not overlapped
-    with backward: one all-reduce of the whole gradient (RepVGG-A0: 24.7 M parameters = 49.5 MB in bf16) against a 16 ms step.
-
-    ``fwd_bwd`` must work on fixed input buffers and leave gradients in ``p.grad``; ``optimizer`` is one
-    of the multi-tensor HIP optimizers (``advance_for_replay`` does the host half of ``step``).
-    ``capture()`` runs one eager step on a side stream first (lazy allocations, autograd warm-up).
+    ``fwd_bwd`` is one callable (no overlap: one collective after the whole backward) or a list of segment
+    callables, e.g. ``[fwd_and_loss_backward, cut.continue_backward]``.  The first segment must start from
+    ``zero_grad(set_to_none=True)``: which buckets a segment completes is read off ``p.grad is not None`` when
+    the segment is captured.  Segments must work on fixed input buffers; ``optimizer`` is one of the
+    multi-tensor HIP optimizers (``advance_for_replay`` does the host half of ``step``).  ``capture()`` runs
+    one eager step on a side stream first (lazy allocations, autograd warm-up).
     """
 
     def __init__(self, fwd_bwd, optimizer, reducer: Optional["GradReducer"] = None,
                  capture_error_mode: Optional[str] = None) -> None:
-        self.fwd_bwd = fwd_bwd
+        self.segments = list(fwd_bwd) if isinstance(fwd_bwd, (list, tuple)) else [fwd_bwd]
         self.optimizer = optimizer
         self.reducer = reducer if (reducer is not None and reducer.active) else None
         # With a process group alive, its watchdog thread polls the events of outstanding collectives
@@ -259,13 +325,41 @@ class GraphedStep:
             capture_error_mode = "thread_local" if dist.is_initialized() else "global"
         self.capture_error_mode = capture_error_mode
         self.graphs: List[torch.cuda.CUDAGraph] = []
+        self.spans: List[List[torch.Tensor]] = []      # per segment graph: the slices reduced after it
+        self.final: Optional[torch.cuda.CUDAGraph] = None
         if self.reducer is not None:
             self.reducer.set_overlap(False)
 
+    def fwd_bwd(self) -> None:
+        for seg in self.segments:
+            seg()
+
+    def _ready_after(self, i: int, packed: set) -> set:
+        red = self.reducer
+        if i == len(self.segments) - 1:
+            return set(range(len(red.buckets))) - packed
+        return set(red.buckets_with_all_grads(packed))
+
     def eager(self) -> None:
-        self.fwd_bwd()
-        if self.reducer is not None:
-            self.reducer.finalize()
+        """The same step without graphs (also the warm-up of ``capture``): with several segments the early
+        buckets' collectives still run behind the later segments."""
+        red = self.reducer
+        if red is None:
+            self.fwd_bwd()
+            self.optimizer.step()
+            return
+        packed, works = set(), []
+        for i, seg in enumerate(self.segments):
+            seg()
+            ready = self._ready_after(i, packed)
+            with torch.no_grad():
+                for bi in sorted(ready):
+                    red._pack_bucket(red.buckets[bi])
+            packed |= ready
+            works += self._reduce_spans(red.spans(ready))
+        for w in works:
+            w.wait()
+        red.unpack()
         self.optimizer.step()
 
     @staticmethod
@@ -275,6 +369,9 @@ class GraphedStep:
             import time
             time.sleep(0.3)              # > the watchdog's 100 ms polling period
 
+    def _reduce_spans(self, spans):
+        return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.reducer.group, async_op=True) for t in spans]
+
     def capture(self) -> None:
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -283,30 +380,43 @@ class GraphedStep:
             self.eager()
         cur.wait_stream(side)
         self._quiesce()
-        ga = torch.cuda.CUDAGraph()
+        mode = self.capture_error_mode
         if self.reducer is None:
-            with torch.cuda.graph(ga, capture_error_mode=self.capture_error_mode):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode=mode):
                 self.fwd_bwd()
                 self.optimizer.step()
-            self.graphs = [ga]
+            self.graphs, self.spans, self.final = [g], [[]], None
         else:
-            with torch.cuda.graph(ga, capture_error_mode=self.capture_error_mode):
-                self.fwd_bwd()
-                self.reducer.pack()
-            self.reducer.reduce()        # keeps the ranks' collective sequences identical
-            self._quiesce()
+            red = self.reducer
+            graphs, spans, packed, pool = [], [], set(), None
+            for i, seg in enumerate(self.segments):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+                    seg()
+                    ready = self._ready_after(i, packed)
+                    with torch.no_grad():
+                        for bi in sorted(ready):
+                            red._pack_bucket(red.buckets[bi])
+                pool = g.pool() if pool is None else pool
+                packed |= ready
+                graphs.append(g)
+                spans.append(red.spans(ready))
+                for w in self._reduce_spans(spans[-1]):   # keeps the ranks' collective sequences identical
+                    w.wait()
+                self._quiesce()
             gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode=self.capture_error_mode):
-                self.reducer.unpack()
+            with torch.cuda.graph(gb, pool=pool, capture_error_mode=mode):
+                red.unpack()
                 self.optimizer.step()
-            self.graphs = [ga, gb]
+            self.graphs, self.spans, self.final = graphs, spans, gb
         rewind = getattr(self.optimizer, "rewind_after_capture", None)
         if rewind is not None:           # the captured optimizer launch did not execute
             rewind()
         torch.cuda.synchronize()
 
     def release(self) -> None:
-        self.graphs = []
+        self.graphs, self.spans, self.final = [], [], None
 
     def run(self) -> None:
         if not self.graphs:
@@ -315,7 +425,12 @@ class GraphedStep:
         advance = getattr(self.optimizer, "advance_for_replay", None)
         if advance is not None:
             advance()
-        self.graphs[0].replay()
-        if len(self.graphs) == 2:
-            self.reducer.reduce()
-            self.graphs[1].replay()
+        works = []
+        for g, spans in zip(self.graphs, self.spans):
+            g.replay()
+            if spans:
+                works += self._reduce_spans(spans)
+        for w in works:
+            w.wait()                     # stream-side wait: the host does not block
+        if self.final is not None:
+            self.final.replay()

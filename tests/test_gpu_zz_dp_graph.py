@@ -40,10 +40,10 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16])
-def test_two_graph_dp_step_trains_like_eager(comm_dtype):
+@pytest.mark.parametrize("comm_dtype,cut_backward", [(torch.float32, False), (torch.bfloat16, False), (torch.bfloat16, True)])
+def test_two_graph_dp_step_trains_like_eager(comm_dtype, cut_backward):
     import torch.distributed as dist
-    from holocron_amd.parallel import GradReducer, GraphedStep
+    from holocron_amd.parallel import BackwardCut, GradReducer, GraphedStep
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     own = not dist.is_initialized()
@@ -67,11 +67,21 @@ def test_two_graph_dp_step_trains_like_eager(comm_dtype):
         # forced reducer + two graphs around the collective
         m1, opt1, fb1, loss1 = _make(dev, x, t)
         assert all(torch.equal(a, b) for a, b in zip(init, m1.parameters()))
-        red = GradReducer(m1.parameters(), bucket_mb=0.25, comm_dtype=comm_dtype, force=True)
+        if cut_backward:                   # backward in two graphs, the rear bucket reduced behind the second one
+            rear_mod = m1.features[-1][-1]
+            rear = {id(p) for p in rear_mod.parameters()} | {id(p) for p in m1.head.parameters()}
+            front_last = next(p for p in reversed(list(m1.parameters())) if id(p) not in rear)
+            red = GradReducer(m1.parameters(), bucket_mb=64.0, comm_dtype=comm_dtype, force=True, new_bucket_at=[front_last])
+            cut = BackwardCut(rear_mod)
+            gs = GraphedStep([fb1, cut.continue_backward], opt1, red)
+        else:
+            red = GradReducer(m1.parameters(), bucket_mb=0.25, comm_dtype=comm_dtype, force=True)
+            gs = GraphedStep(fb1, opt1, red)
         assert red.active and len(red.buckets) > 1 and red.flat.dtype == comm_dtype
-        gs = GraphedStep(fb1, opt1, red)
         gs.capture()                       # runs step 1 eagerly (deferred reducer), then captures
-        assert len(gs.graphs) == 2 and not red._hooks
+        assert len(gs.graphs) == (2 if cut_backward else 1) and gs.final is not None and not red._hooks
+        if cut_backward:
+            assert [sum(t.numel() for t in sp) for sp in gs.spans] == [b.numel for b in red.buckets]
         losses1 = [float(loss1.item())]
         for _ in range(n_steps - 1):
             gs.run()

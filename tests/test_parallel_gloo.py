@@ -139,3 +139,86 @@ def _worker_single(rank, world, port):
 
 def test_grad_reducer_forced_world1():
     mp.spawn(_worker_single, args=(1, _free_port()), nprocs=1, join=True)
+
+
+def test_backward_cut_same_gradients():
+    """Backward in two pieces through a BackwardCut gives the gradients of the uncut backward."""
+    from holocron_amd.parallel import BackwardCut
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                                torch.nn.Linear(16, 4))
+    x, t = torch.randn(5, 8), torch.randn(5, 4)
+    ((model(x) - t) ** 2).sum().backward()
+    want = [p.grad.clone() for p in model.parameters()]
+    for p in model.parameters():
+        p.grad = None
+    cut = BackwardCut(model[2])
+    ((model(x) - t) ** 2).sum().backward()
+    got_rear = [p.grad is not None for p in model.parameters()]
+    assert got_rear == [False, False, True, True, True, True]      # stopped at the cut
+    cut.continue_backward()
+    assert all(torch.allclose(p.grad, w) for p, w in zip(model.parameters(), want))
+    with torch.no_grad():                                          # no autograd: the hook leaves the input alone
+        model(x)
+    assert cut.pair is None
+    cut.remove()
+
+
+class _PlainSGD:
+    def __init__(self, params, lr):
+        self.params, self.lr = list(params), lr
+
+    def step(self):
+        with torch.no_grad():
+            for p in self.params:
+                p -= self.lr * p.grad
+
+
+def _worker_segments(rank, world, port):
+    """GraphedStep.eager with two backward segments: buckets aligned with the cut, the rear buckets reduced after the
+    first segment, the front ones after the second; result = serial full-batch training."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from holocron_amd.parallel import BackwardCut, GradReducer, GraphedStep
+
+    def make():
+        torch.manual_seed(100)
+        return torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                                   torch.nn.Linear(16, 4))
+    model = make()
+    front_last = list(model[0].parameters())[-1]       # walking backwards, the first parameter in front of the cut
+    red = GradReducer(model.parameters(), bucket_mb=32.0, new_bucket_at=[front_last], overlap=False)
+    assert [len(b.params) for b in red.buckets] == [4, 2]
+    assert len(red.spans([0, 1])) == 1 and red.spans([0, 1])[0].numel() == red.flat.numel()
+    assert [t.numel() for t in red.spans([1])] == [red.buckets[1].numel]
+    cut = BackwardCut(model[2])
+    torch.manual_seed(7)
+    data, target = torch.randn(2 * world, 8), torch.randn(2 * world, 4)
+    x, t = data[rank * 2:(rank + 1) * 2], target[rank * 2:(rank + 1) * 2]
+    seen = []
+
+    def seg0():
+        for p in model.parameters():
+            p.grad = None
+        ((model(x) - t) ** 2).sum().backward()
+        seen.append(red.buckets_with_all_grads())
+
+    step = GraphedStep([seg0, cut.continue_backward], _PlainSGD(model.parameters(), 0.01), red)
+    for _ in range(2):
+        step.run()                                     # no graphs captured: the eager form
+    assert seen == [[0], [0]]                          # after the first segment exactly the rear bucket is complete
+    ref = make()
+    for _ in range(2):
+        for p in ref.parameters():
+            p.grad = None
+        (((ref(data) - target) ** 2).sum() / world).backward()
+        with torch.no_grad():
+            for p in ref.parameters():
+                p -= 0.01 * p.grad
+    for a, b in zip(model.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, atol=1e-5, rtol=1e-5), (a - b).abs().max()
+    dist.destroy_process_group()
+
+
+def test_graphed_step_segments_world2_eager_form():
+    mp.spawn(_worker_segments, args=(2, _free_port()), nprocs=2, join=True)
