@@ -37,6 +37,7 @@ struct Args {
     int nja, njb;              // DMA instructions per wave for window A / B
     int qa, qb;                // DMA instructions per window (the last wave pass may be partial)
     int wrows;                 // weight rows kept in LDS (Cout rounded up to 16; MFMA rows beyond read finite junk)
+    int dbg;                   // HC_CSM_DBG knock-outs (timing experiments only): 1 no MFMA/LDS reads, 2 no stats, 4 no stores, 8 no DMA
 };
 
 template <int KC>   // KC = C / 16 (1, 2, 3)
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(NT, 1) void conv_small_kernel(const Args a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                       // window `buf` landed everywhere; previous tile fully consumed
         const int nxt = tile + gridDim.x;
-        if (nxt < a.ntiles) issue(nxt, buf ^ 1);
+        if (nxt < a.ntiles && !(a.dbg & 8)) issue(nxt, buf ^ 1);
 
         const char* wa = smem + a.off_win + buf * a.win_bytes;
         f32x16 acc3[2], acc1[2];   // [pixel block]
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(NT, 1) void conv_small_kernel(const Args a) {
         for (int nr = 0; nr < 2; ++nr)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc3[nr][r] = 0.f; acc1[nr][r] = 0.f; }
+        if (!(a.dbg & 1))
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             // batch the LDS reads of a whole kernel row (3 taps x KC chunks x 2 pixel blocks) ahead of its MFMAs
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(NT, 1) void conv_small_kernel(const Args a) {
         bool live[2];
 #pragma unroll
         for (int nr = 0; nr < 2; ++nr) live[nr] = pin[nr] && (oy0 + prr[nr] < H);
-        if (stats3 != nullptr) {
+        if (stats3 != nullptr && !(a.dbg & 2)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float a0_ = live[0] ? acc3[0][r] : 0.f, a1_ = live[1] ? acc3[1][r] : 0.f;
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(NT, 1) void conv_small_kernel(const Args a) {
         }
         // Stores: the tile's pixels x Cout channels are ONE contiguous run of NHWC memory.  Stage the tile in
         // LDS ([tensor][pixel][112 B]) and write it out as 16-byte chunks, thread-linear = fully coalesced.
-        {
+        if (!(a.dbg & 4)) {
             char* stg = smem + a.off_stage;
 #pragma unroll
             for (int which = 0; which < 2; ++which) {
@@ -311,6 +313,318 @@ __global__ __launch_bounds__(NT, 1) void conv_small_kernel(const Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Software-pipelined form of the kernel above.  With one wave per SIMD nothing overlaps by itself: a knock-out
+// timing of the 48-channel 112^2 layer (HC_CSM_DBG) showed the phases of a tile simply adding up - loop skeleton
+// 66 us, DMA issue 78, LDS reads + MFMAs 268, statistics 60, staging + stores 172 of 591 us.  Here the epilogue of
+// tile i-1 (statistics, bf16 packing, staging, coalesced stores) is issued inside the MFMA stream of tile i: the
+// accumulators of the previous tile stay in registers (P3 / P1), the statistics and staging writes sit in the same
+// basic block as the first kernel row's MFMAs, the stores are issued right after the staging barrier and drain behind
+// the remaining two kernel rows.  Stores / residual loads are buffer instructions predicated by an out-of-range
+// offset (no divergent loop), their chunk -> (pixel, part) split is hoisted out of the tile loop, the DMA goes through
+// inline asm (common.h hc_dma16) and the barriers are raw s_barrier + explicit waits, so that neither the next
+// window's DMA nor the draining stores are waited for in the middle of a tile.
+template <int KC, bool DGRAD, bool STATS, int NJA, int NJB>
+__global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const hc_conv_small_desc& d = a.d;
+    constexpr int C = 16 * KC;
+    constexpr int NCC = C / 8;
+    constexpr int NOUT = DGRAD ? 1 : 2;        // tensors written
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int H = d.H, W = d.W, Cout = d.Cout;
+    const unsigned img_bytes = (unsigned)d.N * H * W * C * 2u;
+    const unsigned out_bytes = (unsigned)d.N * H * W * Cout * 2u;
+    const u32x4 rsa = hc_raw_rsrc(d.srcA, img_bytes);
+    const u32x4 rsb = hc_raw_rsrc(DGRAD ? d.srcB : d.srcA, img_bytes);
+    const __amdgpu_buffer_rsrc_t rso3 = make_rsrc(d.out3, out_bytes);
+    const __amdgpu_buffer_rsrc_t rso1 = make_rsrc(DGRAD ? d.out3 : d.out1, out_bytes);
+    const __amdgpu_buffer_rsrc_t rsr = make_rsrc(d.resid, (DGRAD && d.resid != nullptr) ? out_bytes : 0u);   // null: reads 0
+    const unsigned smem0 = hc_lds_addr(smem);
+
+    const int mb = wid & 1, ph = wid >> 1;
+    bf16x8 wreg3[9 * KC], wreg1[KC];
+    {
+        const bf16_t* w3 = reinterpret_cast<const bf16_t*>(d.w3);
+        const bf16_t* w1 = reinterpret_cast<const bf16_t*>(d.w1);
+        const int row = mb * 32 + (lane & 31), lh_ = lane >> 5;
+        const bool ok = row < Cout;
+#pragma unroll
+        for (int i = 0; i < 9 * KC; ++i) {
+            u32x4 v = u32x4{0, 0, 0, 0};
+            if (ok) v = *reinterpret_cast<const u32x4*>(w3 + (long)row * d.w3_rstride + i * 16 + lh_ * 8);
+            wreg3[i] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+            u32x4 v = u32x4{0, 0, 0, 0};
+            if (ok) v = *reinterpret_cast<const u32x4*>(w1 + (long)row * d.w1_rstride + i * 16 + lh_ * 8);
+            wreg1[i] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    float* sstat = reinterpret_cast<float*>(smem + a.off_stat);
+    sstat[tid] = 0.f;
+
+    int a_rel[MAXJ], a_wr[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int q16 = (wid + j * NW) * 64 + lane;
+        const int pix = q16 / 7, cc = q16 - pix * 7;
+        const int wr = pix / a.XWp, wc = pix - wr * a.XWp;
+        const bool ok = (wid + j * NW < a.qa) && (cc < NCC) && (wr < a.R + 2) && (wc >= 1) && (wc <= W);
+        a_rel[j] = ok ? ((wr * W + (wc - 1)) * C + cc * 8) * 2 : -1;
+        a_wr[j] = wr;
+    }
+    int b_rel[MAXJ / 2], b_pix[MAXJ / 2];
+#pragma unroll
+    for (int j = 0; j < MAXJ / 2; ++j) {
+        const int q16 = (wid + j * NW) * 64 + lane;
+        const int pix = q16 / 7, cc = q16 - pix * 7;
+        const bool ok = DGRAD && (wid + j * NW < a.qb) && (cc < NCC) && (pix < a.P);
+        b_rel[j] = ok ? (pix * C + cc * 8) * 2 : -1;
+        b_pix[j] = pix;
+    }
+    const unsigned dummy = smem0 + a.off_stat + 1024;
+    auto issue = [&](int tile, int buf) {
+        const int n = tile / a.tiles_per_img;
+        const int oy0 = (tile - n * a.tiles_per_img) * a.R;
+        const int rowbase = ((n * H + oy0 - 1) * W) * C * 2;
+        const unsigned wa = smem0 + a.off_win + buf * a.win_bytes;
+        // branch-free: instruction slots beyond the window (wave-uniform) are aimed at a 1 KB dummy area with an
+        // out-of-range source (the DMA writes zeros there); NJA / NJB bound the unrolled count
+#pragma unroll
+        for (int j = 0; j < NJA; ++j) {
+            const bool act = wid + j * NW < a.qa;
+            const int iy = oy0 - 1 + a_wr[j];
+            const bool ok = act && (a_rel[j] >= 0) && ((unsigned)iy < (unsigned)H);
+            hc_dma16(rsa, __builtin_amdgcn_readfirstlane(act ? wa + (wid + j * NW) * 1024 : dummy), ok ? (unsigned)(rowbase + a_rel[j]) : HC_OOB);
+        }
+        if (DGRAD) {
+            const unsigned wb = smem0 + a.off_win2 + buf * a.win2_bytes;
+            const int rows_left = H - oy0;
+            const int pvalid = (rows_left < a.R ? rows_left : a.R) * W;
+            const int base2 = ((n * H + oy0) * W) * C * 2;
+#pragma unroll
+            for (int j = 0; j < NJB; ++j) {
+                const bool act = wid + j * NW < a.qb;
+                const bool ok = act && (b_rel[j] >= 0) && (b_pix[j] < pvalid);
+                hc_dma16(rsb, __builtin_amdgcn_readfirstlane(act ? wb + (wid + j * NW) * 1024 : dummy), ok ? (unsigned)(base2 + b_rel[j]) : HC_OOB);
+            }
+        }
+    };
+
+    const int lr = lane & 31, lh = lane >> 5;
+    int xoff[2], xoff2[2], prr[2];
+    bool pin[2];
+#pragma unroll
+    for (int nr = 0; nr < 2; ++nr) {
+        const int p = ph * 64 + nr * 32 + lr;
+        pin[nr] = p < a.P;
+        const int pr = pin[nr] ? p / W : 0, pc = pin[nr] ? p - pr * W : 0;
+        prr[nr] = pr;
+        xoff[nr] = (pr * a.XWp + pc) * SX + lh * 16;
+        xoff2[nr] = (pin[nr] ? p : 0) * SX + lh * 16;
+    }
+    // coalesced stores: chunk c = tid + 256 k of the tile -> staging offset (tile invariant), global offset 16 c
+    const int cpp = Cout / 8;
+    int st_lds[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = tid + k * NT;
+        const int px = c / cpp, part = c - px * cpp;
+        st_lds[k] = (px < 128 ? px : 0) * SXO + part * 16;
+    }
+    char* stg = smem + a.off_stage;
+
+    float rs1[2][16], rs2[2][16];
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { rs1[w][r] = 0.f; rs2[w][r] = 0.f; }
+
+    // ---- pieces of a tile -------------------------------------------------------------------------------
+    auto mfma_row = [&](const int kh, const char* wa, f32x16 (&acc3)[2], f32x16 (&acc1)[2]) {
+        bf16x8 bfr[3][KC][2];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                for (int nr = 0; nr < 2; ++nr)
+                    bfr[kw][kc][nr] = *reinterpret_cast<const bf16x8*>(wa + xoff[nr] + (kh * a.XWp + kw) * SX + kc * 32);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                for (int nr = 0; nr < 2; ++nr) {
+                    acc3[nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg3[(kh * 3 + kw) * KC + kc], bfr[kw][kc][nr], acc3[nr], 0, 0, 0);
+                    if (kh == 1 && kw == 1 && !DGRAD)
+                        acc1[nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg1[kc], bfr[kw][kc][nr], acc1[nr], 0, 0, 0);
+                }
+    };
+    auto mfma_second = [&](const char* wb, f32x16 (&acc3)[2]) {   // dgrad: + W1^T . dy1
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int nr = 0; nr < 2; ++nr) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + xoff2[nr] + kc * 32);
+                acc3[nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg1[kc], b, acc3[nr], 0, 0, 0);
+            }
+    };
+    auto stage = [&](const int ptile, const f32x16 (&P3)[2], const f32x16 (&P1)[2]) {   // statistics + bf16 staging of a finished tile
+        if (STATS) {
+            const int n = ptile / a.tiles_per_img;
+            const int oy0 = (ptile - n * a.tiles_per_img) * a.R;
+            const float m0 = (pin[0] && (oy0 + prr[0] < H)) ? 1.f : 0.f, m1 = (pin[1] && (oy0 + prr[1] < H)) ? 1.f : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a0_ = m0 * P3[0][r], a1_ = m1 * P3[1][r];
+                const float b0_ = m0 * P1[0][r], b1_ = m1 * P1[1][r];
+                rs1[0][r] += a0_ + a1_; rs2[0][r] += a0_ * a0_ + a1_ * a1_;
+                rs1[1][r] += b0_ + b1_; rs2[1][r] += b0_ * b0_ + b1_ * b1_;
+            }
+        }
+#pragma unroll
+        for (int which = 0; which < NOUT; ++which)
+#pragma unroll
+            for (int nr = 0; nr < 2; ++nr) {
+                char* row = stg + which * (128 * SXO) + (ph * 64 + nr * 32 + lr) * SXO;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // rows >= Cout are zero-weight rows: their (zero) results land in the slack of the 144-byte staging
+                    // row (64 channels = 128 bytes fit), which the store loop never reads - no branch in this block
+                    const int co = mb * 32 + 8 * q + 4 * lh;
+                    u32x2 o;
+                    if (which == 0) {
+                        o[0] = pack_bf16x2(P3[nr][4 * q], P3[nr][4 * q + 1]);
+                        o[1] = pack_bf16x2(P3[nr][4 * q + 2], P3[nr][4 * q + 3]);
+                    } else {
+                        o[0] = pack_bf16x2(P1[nr][4 * q], P1[nr][4 * q + 1]);
+                        o[1] = pack_bf16x2(P1[nr][4 * q + 2], P1[nr][4 * q + 3]);
+                    }
+                    *reinterpret_cast<u32x2*>(row + co * 2) = o;
+                }
+            }
+    };
+    auto store = [&](const int ptile) {   // staging -> HBM, 16 bytes per lane, thread-linear; tile = one contiguous run of NHWC memory
+        const int n = ptile / a.tiles_per_img;
+        const int oy0 = (ptile - n * a.tiles_per_img) * a.R;
+        const int rows_left = H - oy0;
+        const int nchunks = (rows_left < a.R ? rows_left : a.R) * W * cpp;
+        const unsigned gbase = (unsigned)(((n * H + oy0) * W) * Cout) * 2u;
+        unsigned voff[4];
+        u32x4 rv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = tid + k * NT;
+            voff[k] = c < nchunks ? gbase + (unsigned)c * 16u : HC_OOB;
+            if (DGRAD) rv[k] = buf_load16(rsr, voff[k]);
+        }
+#pragma unroll
+        for (int which = 0; which < NOUT; ++which)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u32x4 v = *reinterpret_cast<const u32x4*>(stg + which * (128 * SXO) + st_lds[k]);
+                if (DGRAD) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = pack_bf16x2(bf16lo(v[e]) + bf16lo(rv[k][e]), bf16hi(v[e]) + bf16hi(rv[k][e]));
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(v, which == 0 ? rso3 : rso1, voff[k], 0, 0);
+            }
+    };
+    auto lds_barrier = [&]() {     // LDS traffic of this wave done, then the workgroup barrier; outstanding DMA / stores are NOT waited for
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // ---- first tile: nothing to overlap with yet ---------------------------------------------------------
+    const int G = gridDim.x;
+    int tile = blockIdx.x;                     // < ntiles: the grid never exceeds the tile count
+    issue(tile, 0);
+    f32x16 P3[2], P1[2];
+    int ptile = tile;
+    {
+        hc_wait_vmcnt<0>();
+        lds_barrier();
+        if (tile + G < a.ntiles) issue(tile + G, 1);
+        const char* wa = smem + a.off_win;
+#pragma unroll
+        for (int nr = 0; nr < 2; ++nr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { P3[nr][r] = 0.f; P1[nr][r] = 0.f; }
+        mfma_row(0, wa, P3, P1);
+        mfma_row(1, wa, P3, P1);
+        mfma_row(2, wa, P3, P1);
+        if (DGRAD) mfma_second(smem + a.off_win2, P3);
+    }
+    int buf = 1;
+    for (tile += G; tile < a.ntiles; tile += G, buf ^= 1) {
+        hc_wait_vmcnt<0>();                    // this tile's window (issued one tile ago) and the previous tile's stores
+        lds_barrier();                         // ... everywhere; all waves are done with the other window and the staging tile
+        if (tile + G < a.ntiles) issue(tile + G, buf ^ 1);
+        const char* wa = smem + a.off_win + buf * a.win_bytes;
+        f32x16 acc3[2], acc1[2];
+#pragma unroll
+        for (int nr = 0; nr < 2; ++nr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc3[nr][r] = 0.f; acc1[nr][r] = 0.f; }
+        mfma_row(0, wa, acc3, acc1);           // same basic block as the previous tile's statistics and staging writes
+        stage(ptile, P3, P1);
+        lds_barrier();                         // staging tile complete
+        store(ptile);                          // stores drain behind the remaining MFMAs ...
+        __builtin_amdgcn_sched_barrier(0);     // ... so they must be ISSUED before them (the scheduler sank them to the loop end)
+        mfma_row(1, wa, acc3, acc1);
+        mfma_row(2, wa, acc3, acc1);
+        if (DGRAD) mfma_second(smem + a.off_win2 + buf * a.win2_bytes, acc3);
+#pragma unroll
+        for (int nr = 0; nr < 2; ++nr) { P3[nr] = acc3[nr]; P1[nr] = acc1[nr]; }
+        ptile = tile;
+    }
+    lds_barrier();                             // every wave is past its last reads of the staging tile
+    stage(ptile, P3, P1);
+    lds_barrier();
+    store(ptile);
+
+    if (STATS) {
+        float* stats3 = d.stats3;
+        float* stats1 = d.stats1;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            float s1[16], s2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s1[r] = rs1[which][r]; s2[r] = rs2[which][r]; }
+#pragma unroll
+            for (int w = 8, o = 16; w >= 1; w >>= 1, o >>= 1) {
+                const bool up = (lane & o) != 0;
+#pragma unroll
+                for (int i = 0; i < w; ++i) {
+                    const float k1 = up ? s1[i + w] : s1[i], g1 = up ? s1[i] : s1[i + w];
+                    const float k2 = up ? s2[i + w] : s2[i], g2 = up ? s2[i] : s2[i + w];
+                    s1[i] = k1 + __shfl_xor(g1, o);
+                    s2[i] = k2 + __shfl_xor(g2, o);
+                }
+            }
+            s1[0] += __shfl_xor(s1[0], 1);
+            s2[0] += __shfl_xor(s2[0], 1);
+            if ((lane & 1) == 0) {
+                const int r = 8 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 1) & 1);
+                const int co = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                atomicAdd(&sstat[which * 128 + co], s1[0]);
+                atomicAdd(&sstat[which * 128 + 64 + co], s2[0]);
+            }
+        }
+        __syncthreads();
+        const int which = tid >> 7, kind = (tid >> 6) & 1, co = tid & 63;
+        if (co < Cout) {
+            float* st = (which == 0 ? stats3 : stats1) + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * Cout;
+            atomicAdd(st + kind * Cout + co, sstat[tid]);
+        }
+    }
+}
+
 inline int round112(int bytes) {   // smallest stride >= bytes that is == 112 (mod 256)
     int s = 112;
     while (s < bytes) s += 256;
@@ -352,7 +666,7 @@ inline bool make_args(const hc_conv_small_desc& d, Args& a, int& smem) {
         a.win2_bytes = qb * 1024;
     }
     a.off_stat = a.off_win2 + 2 * a.win2_bytes;
-    smem = a.off_stat + 1024;
+    smem = a.off_stat + 2048;   // + 1 KB dummy DMA target of the pipelined kernel
     // rows 32..63 of the second MFMA row block may lie beyond wrows: they must still be inside the allocation
     if (a.nja > MAXJ || a.njb > MAXJ / 2 || smem > 160 * 1024 || (d.Cout % 8) != 0) return false;
     return true;
@@ -367,6 +681,32 @@ void launch(const Args& a, int grid, int smem, hipStream_t st) {
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, a);
+}
+
+template <int KC, bool DGRAD, bool STATS, int NJA, int NJB>
+void launch_pipe(const Args& a, int grid, int smem, hipStream_t st) {
+    auto kern = conv_small_pipe_kernel<KC, DGRAD, STATS, NJA, NJB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, st, a);
+}
+template <int KC>
+void launch_pipe_mode(const Args& a, int grid, int smem, hipStream_t st) {
+    // the unrolled DMA counts are compile-time: a bucket that covers the window (wide images: 10 + 4; the rest: MAXJ)
+    const bool narrow = a.nja <= 10 && a.njb <= 4;
+    if ((a.d.mode & 1) == 1) {
+        if (narrow) launch_pipe<KC, true, false, 10, 4>(a, grid, smem, st);
+        else launch_pipe<KC, true, false, MAXJ, MAXJ / 2>(a, grid, smem, st);
+    } else if (a.d.stats3 != nullptr) {
+        if (narrow) launch_pipe<KC, false, true, 10, 0>(a, grid, smem, st);
+        else launch_pipe<KC, false, true, MAXJ, 0>(a, grid, smem, st);
+    } else {
+        if (narrow) launch_pipe<KC, false, false, 10, 0>(a, grid, smem, st);
+        else launch_pipe<KC, false, false, MAXJ, 0>(a, grid, smem, st);
+    }
 }
 
 }  // namespace csm
@@ -394,8 +734,24 @@ extern "C" int hc_conv_small(const hc_conv_small_desc* dp, hc_stream_t stream) {
     csm::Args a;
     int smem = 0;
     if (!csm::make_args(d, a, smem)) return HC_ERR_ARG;
+    { const char* e = getenv("HC_CSM_DBG"); a.dbg = e ? atoi(e) : 0; }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int grid = a.ntiles < 256 ? a.ntiles : 256;      // one persistent workgroup per CU
+    // test / experiment knobs: HC_CONV_SMALL_GRID caps the grid (several tiles per workgroup on small inputs),
+    // HC_CONV_SMALL_PIPE=0 selects the non-pipelined kernel
+    const char* e_grid = getenv("HC_CONV_SMALL_GRID");      // read per call: tests flip them inside one process
+    const char* e_pipe = getenv("HC_CONV_SMALL_PIPE");
+    const int grid_cap = e_grid ? atoi(e_grid) : 0;
+    const bool pipe = e_pipe == nullptr || atoi(e_pipe) != 0;
+    if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+    const bool pipe_ok = pipe && a.dbg == 0 && (double)d.N * d.H * d.W * d.Cout * 2.0 < 2147483000.0 &&
+                         (d.stats3 == nullptr) == (d.stats1 == nullptr);
+    if (pipe_ok) {
+        if (d.C == 16) csm::launch_pipe_mode<1>(a, grid, smem, st);
+        else if (d.C == 32) csm::launch_pipe_mode<2>(a, grid, smem, st);
+        else csm::launch_pipe_mode<3>(a, grid, smem, st);
+        return hc_launch_status();
+    }
     if (d.C == 16) csm::launch<1>(a, grid, smem, st);
     else if (d.C == 32) csm::launch<2>(a, grid, smem, st);
     else csm::launch<3>(a, grid, smem, st);

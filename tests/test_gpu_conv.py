@@ -169,6 +169,18 @@ def test_conv_small_forward_and_dgrad(N, C, Cout, H, W):
         assert rel_l2(_to_nchw_f32(dx), du + res) < 3e-3
 
 
+@pytest.mark.parametrize("pipe", ["1", "0"])
+@pytest.mark.parametrize("grid", ["3", "7"])
+def test_conv_small_many_tiles_per_workgroup(grid, pipe, monkeypatch):
+    """The persistent kernel walks several tiles per workgroup (software-pipelined form: the epilogue of tile i-1 runs inside
+    the MFMA stream of tile i).  HC_CONV_SMALL_GRID caps the grid so that small inputs exercise first / steady-state / last
+    iterations, ragged last row tiles included; HC_CONV_SMALL_PIPE=0 is the non-pipelined kernel.  Both must match conv2d."""
+    monkeypatch.setenv("HC_CONV_SMALL_GRID", grid)
+    monkeypatch.setenv("HC_CONV_SMALL_PIPE", pipe)
+    for args in [(2, 48, 48, 20, 112), (3, 48, 48, 9, 56), (2, 32, 48, 7, 30), (2, 16, 64, 5, 17), (1, 48, 40, 3, 128)]:
+        test_conv_small_forward_and_dgrad(*args)
+
+
 def test_resident_image_conv_forward_and_dgrad():
     """hc_conv_small on 64..256 channels (conv_resident.hip: the image resident in LDS): fused 3x3 + 1x1 forward with BatchNorm
     statistics, and the two-source data gradient with residual, against fp32 torch on the same bf16 inputs."""
