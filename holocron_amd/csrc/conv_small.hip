@@ -17,6 +17,7 @@
 // ds_read_b128 hit 16 distinct 16-byte bank slots (rows r*112 mod 256 are all different for the
 // group row sets {0-3,12-15,20-27} / {4-11,16-19,28-31}).
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "../../include/holocron_hip.h"
 
@@ -443,35 +444,56 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
         for (int r = 0; r < 16; ++r) { rs1[w][r] = 0.f; rs2[w][r] = 0.f; }
 
     // ---- pieces of a tile -------------------------------------------------------------------------------
-    auto mfma_row = [&](const int kh, const char* wa, f32x16 (&acc3)[2], f32x16 (&acc1)[2]) {
-        bf16x8 bfr[3][KC][2];
+    // MFMA stream of a tile as 9 (+1) chunks: chunk t = tap (kh, kw) = KC x 2 fragments (k16 chunk x pixel block), chunk 9 = the
+    // second source of the data gradient.  Fragments are fetched from LDS TWO chunks ahead of their MFMAs (the scheduler
+    // otherwise sinks every ds_read next to its use and each MFMA pair eats a full LDS latency: 5.7k clocks per tile for
+    // 1.9k clocks of MFMA); sched_group_barrier pins the read / MFMA interleave.  [T0, T1) is the chunk range of one
+    // basic block (the tile is split by the staging barrier).
+    constexpr int NCH = DGRAD ? 10 : 9;
+    auto load_chunk = [&](const int t, const char* wa, const char* wb, bf16x8 (&f)[KC][2]) {
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
+        for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-                for (int nr = 0; nr < 2; ++nr)
-                    bfr[kw][kc][nr] = *reinterpret_cast<const bf16x8*>(wa + xoff[nr] + (kh * a.XWp + kw) * SX + kc * 32);
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-                for (int nr = 0; nr < 2; ++nr) {
-                    acc3[nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg3[(kh * 3 + kw) * KC + kc], bfr[kw][kc][nr], acc3[nr], 0, 0, 0);
-                    if (kh == 1 && kw == 1 && !DGRAD)
-                        acc1[nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg1[kc], bfr[kw][kc][nr], acc1[nr], 0, 0, 0);
-                }
+            for (int nr = 0; nr < 2; ++nr)
+                f[kc][nr] = (t < 9) ? *reinterpret_cast<const bf16x8*>(wa + xoff[nr] + ((t / 3) * a.XWp + (t % 3)) * SX + kc * 32)
+                                    : *reinterpret_cast<const bf16x8*>(wb + xoff2[nr] + kc * 32);
     };
-    auto mfma_second = [&](const char* wb, f32x16 (&acc3)[2]) {   // dgrad: + W1^T . dy1
+    auto mfma_chunk = [&](const int t, const bf16x8 (&f)[KC][2], f32x16 (&acc3)[2], f32x16 (&acc1)[2]) {
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
             for (int nr = 0; nr < 2; ++nr) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + xoff2[nr] + kc * 32);
-                acc3[nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg1[kc], b, acc3[nr], 0, 0, 0);
+                acc3[nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t < 9 ? wreg3[t * KC + kc] : wreg1[kc], f[kc][nr], acc3[nr], 0, 0, 0);
+                if (t == 4 && !DGRAD)   // the 1x1 branch shares the centre-tap pixels
+                    acc1[nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg1[kc], f[kc][nr], acc1[nr], 0, 0, 0);
             }
     };
+#define CSM_STEP(T)                                                                          \
+    if ((T) >= T0 && (T) < T1) {                                                             \
+        if ((T) + 2 < T1) load_chunk((T) + 2, wa, wb, fr[((T) + 2) % 3]);                    \
+        mfma_chunk((T), fr[(T) % 3], acc3, acc1);                                            \
+    }
+#define CSM_PIN(T)                                                                           \
+    if ((T) >= T0 && (T) < T1) {                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < KC * 2; ++i_) {                              \
+            if ((T) + 2 < T1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             \
+            __builtin_amdgcn_sched_group_barrier(0x008, ((T) == 4 && !DGRAD) ? 2 : 1, 0);    \
+        }                                                                                    \
+    }
+    auto mfma_range = [&](auto t0c, auto t1c, const char* wa, const char* wb, f32x16 (&acc3)[2], f32x16 (&acc1)[2]) {
+        constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
+        bf16x8 fr[3][KC][2];
+        load_chunk(T0, wa, wb, fr[T0 % 3]);
+        if (T0 + 1 < T1) load_chunk(T0 + 1, wa, wb, fr[(T0 + 1) % 3]);
+        CSM_STEP(0) CSM_STEP(1) CSM_STEP(2) CSM_STEP(3) CSM_STEP(4) CSM_STEP(5) CSM_STEP(6) CSM_STEP(7) CSM_STEP(8) CSM_STEP(9)
+        __builtin_amdgcn_sched_group_barrier(0x100, (T0 + 1 < T1 ? 2 : 1) * KC * 2, 0);
+        CSM_PIN(0) CSM_PIN(1) CSM_PIN(2) CSM_PIN(3) CSM_PIN(4) CSM_PIN(5) CSM_PIN(6) CSM_PIN(7) CSM_PIN(8) CSM_PIN(9)
+    };
+#undef CSM_STEP
+#undef CSM_PIN
+    using i0_t = std::integral_constant<int, 0>;
+    using i3_t = std::integral_constant<int, 3>;
+    using iN_t = std::integral_constant<int, NCH>;
     auto stage = [&](const int ptile, const f32x16 (&P3)[2], const f32x16 (&P1)[2]) {   // statistics + bf16 staging of a finished tile
         if (STATS) {
             const int n = ptile / a.tiles_per_img;
@@ -555,10 +577,7 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
         for (int nr = 0; nr < 2; ++nr)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { P3[nr][r] = 0.f; P1[nr][r] = 0.f; }
-        mfma_row(0, wa, P3, P1);
-        mfma_row(1, wa, P3, P1);
-        mfma_row(2, wa, P3, P1);
-        if (DGRAD) mfma_second(smem + a.off_win2, P3);
+        mfma_range(i0_t{}, iN_t{}, wa, smem + a.off_win2, P3, P1);
     }
     int buf = 1;
     for (tile += G; tile < a.ntiles; tile += G, buf ^= 1) {
@@ -571,14 +590,13 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
         for (int nr = 0; nr < 2; ++nr)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc3[nr][r] = 0.f; acc1[nr][r] = 0.f; }
-        mfma_row(0, wa, acc3, acc1);           // same basic block as the previous tile's statistics and staging writes
+        const char* wb = smem + a.off_win2 + buf * a.win2_bytes;
+        mfma_range(i0_t{}, i3_t{}, wa, wb, acc3, acc1);   // first kernel row: same basic block as the previous tile's statistics and staging writes
         stage(ptile, P3, P1);
         lds_barrier();                         // staging tile complete
         store(ptile);                          // stores drain behind the remaining MFMAs ...
         __builtin_amdgcn_sched_barrier(0);     // ... so they must be ISSUED before them (the scheduler sank them to the loop end)
-        mfma_row(1, wa, acc3, acc1);
-        mfma_row(2, wa, acc3, acc1);
-        if (DGRAD) mfma_second(smem + a.off_win2 + buf * a.win2_bytes, acc3);
+        mfma_range(i3_t{}, iN_t{}, wa, wb, acc3, acc1);
 #pragma unroll
         for (int nr = 0; nr < 2; ++nr) { P3[nr] = acc3[nr]; P1[nr] = acc1[nr]; }
         ptile = tile;
