@@ -332,12 +332,11 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
     constexpr int C = 16 * KC;
     constexpr int NCC = C / 8;
     constexpr int NOUT = DGRAD ? 1 : 2;        // tensors written
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keep it in an SGPR
     const int H = d.H, W = d.W, Cout = d.Cout;
-    const unsigned img_bytes = (unsigned)d.N * H * W * C * 2u;
+    const unsigned one_img = (unsigned)H * W * C * 2u;             // bytes of one input image
     const unsigned out_bytes = (unsigned)d.N * H * W * Cout * 2u;
-    const u32x4 rsa = hc_raw_rsrc(d.srcA, img_bytes);
-    const u32x4 rsb = hc_raw_rsrc(DGRAD ? d.srcB : d.srcA, img_bytes);
     const __amdgpu_buffer_rsrc_t rso3 = make_rsrc(d.out3, out_bytes);
     const __amdgpu_buffer_rsrc_t rso1 = make_rsrc(DGRAD ? d.out3 : d.out1, out_bytes);
     const __amdgpu_buffer_rsrc_t rsr = make_rsrc(d.resid, (DGRAD && d.resid != nullptr) ? out_bytes : 0u);   // null: reads 0
@@ -366,51 +365,47 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
     float* sstat = reinterpret_cast<float*>(smem + a.off_stat);
     sstat[tid] = 0.f;
 
-    int a_rel[MAXJ], a_wr[MAXJ];
+    // ---- DMA bookkeeping.  The source descriptor is rebuilt PER IMAGE (base = image n, range = one image), so that the halo
+    // row above the first and below the last image row is out of range by itself (a negative row offset wraps) and the DMA
+    // writes the zero padding; per instruction that leaves one v_add: lanes that carry no pixel (halo columns, slack
+    // behind the window) add BIG instead of their offset and are out of range for every row.
+    constexpr unsigned BIG = 0x40000000u;      // host: one image < BIG - one row
+    unsigned a_rel[NJA > 0 ? NJA : 1];
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
+    for (int j = 0; j < NJA; ++j) {
         const int q16 = (wid + j * NW) * 64 + lane;
         const int pix = q16 / 7, cc = q16 - pix * 7;
         const int wr = pix / a.XWp, wc = pix - wr * a.XWp;
         const bool ok = (wid + j * NW < a.qa) && (cc < NCC) && (wr < a.R + 2) && (wc >= 1) && (wc <= W);
-        a_rel[j] = ok ? ((wr * W + (wc - 1)) * C + cc * 8) * 2 : -1;
-        a_wr[j] = wr;
+        a_rel[j] = ok ? (unsigned)(((wr * W + (wc - 1)) * C + cc * 8) * 2) : BIG;
     }
-    int b_rel[MAXJ / 2], b_pix[MAXJ / 2];
+    unsigned b_rel[NJB > 0 ? NJB : 1];
 #pragma unroll
-    for (int j = 0; j < MAXJ / 2; ++j) {
+    for (int j = 0; j < NJB; ++j) {
         const int q16 = (wid + j * NW) * 64 + lane;
         const int pix = q16 / 7, cc = q16 - pix * 7;
         const bool ok = DGRAD && (wid + j * NW < a.qb) && (cc < NCC) && (pix < a.P);
-        b_rel[j] = ok ? (pix * C + cc * 8) * 2 : -1;
-        b_pix[j] = pix;
+        b_rel[j] = ok ? (unsigned)((pix * C + cc * 8) * 2) : BIG;
     }
     const unsigned dummy = smem0 + a.off_stat + 1024;
     auto issue = [&](int tile, int buf) {
         const int n = tile / a.tiles_per_img;
         const int oy0 = (tile - n * a.tiles_per_img) * a.R;
-        const int rowbase = ((n * H + oy0 - 1) * W) * C * 2;
+        const u32x4 rsa = hc_raw_rsrc(reinterpret_cast<const char*>(d.srcA) + (size_t)n * one_img, one_img);
+        const unsigned rowrel = (unsigned)((oy0 - 1) * W * C * 2);          // "negative" for the first tile of an image
         const unsigned wa = smem0 + a.off_win + buf * a.win_bytes;
-        // branch-free: instruction slots beyond the window (wave-uniform) are aimed at a 1 KB dummy area with an
-        // out-of-range source (the DMA writes zeros there); NJA / NJB bound the unrolled count
+        // branch-free: instruction slots beyond the window (wave-uniform) are aimed at a 1 KB dummy area (their lanes are
+        // all BIG: the DMA writes zeros there); NJA / NJB bound the unrolled count
 #pragma unroll
-        for (int j = 0; j < NJA; ++j) {
-            const bool act = wid + j * NW < a.qa;
-            const int iy = oy0 - 1 + a_wr[j];
-            const bool ok = act && (a_rel[j] >= 0) && ((unsigned)iy < (unsigned)H);
-            hc_dma16(rsa, __builtin_amdgcn_readfirstlane(act ? wa + (wid + j * NW) * 1024 : dummy), ok ? (unsigned)(rowbase + a_rel[j]) : HC_OOB);
-        }
+        for (int j = 0; j < NJA; ++j)
+            hc_dma16(rsa, (wid + j * NW < a.qa) ? wa + (wid + j * NW) * 1024 : dummy, rowrel + a_rel[j]);
         if (DGRAD) {
+            const u32x4 rsb = hc_raw_rsrc(reinterpret_cast<const char*>(d.srcB) + (size_t)n * one_img, one_img);
             const unsigned wb = smem0 + a.off_win2 + buf * a.win2_bytes;
-            const int rows_left = H - oy0;
-            const int pvalid = (rows_left < a.R ? rows_left : a.R) * W;
-            const int base2 = ((n * H + oy0) * W) * C * 2;
+            const unsigned base2 = (unsigned)(oy0 * W * C * 2);               // rows past the image end are out of range
 #pragma unroll
-            for (int j = 0; j < NJB; ++j) {
-                const bool act = wid + j * NW < a.qb;
-                const bool ok = act && (b_rel[j] >= 0) && (b_pix[j] < pvalid);
-                hc_dma16(rsb, __builtin_amdgcn_readfirstlane(act ? wb + (wid + j * NW) * 1024 : dummy), ok ? (unsigned)(base2 + b_rel[j]) : HC_OOB);
-            }
+            for (int j = 0; j < NJB; ++j)
+                hc_dma16(rsb, (wid + j * NW < a.qb) ? wb + (wid + j * NW) * 1024 : dummy, base2 + b_rel[j]);
         }
     };
 
@@ -437,11 +432,15 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
     }
     char* stg = smem + a.off_stage;
 
-    float rs1[2][16], rs2[2][16];
+    // running BN sums [tensor][pair of accumulator registers]: kept as float2 so that the updates are v_pk_mul / v_pk_add /
+    // v_pk_fma_f32 - the epilogue of tile i-1 shares the VALU with the address work of tile i, and with one wave per SIMD
+    // the VALU, not the MFMA pipe, was the busier unit
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    f2_t rs1[2][8], rs2[2][8];
 #pragma unroll
     for (int w = 0; w < 2; ++w)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { rs1[w][r] = 0.f; rs2[w][r] = 0.f; }
+        for (int r = 0; r < 8; ++r) { rs1[w][r] = f2_t{0.f, 0.f}; rs2[w][r] = f2_t{0.f, 0.f}; }
 
     // ---- pieces of a tile -------------------------------------------------------------------------------
     // MFMA stream of a tile as 9 (+1) chunks: chunk t = tap (kh, kw) = KC x 2 fragments (k16 chunk x pixel block), chunk 9 = the
@@ -499,10 +498,11 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
             const int n = ptile / a.tiles_per_img;
             const int oy0 = (ptile - n * a.tiles_per_img) * a.R;
             const float m0 = (pin[0] && (oy0 + prr[0] < H)) ? 1.f : 0.f, m1 = (pin[1] && (oy0 + prr[1] < H)) ? 1.f : 0.f;
+            const f2_t m0v = {m0, m0}, m1v = {m1, m1};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float a0_ = m0 * P3[0][r], a1_ = m1 * P3[1][r];
-                const float b0_ = m0 * P1[0][r], b1_ = m1 * P1[1][r];
+            for (int r = 0; r < 8; ++r) {
+                const f2_t a0_ = f2_t{P3[0][2 * r], P3[0][2 * r + 1]} * m0v, a1_ = f2_t{P3[1][2 * r], P3[1][2 * r + 1]} * m1v;
+                const f2_t b0_ = f2_t{P1[0][2 * r], P1[0][2 * r + 1]} * m0v, b1_ = f2_t{P1[1][2 * r], P1[1][2 * r + 1]} * m1v;
                 rs1[0][r] += a0_ + a1_; rs2[0][r] += a0_ * a0_ + a1_ * a1_;
                 rs1[1][r] += b0_ + b1_; rs2[1][r] += b0_ * b0_ + b1_ * b1_;
             }
@@ -562,43 +562,46 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
         asm volatile("" ::: "memory");
     };
 
-    // ---- first tile: nothing to overlap with yet ---------------------------------------------------------
+    // ---- tile loop: two accumulator sets whose roles (being computed / being written out) swap every tile --------
     const int G = gridDim.x;
-    int tile = blockIdx.x;                     // < ntiles: the grid never exceeds the tile count
-    issue(tile, 0);
-    f32x16 P3[2], P1[2];
-    int ptile = tile;
-    {
-        hc_wait_vmcnt<0>();
-        lds_barrier();
-        if (tile + G < a.ntiles) issue(tile + G, 1);
-        const char* wa = smem + a.off_win;
+    auto zero = [&](f32x16 (&x3)[2], f32x16 (&x1)[2]) {
 #pragma unroll
         for (int nr = 0; nr < 2; ++nr)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { P3[nr][r] = 0.f; P1[nr][r] = 0.f; }
-        mfma_range(i0_t{}, iN_t{}, wa, smem + a.off_win2, P3, P1);
-    }
-    int buf = 1;
-    for (tile += G; tile < a.ntiles; tile += G, buf ^= 1) {
+            for (int r = 0; r < 16; ++r) { x3[nr][r] = 0.f; x1[nr][r] = 0.f; }
+    };
+    auto body = [&](const int tile, const int buf, const int ptile, f32x16 (&cur3)[2], f32x16 (&cur1)[2],
+                    const f32x16 (&prv3)[2], const f32x16 (&prv1)[2]) {
         hc_wait_vmcnt<0>();                    // this tile's window (issued one tile ago) and the previous tile's stores
         lds_barrier();                         // ... everywhere; all waves are done with the other window and the staging tile
         if (tile + G < a.ntiles) issue(tile + G, buf ^ 1);
         const char* wa = smem + a.off_win + buf * a.win_bytes;
-        f32x16 acc3[2], acc1[2];
-#pragma unroll
-        for (int nr = 0; nr < 2; ++nr)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc3[nr][r] = 0.f; acc1[nr][r] = 0.f; }
         const char* wb = smem + a.off_win2 + buf * a.win2_bytes;
-        mfma_range(i0_t{}, i3_t{}, wa, wb, acc3, acc1);   // first kernel row: same basic block as the previous tile's statistics and staging writes
-        stage(ptile, P3, P1);
+        zero(cur3, cur1);
+        mfma_range(i0_t{}, i3_t{}, wa, wb, cur3, cur1);   // first kernel row: same basic block as the previous tile's statistics and staging writes
+        stage(ptile, prv3, prv1);
         lds_barrier();                         // staging tile complete
         store(ptile);                          // stores drain behind the remaining MFMAs ...
         __builtin_amdgcn_sched_barrier(0);     // ... so they must be ISSUED before them (the scheduler sank them to the loop end)
-        mfma_range(i3_t{}, iN_t{}, wa, wb, acc3, acc1);
+        mfma_range(i3_t{}, iN_t{}, wa, wb, cur3, cur1);
+    };
+    // (Swapping two accumulator sets between "being computed" and "being written out" instead of copying 64 registers per
+    // tile was tried: the doubled loop body spills ~75 VGPRs.)
+    f32x16 P3[2], P1[2], Q3[2], Q1[2];
+    int tile = blockIdx.x;                     // < ntiles: the grid never exceeds the tile count
+    issue(tile, 0);
+    {                                          // first tile: nothing to overlap with yet
+        hc_wait_vmcnt<0>();
+        lds_barrier();
+        if (tile + G < a.ntiles) issue(tile + G, 1);
+        zero(P3, P1);
+        mfma_range(i0_t{}, iN_t{}, smem + a.off_win, smem + a.off_win2, P3, P1);
+    }
+    int ptile = tile, buf = 1;
+    for (tile += G; tile < a.ntiles; tile += G, buf ^= 1) {
+        body(tile, buf, ptile, Q3, Q1, P3, P1);
 #pragma unroll
-        for (int nr = 0; nr < 2; ++nr) { P3[nr] = acc3[nr]; P1[nr] = acc1[nr]; }
+        for (int nr = 0; nr < 2; ++nr) { P3[nr] = Q3[nr]; P1[nr] = Q1[nr]; }
         ptile = tile;
     }
     lds_barrier();                             // every wave is past its last reads of the staging tile
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
         for (int which = 0; which < 2; ++which) {
             float s1[16], s2[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s1[r] = rs1[which][r]; s2[r] = rs2[which][r]; }
+            for (int r = 0; r < 16; ++r) { s1[r] = rs1[which][r >> 1][r & 1]; s2[r] = rs2[which][r >> 1][r & 1]; }
 #pragma unroll
             for (int w = 8, o = 16; w >= 1; w >>= 1, o >>= 1) {
                 const bool up = (lane & o) != 0;
@@ -763,6 +766,7 @@ extern "C" int hc_conv_small(const hc_conv_small_desc* dp, hc_stream_t stream) {
     const bool pipe = e_pipe == nullptr || atoi(e_pipe) != 0;
     if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
     const bool pipe_ok = pipe && a.dbg == 0 && (double)d.N * d.H * d.W * d.Cout * 2.0 < 2147483000.0 &&
+                         (double)d.H * d.W * d.C * 2.0 < 1.0e9 &&
                          (d.stats3 == nullptr) == (d.stats1 == nullptr);
     if (pipe_ok) {
         if (d.C == 16) csm::launch_pipe_mode<1>(a, grid, smem, st);

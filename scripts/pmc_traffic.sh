@@ -13,6 +13,6 @@ for f in sorted(glob.glob("gpurun_out/pmc2/**/*counter_collection.csv", recursiv
         k = (r["Kernel_Name"][:60], r["Counter_Name"])
         agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     for (k, c), (v, n) in agg.items():
-        if "conv_gather" in k or "wgrad" in k:
+        if "conv_gather" in k or "wgrad" in k or "conv_small" in k:
             print(f.split("/")[-1][:3], k, c, "per launch:", round(v / n, 1), "launches", n)
 PY
