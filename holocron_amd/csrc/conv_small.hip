@@ -570,11 +570,11 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { x3[nr][r] = 0.f; x1[nr][r] = 0.f; }
     };
-    auto body = [&](const int tile, const int buf, const int ptile, f32x16 (&cur3)[2], f32x16 (&cur1)[2],
+    auto body = [&](const int ntile, const int buf, const int ptile, f32x16 (&cur3)[2], f32x16 (&cur1)[2],
                     const f32x16 (&prv3)[2], const f32x16 (&prv1)[2]) {
         hc_wait_vmcnt<0>();                    // this tile's window (issued one tile ago) and the previous tile's stores
         lds_barrier();                         // ... everywhere; all waves are done with the other window and the staging tile
-        if (tile + G < a.ntiles) issue(tile + G, buf ^ 1);
+        if (ntile < a.ntiles) issue(ntile, buf ^ 1);
         const char* wa = smem + a.off_win + buf * a.win_bytes;
         const char* wb = smem + a.off_win2 + buf * a.win2_bytes;
         zero(cur3, cur1);
@@ -587,19 +587,30 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
     };
     // (Swapping two accumulator sets between "being computed" and "being written out" instead of copying 64 registers per
     // tile was tried: the doubled loop body spills ~75 VGPRs.)
+    // Tile order.  A window is R + 2 input rows, so a row is wanted by up to three tiles; handed out round-robin
+    // (tile = block + k * grid) those are three workgroups on three different XCDs, i.e. three L2s, and the input came in
+    // from the memory side three times (PMC: 920 MB fetched for a 308 MB tensor).  Workgroups are dispatched to XCD
+    // (block % 8), so instead the grid/8 workgroups of one XCD take grid/8 CONSECUTIVE tiles at every step: neighbouring
+    // rows meet in one L2 at the same time and only the rows at the ends of such a run are fetched twice.
+    const int per = G >> 3;
+    const bool xcd_order = (G & 7) == 0;
+    auto tile_of = [&](const int k) {
+        return xcd_order ? (k * 8 + (int)(blockIdx.x & 7)) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x + k * G;
+    };
     f32x16 P3[2], P1[2], Q3[2], Q1[2];
-    int tile = blockIdx.x;                     // < ntiles: the grid never exceeds the tile count
+    int k = 0;
+    int tile = tile_of(0);                     // < ntiles: the grid never exceeds the tile count
     issue(tile, 0);
     {                                          // first tile: nothing to overlap with yet
         hc_wait_vmcnt<0>();
         lds_barrier();
-        if (tile + G < a.ntiles) issue(tile + G, 1);
+        if (tile_of(1) < a.ntiles) issue(tile_of(1), 1);
         zero(P3, P1);
         mfma_range(i0_t{}, iN_t{}, smem + a.off_win, smem + a.off_win2, P3, P1);
     }
     int ptile = tile, buf = 1;
-    for (tile += G; tile < a.ntiles; tile += G, buf ^= 1) {
-        body(tile, buf, ptile, Q3, Q1, P3, P1);
+    for (k = 1, tile = tile_of(1); tile < a.ntiles; ++k, tile = tile_of(k), buf ^= 1) {
+        body(tile_of(k + 1), buf, ptile, Q3, Q1, P3, P1);
 #pragma unroll
         for (int nr = 0; nr < 2; ++nr) { P3[nr] = Q3[nr]; P1[nr] = Q1[nr]; }
         ptile = tile;

@@ -170,7 +170,7 @@ def test_conv_small_forward_and_dgrad(N, C, Cout, H, W):
 
 
 @pytest.mark.parametrize("pipe", ["1", "0"])
-@pytest.mark.parametrize("grid", ["3", "7"])
+@pytest.mark.parametrize("grid", ["3", "7", "8", "16"])   # multiples of 8: the XCD-grouped tile order
 def test_conv_small_many_tiles_per_workgroup(grid, pipe, monkeypatch):
     """The persistent kernel walks several tiles per workgroup (software-pipelined form: the epilogue of tile i-1 runs inside
     the MFMA stream of tile i).  HC_CONV_SMALL_GRID caps the grid so that small inputs exercise first / steady-state / last
