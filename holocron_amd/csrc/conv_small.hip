@@ -529,20 +529,22 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
                 }
             }
     };
-    auto store = [&](const int ptile) {   // staging -> HBM, 16 bytes per lane, thread-linear; tile = one contiguous run of NHWC memory
+    // addresses of a finished tile's 16-byte chunks (out of range past the tile) and, for the data gradient, its residual:
+    // loaded at the top of the next tile, a kernel row of MFMAs ahead of the adds that use it
+    auto store_prep = [&](const int ptile, unsigned (&voff)[4], u32x4 (&rv)[4]) {
         const int n = ptile / a.tiles_per_img;
         const int oy0 = (ptile - n * a.tiles_per_img) * a.R;
         const int rows_left = H - oy0;
         const int nchunks = (rows_left < a.R ? rows_left : a.R) * W * cpp;
         const unsigned gbase = (unsigned)(((n * H + oy0) * W) * Cout) * 2u;
-        unsigned voff[4];
-        u32x4 rv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = tid + k * NT;
             voff[k] = c < nchunks ? gbase + (unsigned)c * 16u : HC_OOB;
             if (DGRAD) rv[k] = buf_load16(rsr, voff[k]);
         }
+    };
+    auto store = [&](const unsigned (&voff)[4], const u32x4 (&rv)[4]) {   // staging -> HBM, 16 bytes per lane, thread-linear
 #pragma unroll
         for (int which = 0; which < NOUT; ++which)
 #pragma unroll
@@ -578,10 +580,13 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
         const char* wa = smem + a.off_win + buf * a.win_bytes;
         const char* wb = smem + a.off_win2 + buf * a.win2_bytes;
         zero(cur3, cur1);
+        unsigned voff[4];
+        u32x4 rv[4];
+        store_prep(ptile, voff, rv);
         mfma_range(i0_t{}, i3_t{}, wa, wb, cur3, cur1);   // first kernel row: same basic block as the previous tile's statistics and staging writes
         stage(ptile, prv3, prv1);
         lds_barrier();                         // staging tile complete
-        store(ptile);                          // stores drain behind the remaining MFMAs ...
+        store(voff, rv);                       // stores drain behind the remaining MFMAs ...
         __builtin_amdgcn_sched_barrier(0);     // ... so they must be ISSUED before them (the scheduler sank them to the loop end)
         mfma_range(i3_t{}, iN_t{}, wa, wb, cur3, cur1);
     };
@@ -617,8 +622,13 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
     }
     lds_barrier();                             // every wave is past its last reads of the staging tile
     stage(ptile, P3, P1);
-    lds_barrier();
-    store(ptile);
+    {
+        unsigned voff[4];
+        u32x4 rv[4];
+        store_prep(ptile, voff, rv);
+        lds_barrier();
+        store(voff, rv);
+    }
 
     if (STATS) {
         float* stats3 = d.stats3;
