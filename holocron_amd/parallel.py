@@ -119,13 +119,18 @@ class GradReducer:
             size += p.numel()
         if cur:
             groups.append(cur)
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=self.comm_dtype, device=self.params[0].device)
-        off = 0
-        for g in groups:
-            n = sum(p.numel() for p in g)
-            self.buckets.append(_Bucket(g, self.flat[off:off + n]))
-            off += n
+        # every bucket starts on a 256-byte boundary of the buffer (RCCL's vectorised paths, and a slice handed to a
+        # collective on its own keeps the alignment of the whole); the padding stays zero on every rank
+        align = 256 // torch.empty((), dtype=self.comm_dtype).element_size()
+        sizes = [sum(p.numel() for p in g) for g in groups]
+        starts, off = [], 0
+        for n in sizes:
+            starts.append(off)
+            off += (n + align - 1) // align * align
+        self.flat = torch.zeros(max(off, 1), dtype=self.comm_dtype, device=self.params[0].device)
+        self._starts_of = starts + [off]
+        for g, n, st in zip(groups, sizes, starts):
+            self.buckets.append(_Bucket(g, self.flat[st:st + n]))
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 self._of[p] = (b, i)
@@ -189,9 +194,7 @@ class GradReducer:
     def spans(self, indices: Iterable[int]) -> List[torch.Tensor]:
         """The buckets ``indices`` as maximal contiguous slices of the communication buffer."""
         out: List[torch.Tensor] = []
-        offs = [0]
-        for b in self.buckets:
-            offs.append(offs[-1] + b.numel)
+        offs = self._starts_of            # bucket i occupies [offs[i], offs[i + 1]) including its tail padding
         run = None
         for i in sorted(indices):
             if run is not None and run[1] == i:

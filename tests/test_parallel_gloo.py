@@ -26,8 +26,9 @@ def _worker(rank, world, port, bucket_mb, comm_dtype, mode):
     red = GradReducer(model.parameters(), bucket_mb=bucket_mb, comm_dtype=comm_dtype, overlap=(mode == "overlap"))
     assert len(red.buckets) >= 1
     # one communication buffer, the buckets are contiguous slices of it
-    assert red.flat.numel() == sum(p.numel() for p in model.parameters())
-    assert sum(b.flat.numel() for b in red.buckets) == red.flat.numel()
+    assert sum(b.flat.numel() for b in red.buckets) == sum(p.numel() for p in model.parameters())
+    assert red.flat.numel() >= sum(b.flat.numel() for b in red.buckets)       # buckets start on 256-byte boundaries
+    assert all(b.flat.data_ptr() % 256 == red.flat.data_ptr() % 256 for b in red.buckets)
     assert (len(red._hooks) > 0) == (mode == "overlap")
     torch.manual_seed(7)
     data = torch.randn(2 * world, 8)
@@ -190,7 +191,8 @@ def _worker_segments(rank, world, port):
     red = GradReducer(model.parameters(), bucket_mb=32.0, new_bucket_at=[front_last], overlap=False)
     assert [len(b.params) for b in red.buckets] == [4, 2]
     assert len(red.spans([0, 1])) == 1 and red.spans([0, 1])[0].numel() == red.flat.numel()
-    assert [t.numel() for t in red.spans([1])] == [red.buckets[1].numel]
+    assert all(t.numel() >= red.buckets[1].numel and t.data_ptr() == red.buckets[1].flat.data_ptr() for t in red.spans([1]))
+    assert len(red.spans([1])) == 1
     cut = BackwardCut(model[2])
     torch.manual_seed(7)
     data, target = torch.randn(2 * world, 8), torch.randn(2 * world, 4)
