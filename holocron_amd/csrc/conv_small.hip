@@ -23,6 +23,13 @@
 
 namespace csm {
 
+#ifdef HC_CSM_TRACE
+__device__ unsigned long long g_trace[16];   // cycle sums per phase of one wave (scripts/probes/csm_trace.py; experiments only)
+#define CSM_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (trace_on) tr[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define CSM_T(i) do { } while (0)
+#endif
+
 constexpr int SX = 112;        // bytes per staged pixel (C <= 48 -> <= 96 used)
 constexpr int SXO = 144;       // bytes per pixel of the output staging tile (Cout <= 64 -> <= 128 used)
 constexpr int NT = 256, NW = 4;
@@ -572,11 +579,19 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { x3[nr][r] = 0.f; x1[nr][r] = 0.f; }
     };
+#ifdef HC_CSM_TRACE
+    const bool trace_on = blockIdx.x == 8 && tid == 0;
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     auto body = [&](const int ntile, const int buf, const int ptile, f32x16 (&cur3)[2], f32x16 (&cur1)[2],
                     const f32x16 (&prv3)[2], const f32x16 (&prv1)[2]) {
+        CSM_T(0);
         hc_wait_vmcnt<0>();                    // this tile's window (issued one tile ago) and the previous tile's stores
+        CSM_T(1);
         lds_barrier();                         // ... everywhere; all waves are done with the other window and the staging tile
+        CSM_T(2);
         if (ntile < a.ntiles) issue(ntile, buf ^ 1);
+        CSM_T(3);
         const char* wa = smem + a.off_win + buf * a.win_bytes;
         const char* wb = smem + a.off_win2 + buf * a.win2_bytes;
         zero(cur3, cur1);
@@ -585,10 +600,14 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
         store_prep(ptile, voff, rv);
         mfma_range(i0_t{}, i3_t{}, wa, wb, cur3, cur1);   // first kernel row: same basic block as the previous tile's statistics and staging writes
         stage(ptile, prv3, prv1);
+        CSM_T(4);
         lds_barrier();                         // staging tile complete
+        CSM_T(5);
         store(voff, rv);                       // stores drain behind the remaining MFMAs ...
         __builtin_amdgcn_sched_barrier(0);     // ... so they must be ISSUED before them (the scheduler sank them to the loop end)
+        CSM_T(6);
         mfma_range(i3_t{}, iN_t{}, wa, wb, cur3, cur1);
+        CSM_T(7);
     };
     // (Swapping two accumulator sets between "being computed" and "being written out" instead of copying 64 registers per
     // tile was tried: the doubled loop body spills ~75 VGPRs.)
@@ -630,6 +649,9 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
         store(voff, rv);
     }
 
+#ifdef HC_CSM_TRACE
+    if (trace_on) for (int q = 0; q < 8; ++q) g_trace[q] = tr[q];
+#endif
     if (STATS) {
         float* stats3 = d.stats3;
         float* stats1 = d.stats1;
@@ -800,6 +822,12 @@ extern "C" int hc_conv_small(const hc_conv_small_desc* dp, hc_stream_t stream) {
     else csm::launch<3>(a, grid, smem, st);
     return hc_launch_status();
 }
+
+#ifdef HC_CSM_TRACE
+extern "C" int hc_conv_small_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(csm::g_trace), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
+#endif
 
 extern "C" int hc_conv_small_supported(const hc_conv_small_desc* dp) {
     if (dp == nullptr) return 0;
