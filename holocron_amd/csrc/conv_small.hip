@@ -618,9 +618,11 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
     // rows meet in one L2 at the same time and only the rows at the ends of such a run are fetched twice.
     const int per = G >> 3;
     const bool xcd_order = (G & 7) == 0;
-    auto tile_of = [&](const int k) {
-        return xcd_order ? (k * 8 + (int)(blockIdx.x & 7)) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x + k * G;
-    };
+    // (k * 8 + x) * per + s  ==  k * G + (x * per + s): the two orders differ in the first tile only - no select inside the
+    // loop (a branch there gave the loop a separate latch block, and the compiler sank the statistics update into it, behind
+    // the last MFMA)
+    const int tile0 = xcd_order ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    auto tile_of = [&](const int k) { return tile0 + k * G; };
     f32x16 P3[2], P1[2], Q3[2], Q1[2];
     int k = 0;
     int tile = tile_of(0);                     // < ntiles: the grid never exceeds the tile count
