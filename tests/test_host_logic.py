@@ -164,3 +164,48 @@ def test_mixup_and_metrics_host_contract():
     with pytest.raises(_lib.HipError):
         h.utils.metrics.TopKAccuracy().update(torch.rand(2, 10), torch.tensor([1, 2]))
     assert h.utils.metrics.TopKAccuracy().compute() == (0.0, 0.0, 0)
+
+
+def test_small_channel_conv_planner_accepts_and_rejects():
+    """hc_conv_small_supported is pure host code (LDS budget, DMA instruction counts, tile geometry): the RepVGG-A0 shapes the
+    persistent / image-resident kernels are built for are accepted, everything else falls back to the gather-conv (None)."""
+    from holocron_amd.ops import conv as cv
+    ok = [(256, 112, 112, 48, 48, 0), (256, 112, 112, 48, 48, 1), (256, 56, 56, 48, 48, 0), (256, 56, 56, 48, 48, 1),
+          (4, 30, 30, 32, 48, 0), (2, 17, 17, 16, 64, 0), (1, 3, 128, 48, 40, 0),       # persistent kernel: C <= 48, W <= 128
+          (256, 14, 14, 192, 192, 0), (256, 14, 14, 192, 192, 1), (8, 16, 16, 64, 64, 1)]   # image-resident kernel: 64 .. 256 channels
+    no = [(2, 20, 200, 48, 48, 0),      # wider than a 128-pixel tile
+          (2, 20, 112, 40, 48, 0),      # C not a multiple of 16
+          (2, 20, 112, 48, 72, 0),      # more than 64 output channels in the persistent kernel
+          (2, 28, 28, 96, 96, 0), (2, 40, 40, 96, 96, 0),   # 96 channels: map too large to keep an image in LDS
+          (2, 7, 7, 1280, 1280, 0)]
+    for a in ok:
+        d = cv.conv_small_desc(*a)
+        assert d is not None, a
+        assert (d.N, d.H, d.W, d.C, d.Cout, d.mode) == a
+    for a in no:
+        assert cv.conv_small_desc(*a) is None, a
+
+
+def test_weight_gradient_workspace_planner():
+    """hc_conv_wgrad_ws_bytes (host): split-K slabs are whole fp32 copies of the weight tensor, so the workspace is a
+    multiple of it, grows with the number of splits the planner picks, and a degenerate problem needs none of a negative size."""
+    import ctypes as C
+    from holocron_amd import _lib
+    lib = _lib.load()
+
+    def ws(N, Cin, H, Cout, k, s):
+        d = _lib.WgradDesc()
+        OH = (H + 2 * (k // 2) - k) // s + 1
+        d.N, d.IH, d.IW, d.Cin, d.OH, d.OW, d.Cout = N, H, H, Cin, OH, OH, Cout
+        d.KH = d.KW = k
+        d.stride, d.pad = s, k // 2
+        return int(lib.hc_conv_wgrad_ws_bytes(C.byref(d)))
+
+    for (N, Cin, H, Cout, k, s) in [(256, 48, 112, 48, 3, 1), (256, 48, 112, 48, 1, 1), (256, 96, 28, 192, 3, 2),
+                                    (256, 192, 14, 192, 3, 1), (256, 1280, 7, 1280, 3, 1), (2, 16, 9, 32, 3, 1)]:
+        b = ws(N, Cin, H, Cout, k, s)
+        slab = 4 * Cout * Cin * k * k
+        assert b >= slab and b % 4 == 0, (N, Cin, H, Cout, k, s, b)
+        assert b < 64 * slab + (1 << 20) or b < (1 << 31), (b, slab)       # bounded: never more than a few dozen slabs
+    # more images -> at least as many splits for the same layer
+    assert ws(256, 192, 14, 192, 3, 1) >= ws(8, 192, 14, 192, 3, 1)
