@@ -140,7 +140,7 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.drop = (keep, count)
         ctx.st, ctx.meta2 = st, (stride, pad, act, slope, im2col, training)
         ctx.geom = (N, Cin, H, W, Cout, KH, KW, OH, OW)
-        ctx.red = POOL.take((_lib.HC_STAT_REPLICAS, 4, Cout), dev) if training else None
+        ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.HC_STAT_REPLICAS, 4, Cout), dev) if training else (None, -1)
         ctx.has_res = res is not None
         ctx.save_for_backward(src, y, coef, save, gamma, w)
         return out
@@ -158,10 +158,8 @@ class ConvBnActFn(torch.autograd.Function):
         g, g_ld = as_cl_view(g)
         keep, count = ctx.drop
         npix = N * OH * OW
-        red = ctx.red
+        red = POOL.claim(ctx.red, ctx.red_gen, (_lib.HC_STAT_REPLICAS, 4, Cout), dev)   # stale after another forward's POOL.begin()
         ctx.red = None
-        if red is None:
-            red = torch.zeros((_lib.HC_STAT_REPLICAS, 4, Cout), dtype=torch.float32, device=dev)
         check(lib.hc_bn_act_bwd_reduce(ptr(g), g_ld, ptr(y), ptr(coef), ptr(keep), ptr(count), ptr(red), npix, Cout, act, slope,
                                        stream()), "hc_bn_act_bwd_reduce")
         dgam = torch.empty((Cout,), dtype=torch.float32, device=dev)

@@ -142,7 +142,7 @@ class PadConvBnActFn(torch.autograd.Function):
               "hc_bn_act_apply")
         ctx.st, ctx.meta2 = st, (stride, pad, act, slope, training, depthwise, res_C)
         ctx.geom = (N, Cin, Cin_p, H, W, Cout, Cout_p, KH, KW, OH, OW)
-        ctx.red = POOL.take((_lib.HC_STAT_REPLICAS, 4, Cout_p), dev) if training else None
+        ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.HC_STAT_REPLICAS, 4, Cout_p), dev) if training else (None, -1)
         ctx.has_cbias = cbias is not None
         ctx.save_for_backward(x, y, coef, save, gamma, w)
         return out
@@ -159,10 +159,8 @@ class PadConvBnActFn(torch.autograd.Function):
         dev = g.device
         g, g_ld = as_cl_view(g)
         npix = N * OH * OW
-        red = ctx.red
+        red = POOL.claim(ctx.red, ctx.red_gen, (_lib.HC_STAT_REPLICAS, 4, Cout_p), dev)   # stale after another forward's POOL.begin()
         ctx.red = None
-        if red is None:
-            red = torch.zeros((_lib.HC_STAT_REPLICAS, 4, Cout_p), dtype=torch.float32, device=dev)
         check(lib.hc_bn_act_bwd_reduce(ptr(g), g_ld, ptr(y), ptr(coef), None, None, ptr(red), npix, Cout_p, act, slope, stream()),
               "hc_bn_act_bwd_reduce")
         dgam = torch.empty((Cout,), dtype=torch.float32, device=dev)

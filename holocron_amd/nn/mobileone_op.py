@@ -68,10 +68,8 @@ def _io(srcs, lds, npix, Cp):
 def _msbn_backward(ctx, lib, g, out, save, io, B, gammas, Cp, c_valid, npix, dy_ptrs, dy_lds, dev):
     """reduce -> finalize -> apply; returns the per-branch [B, 2, c_valid] parameter gradients."""
     g, g_ld = as_cl_view(g)
-    red = ctx.red
+    red = POOL.claim(ctx.red, getattr(ctx, "red_gen", -1), (R, B + 1, Cp), dev)   # stale after another forward's POOL.begin()
     ctx.red = None
-    if red is None:
-        red = torch.zeros((R, B + 1, Cp), dtype=torch.float32, device=dev)
     check(lib.hc_msbn_bwd_reduce(C.byref(io), ptr(g), g_ld, ptr(out), ptr(red), ctx.act, stream()), "hc_msbn_bwd_reduce")
     pgrad = torch.empty((B, 2, max(c_valid, 1)), dtype=torch.float32, device=dev)
     bcoef = torch.empty((B, 3, Cp), dtype=torch.float32, device=dev)
@@ -154,7 +152,8 @@ class DepthRepFn(torch.autograd.Function):
         ctx.st, ctx.meta = st, meta
         ctx.act, ctx.training = act, training
         ctx.geom = (N, Cp, H, W, OH, OW, P, B)
-        ctx.red = POOL.take((R, B + 1, Cp), dev) if any(t.requires_grad for t in params) or x.requires_grad else None
+        ctx.red, ctx.red_gen = (POOL.take_for_backward((R, B + 1, Cp), dev)
+                                if any(t.requires_grad for t in params) or x.requires_grad else (None, -1))
         ctx.nb = (P, B)
         ctx.save_for_backward(x, out, save, planes, *gammas, *ws)
         return out
@@ -274,7 +273,8 @@ class PointRepFn(torch.autograd.Function):
         ctx.st, ctx.meta = st, meta
         ctx.act, ctx.training = act, training
         ctx.geom = (N, H, W, Cin_p, Cout_p, K, B)
-        ctx.red = POOL.take((R, B + 1, Cout_p), dev) if any(t.requires_grad for t in params) or x.requires_grad else None
+        ctx.red, ctx.red_gen = (POOL.take_for_backward((R, B + 1, Cout_p), dev)
+                                if any(t.requires_grad for t in params) or x.requires_grad else (None, -1))
         ctx.save_for_backward(x, out, save, Y, *gammas)
         return out
 

@@ -26,24 +26,42 @@ STEM_KPAD = 32
 class ZeroPool:
     """One zero-filled fp32 arena per training step instead of ~100 tiny ``torch.zeros`` launches:
     ``begin()`` zeroes the extent used so far with a single memset, ``take(n)`` hands out views.
-    The buffer is allocated during warm-up, so a captured hipGraph keeps using the same addresses."""
+    The buffer is allocated during warm-up, so a captured hipGraph keeps using the same addresses; a buffer that had to
+    grow is retired, not freed, for the same reason.
+
+    Views are only valid until the next ``begin()``: ``gen`` counts the arena's generations, and anything that is taken
+    in one autograd node's forward for use in its backward (``take_for_backward``) is re-validated there with ``claim`` -
+    a second training-mode forward before the first backward (siamese / multi-crop / GAN steps, teacher + student) has
+    re-zeroed and re-issued the same offsets, and the stale node then gets a private zero buffer instead."""
 
     def __init__(self):
         self.buf = None
         self.used = 0
         self.high = 0
-        self.active = False
+        self.depth = 0
+        self.gen = 0
+        self.retired = []
+
+    @property
+    def active(self):
+        return self.depth > 0
 
     def begin(self, device):
+        if self.depth > 0:          # a model called inside another model's forward shares the outer arena
+            self.depth += 1
+            return
         if self.buf is None or self.buf.device != device or self.buf.numel() < self.high:
+            if self.buf is not None:
+                self.retired.append(self.buf)
             self.buf = torch.zeros(max(self.high * 2, 1 << 20), dtype=torch.float32, device=device)
         else:
             self.buf[: max(self.high, 1)].zero_()
         self.used = 0
-        self.active = True
+        self.gen += 1
+        self.depth = 1
 
     def end(self):
-        self.active = False
+        self.depth = max(0, self.depth - 1)
 
     def take(self, shape, device):
         n = 1
@@ -59,6 +77,16 @@ class ZeroPool:
         self.used += n4
         self.high = max(self.high, self.used)
         return out
+
+    def take_for_backward(self, shape, device):
+        """(zeroed view, generation) - pass both to ``claim`` in backward."""
+        return self.take(shape, device), self.gen
+
+    def claim(self, view, gen, shape, device):
+        """The view handed out in forward if the arena has not been recycled since, else a fresh zero buffer."""
+        if view is not None and gen == self.gen:
+            return view
+        return torch.zeros(shape, dtype=torch.float32, device=device)
 
 
 POOL = ZeroPool()
@@ -148,6 +176,62 @@ def _stats_of(x):
     return st
 
 
+# ------------------------------------------------------------------ the three MFMA passes of a block
+# (kept as free functions so that the full-size parity tests drive exactly the launch paths the block uses)
+def block_convs_forward(st, src, w3, w1, geom, stats=None, stem_cin=None):
+    """y3 = conv3x3(src), y1 = conv1x1(src) (+ per-channel sum / sum of squares into stats[0] / stats[1]).
+    ``geom`` = (N, Cin, H, W, Cout); ``src`` is NHWC bf16 (the im2col tensor for the stem, then ``stem_cin`` = 3)."""
+    N, Cin, H, W, Cout = geom
+    f3, f1, _, sf, _ = st.descs(N, Cin, H, W, Cout)
+    OH, OW = f3.OH, f3.OW
+    dev = src.device
+    wp3, wp1, _ = st.ensure_packed(w3, w1)
+    y3 = cv.empty_cl(N, Cout, OH, OW, dev)
+    y1 = cv.empty_cl(N, Cout, OH, OW, dev)
+    fl3 = fl1 = None
+    if stem_cin is not None:  # algorithmic flops of the real 3x3 / 1x1 convs, not of the padded im2col GEMM
+        fl3, fl1 = 2.0 * N * OH * OW * Cout * 9 * stem_cin, 2.0 * N * OH * OW * Cout * stem_cin
+    s3 = None if stats is None else stats[0]
+    s1 = None if stats is None else stats[1]
+    if sf is not None:
+        cv.launch_conv_small_fwd(sf, src, wp3, wp1, y3, y1, s3, s1)
+    else:
+        cv.launch_conv(f3, src, wp3, y3, stats=s3, flops=fl3)
+        cv.launch_conv(f1, src, wp1, y1, stats=s1, flops=fl1)
+    return y3, y1
+
+
+def block_dgrad(st, dy3, dy1, dxid, w3, w1, geom):
+    """dx = conv3x3^T(dy3) + conv1x1^T(dy1) [+ dxid] in one accumulator."""
+    N, Cin, H, W, Cout = geom
+    _, _, dg, _, sdg = st.descs(N, Cin, H, W, Cout)
+    wpd = st.ensure_packed(w3, w1)[2]
+    dx = cv.empty_cl(N, Cin, H, W, dy3.device)
+    if sdg is not None:
+        cv.launch_conv_small_dgrad(sdg, dy3, dy1, wpd, dx, resid=dxid)
+    else:
+        cv.launch_conv(dg, dy3, wpd, dx, src1=dy1, resid=dxid)
+    return dx
+
+
+def block_wgrad(st, src, dy3, dy1, w3, w1, geom, stem_cin=None):
+    """(dW3, dW1) fp32 OIHW from the block input ``src`` and the two branch gradients."""
+    N, Cin, H, W, Cout = geom
+    lib = _lib.load()
+    npix = dy3.shape[0] * dy3.shape[2] * dy3.shape[3]
+    if stem_cin is not None:
+        K = STEM_KPAD
+        dwc3 = cv.conv_wgrad(src, dy3, K, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * 9 * stem_cin)
+        dwc1 = cv.conv_wgrad(src, dy1, K, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * stem_cin)
+        dw3 = torch.empty_like(w3, dtype=torch.float32)
+        check(lib.hc_unpack_im2col_grad(ptr(dwc3), ptr(dw3), Cout, stem_cin, 3, 3, K, 0, stream()), "hc_unpack_im2col_grad")
+        dw1 = dwc1.view(Cout, K)[:, 4 * stem_cin:5 * stem_cin].reshape(Cout, stem_cin, 1, 1).contiguous()
+        return dw3, dw1
+    dw3 = cv.conv_wgrad(src, dy3, Cin, Cout, 3, 3, st.stride, 1)
+    dw1 = cv.conv_wgrad(src, dy1, Cin, Cout, 1, 1, st.stride, 0)
+    return dw3, dw1
+
+
 class RepBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w3, w1, g3, b3, g1, b1, g0, b0, st, relu):
@@ -169,20 +253,9 @@ class RepBlockFn(torch.autograd.Function):
                 x_stats = _stats_of(src if src is not x else x)
         if w3.dtype != torch.float32 or not w3.is_contiguous() or not w1.is_contiguous():
             raise RuntimeError("RepBlock (HIP) expects contiguous fp32 conv weights")
-        wp3, wp1, _ = st.ensure_packed(w3, w1)
-        y3 = cv.empty_cl(N, Cout, OH, OW, dev)
-        y1 = cv.empty_cl(N, Cout, OH, OW, dev)
         R = _lib.HC_STAT_REPLICAS
         stats = POOL.take((2, R, 2, Cout), dev) if st.training else None
-        fl3 = fl1 = None
-        if stem:  # algorithmic flops of the real 3x3 / 1x1 convs, not of the padded im2col GEMM
-            fl3, fl1 = 2.0 * N * OH * OW * Cout * 9 * Cin, 2.0 * N * OH * OW * Cout * Cin
-        if sf is not None:
-            cv.launch_conv_small_fwd(sf, src, wp3, wp1, y3, y1, None if stats is None else stats[0],
-                                     None if stats is None else stats[1])
-        else:
-            cv.launch_conv(f3, src, wp3, y3, stats=None if stats is None else stats[0], flops=fl3)
-            cv.launch_conv(f1, src, wp1, y1, stats=None if stats is None else stats[1], flops=fl1)
+        y3, y1 = block_convs_forward(st, src, w3, w1, (N, Cin, H, W, Cout), stats, Cin if stem else None)
 
         coef = torch.empty((4, Cout), dtype=torch.float32, device=dev)
         save = torch.empty((6, Cout), dtype=torch.float32, device=dev)
@@ -206,7 +279,8 @@ class RepBlockFn(torch.autograd.Function):
 
         out = cv.empty_cl(N, Cout, OH, OW, dev)
         out_stats = POOL.take((_lib.HC_STAT_REPLICAS, 2, Cout), dev) if (st.emit_stats and st.training) else None
-        ctx.red = POOL.take((_lib.HC_STAT_REPLICAS, 4, Cout), dev) if st.training else None   # backward's reduction target, zeroed with the rest
+        # backward's reduction target, zeroed with the rest of the arena; re-validated in backward (ZeroPool.claim)
+        ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.HC_STAT_REPLICAS, 4, Cout), dev) if st.training else (None, -1)
         check(lib.hc_rep_apply(ptr(y3), ptr(y1), ptr(src) if st.identity else None, ptr(coef), ptr(out), ptr(out_stats),
                                N * OH * OW, Cout, 1 if relu else 0, stream()), "hc_rep_apply")
         ctx.st, ctx.relu, ctx.stem = st, relu, stem
@@ -230,10 +304,8 @@ class RepBlockFn(torch.autograd.Function):
         mask_src = out if ctx.relu else torch.ones_like(out)
         xid = src if st.identity else None
 
-        red = ctx.red
-        ctx.red = None
-        if red is None:
-            red = torch.zeros((_lib.HC_STAT_REPLICAS, 4, Cout), dtype=torch.float32, device=dev)
+        red = POOL.claim(ctx.red, ctx.red_gen, (_lib.HC_STAT_REPLICAS, 4, Cout), dev)
+        ctx.red = None      # a second backward through this node (retain_graph) gets a fresh buffer
         check(lib.hc_rep_bwd_reduce(ptr(g), ptr(mask_src), ptr(y3), ptr(y1), ptr(xid), ptr(red), npix, Cout, stream()),
               "hc_rep_bwd_reduce")
         nb = 3 if st.identity else 2
@@ -258,28 +330,14 @@ class RepBlockFn(torch.autograd.Function):
                                    ptr(dxid), npix, Cout, stream()), "hc_rep_bwd_apply")
 
         dx = None
+        geom = (N, Cin, H, W, Cout)
         if ctx.needs_input_grad[0]:
             if ctx.stem:
                 raise NotImplementedError("input gradient of the im2col stem path")
-            _, _, dg, _, sdg = st.descs(N, Cin, H, W, Cout)
-            wpd = st.ensure_packed(w3, w1)[2]
-            dx = cv.empty_cl(N, Cin, H, W, dev)
-            if sdg is not None:
-                cv.launch_conv_small_dgrad(sdg, dy3, dy1, wpd, dx, resid=dxid)
-            else:
-                cv.launch_conv(dg, dy3, wpd, dx, src1=dy1, resid=dxid)
+            dx = block_dgrad(st, dy3, dy1, dxid, w3, w1, geom)
 
         with cv.side_stream_for_wgrad((w3, w1), (src, dy3, dy1)) as side:
-            if ctx.stem:
-                K = STEM_KPAD
-                dwc3 = cv.conv_wgrad(src, dy3, K, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * 9 * Cin)
-                dwc1 = cv.conv_wgrad(src, dy1, K, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * Cin)
-                dw3 = torch.empty_like(w3, dtype=torch.float32)
-                check(lib.hc_unpack_im2col_grad(ptr(dwc3), ptr(dw3), Cout, Cin, 3, 3, K, 0, stream()), "hc_unpack_im2col_grad")
-                dw1 = dwc1.view(Cout, K)[:, 4 * Cin:5 * Cin].reshape(Cout, Cin, 1, 1).contiguous()
-            else:
-                dw3 = cv.conv_wgrad(src, dy3, Cin, Cout, 3, 3, st.stride, 1)
-                dw1 = cv.conv_wgrad(src, dy1, Cin, Cout, 1, 1, st.stride, 0)
+            dw3, dw1 = block_wgrad(st, src, dy3, dy1, w3, w1, geom, Cin if ctx.stem else None)
             side.produced(dw3, dw1)
         return (dx, dw3, dw1, dgam[0], dbet[0], dgam[1], dbet[1],
                 dgam[2] if st.identity else None, dbet[2] if st.identity else None, None, None)

@@ -1,0 +1,379 @@
+"""Per-layer parity at the BASELINE sizes: every distinct block shape of repvgg_a0 at batch 256 (BASELINE.json configs[1],
+SURVEY.md §8d table), the distinct YOLOv4 conv shapes at 608 x 608 / batch 16 (configs[3]) and the ReXNet
+depthwise / pointwise shapes at batch 256 (configs[2]) - HIP kernels against torch-CPU fp32 (`F.conv2d` + the closed-form
+gradients `torch.nn.grad.conv2d_input / conv2d_weight`) on identical bf16-representable operands.
+
+These are the launch geometries that only exist at full size (112 tiles per persistent workgroup in the small-channel conv,
+the many-way split-K weight gradients, the DMA kernels on 1280 channels, XCD-grouped tile orders).  Layers are compared in
+ISOLATION: one block of a randomly initialised network has no chaotic amplification, so the bounds are the rounding of the
+stored dtype and nothing else:
+
+* bf16-stored outputs (conv results, data gradients): rel-L2 <= 2e-3.  One round-to-nearest-even to bf16 has a relative error
+  uniform in +-2^-9 -> RMS 2^-9 / sqrt(3) = 1.13e-3 of the element: 1e-3 (north_star's figure) is below what a single bf16
+  store of an exact result can meet, 2e-3 is 1.8 x the rounding RMS.
+* fp32 outputs (weight gradients, BatchNorm statistics and parameter gradients): rel-L2 <= 2e-4 (fp32 accumulation order).
+* a whole RepBlock forward / backward against the bf16-EMULATING oracle (oracle.repvgg.rep_block_bf16: the reference's
+  arithmetic with a bf16 rounding exactly where the HIP path stores bf16): <= 5e-4 on `out` (isolated 1-ulp flips), 3e-3 on dx
+  (the identity-branch gradient is stored in bf16 before the data-gradient kernel adds it), 2e-4 on every fp32 gradient;
+  against the plain fp32 reference block: out <= 4e-3 (three stored roundings: y3, y1, out).
+
+The batch can be lowered with HC_FULLSIZE_N for a quick run; the default is the BASELINE size.
+"""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+N_C2 = int(os.environ.get("HC_FULLSIZE_N", "256"))
+N_C4 = int(os.environ.get("HC_FULLSIZE_N_YOLO", "16"))
+TOL_BF16 = 2e-3
+TOL_F32 = 2e-4
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def nchw(t):
+    return t.float().cpu().contiguous()
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# (Cin, Cout, H, stride, identity): the ten rows of SURVEY.md §8d (repvgg_a0, 224 x 224 input)
+C2_BLOCKS = [
+    (3, 48, 224, 2, False),
+    (48, 48, 112, 1, True),
+    (48, 48, 112, 2, False),
+    (48, 48, 56, 1, True),
+    (48, 96, 56, 2, False),
+    (96, 96, 28, 1, True),
+    (96, 192, 28, 2, False),
+    (192, 192, 14, 1, True),
+    (192, 1280, 14, 2, False),
+    (1280, 1280, 7, 1, True),
+]
+C2_IDS = ["%d@%d-%d_s%d" % (c[0], c[2], c[1], c[3]) for c in C2_BLOCKS]
+
+
+def _stat_check(stats, ref, what):
+    """stats [R][2][C] replicas of sum / sum of squares vs the fp32 conv result `ref` (NCHW)."""
+    s = stats.double().sum(0).cpu()
+    r = ref.double()
+    cnt = r.numel() / r.shape[1]
+    s1, s2 = r.sum((0, 2, 3)), (r * r).sum((0, 2, 3))
+    # a sum of signed values cancels: bound its error against the magnitude the accumulation carries
+    scale1 = torch.sqrt(s2 * cnt) + 1e-30
+    assert float(((s[0] - s1).abs() / scale1).max()) < TOL_F32, (what, "sum")
+    assert rel_l2(s[1], s2) < TOL_F32, (what, "sumsq")
+
+
+@pytest.mark.parametrize("cfg", C2_BLOCKS, ids=C2_IDS)
+def test_c2_conv_passes_vs_fp32_cpu(cfg):
+    """forward 3x3 + 1x1 (with the statistics epilogue), fused data gradient and both weight gradients of one block shape,
+    through the same launch helpers RepBlockFn uses (nn/repblock_op.py: block_convs_forward / block_dgrad / block_wgrad).
+    Reference ops: aten::convolution / convolution_backward behind nn.Conv2d (models/utils.py:73, repvgg.py:57-60)."""
+    from holocron_amd import _lib
+    from holocron_amd.nn import repblock_op as rb
+    from holocron_amd.ops import conv as cv
+    cin, cout, H, stride, ident = cfg
+    N = N_C2
+    g = gen(1000 + cin + cout + H)
+    x = bf16r(torch.rand((N, cin, H, H), generator=g))
+    w3 = bf16r(torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cout * 9)) ** 0.5)
+    w1 = bf16r(torch.randn((cout, cin, 1, 1), generator=g) * (2.0 / cout) ** 0.5)
+    dev = torch.device("cuda:0")
+    st = rb.RepState(stride, ident)
+    stem = cin % 16 != 0
+    xg = x.to(dev)
+    src = cv.im2col_small(xg, 3, 3, stride, 1, rb.STEM_KPAD) if stem else cv.to_cl_bf16(xg)
+    w3g, w1g = w3.to(dev), w1.to(dev)
+    geom = (N, cin, H, H, cout)
+    stats = torch.zeros((2, _lib.HC_STAT_REPLICAS, 2, cout), device=dev)
+    y3, y1 = rb.block_convs_forward(st, src, w3g, w1g, geom, stats, cin if stem else None)
+    torch.cuda.synchronize()
+
+    c3 = F.conv2d(x, w3, None, stride, 1)
+    c1 = F.conv2d(x, w1, None, stride, 0)
+    e3, e1 = rel_l2(nchw(y3), c3), rel_l2(nchw(y1), c1)
+    print(f"{cfg}: fwd y3 {e3:.2e} y1 {e1:.2e}")
+    assert e3 < TOL_BF16 and e1 < TOL_BF16, (cfg, e3, e1)
+    _stat_check(stats[0], c3, (cfg, "3x3"))
+    _stat_check(stats[1], c1, (cfg, "1x1"))
+
+    dy3 = bf16r(torch.randn(c3.shape, generator=g))
+    dy1 = bf16r(torch.randn(c1.shape, generator=g))
+    dy3g, dy1g = cv.to_cl_bf16(dy3.to(dev)), cv.to_cl_bf16(dy1.to(dev))
+    del c3, c1, y3, y1
+    if not stem:
+        res = bf16r(torch.randn(x.shape, generator=g)) if ident else None
+        resg = None if res is None else cv.to_cl_bf16(res.to(dev))
+        dx = rb.block_dgrad(st, dy3g, dy1g, resg, w3g, w1g, geom)
+        torch.cuda.synchronize()
+        ref = torch.nn.grad.conv2d_input(x.shape, w3, dy3, stride, 1) + torch.nn.grad.conv2d_input(x.shape, w1, dy1, stride, 0)
+        if res is not None:
+            ref = ref + res
+        ed = rel_l2(nchw(dx), ref)
+        print(f"{cfg}: dgrad {ed:.2e}")
+        assert ed < TOL_BF16, (cfg, ed)
+        del ref, dx
+    dw3, dw1 = rb.block_wgrad(st, src, dy3g, dy1g, w3g, w1g, geom, cin if stem else None)
+    torch.cuda.synchronize()
+    r3 = torch.nn.grad.conv2d_weight(x, w3.shape, dy3, stride, 1)
+    r1 = torch.nn.grad.conv2d_weight(x, w1.shape, dy1, stride, 0)
+    ew3, ew1 = rel_l2(dw3.cpu(), r3), rel_l2(dw1.cpu(), r1)
+    print(f"{cfg}: wgrad 3x3 {ew3:.2e} 1x1 {ew1:.2e}")
+    assert ew3 < TOL_F32 and ew1 < TOL_F32, (cfg, ew3, ew1)
+
+
+@pytest.mark.parametrize("cfg", C2_BLOCKS, ids=C2_IDS)
+def test_c2_block_vs_oracles(cfg):
+    """one RepBlock training forward + backward (all BatchNorm passes included) at batch 256 against the bf16-emulating
+    oracle (tight) and the plain fp32 reference block (repvgg.py:71-73; three stored roundings)."""
+    import holocron_amd as h
+    from oracle import repvgg as orv
+    cin, cout, H, stride, ident = cfg
+    N = N_C2
+    g = gen(2000 + cin + cout + H)
+    blk = h.models.RepBlock(cin, cout, stride, ident)
+    sd = blk.state_dict()
+    for k, v in sd.items():
+        if v.dim() == 4:
+            v.copy_(bf16r(torch.randn(v.shape, generator=g) * (2.0 / (v.shape[0] * v.shape[2] * v.shape[3])) ** 0.5))
+        elif k.endswith("weight"):
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+        elif k.endswith("bias"):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.2)
+    state = {k: v.clone() for k, v in sd.items()}
+    x = bf16r(torch.rand((N, cin, H, H), generator=g))
+    blk = blk.cuda().train()
+    xg = x.cuda().requires_grad_(cin % 16 == 0)
+    out = blk(xg)
+    r = bf16r(torch.randn(out.shape, generator=g))
+    (out.float() * r.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    out_h = nchw(out.detach())
+    grads_h = {n: p.grad.detach().cpu() for n, p in blk.named_parameters()}
+    dx_h = nchw(xg.grad) if xg.grad is not None else None
+    after = {k: v.detach().cpu().clone() for k, v in blk.state_dict().items()}
+    del out, xg
+
+    def run(fn):
+        osd = {"blk." + k: v.clone() for k, v in state.items()}
+        keys = orv.trainable_keys(osd)
+        for k in keys:
+            osd[k].requires_grad_(True)
+        xe = x.clone().requires_grad_(True)
+        o = fn(xe, osd, "blk", stride, ident, True)
+        gr = torch.autograd.grad((o * r).sum(), [xe] + [osd[k] for k in keys])
+        return o.detach(), gr[0], {k[4:]: v for k, v in zip(keys, gr[1:])}, osd
+
+    eo, edx, eg, esd = run(orv.rep_block_bf16)
+    e_out = rel_l2(out_h, eo)
+    mism = float((out_h != eo).double().mean())
+    print(f"{cfg}: out vs bf16 oracle {e_out:.2e} (differing elements {mism:.2e})")
+    assert e_out < 5e-4, (cfg, e_out)
+    if dx_h is not None:
+        e = rel_l2(dx_h, bf16r(edx))
+        print(f"{cfg}: dx vs bf16 oracle {e:.2e}")
+        assert e < 3e-3, (cfg, e)
+    for n, gh in grads_h.items():
+        e = rel_l2(gh, eg[n])
+        print(f"{cfg}: d {n} vs bf16 oracle {e:.2e}")
+        assert e < TOL_F32 or float((gh - eg[n]).abs().max()) < 1e-5 * float(eg[n].abs().max() + 1), (cfg, n, e)
+    for k, v in after.items():
+        ref = esd["blk." + k].detach()
+        if "running" in k:
+            assert rel_l2(v, ref) < 1e-5, (cfg, k)
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(ref) == 1
+    del eo, edx, eg, esd
+    fo, fdx, fg, _ = run(orv.rep_block)
+    e_ref = rel_l2(out_h, fo)
+    print(f"{cfg}: out vs fp32 reference {e_ref:.2e}; dW3 vs fp32 reference "
+          f"{rel_l2(grads_h['branches.0.0.weight'], fg['branches.0.0.weight']):.2e}")
+    assert e_ref < 4e-3, (cfg, e_ref)
+    # gradients against the un-rounded reference: pre-activations within the bf16 rounding of zero flip their ReLU mask (a
+    # property of bf16 storage, measured ~1e-3 of the elements), so this is a sanity bound, the kernel-level bound is above
+    assert rel_l2(grads_h["branches.0.0.weight"], fg["branches.0.0.weight"]) < 0.1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# YOLOv4 @ 608 x 608: every distinct (Cin, H, Cout, k, stride) of backbone, neck and head
+C4_CONVS = [
+    (3, 608, 32, 3, 1), (32, 608, 64, 3, 2), (64, 304, 128, 1, 1), (64, 304, 32, 1, 1), (32, 304, 64, 3, 1), (64, 304, 64, 1, 1),
+    (128, 304, 64, 1, 1), (64, 304, 128, 3, 2), (128, 152, 128, 1, 1), (64, 152, 64, 1, 1), (64, 152, 64, 3, 1),
+    (128, 152, 256, 3, 2), (256, 76, 256, 1, 1), (128, 76, 128, 1, 1), (128, 76, 128, 3, 1), (256, 76, 512, 3, 2),
+    (512, 38, 512, 1, 1), (256, 38, 256, 1, 1), (256, 38, 256, 3, 1), (512, 38, 1024, 3, 2), (1024, 19, 1024, 1, 1),
+    (512, 19, 512, 1, 1), (512, 19, 512, 3, 1),
+    (1024, 19, 512, 1, 1), (512, 19, 1024, 3, 1), (2048, 19, 512, 1, 1), (512, 19, 256, 1, 1), (512, 38, 256, 1, 1),
+    (256, 38, 512, 3, 1), (256, 38, 128, 1, 1), (256, 76, 128, 1, 1), (128, 76, 256, 3, 1),
+    (256, 76, 256, 1, 1), (128, 76, 256, 3, 2), (256, 38, 512, 3, 2),
+]
+C4_IDS = ["%d@%d-%d_k%d_s%d" % c for c in C4_CONVS]
+
+
+def _conv_passes(N, cin, H, cout, k, stride, seed, dev):
+    """forward (+ statistics), data gradient and weight gradient of one plain conv through the conv_sequence launch path
+    (nn/convbn_op.py: cv.launch_conv on fwd_desc / dgrad_desc, cv.conv_wgrad) against torch-CPU fp32."""
+    from holocron_amd import _lib
+    from holocron_amd.ops import conv as cv
+    g = gen(seed)
+    pad = k // 2
+    x = bf16r(torch.rand((N, cin, H, H), generator=g))
+    w = bf16r(torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cout * k * k)) ** 0.5)
+    xg, wg = x.to(dev), w.to(dev)
+    stats = torch.zeros((_lib.HC_STAT_REPLICAS, 2, cout), device=dev)
+    y = cv.conv2d(xg, wg, None, stride, pad, stats=stats)
+    torch.cuda.synchronize()
+    c = F.conv2d(x, w, None, stride, pad)
+    e = rel_l2(nchw(y), c)
+    assert e < TOL_BF16, ("fwd", e)
+    _stat_check(stats, c, "stats")
+    dy = bf16r(torch.randn(c.shape, generator=g))
+    dyg = cv.to_cl_bf16(dy.to(dev))
+    del c, y
+    out = {"fwd": e}
+    if cin % 16 == 0:
+        src = cv.to_cl_bf16(xg)
+        d = cv.dgrad_desc(N, cin, H, H, cout, [(k, k, pad, 0, 0)], stride)
+        dx = cv.empty_cl(N, cin, H, H, dev)
+        cv.launch_conv(d, dyg, cv.pack_weight(wg, 1), dx)
+        torch.cuda.synchronize()
+        ed = rel_l2(nchw(dx), torch.nn.grad.conv2d_input(x.shape, w, dy, stride, pad))
+        assert ed < TOL_BF16, ("dgrad", ed)
+        dw = cv.conv_wgrad(src, dyg, cin, cout, k, k, stride, pad)
+        torch.cuda.synchronize()
+        ew = rel_l2(dw.cpu(), torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad))
+        assert ew < TOL_F32, ("wgrad", ew)
+        out.update(dgrad=ed, wgrad=ew)
+    else:   # Cin = 3: explicit im2col, the weight gradient is a GEMM over the column tensor
+        K = cin * k * k
+        Kpad = (K + 15) // 16 * 16
+        col = cv.im2col_small(xg, k, k, stride, pad, Kpad)
+        dwc = cv.conv_wgrad(col, dyg, Kpad, cout, 1, 1, 1, 0)
+        torch.cuda.synchronize()
+        ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)        # [co][ci][kh][kw]
+        got = dwc.view(cout, Kpad)[:, :K].reshape(cout, k, k, cin).permute(0, 3, 1, 2).cpu()
+        ew = rel_l2(got, ref)
+        assert ew < TOL_F32, ("wgrad im2col", ew)
+        out.update(wgrad=ew)
+    return out
+
+
+@pytest.mark.parametrize("cfg", C4_CONVS, ids=C4_IDS)
+def test_c4_yolov4_conv_shapes_vs_fp32_cpu(cfg):
+    cin, H, cout, k, stride = cfg
+    r = _conv_passes(N_C4, cin, H, cout, k, stride, 3000 + cin + cout + H + k, torch.device("cuda:0"))
+    print(cfg, {a: "%.2e" % b for a, b in r.items()})
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ReXNet-1.0x @ 224 x 224, batch 256: depthwise 3x3 and pointwise shapes of the blocks
+C3_DW = [(32, 112, 1), (96, 112, 2), (162, 56, 1), (228, 56, 2), (300, 28, 1), (366, 28, 2), (432, 14, 1), (768, 14, 2), (1044, 7, 1)]
+C3_PW = [(32, 112, 16), (16, 112, 96), (96, 56, 27), (27, 56, 162), (228, 28, 50), (366, 14, 72), (768, 7, 140), (185, 7, 1280)]
+
+
+@pytest.mark.parametrize("cfg", C3_DW, ids=["dw%d@%d_s%d" % c for c in C3_DW])
+def test_c3_rexnet_depthwise_vs_fp32_cpu(cfg):
+    """hc_dw3x3_fwd / dgrad / wgrad (csrc/dwconv.hip; reference: the groups=C nn.Conv2d of rexnet.py:104-112) with the
+    channel count padded to a multiple of 16 as nn/mbconv_op.py does."""
+    import ctypes as C
+    from holocron_amd import _lib
+    from holocron_amd._lib import check, ptr, stream
+    from holocron_amd.nn.mbconv_op import ceil16
+    from holocron_amd.ops import conv as cv
+    ch, H, stride = cfg
+    N = N_C2
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    g = gen(4000 + ch + H)
+    Cp = ceil16(ch)
+    x = bf16r(torch.rand((N, ch, H, H), generator=g))
+    w = torch.randn((ch, 1, 3, 3), generator=g) * 0.3        # depthwise taps stay fp32 in the kernels
+    xp = torch.zeros((N, Cp, H, H))
+    xp[:, :ch] = x
+    xg = cv.to_cl_bf16(xp.to(dev))
+    wf = torch.empty((9, Cp), dtype=torch.float32, device=dev)
+    wb = torch.empty((9, Cp), dtype=torch.float32, device=dev)
+    wg = w.to(dev).contiguous()
+    check(lib.hc_dw3x3_pack(ptr(wg), ptr(wf), ch, Cp, 0, stream()), "hc_dw3x3_pack")
+    check(lib.hc_dw3x3_pack(ptr(wg), ptr(wb), ch, Cp, 1, stream()), "hc_dw3x3_pack")
+    OH = (H + 2 - 3) // stride + 1
+    y = cv.empty_cl(N, Cp, OH, OH, dev)
+    stats = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Cp), device=dev)
+    check(lib.hc_dw3x3_fwd(ptr(xg), ptr(wf), ptr(y), ptr(stats), N, H, H, Cp, stride, stream()), "hc_dw3x3_fwd")
+    torch.cuda.synchronize()
+    c = F.conv2d(x, w, None, stride, 1, groups=ch)
+    e = rel_l2(nchw(y)[:, :ch], c)
+    assert e < TOL_BF16, (cfg, "fwd", e)
+    assert float(nchw(y)[:, ch:].abs().max()) == 0.0 if Cp > ch else True
+    _stat_check(stats[:, :, :ch], c, (cfg, "stats"))
+    dy = bf16r(torch.randn(c.shape, generator=g))
+    dyp = torch.zeros((N, Cp, OH, OH))
+    dyp[:, :ch] = dy
+    dyg = cv.to_cl_bf16(dyp.to(dev))
+    dx = cv.empty_cl(N, Cp, H, H, dev)
+    check(lib.hc_dw3x3_dgrad(ptr(dyg), ptr(wf), ptr(wb), ptr(dx), N, H, H, Cp, stride, stream()), "hc_dw3x3_dgrad")
+    torch.cuda.synchronize()
+    ed = rel_l2(nchw(dx)[:, :ch], torch.nn.grad.conv2d_input(x.shape, w, dy, stride, 1, groups=ch))
+    assert ed < TOL_BF16, (cfg, "dgrad", ed)
+    ws = torch.empty((lib.hc_dw3x3_wgrad_ws_bytes(Cp) // 4,), dtype=torch.float32, device=dev)
+    dw = torch.empty((ch, 1, 3, 3), dtype=torch.float32, device=dev)
+    check(lib.hc_dw3x3_wgrad(ptr(xg), ptr(dyg), ptr(ws), ptr(dw), N, H, H, Cp, ch, stride, 0, stream()), "hc_dw3x3_wgrad")
+    torch.cuda.synchronize()
+    ew = rel_l2(dw.cpu(), torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, 1, groups=ch))
+    assert ew < TOL_F32, (cfg, "wgrad", ew)
+    print(cfg, f"fwd {e:.2e} dgrad {ed:.2e} wgrad {ew:.2e}")
+
+
+@pytest.mark.parametrize("cfg", C3_PW, ids=["pw%d@%d-%d" % c for c in C3_PW])
+def test_c3_rexnet_pointwise_vs_fp32_cpu(cfg):
+    """1x1 convs with channel counts that are not multiples of 16: activations carry ceil16(C) channels per pixel with zero
+    padding, weights zero rows / columns (nn/mbconv_op.py)."""
+    from holocron_amd import _lib
+    from holocron_amd.nn.mbconv_op import ceil16
+    from holocron_amd.ops import conv as cv
+    cin, H, cout = cfg
+    N = N_C2
+    dev = torch.device("cuda:0")
+    g = gen(5000 + cin + cout + H)
+    Ci, Co = ceil16(cin), ceil16(cout)
+    x = bf16r(torch.rand((N, cin, H, H), generator=g))
+    w = bf16r(torch.randn((cout, cin, 1, 1), generator=g) * (2.0 / cout) ** 0.5)
+    xp = torch.zeros((N, Ci, H, H))
+    xp[:, :cin] = x
+    wp = torch.zeros((Co, Ci, 1, 1))
+    wp[:cout, :cin] = w
+    xg, wg = cv.to_cl_bf16(xp.to(dev)), wp.to(dev)
+    stats = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Co), device=dev)
+    d = cv.fwd_desc(N, Ci, H, H, Co, 1, 1, 1, 0)
+    y = cv.empty_cl(N, Co, H, H, dev)
+    cv.launch_conv(d, xg, cv.pack_weight(wg, 0), y, stats=stats)
+    torch.cuda.synchronize()
+    c = F.conv2d(x, w)
+    e = rel_l2(nchw(y)[:, :cout], c)
+    assert e < TOL_BF16, (cfg, "fwd", e)
+    _stat_check(stats[:, :, :cout], c, (cfg, "stats"))
+    dy = bf16r(torch.randn(c.shape, generator=g))
+    dyp = torch.zeros((N, Co, H, H))
+    dyp[:, :cout] = dy
+    dyg = cv.to_cl_bf16(dyp.to(dev))
+    dd = cv.dgrad_desc(N, Ci, H, H, Co, [(1, 1, 0, 0, 0)], 1)
+    dx = cv.empty_cl(N, Ci, H, H, dev)
+    cv.launch_conv(dd, dyg, cv.pack_weight(wg, 1), dx)
+    torch.cuda.synchronize()
+    ed = rel_l2(nchw(dx)[:, :cin], torch.nn.grad.conv2d_input(x.shape, w, dy))
+    assert ed < TOL_BF16, (cfg, "dgrad", ed)
+    dw = cv.conv_wgrad(xg, dyg, Ci, Co, 1, 1, 1, 0)
+    torch.cuda.synchronize()
+    ew = rel_l2(dw.cpu()[:cout, :cin], torch.nn.grad.conv2d_weight(x, w.shape, dy))
+    assert ew < TOL_F32, (cfg, "wgrad", ew)
+    print(cfg, f"fwd {e:.2e} dgrad {ed:.2e} wgrad {ew:.2e}")

@@ -131,9 +131,22 @@ def test_repvgg_small_train_steps(golden):
     cos = float(torch.nn.functional.cosine_similarity(flat_h.double(), flat_e.double(), dim=0))
     assert cos > 0.98, cos
     assert rel_l2(flat_h, flat_e) < 0.2
+    before = {n: p.detach().cpu().clone() for n, p in m2.named_parameters()}
+    grads_h = {n: p.grad.detach().cpu().clone() for n, p in m2.named_parameters()}
     opt2.step()
+    # (i) the optimizer step itself, exactly: the oracle's AdaBelief applied to the HIP path's OWN gradients
+    from oracle.optim import adabelief_step
     for n, p in m2.named_parameters():
-        assert torch.allclose(p.detach().cpu(), sd[n], rtol=0, atol=2.5e-3), n   # first AdaBelief step moves every weight by ~lr/beta1
+        want = before[n].clone()
+        adabelief_step(want, grads_h[n], torch.zeros_like(want), torch.zeros_like(want), 1, 1e-3, 0.95, 0.99, 1e-6, 0.0)
+        assert torch.allclose(p.detach().cpu(), want, rtol=1e-5, atol=1e-6), n
+    # (ii) the update against the oracle's: a first AdaBelief step is ~ -lr/beta1 * sign(g) per element (1.05e-3), so "close to the
+    # oracle's weights" would also pass with no step or a step the wrong way; compare the UPDATES: direction and size
+    d_h = torch.cat([(p.detach().cpu() - before[n]).flatten() for n, p in m2.named_parameters()]).double()
+    d_e = torch.cat([(sd[n] - before[n]).flatten() for n, _ in m2.named_parameters()]).double()
+    cos_u = float(torch.nn.functional.cosine_similarity(d_h, d_e, dim=0))
+    assert cos_u > 0.8, cos_u
+    assert float(d_h.abs().max()) < 1.06e-3 and abs(float(d_h.abs().mean()) / float(d_e.abs().mean()) - 1) < 0.1
     with torch.no_grad():
         m.eval()
         ev = m(x)
@@ -160,3 +173,29 @@ def test_repvgg_a0_forward_vs_oracle_eval():
         ref = orv.forward(sd, x, nb, ch, training=False)
         out = m.cuda().eval()(x.cuda())
     assert rel_l2(out.float().cpu(), ref) < 3e-2
+
+
+def test_two_forwards_before_backward():
+    """loss = f(model(x1)) + f(model(x2)) (siamese / multi-crop / GAN-style steps): the second forward recycles the zero arena the
+    first forward took its backward reduction buffer from (nn/repblock_op.py ZeroPool.claim).  The gradients must equal
+    the sum of the two single-forward gradients."""
+    import holocron_amd as h
+    torch.manual_seed(3)
+    cfg = dict(num_blocks=[1, 1, 1, 1, 1], planes=[16, 16, 32, 64, 64], width_multiplier=1, final_width_multiplier=1)
+    m = h.models.RepVGG(**cfg).cuda().train()
+    x1 = torch.rand(8, 3, 64, 64, device="cuda")
+    x2 = torch.rand(8, 3, 64, 64, device="cuda")
+
+    def grads(fn):
+        for p in m.parameters():
+            p.grad = None
+        fn().backward()
+        torch.cuda.synchronize()
+        return [p.grad.detach().clone() for p in m.parameters()]
+
+    g1 = grads(lambda: m(x1).float().square().mean())
+    g2 = grads(lambda: m(x2).float().square().mean())
+    g12 = grads(lambda: m(x1).float().square().mean() + m(x2).float().square().mean())
+    # run to run (statistics atomics) the same gradient moves by ~1e-3; a recycled reduction buffer is O(1) wrong
+    for a, b, c, (n, _) in zip(g1, g2, g12, m.named_parameters()):
+        assert rel_l2(c, a + b) < 2e-2, (n, rel_l2(c, a + b))
