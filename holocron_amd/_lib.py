@@ -46,6 +46,16 @@ class WgradDesc(C.Structure):
                 ("beta", c_int32)]
 
 
+HC_WREP_MAX_JOBS = 16
+
+
+class RepWgradDesc(C.Structure):
+    _fields_ = [("x", c_void_p * HC_WREP_MAX_JOBS), ("dy3", c_void_p * HC_WREP_MAX_JOBS), ("dy1", c_void_p * HC_WREP_MAX_JOBS),
+                ("dw3", c_void_p * HC_WREP_MAX_JOBS), ("dw1", c_void_p * HC_WREP_MAX_JOBS), ("ws", c_void_p),
+                ("njobs", c_int32), ("N", c_int32), ("IH", c_int32), ("IW", c_int32), ("Cin", c_int32), ("OH", c_int32),
+                ("OW", c_int32), ("Cout", c_int32), ("stride", c_int32), ("accumulate", c_int32)]
+
+
 class PackItem(C.Structure):
     _fields_ = [("w", c_void_p), ("dst", c_void_p), ("Cout", c_int32), ("Cin", c_int32), ("KH", c_int32),
                 ("KW", c_int32), ("mode", c_int32), ("tap0", c_int32), ("T", c_int32), ("ld", c_int32)]
@@ -148,6 +158,10 @@ SIGNATURES = {
     "hc_conv_small_supported": (c_int32, [C.POINTER(ConvSmallDesc)]),
     "hc_conv_wgrad_ws_bytes": (c_int64, [C.POINTER(WgradDesc)]),
     "hc_conv_wgrad": (c_int32, [C.POINTER(WgradDesc), c_void_p]),
+    "hc_rep_wgrad_supported": (c_int32, [C.POINTER(RepWgradDesc)]),
+    "hc_rep_wgrad_ws_bytes": (c_int64, [C.POINTER(RepWgradDesc)]),
+    "hc_rep_wgrad_plan": (c_int32, [C.POINTER(RepWgradDesc), c_void_p]),
+    "hc_rep_wgrad": (c_int32, [C.POINTER(RepWgradDesc), c_void_p]),
     "hc_pack_conv_weight": (c_int32, [c_void_p, c_void_p] + [c_int32] * 7 + [c_void_p]),
     "hc_pack_conv_weights_multi": (c_int32, [c_void_p, c_int32, c_int64, c_void_p]),
     "hc_nchw_to_nhwc_bf16": (c_int32, [c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),

@@ -22,6 +22,7 @@ SOURCES = {
     "conv_wgrad.hip": [],
     "conv_wgrad_tr.hip": [],
     "conv_wgrad_dma.hip": [],
+    "conv_wgrad_rep.hip": [],
     "rep_bn.hip": [],
     "optim.hip": [],
     "nhwc_ops.hip": [],

@@ -1,0 +1,491 @@
+// Both weight gradients of a RepVGG block - dW3 (3x3, pad 1) and dW1 (1x1, pad 0), same stride - in ONE launch, from ONE
+// staging of the block input, for up to 16 blocks of the same shape at a time.
+//
+//   dW3[co][ci][kh][kw] = sum_m dy3[m][co] * x[pix(m) + (kh-1, kw-1)][ci]
+//   dW1[co][ci]         = sum_m dy1[m][co] * x[pix(m)][ci]                       m = (n, oy, ox),  pix(m) = (n, s*oy, s*ox)
+//
+// Replaces the two aten::convolution_backward(weight) calls behind the two nn.Conv2d of a RepBlock
+// (holocron/models/classification/repvgg.py:57-60 via models/utils.py:73).
+//
+// Why one kernel.  The separate kernels (conv_wgrad_tr.hip) launch 3x3 and 1x1 apart (x staged twice), stage through
+// registers (no load / MFMA overlap with one workgroup per CU), and need a ~40-way split-K on the 14 x 14 layers whose fp32
+// slabs double the HBM traffic of the layer.  Here:
+//   * a workgroup owns a (16*MR ci) x (16*NR co) tile of ALL TEN taps.  Its four waves split the taps, not the tile: wave kh
+//     (0..2) accumulates kernel row kh (3 taps) against dy3, wave 3 the 1x1 against dy1 (the 1x1 input pixel is tap (1,1)).
+//     A wave's three taps share their dy fragments, and nobody re-reads a neighbour's x fragments: 2*(3*MR + NR) transposing
+//     LDS reads per 3*MR*NR MFMAs instead of 2*(9*MR + NR) per 9*MR*NR/WAVES.
+//   * operands stream HBM/L2 -> LDS by DMA (buffer_load ... lds) in their natural NHWC layout, one step (R output rows)
+//     ahead of the MFMAs, no staging registers.  The batch is walked as ONE tall image: image n owns virtual input rows
+//     [n*PI, (n+1)*PI), PI = s*(OH+1), row 0 = the zero halo row (out-of-range DMA -> zeros), and virtual output rows
+//     [n*(OH+1), ...) whose last one is a gap row with dy = 0.  x rows live in a ring of LDS row slots (slot = V mod NSLOT):
+//     every input row is fetched once per workgroup, whatever the kernel height, and steps never see an image boundary.
+//   * up to 16 blocks of one shape (the 14 identical 192-channel blocks of repvgg_a0) share a launch: blockIdx ->
+//     (block, tile, split).  With 14 x 8 tiles the pixel range is split 2 ways instead of 41, the slab traffic drops from
+//     ~100% of the layer's input bytes to ~8%, and one reduce launch serves all 28 gradients.
+//   * MFMA operands come out of LDS through ds_read_b64_tr_b16 exactly as in conv_wgrad_tr.hip (semantics probed in
+//     scripts/probes/tr16_probe.hip); v_mfma_f32_16x16x32_bf16, A = x (rows = ci), B = dy (cols = co), k = 32 pixels.
+//
+// Output: fp32 slabs [job][split][co][10][ci] -> wrep_reduce_kernel sums the splits in a FIXED order (no atomics: the result
+// is bit-reproducible) and writes the reference layouts OIHW [co][ci][3][3] and [co][ci][1][1].
+#include "common.h"
+#include <stdlib.h>
+#include "../../include/holocron_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) short wr_s16x4;
+typedef __attribute__((address_space(3))) wr_s16x4 wr_lds_s16x4;
+
+namespace wrep {
+
+struct Args {
+    const void* x[HC_WREP_MAX_JOBS];
+    const void* dy3[HC_WREP_MAX_JOBS];
+    const void* dy1[HC_WREP_MAX_JOBS];
+    float* ws;
+    int N, IH, IW, Cin, OH, OW, Cout, s;
+    int njobs, nsplit, steps_per_split, total_steps;
+    int n_ci, n_co;             // tiles
+    int R, P, P32;              // output rows per step, pixels per step, padded to 32
+    int PO, PI;                 // virtual rows per image: output (OH + 1), input (s * PO)
+    int XW, SX, XJ, ROWB;       // staged pixels per x row, LDS pixel stride, DMA instructions / bytes per row
+    int NSLOT, PF;              // ring slots, steps in flight
+    int SD, DJ, DHALF, DSLOT;   // dy: LDS pixel stride, DMA instructions per tensor, bytes per tensor / per stage
+    int off_dy, off_tab, off_sink;
+    int nd;                     // DMA instructions per wave and step (uniform: padded with zero-fill dummies when PF > 1)
+};
+
+__device__ __forceinline__ wr_s16x4 tr_read(const char* lds_base, int off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((wr_lds_s16x4*)(lds_base + off));
+}
+__device__ __forceinline__ bf16x8 tr_pair(const char* lds_base, int o0, int o1) {
+    const wr_s16x4 lo = tr_read(lds_base, o0), hi = tr_read(lds_base, o1);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n) for a wave-uniform runtime n
+    switch (n) {
+#define WR_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        WR_W(0) WR_W(1) WR_W(2) WR_W(3) WR_W(4) WR_W(5) WR_W(6) WR_W(7) WR_W(8) WR_W(9) WR_W(10) WR_W(11) WR_W(12) WR_W(13)
+        WR_W(14) WR_W(15) WR_W(16) WR_W(17) WR_W(18) WR_W(19) WR_W(20) WR_W(21) WR_W(22) WR_W(23) WR_W(24) WR_W(25) WR_W(26)
+        WR_W(27) WR_W(28) WR_W(29) WR_W(30) WR_W(31) WR_W(32)
+#undef WR_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+constexpr int XJW = 4;   // x DMA instructions per row and wave (rows up to 12 KB)
+constexpr int DJW = 4;   // dy DMA instructions per tensor and wave (stages up to 16 KB per tensor)
+
+template <int MR, int NR>
+__global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- blockIdx -> (job, split, tile): the tiles of one (job, split) - same pixels, different channels - share an XCD's L2
+    const int NT = a.n_ci * a.n_co;
+    const int xcd = blockIdx.x & 7, rr_ = blockIdx.x >> 3;
+    const int tile = rr_ % NT, u = (rr_ / NT) * 8 + xcd;
+    if (u >= a.njobs * a.nsplit) return;
+    const int job = u / a.nsplit, split = u - job * a.nsplit;
+    const int cit = tile / a.n_co, cot = tile - cit * a.n_co;
+    const int ci0 = cit * 16 * MR, co0 = cot * 16 * NR;
+
+    const int s = a.s;
+    const int step0 = split * a.steps_per_split;
+    int step1 = step0 + a.steps_per_split;
+    if (step1 > a.total_steps) step1 = a.total_steps;
+    const int nsteps = step1 - step0;
+    const int Ua = step0 * a.R, Ub = step1 * a.R;          // virtual output rows of this split
+
+    const u32x4 rsx = hc_raw_rsrc(a.x[job], (unsigned)a.N * a.IH * a.IW * a.Cin * 2u);
+    const u32x4 rs3 = hc_raw_rsrc(a.dy3[job], (unsigned)a.N * a.OH * a.OW * a.Cout * 2u);
+    const u32x4 rs1 = hc_raw_rsrc(a.dy1[job], (unsigned)a.N * a.OH * a.OW * a.Cout * 2u);
+    const unsigned lds0 = hc_lds_addr(smem);
+
+    // ---- pixel table (step-invariant): {s * row, s * col * SX} of step pixel p; padding pixels alias pixel 0 (their dy is 0)
+    int* tab = reinterpret_cast<int*>(smem + a.off_tab);
+    for (int p = tid; p < a.P32; p += 256) {
+        int r = 0, c = 0;
+        if (p < a.P) { r = p / a.OW; c = p - r * a.OW; }
+        tab[2 * p] = r * s;
+        tab[2 * p + 1] = c * s * a.SX;
+    }
+
+    // ---- DMA lane constants ----------------------------------------------------------------------------------------
+    // x row: LDS slot q = 64 j + lane of the row  ->  staged pixel q / S16 (pixel 0 = the left halo column), 16-byte piece q % S16
+    const int S16 = a.SX >> 4, CI16 = 2 * MR;
+    unsigned xsrc[XJW];
+#pragma unroll
+    for (int jj = 0; jj < XJW; ++jj) {
+        const int j = wid + 4 * jj;
+        const int q = 64 * j + lane;
+        const int px = q / S16, sub = q - px * S16;
+        const int ix = px - 1;
+        const bool ok = (j < a.XJ) && (px < a.XW) && (sub < CI16) && (ix >= 0) && (ix < a.IW);
+        xsrc[jj] = ok ? (unsigned)(ix * a.Cin + ci0) * 2u + (unsigned)sub * 16u : HC_OOB;
+    }
+    // dy stage: slot q = 64 j + lane -> step pixel q / SD16 (row r, column c of the step), piece q % SD16
+    const int SD16 = a.SD >> 4, CO16 = 2 * NR;
+    int dyr[DJW];
+    unsigned dyc[DJW];
+#pragma unroll
+    for (int jj = 0; jj < DJW; ++jj) {
+        const int j = wid + 4 * jj;
+        const int q = 64 * j + lane;
+        const int p = q / SD16, sub = q - p * SD16;
+        const bool ok = (j < a.DJ) && (p < a.P) && (sub < CO16);
+        const int r = p / a.OW, c = p - r * a.OW;
+        dyr[jj] = ok ? r : -1;
+        dyc[jj] = (unsigned)(c * a.Cout + co0) * 2u + (unsigned)sub * 16u;
+    }
+
+    // ---- running positions (wave-uniform) ----------------------------------------------------------------------
+    int Vhi = s * Ua;                                      // next virtual input row to fetch
+    int xn = Vhi / a.PI, xv = Vhi - xn * a.PI;             // ... = row xv of image xn (xv = 0: zero halo, 1..IH: real)
+    int xslot = Vhi % a.NSLOT;
+    int dU = Ua;                                           // first virtual output row of the next step to fetch
+    int dn = dU / a.PO, doy = dU - dn * a.PO;
+    int dstage = 0;
+
+    auto issue_x_rows = [&](int nrows) {
+        for (int k = 0; k < nrows; ++k) {
+            const bool real = (xv >= 1) && (xv <= a.IH) && (xn < a.N);
+            const unsigned rowbase = real ? (unsigned)((xn * a.IH + (xv - 1)) * a.IW) * (unsigned)a.Cin * 2u : 0u;
+            const unsigned dst = lds0 + (unsigned)xslot * (unsigned)a.ROWB;
+#pragma unroll
+            for (int jj = 0; jj < XJW; ++jj) {
+                const int j = wid + 4 * jj;
+                if (j < a.XJ) {
+                    hc_dma16(rsx, __builtin_amdgcn_readfirstlane(dst + (unsigned)j * 1024u),
+                             (real && xsrc[jj] != HC_OOB) ? rowbase + xsrc[jj] : HC_OOB);
+                } else if (a.PF > 1 && 4 * jj < a.XJ) {    // keep the per-wave instruction count uniform for the counted wait
+                    hc_dma16(rsx, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)a.off_sink), HC_OOB);
+                }
+            }
+            if (++xv == a.PI) { xv = 0; ++xn; }
+            if (++xslot == a.NSLOT) xslot = 0;
+            ++Vhi;
+        }
+    };
+    auto issue_dy = [&]() {
+        const unsigned dst = lds0 + (unsigned)a.off_dy + (unsigned)dstage * (unsigned)a.DSLOT;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+#pragma unroll
+            for (int jj = 0; jj < DJW; ++jj) {
+                const int j = wid + 4 * jj;
+                if (j < a.DJ) {
+                    int oy = doy + dyr[jj], n = dn;
+                    if (oy >= a.PO) { oy -= a.PO; ++n; }
+                    const bool ok = (dyr[jj] >= 0) && (oy < a.OH) && (n < a.N) && (dU + dyr[jj] < Ub);
+                    const unsigned off = ok ? (unsigned)((n * a.OH + oy) * a.OW) * (unsigned)a.Cout * 2u + dyc[jj] : HC_OOB;
+                    hc_dma16(which == 0 ? rs3 : rs1,
+                             __builtin_amdgcn_readfirstlane(dst + (unsigned)which * (unsigned)a.DHALF + (unsigned)j * 1024u), off);
+                } else if (a.PF > 1 && 4 * jj < a.DJ) {
+                    hc_dma16(rs3, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)a.off_sink), HC_OOB);
+                }
+            }
+        }
+        dU += a.R;
+        doy += a.R;
+        if (doy >= a.PO) { doy -= a.PO; ++dn; }
+        if (++dstage > a.PF) dstage = 0;
+    };
+
+    // ---- accumulators and fragment lane constants -----------------------------------------------------------------
+    f32x4 acc[3][MR][NR];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) acc[t][m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int la = lane & 15, kq = lane >> 4;
+    const int prow = 4 * kq + (la >> 2);                   // k-slot -> pixel map of conv_wgrad_tr.hip (same for both operands)
+    const int cq2 = 8 * (la & 3);                          // byte offset of this lane's channel quad in a 16-channel block
+    const int khw = wid < 3 ? wid : 1;                     // kernel row of this wave (the 1x1 reads the centre row)
+    const int kwoff = wid < 3 ? 0 : a.SX;                  // ... and the centre column
+    const int dywave = wid < 3 ? 0 : a.DHALF;              // dy3 for the kernel-row waves, dy1 for the 1x1 wave
+    const int SX1 = a.SX, SX2 = 2 * a.SX;
+    const int SD16B = 16 * a.SD;
+    const int nk = a.P32 >> 5;
+
+    // ---- prologue: the first window (rows of step 0 incl. halo) and PF steps of dy; each later step adds R*s rows ----
+    issue_x_rows((a.R - 1) * s + 3);
+    issue_dy();
+    if (a.PF > 1) {
+        issue_x_rows(a.R * s);
+        issue_dy();
+    }
+    int base = (s * Ua) % a.NSLOT;                         // ring slot of the first input row of the current step
+    int cstage = 0;
+    const int RS = a.R * s;
+    for (int t = 0; t < nsteps; ++t) {
+        // everything but the newest step in flight has landed (first iteration: the prologue's extra rows too)
+        if (a.PF > 1 && t > 0) wait_vm(a.nd); else if (a.PF > 1) wait_vm(a.nd); else wait_vm(0);
+        __syncthreads();                                   // step t visible to all waves; compute(t-1) finished everywhere
+        issue_x_rows(RS);                                  // step t + PF (past the end of the split: harmless real / zero rows)
+        issue_dy();
+        const char* dyb = smem + a.off_dy + cstage * a.DSLOT + dywave;
+        for (int g = 0; g < nk; ++g) {
+            const int p0 = 32 * g + prow;
+            const int r0 = tab[2 * p0], c0 = tab[2 * p0 + 1], r1 = tab[2 * p0 + 32], c1 = tab[2 * p0 + 33];
+            int s0 = base + r0 + khw, s1 = base + r1 + khw;
+            if (s0 >= a.NSLOT) s0 -= a.NSLOT;
+            if (s1 >= a.NSLOT) s1 -= a.NSLOT;
+            const int xa0 = s0 * a.ROWB + c0 + cq2 + kwoff, xa1 = s1 * a.ROWB + c1 + cq2 + kwoff;
+            const int d0 = p0 * a.SD + cq2;
+            bf16x8 fb[NR];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) fb[q] = tr_pair(dyb, d0 + 32 * q, d0 + SD16B + 32 * q);
+            if (wid < 3) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ko = kw == 0 ? 0 : (kw == 1 ? SX1 : SX2);
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) {
+                        const bf16x8 fa = tr_pair(smem, xa0 + ko + 32 * m, xa1 + ko + 32 * m);
+#pragma unroll
+                        for (int q = 0; q < NR; ++q)
+                            acc[kw][m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[q], acc[kw][m][q], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    const bf16x8 fa = tr_pair(smem, xa0 + 32 * m, xa1 + 32 * m);
+#pragma unroll
+                    for (int q = 0; q < NR; ++q)
+                        acc[0][m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[q], acc[0][m][q], 0, 0, 0);
+                }
+            }
+        }
+        base += RS;
+        if (base >= a.NSLOT) base -= a.NSLOT;
+        if (++cstage > a.PF) cstage = 0;
+    }
+    wait_vm(0);                                            // drain the run-ahead DMA before the workgroup retires
+
+    // ---- slab[job][split][co][10][ci]: lane = co column, the 4 accumulator values = 4 consecutive ci -----------------
+    float* ws = a.ws + (size_t)(job * a.nsplit + split) * (size_t)a.Cout * 10u * (size_t)a.Cin;
+    const int ntap = wid < 3 ? 3 : 1;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int co = co0 + 16 * q + la;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (t < ntap) {
+                const int tap = wid < 3 ? 3 * wid + t : 9;
+                float* row = ws + ((size_t)co * 10 + tap) * a.Cin + ci0 + 4 * kq;
+#pragma unroll
+                for (int m = 0; m < MR; ++m) *reinterpret_cast<f32x4*>(row + 16 * m) = acc[t][m][q];
+            }
+        }
+    }
+}
+
+// dw3[co][ci][t] (t < 9), dw1[co][ci] = (accumulate ? old : 0) + sum_split slab[job][split][co][t][ci], splits added in a fixed
+// order.  One workgroup per (co, 64 / SG consecutive ci, job): thread (sg, t, c) sums the splits sg, sg + SG, ... with reads
+// contiguous along ci; the SG partial sums are combined in order through LDS and the tile is written as contiguous runs of
+// the two OIHW gradients.
+template <int SG>
+__global__ __launch_bounds__(640) void wrep_reduce_kernel(const float* __restrict__ ws, hc_rep_wgrad_desc d, int nsplit) {
+    constexpr int CT = 64 / SG;
+    __shared__ float sm[SG][10][CT + 1];
+    const int co = blockIdx.x, ci0 = blockIdx.y * CT, job = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int c = tid % CT, t = (tid / CT) % 10, sg = tid / (CT * 10);
+    const size_t slab = (size_t)d.Cout * 10u * (size_t)d.Cin;
+    float sum = 0.f;
+    if (ci0 + c < d.Cin) {
+        const float* p = ws + (size_t)job * nsplit * slab + ((size_t)co * 10 + t) * d.Cin + ci0 + c;
+        int k = sg;
+        for (; k + 3 * SG < nsplit; k += 4 * SG) {      // four independent loads in flight
+            const float v0 = p[(size_t)k * slab], v1 = p[(size_t)(k + SG) * slab], v2 = p[(size_t)(k + 2 * SG) * slab],
+                        v3 = p[(size_t)(k + 3 * SG) * slab];
+            sum += v0; sum += v1; sum += v2; sum += v3;
+        }
+        for (; k < nsplit; k += SG) sum += p[(size_t)k * slab];
+    }
+    sm[sg][t][c] = sum;
+    __syncthreads();
+    // 9 * CT contiguous floats of dw3 (element j: ci = j / 9, tap = j % 9), then CT of dw1
+    for (int j = tid; j < 10 * CT; j += 640) {
+        const bool is3 = j < 9 * CT;
+        const int cl = is3 ? j / 9 : j - 9 * CT, tt = is3 ? j - cl * 9 : 9;
+        if (ci0 + cl >= d.Cin) continue;
+        float v = sm[0][tt][cl];
+#pragma unroll
+        for (int g = 1; g < SG; ++g) v += sm[g][tt][cl];
+        float* o = is3 ? d.dw3[job] + ((size_t)co * d.Cin + ci0 + cl) * 9 + tt : d.dw1[job] + (size_t)co * d.Cin + ci0 + cl;
+        *o = d.accumulate ? *o + v : v;
+    }
+}
+
+// LDS pixel stride >= bytes, 16-byte aligned, such that 8 consecutive step pixels (input pixel step = conv stride) land on
+// 8 distinct 32-byte slots of the 256-byte bank row (tr_b64 reads; same rule as conv_wgrad_tr.hip)
+inline int round_stride(int bytes, int stride) {
+    int sx = (bytes + 15) / 16 * 16;
+    for (;; sx += 16) {
+        bool ok = true;
+        unsigned seen = 0;
+        for (int i = 0; i < 8 && ok; ++i) {
+            const int pos = (i * stride * sx) % 256;
+            if (pos % 32) { ok = false; break; }
+            const unsigned bit = 1u << (pos / 32);
+            if (seen & bit) ok = false;
+            seen |= bit;
+        }
+        if (ok) return sx;
+    }
+}
+
+struct Plan {
+    bool ok;
+    Args a;
+    int MR, NR, smem, grid;
+};
+
+inline Plan make_plan(const hc_rep_wgrad_desc& d) {
+    Plan pl{};
+    pl.ok = false;
+    static const int enable = getenv("HC_WREP") ? atoi(getenv("HC_WREP")) : 1;
+    if (!enable) return pl;
+    if (d.njobs < 1 || d.njobs > HC_WREP_MAX_JOBS || d.N < 1) return pl;
+    const int s = d.stride;
+    if (s != 1 && s != 2) return pl;
+    if (d.OH != (d.IH + 2 - 3) / s + 1 || d.OW != (d.IW + 2 - 3) / s + 1) return pl;
+    if (d.OH != (d.IH - 1) / s + 1 || d.OW != (d.IW - 1) / s + 1) return pl;     // the 1x1 branch's output size
+    if ((double)d.N * d.IH * d.IW * d.Cin * 2.0 >= 4294967040.0 || (double)d.N * d.OH * d.OW * d.Cout * 2.0 >= 4294967040.0) return pl;
+    int MR = 0, NR = 0;
+    if (d.Cin % 96 == 0 && d.Cout % 48 == 0) { MR = 6; NR = 3; }
+    else if (d.Cin % 64 == 0 && d.Cout % 64 == 0) { MR = 4; NR = 4; }
+    else if (d.Cin % 48 == 0 && d.Cout % 48 == 0) { MR = 3; NR = 3; }
+    else return pl;
+    static const int max_c = getenv("HC_WREP_MAXC") ? atoi(getenv("HC_WREP_MAXC")) : 512;
+    if (d.Cin > max_c || d.Cout > max_c) return pl;       // wide layers: the k-pipelined DMA kernel (conv_wgrad_dma.hip)
+    Args& a = pl.a;
+    for (int j = 0; j < d.njobs; ++j) { a.x[j] = d.x[j]; a.dy3[j] = d.dy3[j]; a.dy1[j] = d.dy1[j]; }
+    a.ws = reinterpret_cast<float*>(d.ws);
+    a.N = d.N; a.IH = d.IH; a.IW = d.IW; a.Cin = d.Cin; a.OH = d.OH; a.OW = d.OW; a.Cout = d.Cout; a.s = s;
+    a.njobs = d.njobs;
+    a.n_ci = d.Cin / (16 * MR);
+    a.n_co = d.Cout / (16 * NR);
+    a.PO = d.OH + 1;
+    a.PI = s * a.PO;
+    a.XW = (d.OW - 1) * s + 3;
+    a.SX = round_stride(16 * MR * 2, s);
+    a.XJ = (a.XW * (a.SX / 16) + 63) / 64;
+    a.ROWB = a.XJ * 1024;
+    a.SD = round_stride(16 * NR * 2, 1);
+    if (a.XJ > 4 * XJW) return pl;
+    static const int pf_env = getenv("HC_WREP_PF") ? atoi(getenv("HC_WREP_PF")) : 0;
+    static const int r_env = getenv("HC_WREP_R") ? atoi(getenv("HC_WREP_R")) : 0;
+    const int LDS_MAX = 160 * 1024 - 512;
+    // rows per step: best fill of the 32-pixel k-steps, then the longest step; deepest prefetch that fits
+    double best = -1.0;
+    int bestR = 0, bestPF = 0;
+    for (int R = 1; R <= a.PO && R * d.OW <= 128; ++R) {
+        if (r_env > 0 && R != r_env) continue;
+        const int P = R * d.OW, P32 = (P + 31) / 32 * 32;
+        const int DJ = (P32 * (a.SD / 16) + 63) / 64;
+        if (DJ > 4 * DJW) continue;
+        for (int PF = 2; PF >= 1; --PF) {
+            if (pf_env > 0 && PF != pf_env) continue;
+            const int NSLOT = (R - 1) * s + 3 + PF * R * s;
+            const long bytes = (long)NSLOT * a.ROWB + (long)(PF + 1) * 2 * DJ * 1024 + P32 * 8 + 1024;
+            if (bytes > LDS_MAX) continue;
+            // PF = 2 only pays while a step is short (HBM latency not covered by one step of MFMAs)
+            const double score = (double)P / P32 + 1e-3 * P + (PF == 2 && P32 <= 64 ? 0.05 : 0.0) - (PF == 2 && P32 > 64 ? 0.5 : 0.0);
+            if (score > best) { best = score; bestR = R; bestPF = PF; }
+        }
+    }
+    if (bestR == 0) return pl;
+    a.R = bestR;
+    a.PF = bestPF;
+    a.P = a.R * d.OW;
+    a.P32 = (a.P + 31) / 32 * 32;
+    a.DJ = (a.P32 * (a.SD / 16) + 63) / 64;
+    a.DHALF = a.DJ * 1024;
+    a.DSLOT = 2 * a.DHALF;
+    a.NSLOT = (a.R - 1) * s + 3 + a.PF * a.R * s;
+    a.off_dy = a.NSLOT * a.ROWB;
+    a.off_tab = a.off_dy + (a.PF + 1) * a.DSLOT;
+    a.off_sink = (a.off_tab + a.P32 * 8 + 1023) / 1024 * 1024;
+    pl.smem = a.off_sink + 1024;
+    a.nd = a.R * s * ((a.XJ + 3) / 4) + 2 * ((a.DJ + 3) / 4);
+    if (a.PF > 1 && a.nd > 32) return pl;
+    const int UT = d.N * a.PO;
+    a.total_steps = (UT + a.R - 1) / a.R;
+    const int NT = a.n_ci * a.n_co;
+    int nsplit = 256 / (d.njobs * NT);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > a.total_steps) nsplit = a.total_steps;
+    a.steps_per_split = (a.total_steps + nsplit - 1) / nsplit;
+    a.nsplit = (a.total_steps + a.steps_per_split - 1) / a.steps_per_split;
+    pl.grid = ((d.njobs * a.nsplit + 7) / 8) * 8 * NT;
+    pl.MR = MR;
+    pl.NR = NR;
+    pl.ok = true;
+    return pl;
+}
+
+template <int MR, int NR>
+int launch(const Plan& pl, hipStream_t st) {
+    auto kern = wrep_kernel<MR, NR>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.smem, st, pl.a);
+    return hc_launch_status();
+}
+
+}  // namespace wrep
+
+extern "C" int hc_rep_wgrad_supported(const hc_rep_wgrad_desc* d) {
+    if (d == nullptr) return 0;
+    return wrep::make_plan(*d).ok ? 1 : 0;
+}
+
+extern "C" int64_t hc_rep_wgrad_ws_bytes(const hc_rep_wgrad_desc* d) {
+    if (d == nullptr) return -1;
+    const wrep::Plan pl = wrep::make_plan(*d);
+    if (!pl.ok) return -1;
+    return (int64_t)d->njobs * pl.a.nsplit * d->Cout * 10 * d->Cin * 4;
+}
+
+extern "C" int hc_rep_wgrad_plan(const hc_rep_wgrad_desc* d, int32_t* out8) {
+    if (d == nullptr || out8 == nullptr) return HC_ERR_ARG;
+    const wrep::Plan pl = wrep::make_plan(*d);
+    if (!pl.ok) return HC_ERR_ARG;
+    out8[0] = pl.MR; out8[1] = pl.NR; out8[2] = pl.a.R; out8[3] = pl.a.PF; out8[4] = pl.a.nsplit; out8[5] = pl.grid;
+    out8[6] = pl.smem; out8[7] = pl.a.NSLOT;
+    return HC_OK;
+}
+
+extern "C" int hc_rep_wgrad(const hc_rep_wgrad_desc* dp, hc_stream_t stream) {
+    if (dp == nullptr) return HC_ERR_ARG;
+    const hc_rep_wgrad_desc& d = *dp;
+    if (d.ws == nullptr) return HC_ERR_ARG;
+    for (int j = 0; j < d.njobs && j < HC_WREP_MAX_JOBS; ++j)
+        if (d.x[j] == nullptr || d.dy3[j] == nullptr || d.dy1[j] == nullptr || d.dw3[j] == nullptr || d.dw1[j] == nullptr) return HC_ERR_ARG;
+    const wrep::Plan pl = wrep::make_plan(d);
+    if (!pl.ok) return HC_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    if (pl.MR == 6) rc = wrep::launch<6, 3>(pl, st);
+    else if (pl.MR == 4) rc = wrep::launch<4, 4>(pl, st);
+    else rc = wrep::launch<3, 3>(pl, st);
+    if (rc != HC_OK) return rc;
+    const int ns = pl.a.nsplit;
+    if (ns <= 32) {
+        hipLaunchKernelGGL(wrep::wrep_reduce_kernel<1>, dim3(d.Cout, (d.Cin + 63) / 64, d.njobs), dim3(640), 0, st, pl.a.ws, d, ns);
+    } else if (ns <= 128) {
+        hipLaunchKernelGGL(wrep::wrep_reduce_kernel<4>, dim3(d.Cout, (d.Cin + 15) / 16, d.njobs), dim3(640), 0, st, pl.a.ws, d, ns);
+    } else {
+        hipLaunchKernelGGL(wrep::wrep_reduce_kernel<8>, dim3(d.Cout, (d.Cin + 7) / 8, d.njobs), dim3(640), 0, st, pl.a.ws, d, ns);
+    }
+    return hc_launch_status();
+}

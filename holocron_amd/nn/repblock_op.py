@@ -214,8 +214,9 @@ def block_dgrad(st, dy3, dy1, dxid, w3, w1, geom):
     return dx
 
 
-def block_wgrad(st, src, dy3, dy1, w3, w1, geom, stem_cin=None):
-    """(dW3, dW1) fp32 OIHW from the block input ``src`` and the two branch gradients."""
+def block_wgrad(st, src, dy3, dy1, w3, w1, geom, stem_cin=None, defer=False):
+    """(dW3, dW1) fp32 OIHW from the block input ``src`` and the two branch gradients.  ``defer`` (only inside an autograd
+    backward pass): the fused kernel's launch may be queued and grouped with same-shaped blocks (ops/conv.py _RepWgradQueue)."""
     N, Cin, H, W, Cout = geom
     lib = _lib.load()
     npix = dy3.shape[0] * dy3.shape[2] * dy3.shape[3]
@@ -227,6 +228,9 @@ def block_wgrad(st, src, dy3, dy1, w3, w1, geom, stem_cin=None):
         check(lib.hc_unpack_im2col_grad(ptr(dwc3), ptr(dw3), Cout, stem_cin, 3, 3, K, 0, stream()), "hc_unpack_im2col_grad")
         dw1 = dwc1.view(Cout, K)[:, 4 * stem_cin:5 * stem_cin].reshape(Cout, stem_cin, 1, 1).contiguous()
         return dw3, dw1
+    fused = cv.rep_block_wgrad(src, dy3, dy1, w3, w1, st.stride, defer=defer)   # one launch for both (and for same-shaped blocks)
+    if fused is not None:
+        return fused
     dw3 = cv.conv_wgrad(src, dy3, Cin, Cout, 3, 3, st.stride, 1)
     dw1 = cv.conv_wgrad(src, dy1, Cin, Cout, 1, 1, st.stride, 0)
     return dw3, dw1
@@ -337,7 +341,7 @@ class RepBlockFn(torch.autograd.Function):
             dx = block_dgrad(st, dy3, dy1, dxid, w3, w1, geom)
 
         with cv.side_stream_for_wgrad((w3, w1), (src, dy3, dy1)) as side:
-            dw3, dw1 = block_wgrad(st, src, dy3, dy1, w3, w1, geom, Cin if ctx.stem else None)
+            dw3, dw1 = block_wgrad(st, src, dy3, dy1, w3, w1, geom, Cin if ctx.stem else None, defer=True)
             side.produced(dw3, dw1)
         return (dx, dw3, dw1, dgam[0], dbet[0], dgam[1], dbet[1],
                 dgam[2] if st.identity else None, dbet[2] if st.identity else None, None, None)

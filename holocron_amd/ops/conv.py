@@ -11,7 +11,7 @@ import os
 import torch
 
 from .. import _lib
-from .._lib import ConvDesc, ConvSmallDesc, WgradDesc, check, ptr, stream, tap
+from .._lib import ConvDesc, ConvSmallDesc, RepWgradDesc, WgradDesc, check, ptr, stream, tap
 
 _WEIGHTS_EPOCH = [0]  # bumped by holocron_amd.optim after every raw-pointer parameter update
 
@@ -303,6 +303,121 @@ def conv_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, out=None, accumulate=False
         return out
     check(lib.hc_conv_wgrad(C.byref(d), stream()), "hc_conv_wgrad")
     return out
+
+
+# ------------------------------------------------------------------ RepBlock weight gradients: fused, grouped, deferred
+class _RepWgradQueue:
+    """Both weight gradients (3x3 and 1x1) of a RepBlock from one launch (``hc_rep_wgrad``, csrc/conv_wgrad_rep.hip), and the
+    launches of same-shaped blocks folded into one.
+
+    A block's weight gradients feed nothing but the optimizer, so a backward node only ENQUEUES them (the tensors it returns to
+    autograd are allocated, not yet written); the queue is flushed - one launch per group of up to 16 same-shaped blocks - by an
+    autograd final callback at the end of the backward call, or earlier by anything that is about to read a gradient
+    (``flush_deferred_wgrads``: GradReducer before it packs a bucket).  Grouping is what keeps the split-K factor small: the 14
+    identical 192-channel blocks of repvgg_a0 are 112 (block, channel tile) pairs, so each needs a 2-way pixel split instead of
+    the 41-way split a single block needs to fill the chip (whose fp32 partial sums doubled the HBM traffic of the layer).
+
+    Deferral is only used when it is safe by construction: the parameters have no ``.grad`` yet (autograd then adopts the
+    returned tensor without launching anything that would read it before the flush); otherwise the launch happens in place.
+    The inputs stay referenced by the queue until the flush (a few GB at batch 256: nothing on a 288 GB part)."""
+
+    def __init__(self):
+        self.jobs = []
+        self.armed = False
+        self.support = {}
+        self.enabled = os.environ.get("HC_WREP_DEFER", "1") != "0"
+
+    @staticmethod
+    def _desc(key, njobs=1):
+        N, Cin, H, W, Cout, stride = key
+        d = RepWgradDesc()
+        d.njobs, d.N, d.IH, d.IW, d.Cin, d.Cout, d.stride = njobs, N, H, W, Cin, Cout, stride
+        d.OH, d.OW = conv_out_size(H, 3, stride, 1), conv_out_size(W, 3, stride, 1)
+        d.accumulate = 0
+        return d
+
+    def supported(self, key):
+        ok = self.support.get(key)
+        if ok is None:
+            ok = self.support[key] = bool(_lib.load().hc_rep_wgrad_supported(C.byref(self._desc(key))))
+        return ok
+
+    def launch(self, key, jobs):
+        """One launch per group of up to 16 ``jobs`` = (x, dy3, dy1, dw3 pointer, dw1 pointer) of shape ``key``."""
+        lib = _lib.load()
+        for i in range(0, len(jobs), _lib.HC_WREP_MAX_JOBS):
+            grp = jobs[i:i + _lib.HC_WREP_MAX_JOBS]
+            d = self._desc(key, len(grp))
+            for j, (x, dy3, dy1, p3, p1) in enumerate(grp):
+                d.x[j], d.dy3[j], d.dy1[j], d.dw3[j], d.dw1[j] = ptr(x), ptr(dy3), ptr(dy1), p3, p1
+            nbytes = lib.hc_rep_wgrad_ws_bytes(C.byref(d))
+            if nbytes < 0:
+                raise _lib.HipError("hc_rep_wgrad: unsupported shape %s" % (key,))
+            ws = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=grp[0][0].device)
+            d.ws = ptr(ws)
+            if PROFILE is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(lib.hc_rep_wgrad(C.byref(d), stream()), "hc_rep_wgrad")
+                e1.record()
+                N, Cin, H, W, Cout, stride = key
+                flops = 2.0 * N * d.OH * d.OW * Cout * 10 * Cin * len(grp)
+                nb = len(grp) * (2 * N * H * W * Cin + 4 * N * d.OH * d.OW * Cout + 40 * Cout * Cin)
+                PROFILE.append(("conv_wgrad", flops, e0, e1, nb))
+            else:
+                check(lib.hc_rep_wgrad(C.byref(d), stream()), "hc_rep_wgrad")
+
+    def submit(self, key, x, dy3, dy1, dw3, dw1, w3, w1):
+        # The queue must not hold the gradient TENSORS: AccumulateGrad only adopts a gradient it holds the sole reference to
+        # (otherwise it clones it on the spot - uninitialised memory here).  The storages keep the memory alive instead.
+        self.jobs.append((key, x, dy3, dy1, dw3.untyped_storage(), dw3.data_ptr(), dw1.untyped_storage(), dw1.data_ptr(), w3, w1))
+        if not self.armed:
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def flush(self):
+        self.armed = False
+        if not self.jobs:
+            return
+        jobs, self.jobs = self.jobs, []
+        groups = {}
+        for job in jobs:
+            groups.setdefault(job[0], []).append(job)
+        for key, grp in groups.items():
+            self.launch(key, [(x, dy3, dy1, p3, p1) for (_, x, dy3, dy1, _, p3, _, p1, _, _) in grp])
+            # a gradient that autograd cloned instead of adopting (create_graph, a tensor hook that kept a reference):
+            # the clone was taken before the launch - overwrite it now that the values exist
+            for (_, x, _, _, s3, p3, s1, p1, w3, w1) in grp:
+                for w, st, p in ((w3, s3, p3), (w1, s1, p1)):
+                    g = w.grad
+                    if g is not None and g.data_ptr() != p:
+                        g.copy_(torch.empty(0, dtype=torch.float32, device=x.device).set_(st, 0, g.shape))
+
+
+_WREP = _RepWgradQueue()
+
+
+def flush_deferred_wgrads() -> None:
+    """Launch every weight gradient that is still queued (call before reading ``.grad`` from inside a backward pass)."""
+    if _WREP.jobs:
+        _WREP.flush()
+
+
+def rep_block_wgrad(x, dy3, dy1, w3, w1, stride, defer=False):
+    """(dW3, dW1) of a RepBlock through the fused kernel, or None when the shape is outside its plan.  ``defer``: inside an
+    autograd backward pass, enqueue and return tensors that the flush at the end of the pass fills."""
+    N, Cin, H, W = x.shape
+    Cout = w3.shape[0]
+    key = (N, Cin, H, W, Cout, stride)
+    if not _WREP.supported(key):
+        return None
+    dw3 = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
+    dw1 = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
+    if defer and _WREP.enabled and w3.grad is None and w1.grad is None:
+        _WREP.submit(key, x, dy3, dy1, dw3, dw1, w3, w1)
+    else:
+        _WREP.launch(key, [(x, dy3, dy1, dw3.data_ptr(), dw1.data_ptr())])
+    return dw3, dw1
 
 
 def im2col_small(x, KH, KW, stride, pad, Kpad):

@@ -153,6 +153,8 @@ class GradReducer:
     # ---- bucket-level pieces ----------------------------------------------------------------
     @staticmethod
     def _pack_bucket(b: _Bucket) -> None:
+        from .ops import conv as _cv
+        _cv.flush_deferred_wgrads()          # gradients that a backward node has only queued so far (fused RepBlock wgrad)
         dst, src = [], []
         for v, p in zip(b.views, b.params):
             if p.grad is None:               # no gradient this step: contributes zeros

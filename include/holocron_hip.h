@@ -105,6 +105,28 @@ typedef struct {
 int64_t hc_conv_wgrad_ws_bytes(const hc_wgrad_desc* d);
 int hc_conv_wgrad(const hc_wgrad_desc* d, hc_stream_t stream);
 
+/* Both weight gradients of a RepBlock (repvgg.py:57-60: a 3x3 / pad 1 and a 1x1 / pad 0 conv on the same input with the same
+ * stride; aten::convolution_backward(weight) of both) in ONE launch from ONE staging of x, for up to HC_WREP_MAX_JOBS blocks of
+ * the same shape at a time (csrc/conv_wgrad_rep.hip).  x[j] NHWC bf16 [N][IH][IW][Cin], dy3[j] / dy1[j] NHWC bf16
+ * [N][OH][OW][Cout], dw3[j] fp32 OIHW [Cout][Cin][3][3], dw1[j] fp32 [Cout][Cin][1][1] (= or += when `accumulate`); ws: scratch of
+ * hc_rep_wgrad_ws_bytes().  The split-K partial sums are reduced in a fixed order: results are bit-reproducible.
+ * hc_rep_wgrad_supported: shapes outside the kernel's plan (channel counts, LDS) -> 0, use hc_conv_wgrad twice instead.
+ * hc_rep_wgrad_plan: diagnostic, out8 = {MR, NR, rows per step, steps in flight, nsplit, grid, LDS bytes, ring slots}. */
+#define HC_WREP_MAX_JOBS 16
+typedef struct {
+    const void* x[HC_WREP_MAX_JOBS];
+    const void* dy3[HC_WREP_MAX_JOBS];
+    const void* dy1[HC_WREP_MAX_JOBS];
+    float* dw3[HC_WREP_MAX_JOBS];
+    float* dw1[HC_WREP_MAX_JOBS];
+    void* ws;
+    int32_t njobs, N, IH, IW, Cin, OH, OW, Cout, stride, accumulate;
+} hc_rep_wgrad_desc;
+int hc_rep_wgrad_supported(const hc_rep_wgrad_desc* d);
+int64_t hc_rep_wgrad_ws_bytes(const hc_rep_wgrad_desc* d);
+int hc_rep_wgrad_plan(const hc_rep_wgrad_desc* d, int32_t* out8);
+int hc_rep_wgrad(const hc_rep_wgrad_desc* d, hc_stream_t stream);
+
 /* fp32 OIHW master weights -> packed bf16.  mode 0: forward  [Cout][KH*KW][Cin];
  * mode 1: data-gradient [Cin][KH*KW (spatially flipped)][Cout]; mode 2: im2col order (see below).  `tap0`/`T` let several
  * kernels (3x3 + 1x1) share one packed tensor: taps are written at [tap0, tap0+KH*KW). */

@@ -107,10 +107,89 @@ def _bn_emulated(c, y_r, sd, prefix, training):
     return y_r * a.view(1, -1, 1, 1) + (sd[prefix + ".bias"] - a * mean).view(1, -1, 1, 1)
 
 
-def rep_block_bf16(x, sd, prefix, stride, identity, training):
-    """The reference block (repvgg.py:71-73) with bf16 rounding injected exactly where the HIP path
-    keeps bf16 tensors in HBM (x, y3, y1, out and their gradients; packed weights).  Test harness
-    only: it separates kernel bugs from legitimate bf16 effects (ReLU-kink flips, tiny-batch BN)."""
+class _RepBlockBf16Fn(torch.autograd.Function):
+    """Training-mode RepBlock with EVERY rounding of the HIP path at the place the HIP path has it - forward and backward
+    (nn/repblock_op.py, csrc/rep_bn.hip): the tensors kept in HBM as bf16 are x, y3, y1, out and, in backward, the incoming
+    gradient g, the three BatchNorm-input gradients dy3, dy1, dx_id (each rounded AFTER the complete expression
+    a_b (dz - mean(dz) - yhat_b mean(dz yhat_b)) has been formed in fp32 - a finding of round 2: the two centring terms are far
+    below one bf16 ulp of a_b dz at batch 256, so where the rounding sits decides whether they survive) and dx.  Statistics come
+    from the fp32 conv results, normalisation is applied to the bf16-stored values.  Sums are fp32 (here: torch-CPU reductions)."""
+
+    @staticmethod
+    def forward(ctx, x, w3, w1, g3, b3, g1, b1, g0, b0, stride, identity, dx_staged, bufs):
+        w3r, w1r = bf16r(w3), bf16r(w1)
+        c3 = F.conv2d(x, w3r, None, stride, 1)
+        c1 = F.conv2d(x, w1r, None, stride, 0)
+        y3, y1 = bf16r(c3), bf16r(c1)
+        n = c3.numel() / c3.shape[1]
+        V = lambda t: t.view(1, -1, 1, 1)
+        branches = [(c3, y3, g3, b3), (c1, y1, g1, b1)] + ([(x, x, g0, b0)] if identity else [])
+        pre = 0
+        stats = []
+        for (c, y, gam, bet), (rm, rv) in zip(branches, bufs):
+            mean = c.mean((0, 2, 3))
+            var = c.var((0, 2, 3), unbiased=False)
+            rm.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean)
+            rv.mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var * n / max(n - 1, 1))
+            invstd = torch.rsqrt(var + BN_EPS)
+            a = gam * invstd
+            pre = pre + y * V(a) + V(bet - a * mean)
+            stats.append((mean, invstd))
+        out = bf16r(F.relu(pre))
+        ctx.cfg = (stride, identity, dx_staged, n)
+        ctx.save_for_backward(x, w3r, w1r, y3, y1, out, g3, g1, g0 if identity else None, *[t for st_ in stats for t in st_])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        stride, identity, dx_staged, n = ctx.cfg
+        x, w3r, w1r, y3, y1, out, g3, g1, g0 = ctx.saved_tensors[:9]
+        st = ctx.saved_tensors[9:]
+        V = lambda t: t.view(1, -1, 1, 1)
+        dz = bf16r(g) * (out > 0)
+        s_dz = dz.sum((0, 2, 3))
+        ys = [y3, y1] + ([x] if identity else [])
+        gams = [g3, g1] + ([g0] if identity else [])
+        dys, dgam, dbet = [], [], []
+        for b, (y, gam) in enumerate(zip(ys, gams)):
+            mean, invstd = st[2 * b], st[2 * b + 1]
+            s_dzy = (dz * y).sum((0, 2, 3))
+            m2 = (s_dzy - mean * s_dz) * invstd / n             # mean(dz * yhat)
+            a = gam * invstd
+            yhat = (y - V(mean)) * V(invstd)
+            dys.append(bf16r(V(a) * (dz - V(s_dz / n) - yhat * V(m2))))
+            dgam.append(m2 * n)
+            dbet.append(s_dz)
+        dy3, dy1 = dys[0], dys[1]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.nn.grad.conv2d_input(x.shape, w3r, dy3, stride, 1) + torch.nn.grad.conv2d_input(x.shape, w1r, dy1, stride, 0)
+            if identity:
+                # the small-channel persistent kernel stages the conv result in bf16 before it adds the identity-branch gradient
+                dx = (bf16r(dx) if dx_staged else dx) + dys[2]
+            dx = bf16r(dx)
+        dw3 = torch.nn.grad.conv2d_weight(x, w3r.shape, dy3, stride, 1)
+        dw1 = torch.nn.grad.conv2d_weight(x, w1r.shape, dy1, stride, 0)
+        return (dx, dw3, dw1, dgam[0], dbet[0], dgam[1], dbet[1], dgam[2] if identity else None, dbet[2] if identity else None,
+                None, None, None, None)
+
+
+def rep_block_bf16(x, sd, prefix, stride, identity, training, dx_staged=False):
+    """The reference block (repvgg.py:71-73) with bf16 rounding injected exactly where the HIP path keeps bf16 tensors in HBM
+    (x, y3, y1, out and, in backward, g, dy3, dy1, dx_id, dx; packed weights).  Test harness only: it separates kernel bugs from
+    legitimate bf16 effects (ReLU-kink flips, tiny-batch BN, sub-ulp centring terms).  ``dx_staged``: the data gradient is
+    staged in bf16 before the identity-branch gradient is added (csrc/conv_small.hip, stride-1 blocks of <= 48 channels)."""
+    if training:
+        names = [prefix + ".branches.0.1", prefix + ".branches.1.1"] + ([prefix + ".branches.2"] if identity else [])
+        bufs = []
+        for nme in names:
+            sd[nme + ".num_batches_tracked"] += 1
+            bufs.append((sd[nme + ".running_mean"], sd[nme + ".running_var"]))
+        g0 = sd[prefix + ".branches.2.weight"] if identity else None
+        b0 = sd[prefix + ".branches.2.bias"] if identity else None
+        return _RepBlockBf16Fn.apply(x, sd[prefix + ".branches.0.0.weight"], sd[prefix + ".branches.1.0.weight"],
+                                     sd[names[0] + ".weight"], sd[names[0] + ".bias"], sd[names[1] + ".weight"], sd[names[1] + ".bias"],
+                                     g0, b0, stride, identity, dx_staged, bufs)
     w3 = _round_weight(sd[prefix + ".branches.0.0.weight"])
     w1 = _round_weight(sd[prefix + ".branches.1.0.weight"])
     c3 = F.conv2d(x, w3, None, stride, 1)
