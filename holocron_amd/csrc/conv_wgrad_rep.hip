@@ -29,6 +29,7 @@
 // is bit-reproducible) and writes the reference layouts OIHW [co][ci][3][3] and [co][ci][1][1].
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/holocron_hip.h"
 
 typedef __attribute__((ext_vector_type(4))) short wr_s16x4;
@@ -51,6 +52,7 @@ struct Args {
     int SD, DJ, DHALF, DSLOT;   // dy: LDS pixel stride, DMA instructions per tensor, bytes per tensor / per stage
     int off_dy, off_tab, off_sink;
     int nd;                     // DMA instructions per wave and step (uniform: padded with zero-fill dummies when PF > 1)
+    int dbg;                    // experiment knob HC_WREP_DBG: 1 = no MFMA phase, 2 = no DMA, 4 = no LDS fragment reads
 };
 
 __device__ __forceinline__ wr_s16x4 tr_read(const char* lds_base, int off) {
@@ -124,10 +126,13 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
         const bool ok = (j < a.XJ) && (px < a.XW) && (sub < CI16) && (ix >= 0) && (ix < a.IW);
         xsrc[jj] = ok ? (unsigned)(ix * a.Cin + ci0) * 2u + (unsigned)sub * 16u : HC_OOB;
     }
-    // dy stage: slot q = 64 j + lane -> step pixel q / SD16 (row r, column c of the step), piece q % SD16
+    // dy stage: slot q = 64 j + lane -> step pixel q / SD16 (row r, column c of the step), piece q % SD16.  In memory the rows of a
+    // step are contiguous except that the virtual gap row of an image does not exist: byte offset = step base + dyo - (rows past
+    // the gap ? one row : 0)
     const int SD16 = a.SD >> 4, CO16 = 2 * NR;
-    int dyr[DJW];
-    unsigned dyc[DJW];
+    const unsigned dyrow = (unsigned)a.OW * (unsigned)a.Cout * 2u;
+    int dyr[DJW];                                          // row of the step, -1: padding lane (always zero-filled)
+    unsigned dyo[DJW];
 #pragma unroll
     for (int jj = 0; jj < DJW; ++jj) {
         const int j = wid + 4 * jj;
@@ -136,13 +141,15 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
         const bool ok = (j < a.DJ) && (p < a.P) && (sub < CO16);
         const int r = p / a.OW, c = p - r * a.OW;
         dyr[jj] = ok ? r : -1;
-        dyc[jj] = (unsigned)(c * a.Cout + co0) * 2u + (unsigned)sub * 16u;
+        dyo[jj] = (unsigned)r * dyrow + (unsigned)(c * a.Cout + co0) * 2u + (unsigned)sub * 16u;
     }
+    const int ndw = (a.DJ - wid + 3) >> 2;                 // dy DMA instructions of this wave per tensor
+    const int nxw = (a.XJ - wid + 3) >> 2;                 // x DMA instructions of this wave per row
 
     // ---- running positions (wave-uniform) ----------------------------------------------------------------------
-    int Vhi = s * Ua;                                      // next virtual input row to fetch
-    int xn = Vhi / a.PI, xv = Vhi - xn * a.PI;             // ... = row xv of image xn (xv = 0: zero halo, 1..IH: real)
-    int xslot = Vhi % a.NSLOT;
+    const int V0 = s * Ua;                                 // first virtual input row to fetch
+    int xn = V0 / a.PI, xv = V0 - xn * a.PI;               // ... = row xv of image xn (xv = 0: zero halo, 1..IH: real)
+    int xslot = V0 % a.NSLOT;
     int dU = Ua;                                           // first virtual output row of the next step to fetch
     int dn = dU / a.PO, doy = dU - dn * a.PO;
     int dstage = 0;
@@ -150,41 +157,38 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
     auto issue_x_rows = [&](int nrows) {
         for (int k = 0; k < nrows; ++k) {
             const bool real = (xv >= 1) && (xv <= a.IH) && (xn < a.N);
-            const unsigned rowbase = real ? (unsigned)((xn * a.IH + (xv - 1)) * a.IW) * (unsigned)a.Cin * 2u : 0u;
-            const unsigned dst = lds0 + (unsigned)xslot * (unsigned)a.ROWB;
+            const unsigned rowbase = real ? (unsigned)((xn * a.IH + (xv - 1)) * a.IW) * (unsigned)a.Cin * 2u : HC_OOB;
+            const unsigned dst = lds0 + (unsigned)xslot * (unsigned)a.ROWB + (unsigned)wid * 1024u;
 #pragma unroll
-            for (int jj = 0; jj < XJW; ++jj) {
-                const int j = wid + 4 * jj;
-                if (j < a.XJ) {
-                    hc_dma16(rsx, __builtin_amdgcn_readfirstlane(dst + (unsigned)j * 1024u),
+            for (int jj = 0; jj < XJW; ++jj)
+                if (jj < nxw)      // HC_OOB + anything stays out of range: unsigned saturation is not needed, the range check is on the sum
+                    hc_dma16(rsx, __builtin_amdgcn_readfirstlane(dst + (unsigned)jj * 4096u),
                              (real && xsrc[jj] != HC_OOB) ? rowbase + xsrc[jj] : HC_OOB);
-                } else if (a.PF > 1 && 4 * jj < a.XJ) {    // keep the per-wave instruction count uniform for the counted wait
-                    hc_dma16(rsx, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)a.off_sink), HC_OOB);
-                }
-            }
             if (++xv == a.PI) { xv = 0; ++xn; }
             if (++xslot == a.NSLOT) xslot = 0;
-            ++Vhi;
         }
     };
     auto issue_dy = [&]() {
-        const unsigned dst = lds0 + (unsigned)a.off_dy + (unsigned)dstage * (unsigned)a.DSLOT;
+        const unsigned dst = lds0 + (unsigned)a.off_dy + (unsigned)dstage * (unsigned)a.DSLOT + (unsigned)wid * 1024u;
+        // rows [0, rgap) of the step belong to image dn, row rgap is its gap row, later rows to image dn + 1; rows >= rend are past
+        // the end of the split / of the batch
+        const int rgap = a.OH - doy;                       // may be negative (the step starts on a gap row: doy == OH) or >= R
+        int rend = Ub - dU;
+        const int rbatch = (a.N - dn) * a.PO - doy;
+        if (rbatch < rend) rend = rbatch;
+        const unsigned base = (unsigned)((dn * a.OH + doy) * a.OW) * (unsigned)a.Cout * 2u;
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
 #pragma unroll
-            for (int jj = 0; jj < DJW; ++jj) {
-                const int j = wid + 4 * jj;
-                if (j < a.DJ) {
-                    int oy = doy + dyr[jj], n = dn;
-                    if (oy >= a.PO) { oy -= a.PO; ++n; }
-                    const bool ok = (dyr[jj] >= 0) && (oy < a.OH) && (n < a.N) && (dU + dyr[jj] < Ub);
-                    const unsigned off = ok ? (unsigned)((n * a.OH + oy) * a.OW) * (unsigned)a.Cout * 2u + dyc[jj] : HC_OOB;
+            for (int jj = 0; jj < DJW; ++jj)
+                if (jj < ndw) {
+                    const int r = dyr[jj];
+                    const bool ok = (r >= 0) && (r < rend) && (r != rgap);
+                    const unsigned off = base + dyo[jj] - (r > rgap ? dyrow : 0u);
                     hc_dma16(which == 0 ? rs3 : rs1,
-                             __builtin_amdgcn_readfirstlane(dst + (unsigned)which * (unsigned)a.DHALF + (unsigned)j * 1024u), off);
-                } else if (a.PF > 1 && 4 * jj < a.DJ) {
-                    hc_dma16(rs3, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)a.off_sink), HC_OOB);
+                             __builtin_amdgcn_readfirstlane(dst + (unsigned)which * (unsigned)a.DHALF + (unsigned)jj * 4096u),
+                             ok ? off : HC_OOB);
                 }
-            }
         }
         dU += a.R;
         doy += a.R;
@@ -192,55 +196,62 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
         if (++dstage > a.PF) dstage = 0;
     };
 
-    // ---- accumulators and fragment lane constants -----------------------------------------------------------------
-    f32x4 acc[3][MR][NR];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int m = 0; m < MR; ++m)
-#pragma unroll
-            for (int q = 0; q < NR; ++q) acc[t][m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- fragment lane constants -------------------------------------------------------------------------------------
     const int la = lane & 15, kq = lane >> 4;
     const int prow = 4 * kq + (la >> 2);                   // k-slot -> pixel map of conv_wgrad_tr.hip (same for both operands)
     const int cq2 = 8 * (la & 3);                          // byte offset of this lane's channel quad in a 16-channel block
-    const int khw = wid < 3 ? wid : 1;                     // kernel row of this wave (the 1x1 reads the centre row)
-    const int kwoff = wid < 3 ? 0 : a.SX;                  // ... and the centre column
-    const int dywave = wid < 3 ? 0 : a.DHALF;              // dy3 for the kernel-row waves, dy1 for the 1x1 wave
     const int SX1 = a.SX, SX2 = 2 * a.SX;
     const int SD16B = 16 * a.SD;
-    const int nk = a.P32 >> 5;
+    const int nk = (a.dbg & 1) ? 0 : (a.P32 >> 5);
+    const int RS = a.R * s;
+    const int ndma = RS * nxw + 2 * ndw;                   // DMA instructions of this wave per step
 
     // ---- prologue: the first window (rows of step 0 incl. halo) and PF steps of dy; each later step adds R*s rows ----
     issue_x_rows((a.R - 1) * s + 3);
     issue_dy();
     if (a.PF > 1) {
-        issue_x_rows(a.R * s);
+        issue_x_rows(RS);
         issue_dy();
     }
-    int base = (s * Ua) % a.NSLOT;                         // ring slot of the first input row of the current step
-    int cstage = 0;
-    const int RS = a.R * s;
-    for (int t = 0; t < nsteps; ++t) {
-        // everything but the newest step in flight has landed (first iteration: the prologue's extra rows too)
-        if (a.PF > 1 && t > 0) wait_vm(a.nd); else if (a.PF > 1) wait_vm(a.nd); else wait_vm(0);
-        __syncthreads();                                   // step t visible to all waves; compute(t-1) finished everywhere
-        issue_x_rows(RS);                                  // step t + PF (past the end of the split: harmless real / zero rows)
-        issue_dy();
-        const char* dyb = smem + a.off_dy + cstage * a.DSLOT + dywave;
-        for (int g = 0; g < nk; ++g) {
-            const int p0 = 32 * g + prow;
-            const int r0 = tab[2 * p0], c0 = tab[2 * p0 + 1], r1 = tab[2 * p0 + 32], c1 = tab[2 * p0 + 33];
-            int s0 = base + r0 + khw, s1 = base + r1 + khw;
-            if (s0 >= a.NSLOT) s0 -= a.NSLOT;
-            if (s1 >= a.NSLOT) s1 -= a.NSLOT;
-            const int xa0 = s0 * a.ROWB + c0 + cq2 + kwoff, xa1 = s1 * a.ROWB + c1 + cq2 + kwoff;
-            const int d0 = p0 * a.SD + cq2;
-            bf16x8 fb[NR];
+
+    // The step loop, once per wave ROLE (TAPS = 3: a kernel row against dy3; TAPS = 1: the 1x1 against dy1).  Two instantiations
+    // instead of a branch inside the loop: with one accumulator array live across `if (role)` the register allocator copied the
+    // accumulators at every join (438 v_accvgpr_mov per k-step, 5 VALU per MFMA in the PMC counters).
+    auto run = [&](auto taps_c) {
+        constexpr int TAPS = decltype(taps_c)::value;
+        f32x4 acc[TAPS][MR][NR];
 #pragma unroll
-            for (int q = 0; q < NR; ++q) fb[q] = tr_pair(dyb, d0 + 32 * q, d0 + SD16B + 32 * q);
-            if (wid < 3) {
+        for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int q = 0; q < NR; ++q) acc[t][m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int khw = TAPS == 3 ? wid : 1;               // kernel row of this wave (the 1x1 reads the centre row ...
+        const int kwoff = TAPS == 3 ? 0 : a.SX;            // ... and the centre column)
+        const int dywave = TAPS == 3 ? 0 : a.DHALF;        // dy3 for the kernel-row waves, dy1 for the 1x1 wave
+        int base = (s * Ua) % a.NSLOT;                     // ring slot of the first input row of the current step
+        int cstage = 0;
+        for (int t = 0; t < nsteps; ++t) {
+            wait_vm(a.PF > 1 ? ndma : 0);                  // everything but the newest step in flight has landed
+            __syncthreads();                               // step t visible to all waves; compute(t-1) finished everywhere
+            if (!(a.dbg & 2)) {
+                issue_x_rows(RS);                          // step t + PF (past the end of the split: harmless real / zero rows)
+                issue_dy();
+            }
+            const char* dyb = smem + a.off_dy + cstage * a.DSLOT + dywave;
+            for (int g = 0; g < nk; ++g) {
+                const int p0 = 32 * g + prow;
+                const int r0 = tab[2 * p0], c0 = tab[2 * p0 + 1], r1 = tab[2 * p0 + 32], c1 = tab[2 * p0 + 33];
+                int s0 = base + r0 + khw, s1 = base + r1 + khw;
+                if (s0 >= a.NSLOT) s0 -= a.NSLOT;
+                if (s1 >= a.NSLOT) s1 -= a.NSLOT;
+                const int xa0 = s0 * a.ROWB + c0 + cq2 + kwoff, xa1 = s1 * a.ROWB + c1 + cq2 + kwoff;
+                const int d0 = p0 * a.SD + cq2;
+                bf16x8 fb[NR];
+#pragma unroll
+                for (int q = 0; q < NR; ++q) fb[q] = tr_pair(dyb, d0 + 32 * q, d0 + SD16B + 32 * q);
+#pragma unroll
+                for (int kw = 0; kw < TAPS; ++kw) {
                     const int ko = kw == 0 ? 0 : (kw == 1 ? SX1 : SX2);
 #pragma unroll
                     for (int m = 0; m < MR; ++m) {
@@ -250,38 +261,29 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
                             acc[kw][m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[q], acc[kw][m][q], 0, 0, 0);
                     }
                 }
-            } else {
-#pragma unroll
-                for (int m = 0; m < MR; ++m) {
-                    const bf16x8 fa = tr_pair(smem, xa0 + 32 * m, xa1 + 32 * m);
-#pragma unroll
-                    for (int q = 0; q < NR; ++q)
-                        acc[0][m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[q], acc[0][m][q], 0, 0, 0);
-                }
             }
+            base += RS;
+            if (base >= a.NSLOT) base -= a.NSLOT;
+            if (++cstage > a.PF) cstage = 0;
         }
-        base += RS;
-        if (base >= a.NSLOT) base -= a.NSLOT;
-        if (++cstage > a.PF) cstage = 0;
-    }
-    wait_vm(0);                                            // drain the run-ahead DMA before the workgroup retires
+        wait_vm(0);                                        // drain the run-ahead DMA before the workgroup retires
 
-    // ---- slab[job][split][co][10][ci]: lane = co column, the 4 accumulator values = 4 consecutive ci -----------------
-    float* ws = a.ws + (size_t)(job * a.nsplit + split) * (size_t)a.Cout * 10u * (size_t)a.Cin;
-    const int ntap = wid < 3 ? 3 : 1;
+        // ---- slab[job][split][co][10][ci]: lane = co column, the 4 accumulator values = 4 consecutive ci -------------
+        float* ws = a.ws + (size_t)(job * a.nsplit + split) * (size_t)a.Cout * 10u * (size_t)a.Cin;
 #pragma unroll
-    for (int q = 0; q < NR; ++q) {
-        const int co = co0 + 16 * q + la;
+        for (int q = 0; q < NR; ++q) {
+            const int co = co0 + 16 * q + la;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            if (t < ntap) {
-                const int tap = wid < 3 ? 3 * wid + t : 9;
+            for (int t = 0; t < TAPS; ++t) {
+                const int tap = TAPS == 3 ? 3 * wid + t : 9;
                 float* row = ws + ((size_t)co * 10 + tap) * a.Cin + ci0 + 4 * kq;
 #pragma unroll
                 for (int m = 0; m < MR; ++m) *reinterpret_cast<f32x4*>(row + 16 * m) = acc[t][m][q];
             }
         }
-    }
+    };
+    if (wid < 3) run(std::integral_constant<int, 3>{});
+    else run(std::integral_constant<int, 1>{});
 }
 
 // dw3[co][ci][t] (t < 9), dw1[co][ci] = (accumulate ? old : 0) + sum_split slab[job][split][co][t][ci], splits added in a fixed
@@ -414,6 +416,8 @@ inline Plan make_plan(const hc_rep_wgrad_desc& d) {
     a.off_sink = (a.off_tab + a.P32 * 8 + 1023) / 1024 * 1024;
     pl.smem = a.off_sink + 1024;
     a.nd = a.R * s * ((a.XJ + 3) / 4) + 2 * ((a.DJ + 3) / 4);
+    static const int dbg_env = getenv("HC_WREP_DBG") ? atoi(getenv("HC_WREP_DBG")) : 0;
+    a.dbg = dbg_env;
     if (a.PF > 1 && a.nd > 32) return pl;
     const int UT = d.N * a.PO;
     a.total_steps = (UT + a.R - 1) / a.R;

@@ -317,15 +317,37 @@ class _RepWgradQueue:
     identical 192-channel blocks of repvgg_a0 are 112 (block, channel tile) pairs, so each needs a 2-way pixel split instead of
     the 41-way split a single block needs to fill the chip (whose fp32 partial sums doubled the HBM traffic of the layer).
 
-    Deferral is only used when it is safe by construction: the parameters have no ``.grad`` yet (autograd then adopts the
-    returned tensor without launching anything that would read it before the flush); otherwise the launch happens in place.
-    The inputs stay referenced by the queue until the flush (a few GB at batch 256: nothing on a 288 GB part)."""
+    Deferral is safe by construction: it is used only when the parameters have no ``.grad`` yet, the tensors handed to autograd
+    are ZERO-filled views of one arena (one memset per backward pass), and the flush ADDS the gradients into them.  Autograd
+    adopts such a tensor as ``p.grad`` without launching anything; whatever it accumulates into it before the flush (a weight
+    shared by two nodes) commutes with the flush's own ``+=``; and if it cloned the tensor instead of adopting it
+    (``create_graph``), the flush adds into the clone.  Reading ``p.grad`` from INSIDE the backward pass (a tensor hook) sees the
+    gradient only after ``flush_deferred_wgrads()``.  The inputs stay referenced by the queue until the flush (a few GB at
+    batch 256: nothing on a 288 GB part)."""
 
     def __init__(self):
         self.jobs = []
         self.armed = False
         self.support = {}
         self.enabled = os.environ.get("HC_WREP_DEFER", "1") != "0"
+        self.arena = None           # zero-filled fp32 buffer of this backward pass (sized by the previous pass)
+        self.arena_used = 0
+        self.arena_want = 0
+        self.arena_high = 0
+
+    def _zeros(self, shape, device):
+        n = 1
+        for v in shape:
+            n *= v
+        n64 = (n + 63) // 64 * 64
+        self.arena_want += n64
+        if self.arena is None and self.arena_high > 0 and self.arena_used == 0:
+            self.arena = torch.zeros((self.arena_high,), dtype=torch.float32, device=device)
+        if self.arena is None or self.arena.device != device or self.arena_used + n64 > self.arena.numel():
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        out = self.arena[self.arena_used:self.arena_used + n].view(shape)
+        self.arena_used += n64
+        return out
 
     @staticmethod
     def _desc(key, njobs=1):
@@ -342,12 +364,13 @@ class _RepWgradQueue:
             ok = self.support[key] = bool(_lib.load().hc_rep_wgrad_supported(C.byref(self._desc(key))))
         return ok
 
-    def launch(self, key, jobs):
+    def launch(self, key, jobs, accumulate=False):
         """One launch per group of up to 16 ``jobs`` = (x, dy3, dy1, dw3 pointer, dw1 pointer) of shape ``key``."""
         lib = _lib.load()
         for i in range(0, len(jobs), _lib.HC_WREP_MAX_JOBS):
             grp = jobs[i:i + _lib.HC_WREP_MAX_JOBS]
             d = self._desc(key, len(grp))
+            d.accumulate = 1 if accumulate else 0
             for j, (x, dy3, dy1, p3, p1) in enumerate(grp):
                 d.x[j], d.dy3[j], d.dy1[j], d.dw3[j], d.dw1[j] = ptr(x), ptr(dy3), ptr(dy1), p3, p1
             nbytes = lib.hc_rep_wgrad_ws_bytes(C.byref(d))
@@ -367,31 +390,39 @@ class _RepWgradQueue:
             else:
                 check(lib.hc_rep_wgrad(C.byref(d), stream()), "hc_rep_wgrad")
 
-    def submit(self, key, x, dy3, dy1, dw3, dw1, w3, w1):
+    def submit(self, key, x, dy3, dy1, w3, w1):
+        """Queue one block; returns the (zero-filled, to be accumulated into) gradient tensors for autograd."""
+        Cout, Cin = key[4], key[1]
+        dw3 = self._zeros((Cout, Cin, 3, 3), x.device)
+        dw1 = self._zeros((Cout, Cin, 1, 1), x.device)
         # The queue must not hold the gradient TENSORS: AccumulateGrad only adopts a gradient it holds the sole reference to
-        # (otherwise it clones it on the spot - uninitialised memory here).  The storages keep the memory alive instead.
-        self.jobs.append((key, x, dy3, dy1, dw3.untyped_storage(), dw3.data_ptr(), dw1.untyped_storage(), dw1.data_ptr(), w3, w1))
+        # (otherwise it clones it on the spot).  The storages keep the memory alive instead.
+        self.jobs.append((key, x, dy3, dy1, dw3.untyped_storage(), dw3.data_ptr(), dw3.storage_offset(),
+                          dw1.untyped_storage(), dw1.data_ptr(), dw1.storage_offset(), w3, w1))
         if not self.armed:
             self.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+        return dw3, dw1
 
     def flush(self):
         self.armed = False
-        if not self.jobs:
-            return
         jobs, self.jobs = self.jobs, []
+        self.arena, self.arena_used = None, 0          # the views handed out keep the buffer alive
+        self.arena_high, self.arena_want = max(self.arena_high, self.arena_want), 0
+        if not jobs:
+            return
         groups = {}
         for job in jobs:
             groups.setdefault(job[0], []).append(job)
         for key, grp in groups.items():
-            self.launch(key, [(x, dy3, dy1, p3, p1) for (_, x, dy3, dy1, _, p3, _, p1, _, _) in grp])
-            # a gradient that autograd cloned instead of adopting (create_graph, a tensor hook that kept a reference):
-            # the clone was taken before the launch - overwrite it now that the values exist
-            for (_, x, _, _, s3, p3, s1, p1, w3, w1) in grp:
-                for w, st, p in ((w3, s3, p3), (w1, s1, p1)):
+            self.launch(key, [(j[1], j[2], j[3], j[5], j[8]) for j in grp], accumulate=True)
+            # a gradient that autograd cloned instead of adopting (create_graph, a hook that kept a reference): the clone was
+            # taken before the launch - add what the launch produced
+            for (_, x, _, _, s3, p3, o3, s1, p1, o1, w3, w1) in grp:
+                for w, st, p, off in ((w3, s3, p3, o3), (w1, s1, p1, o1)):
                     g = w.grad
                     if g is not None and g.data_ptr() != p:
-                        g.copy_(torch.empty(0, dtype=torch.float32, device=x.device).set_(st, 0, g.shape))
+                        g.add_(torch.empty(0, dtype=torch.float32, device=x.device).set_(st, off, g.shape))
 
 
 _WREP = _RepWgradQueue()
@@ -400,7 +431,12 @@ _WREP = _RepWgradQueue()
 def flush_deferred_wgrads() -> None:
     """Launch every weight gradient that is still queued (call before reading ``.grad`` from inside a backward pass)."""
     if _WREP.jobs:
+        jobs, _WREP.jobs = _WREP.jobs, []
+        arena = (_WREP.arena, _WREP.arena_used, _WREP.arena_want)
+        _WREP.jobs = jobs
         _WREP.flush()
+        # a mid-pass flush must not drop the arena of the pass that is still running
+        _WREP.arena, _WREP.arena_used, _WREP.arena_want = arena
 
 
 def rep_block_wgrad(x, dy3, dy1, w3, w1, stride, defer=False):
@@ -411,12 +447,11 @@ def rep_block_wgrad(x, dy3, dy1, w3, w1, stride, defer=False):
     key = (N, Cin, H, W, Cout, stride)
     if not _WREP.supported(key):
         return None
+    if defer and _WREP.enabled and w3.grad is None and w1.grad is None:
+        return _WREP.submit(key, x, dy3, dy1, w3, w1)
     dw3 = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
     dw1 = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)
-    if defer and _WREP.enabled and w3.grad is None and w1.grad is None:
-        _WREP.submit(key, x, dy3, dy1, dw3, dw1, w3, w1)
-    else:
-        _WREP.launch(key, [(x, dy3, dy1, dw3.data_ptr(), dw1.data_ptr())])
+    _WREP.launch(key, [(x, dy3, dy1, dw3.data_ptr(), dw1.data_ptr())])
     return dw3, dw1
 
 
