@@ -77,11 +77,16 @@ __device__ __forceinline__ void wait_vm(int n) {   // s_waitcnt vmcnt(n) for a w
 constexpr int XJW = 4;   // x DMA instructions per row and wave (rows up to 12 KB)
 constexpr int DJW = 4;   // dy DMA instructions per tensor and wave (stages up to 16 KB per tensor)
 
-template <int MR, int NR>
-__global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
+// HV = 2: eight waves, the ci tile split over two groups of four waves (two waves per SIMD at <= 256 registers: while one waits for
+// LDS or issues DMA the other feeds the matrix pipe - with one wave per SIMD nothing overlaps unless the instruction stream says so)
+template <int MR, int NR, int HV>
+__global__ __launch_bounds__(256 * HV, (HV == 2 || MR * NR <= 9) ? 2 : 1) void wrep_kernel(const Args a) {
+    constexpr int NW = 4 * HV, NT_ = 256 * HV, MH = MR / HV;
+    static_assert(MR % HV == 0, "ci tile must split evenly over the wave groups");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wid & 3, half = wid >> 2;             // role 0..2: kernel row, 3: the 1x1; half: which MH ci blocks of the tile
 
     // ---- blockIdx -> (job, split, tile): the tiles of one (job, split) - same pixels, different channels - share an XCD's L2
     const int NT = a.n_ci * a.n_co;
@@ -99,14 +104,25 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
     const int nsteps = step1 - step0;
     const int Ua = step0 * a.R, Ub = step1 * a.R;          // virtual output rows of this split
 
-    const u32x4 rsx = hc_raw_rsrc(a.x[job], (unsigned)a.N * a.IH * a.IW * a.Cin * 2u);
-    const u32x4 rs3 = hc_raw_rsrc(a.dy3[job], (unsigned)a.N * a.OH * a.OW * a.Cout * 2u);
-    const u32x4 rs1 = hc_raw_rsrc(a.dy1[job], (unsigned)a.N * a.OH * a.OW * a.Cout * 2u);
+    // buffer descriptors in SGPRs: the pointers are indexed by `job` (a quotient, i.e. computed on the vector ALU) - make the
+    // uniformity explicit or the inline-asm DMA may be handed a VGPR descriptor
+    auto uniform_rsrc = [](const void* p, unsigned bytes) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+        u32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((unsigned)v);
+        r[1] = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32) & 0xffffu);
+        r[2] = __builtin_amdgcn_readfirstlane(bytes);
+        r[3] = 0x00020000u;
+        return r;
+    };
+    const u32x4 rsx = uniform_rsrc(a.x[job], (unsigned)a.N * a.IH * a.IW * a.Cin * 2u);
+    const u32x4 rs3 = uniform_rsrc(a.dy3[job], (unsigned)a.N * a.OH * a.OW * a.Cout * 2u);
+    const u32x4 rs1 = uniform_rsrc(a.dy1[job], (unsigned)a.N * a.OH * a.OW * a.Cout * 2u);
     const unsigned lds0 = hc_lds_addr(smem);
 
     // ---- pixel table (step-invariant): {s * row, s * col * SX} of step pixel p; padding pixels alias pixel 0 (their dy is 0)
     int* tab = reinterpret_cast<int*>(smem + a.off_tab);
-    for (int p = tid; p < a.P32; p += 256) {
+    for (int p = tid; p < a.P32; p += NT_) {
         int r = 0, c = 0;
         if (p < a.P) { r = p / a.OW; c = p - r * a.OW; }
         tab[2 * p] = r * s;
@@ -119,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
     unsigned xsrc[XJW];
 #pragma unroll
     for (int jj = 0; jj < XJW; ++jj) {
-        const int j = wid + 4 * jj;
+        const int j = wid + NW * jj;
         const int q = 64 * j + lane;
         const int px = q / S16, sub = q - px * S16;
         const int ix = px - 1;
@@ -135,7 +151,7 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
     unsigned dyo[DJW];
 #pragma unroll
     for (int jj = 0; jj < DJW; ++jj) {
-        const int j = wid + 4 * jj;
+        const int j = wid + NW * jj;
         const int q = 64 * j + lane;
         const int p = q / SD16, sub = q - p * SD16;
         const bool ok = (j < a.DJ) && (p < a.P) && (sub < CO16);
@@ -143,8 +159,8 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
         dyr[jj] = ok ? r : -1;
         dyo[jj] = (unsigned)r * dyrow + (unsigned)(c * a.Cout + co0) * 2u + (unsigned)sub * 16u;
     }
-    const int ndw = (a.DJ - wid + 3) >> 2;                 // dy DMA instructions of this wave per tensor
-    const int nxw = (a.XJ - wid + 3) >> 2;                 // x DMA instructions of this wave per row
+    const int ndw = (a.DJ - wid + NW - 1) / NW;            // dy DMA instructions of this wave per tensor
+    const int nxw = (a.XJ - wid + NW - 1) / NW;            // x DMA instructions of this wave per row
 
     // ---- running positions (wave-uniform) ----------------------------------------------------------------------
     const int V0 = s * Ua;                                 // first virtual input row to fetch
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
 #pragma unroll
             for (int jj = 0; jj < XJW; ++jj)
                 if (jj < nxw)      // HC_OOB + anything stays out of range: unsigned saturation is not needed, the range check is on the sum
-                    hc_dma16(rsx, __builtin_amdgcn_readfirstlane(dst + (unsigned)jj * 4096u),
+                    hc_dma16(rsx, __builtin_amdgcn_readfirstlane(dst + (unsigned)(jj * NW) * 1024u),
                              (real && xsrc[jj] != HC_OOB) ? rowbase + xsrc[jj] : HC_OOB);
             if (++xv == a.PI) { xv = 0; ++xn; }
             if (++xslot == a.NSLOT) xslot = 0;
@@ -186,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
                     const bool ok = (r >= 0) && (r < rend) && (r != rgap);
                     const unsigned off = base + dyo[jj] - (r > rgap ? dyrow : 0u);
                     hc_dma16(which == 0 ? rs3 : rs1,
-                             __builtin_amdgcn_readfirstlane(dst + (unsigned)which * (unsigned)a.DHALF + (unsigned)jj * 4096u),
+                             __builtin_amdgcn_readfirstlane(dst + (unsigned)which * (unsigned)a.DHALF + (unsigned)(jj * NW) * 1024u),
                              ok ? off : HC_OOB);
                 }
         }
@@ -219,15 +235,15 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
     // accumulators at every join (438 v_accvgpr_mov per k-step, 5 VALU per MFMA in the PMC counters).
     auto run = [&](auto taps_c) {
         constexpr int TAPS = decltype(taps_c)::value;
-        f32x4 acc[TAPS][MR][NR];
+        f32x4 acc[TAPS][MH][NR];
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-            for (int m = 0; m < MR; ++m)
+            for (int m = 0; m < MH; ++m)
 #pragma unroll
                 for (int q = 0; q < NR; ++q) acc[t][m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int khw = TAPS == 3 ? wid : 1;               // kernel row of this wave (the 1x1 reads the centre row ...
-        const int kwoff = TAPS == 3 ? 0 : a.SX;            // ... and the centre column)
+        const int khw = TAPS == 3 ? role : 1;              // kernel row of this wave (the 1x1 reads the centre row ...
+        const int kwoff = (TAPS == 3 ? 0 : a.SX) + 32 * MH * half;   // ... and the centre column); first ci block of this wave
         const int dywave = TAPS == 3 ? 0 : a.DHALF;        // dy3 for the kernel-row waves, dy1 for the 1x1 wave
         int base = (s * Ua) % a.NSLOT;                     // ring slot of the first input row of the current step
         int cstage = 0;
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
                 for (int kw = 0; kw < TAPS; ++kw) {
                     const int ko = kw == 0 ? 0 : (kw == 1 ? SX1 : SX2);
 #pragma unroll
-                    for (int m = 0; m < MR; ++m) {
+                    for (int m = 0; m < MH; ++m) {
                         const bf16x8 fa = tr_pair(smem, xa0 + ko + 32 * m, xa1 + ko + 32 * m);
 #pragma unroll
                         for (int q = 0; q < NR; ++q)
@@ -275,14 +291,14 @@ __global__ __launch_bounds__(256, 1) void wrep_kernel(const Args a) {
             const int co = co0 + 16 * q + la;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
-                const int tap = TAPS == 3 ? 3 * wid + t : 9;
-                float* row = ws + ((size_t)co * 10 + tap) * a.Cin + ci0 + 4 * kq;
+                const int tap = TAPS == 3 ? 3 * role + t : 9;
+                float* row = ws + ((size_t)co * 10 + tap) * a.Cin + ci0 + 16 * MH * half + 4 * kq;
 #pragma unroll
-                for (int m = 0; m < MR; ++m) *reinterpret_cast<f32x4*>(row + 16 * m) = acc[t][m][q];
+                for (int m = 0; m < MH; ++m) *reinterpret_cast<f32x4*>(row + 16 * m) = acc[t][m][q];
             }
         }
     };
-    if (wid < 3) run(std::integral_constant<int, 3>{});
+    if (role < 3) run(std::integral_constant<int, 3>{});
     else run(std::integral_constant<int, 1>{});
 }
 
@@ -345,7 +361,7 @@ inline int round_stride(int bytes, int stride) {
 struct Plan {
     bool ok;
     Args a;
-    int MR, NR, smem, grid;
+    int MR, NR, HV, smem, grid;
 };
 
 inline Plan make_plan(const hc_rep_wgrad_desc& d) {
@@ -360,7 +376,8 @@ inline Plan make_plan(const hc_rep_wgrad_desc& d) {
     if (d.OH != (d.IH - 1) / s + 1 || d.OW != (d.IW - 1) / s + 1) return pl;     // the 1x1 branch's output size
     if ((double)d.N * d.IH * d.IW * d.Cin * 2.0 >= 4294967040.0 || (double)d.N * d.OH * d.OW * d.Cout * 2.0 >= 4294967040.0) return pl;
     int MR = 0, NR = 0;
-    if (d.Cin % 96 == 0 && d.Cout % 48 == 0) { MR = 6; NR = 3; }
+    static const int tile_env = getenv("HC_WREP_TILE") ? atoi(getenv("HC_WREP_TILE")) : 0;     // 33: force the 48 x 48 tile
+    if (d.Cin % 96 == 0 && d.Cout % 48 == 0 && tile_env != 33) { MR = 6; NR = 3; }
     else if (d.Cin % 64 == 0 && d.Cout % 64 == 0) { MR = 4; NR = 4; }
     else if (d.Cin % 48 == 0 && d.Cout % 48 == 0) { MR = 3; NR = 3; }
     else return pl;
@@ -383,7 +400,10 @@ inline Plan make_plan(const hc_rep_wgrad_desc& d) {
     if (a.XJ > 4 * XJW) return pl;
     static const int pf_env = getenv("HC_WREP_PF") ? atoi(getenv("HC_WREP_PF")) : 0;
     static const int r_env = getenv("HC_WREP_R") ? atoi(getenv("HC_WREP_R")) : 0;
-    const int LDS_MAX = 160 * 1024 - 512;
+    // LDS budget of a workgroup: all of it for the big tiles (one workgroup per CU: 512 registers per lane); the 48 x 48 tile fits
+    // two waves per SIMD, and two / three co-resident workgroups overlap one's DMA issue and barriers with the other's MFMAs
+    static const int lds_env = getenv("HC_WREP_LDS") ? atoi(getenv("HC_WREP_LDS")) : 0;
+    const int LDS_MAX = lds_env > 0 ? lds_env : 160 * 1024 - 512;
     // rows per step: best fill of the 32-pixel k-steps, then the longest step; deepest prefetch that fits
     double best = -1.0;
     int bestR = 0, bestPF = 0;
@@ -422,7 +442,10 @@ inline Plan make_plan(const hc_rep_wgrad_desc& d) {
     const int UT = d.N * a.PO;
     a.total_steps = (UT + a.R - 1) / a.R;
     const int NT = a.n_ci * a.n_co;
-    int nsplit = 256 / (d.njobs * NT);
+    int per_cu = (160 * 1024) / pl.smem;                  // co-resident workgroups: LDS, and registers (2 waves per SIMD at most)
+    if (per_cu > ((MR * NR <= 9) ? 2 : 1)) per_cu = (MR * NR <= 9) ? 2 : 1;
+    if (per_cu < 1) per_cu = 1;
+    int nsplit = 256 * per_cu / (d.njobs * NT);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > a.total_steps) nsplit = a.total_steps;
     a.steps_per_split = (a.total_steps + nsplit - 1) / nsplit;
@@ -430,19 +453,21 @@ inline Plan make_plan(const hc_rep_wgrad_desc& d) {
     pl.grid = ((d.njobs * a.nsplit + 7) / 8) * 8 * NT;
     pl.MR = MR;
     pl.NR = NR;
+    static const int hv_env = getenv("HC_WREP_HV") ? atoi(getenv("HC_WREP_HV")) : 0;
+    pl.HV = (MR % 2 == 0 && hv_env != 1) ? 2 : 1;
     pl.ok = true;
     return pl;
 }
 
-template <int MR, int NR>
+template <int MR, int NR, int HV>
 int launch(const Plan& pl, hipStream_t st) {
-    auto kern = wrep_kernel<MR, NR>;
+    auto kern = wrep_kernel<MR, NR, HV>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.smem, st, pl.a);
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256 * HV), pl.smem, st, pl.a);
     return hc_launch_status();
 }
 
@@ -479,9 +504,9 @@ extern "C" int hc_rep_wgrad(const hc_rep_wgrad_desc* dp, hc_stream_t stream) {
     if (!pl.ok) return HC_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
-    if (pl.MR == 6) rc = wrep::launch<6, 3>(pl, st);
-    else if (pl.MR == 4) rc = wrep::launch<4, 4>(pl, st);
-    else rc = wrep::launch<3, 3>(pl, st);
+    if (pl.MR == 6) rc = pl.HV == 2 ? wrep::launch<6, 3, 2>(pl, st) : wrep::launch<6, 3, 1>(pl, st);
+    else if (pl.MR == 4) rc = pl.HV == 2 ? wrep::launch<4, 4, 2>(pl, st) : wrep::launch<4, 4, 1>(pl, st);
+    else rc = wrep::launch<3, 3, 1>(pl, st);
     if (rc != HC_OK) return rc;
     const int ns = pl.a.nsplit;
     if (ns <= 32) {
