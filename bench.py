@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK = 2.5e15   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12         # HBM3E spec, same guide (6.29 TB/s measured copy)
 WGRAD_STREAM_DEFAULT = "1"   # +2.2 % same-box (16.29k -> 16.65k img/s); HC_WGRAD_STREAM=0 switches it off
 TRAIN_GFLOP_PER_IMG = 16.88  # conv fwd+dgrad+wgrad (stem dgrad excluded), 2*MAC
 
@@ -36,11 +37,16 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--comm-dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="dtype of the gradient all-reduce at N > 1 (fp32 = the reference's gradient precision; bf16 halves the "
+                         "bytes on xGMI but moves an AdaBelief update by ~2e-2, tests/test_parallel_gloo.py)")
     return ap.parse_args()
 
 
 def cpu_baseline(batch, iters):
-    """The reference algorithm on the host cores: oracle train step (fp32), bounded sample."""
+    """The reference algorithm on the host cores: oracle train step (fp32), bounded sample (~20 s).  torch's default of one thread
+    per hardware thread oversubscribes a batch-32 step on a 128 / 256-thread host (round 1: 7.3 img/s on 128 threads against 18.6 on
+    8), so the thread count is chosen first: one timed step at each of a few counts, the best one runs the sample."""
     from oracle import repvgg as orv
     torch.set_flush_denormal(True)
     nb, a, b = orv.ARCH["repvgg_a0"]
@@ -50,14 +56,27 @@ def cpu_baseline(batch, iters):
     x = torch.rand((batch, 3, 224, 224), generator=g)
     t = torch.randint(0, 10, (batch,), generator=g)
     opt = {}
-    orv.train_step(sd, opt, x, t, nb, ch)  # warm-up
+    host = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    orv.train_step(sd, opt, x, t, nb, ch)  # warm-up (allocator, oneDNN primitives)
+    trial = {}
+    for n in sorted({c for c in (8, 16, 32, 64, default_threads) if c <= host}):
+        torch.set_num_threads(n)
+        orv.train_step(sd, opt, x, t, nb, ch)
+        t0 = time.perf_counter()
+        orv.train_step(sd, opt, x, t, nb, ch)
+        trial[n] = batch / (time.perf_counter() - t0)
+    best = max(trial, key=trial.get)
+    torch.set_num_threads(best)
     t0 = time.perf_counter()
     for _ in range(iters):
         orv.train_step(sd, opt, x, t, nb, ch)
     dt = time.perf_counter() - t0
-    return {"value": batch * iters / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    torch.set_num_threads(default_threads)
+    return {"value": batch * iters / dt, "unit": "images/sec", "cores": best, "host_threads": host, "kind": "port",
+            "threads_tried": {str(k): round(v, 2) for k, v in trial.items()},
             "sample": f"oracle (torch-CPU fp32 restatement of the reference) repvgg_a0 train step, batch {batch}, "
-                      f"1 warm-up + {iters} timed iterations"}
+                      f"1 warm-up + {iters} timed iterations on the best of the tried thread counts"}
 
 
 def main():
@@ -103,8 +122,9 @@ def main():
         rear_mod = model.features[-1][-1]
         rear = {id(p) for p in rear_mod.parameters()} | {id(p) for p in model.head.parameters()}
         front_last = next(p for p in reversed(list(model.parameters())) if id(p) not in rear)
-        reducer = parallel.GradReducer(model.parameters(), bucket_mb=64.0, comm_dtype=torch.bfloat16, force=force_dist,
-                                       new_bucket_at=[front_last])
+        comm = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32
+        reducer = parallel.GradReducer(model.parameters(), bucket_mb=128.0 if comm == torch.float32 else 64.0, comm_dtype=comm,
+                                       force=force_dist, new_bucket_at=[front_last])
         cut = parallel.BackwardCut(rear_mod)
 
     g = torch.Generator(device=dev).manual_seed(rank)
@@ -164,9 +184,9 @@ def main():
                 ok, why = 0, "capture failed on another rank"
         if ok:
             graph_note = ("weight gradients on a second stream; " if wgrad_side else "") + ("hipGraph replay of the full step" if not distributed else
-                          "hipGraphs with eager RCCL all-reduces of the bf16 gradient between them (fwd + bwd of last block/head | "
-                          f"all-reduce {sum(t.numel() for t in gstep.spans[0]) * 2 / 1e6:.1f} MB behind: rest of bwd | all-reduce "
-                          f"{sum(t.numel() for t in gstep.spans[-1]) * 2 / 1e6:.1f} MB | unpack + AdaBelief)")
+                          f"hipGraphs with eager RCCL all-reduces of the {args.comm_dtype} gradient between them (fwd + bwd of last block/head | "
+                          f"all-reduce {sum(t.numel() * t.element_size() for t in gstep.spans[0]) / 1e6:.1f} MB behind: rest of bwd | all-reduce "
+                          f"{sum(t.numel() * t.element_size() for t in gstep.spans[-1]) / 1e6:.1f} MB | unpack + AdaBelief)")
         else:
             if gstep is not None:
                 gstep.release()
@@ -222,20 +242,28 @@ def main():
         cv.PROFILE = None
         dom = max(fam, key=lambda k: fam[k][1])
         fl, sec, n, alg_bytes = fam[dom]
-        # HBM bytes per launch from the PMC passes over this same command (scripts/pmc_step.sh; the counters cannot be read
-        # from inside the process), committed next to the kernel-trace summary
-        traffic = None
-        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_step_traffic.json")
-        if args.batch == 256 and os.path.exists(pmc_file):
-            with open(pmc_file) as fh:
-                traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
-        roof = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
-                "unit": "TFLOP/s", "frac": fl / sec / MFMA_BF16_PEAK, "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_step_traffic.json)",
-                "algorithmic_bytes_per_launch": alg_bytes / n,
-                "launches_per_step": n, "avg_launch_ms": sec / n * 1e3,
-                "families": {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] * 1e3, "launches": v[2]}
-                             for k, v in fam.items()}}
+        # which roof bounds the family: its algorithmic FLOPs at the dense bf16 MFMA peak against its algorithmic bytes at the HBM peak
+        t_mfma, t_hbm = fl / MFMA_BF16_PEAK, alg_bytes / HBM_PEAK
+        # HBM bytes per launch from the PMC passes over this same command (scripts/pmc_step.sh; the counters cannot be read from
+        # inside the process): taken from this round's committed file when there is one, else null
+        traffic, traffic_src = None, None
+        for cand in ("r02_pmc_step_traffic.json",):
+            pmc_file = os.path.join(ROOT, "profiles", cand)
+            if args.batch == 256 and os.path.exists(pmc_file):
+                with open(pmc_file) as fh:
+                    traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_src = "profiles/" + cand + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+        if t_hbm > t_mfma:
+            roof = {"bound": "hbm", "kernel": dom, "achieved": alg_bytes / sec / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": alg_bytes / sec / HBM_PEAK}
+        else:
+            roof = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                    "frac": fl / sec / MFMA_BF16_PEAK}
+        roof.update({"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes / n,
+                     "algorithmic_flops_per_launch": fl / n, "launches_per_step": n, "avg_launch_ms": sec / n * 1e3,
+                     "families": {k: {"tflops": v[0] / v[1] / 1e12, "gbps": v[3] / v[1] / 1e9, "ms_per_step": v[1] * 1e3,
+                                      "launches": v[2], "bound": "hbm" if v[3] / HBM_PEAK > v[0] / MFMA_BF16_PEAK else "mfma"}
+                                  for k, v in fam.items()}})
 
     if rank != 0:
         if distributed:

@@ -4,6 +4,6 @@ Mirrors the reference's python surface for the path named in BASELINE.json (mode
 optim); the math runs in hand-written HIP kernels behind the C ABI of include/holocron_hip.h.
 """
 from . import _lib  # noqa: F401
-from . import nn, ops, optim, models, utils  # noqa: F401
+from . import nn, ops, optim, models, trainer, transforms, utils  # noqa: F401
 
 __version__ = "0.1.0"

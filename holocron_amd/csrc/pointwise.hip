@@ -87,6 +87,92 @@ __global__ void box_pairwise_kernel(const float* __restrict__ b1, const float* _
     }
 }
 
+// Gradient of box_pairwise_kernel: db1[i] += sum_j g[i][j] d r_ij / d b1[i], db2[j] += sum_i ... (the caller zeroes db1 / db2).
+// Sub-gradient conventions are torch autograd's for the expressions of ops/boxes.py: binary max / min split a tie evenly,
+// clamp(min=0) passes the gradient where the argument is >= 0.
+__device__ __forceinline__ void max_adj(float x, float y, float g, float& gx, float& gy) {
+    if (x > y) gx += g; else if (x < y) gy += g; else { gx += 0.5f * g; gy += 0.5f * g; }
+}
+__device__ __forceinline__ void min_adj(float x, float y, float g, float& gx, float& gy) {
+    if (x < y) gx += g; else if (x > y) gy += g; else { gx += 0.5f * g; gy += 0.5f * g; }
+}
+__global__ void box_pairwise_bwd_kernel(const float* __restrict__ b1, const float* __restrict__ b2, const float* __restrict__ gout,
+                                        float* __restrict__ db1, float* __restrict__ db2, int M, int N, int kind) {
+    const long total = (long)M * N;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(t / N), j = (int)(t % N);
+        const float g = gout[t];
+        if (g == 0.f) continue;
+        const Box a = {b1[4 * i], b1[4 * i + 1], b1[4 * i + 2], b1[4 * i + 3]};
+        const Box b = {b2[4 * j], b2[4 * j + 1], b2[4 * j + 2], b2[4 * j + 3]};
+        float ga[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};   // adjoints of (x1, y1, x2, y2)
+        if (kind == 5) {   // 4/pi^2 (atan(w1/h1) - atan(w2/h2))^2
+            const float w1 = a.x2 - a.x1, h1 = a.y2 - a.y1, w2 = b.x2 - b.x1, h2 = b.y2 - b.y1;
+            const float q1 = w1 / h1, q2 = w2 / h2;
+            const float v = atanf(q1) - atanf(q2);
+            const float gv = g * 2.f * v * (float)(4.0 / (3.141592653589793 * 3.141592653589793));
+            const float gq1 = gv / (1.f + q1 * q1), gq2 = -gv / (1.f + q2 * q2);
+            const float gw1 = gq1 / h1, gh1 = -gq1 * w1 / (h1 * h1), gw2 = gq2 / h2, gh2 = -gq2 * w2 / (h2 * h2);
+            ga[0] = -gw1; ga[2] = gw1; ga[1] = -gh1; ga[3] = gh1;
+            gb[0] = -gw2; gb[2] = gw2; gb[1] = -gh2; gb[3] = gh2;
+        } else {
+            float g_iou = 0.f, g_pen = 0.f, g_uni = 0.f, g_C = 0.f;
+            // forward pieces
+            const float area1 = box_area(a), area2 = box_area(b);
+            const float ltx = fmaxf(a.x1, b.x1), lty = fmaxf(a.y1, b.y1), rbx = fminf(a.x2, b.x2), rby = fminf(a.y2, b.y2);
+            const float wr = rbx - ltx, hr = rby - lty;
+            const float w = fmaxf(wr, 0.f), h = fmaxf(hr, 0.f);
+            const float inter = w * h, uni = (area1 + area2) - inter;
+            const float cwr = fmaxf(a.x2, b.x2) - fminf(a.x1, b.x1), chr_ = fmaxf(a.y2, b.y2) - fminf(a.y1, b.y1);
+            if (kind == 0) g_iou = g;
+            else if (kind == 1) {
+                const float cw = fmaxf(cwr, 0.f), ch = fmaxf(chr_, 0.f), Carea = cw * ch;
+                g_iou = g;
+                g_uni = g / Carea;                        // giou = iou - 1 + uni / C
+                g_C = -g * uni / (Carea * Carea);
+                const float g_cw = cwr >= 0.f ? g_C * ch : 0.f, g_ch = chr_ >= 0.f ? g_C * cw : 0.f;
+                max_adj(a.x2, b.x2, g_cw, ga[2], gb[2]);
+                min_adj(a.x1, b.x1, -g_cw, ga[0], gb[0]);
+                max_adj(a.y2, b.y2, g_ch, ga[3], gb[3]);
+                min_adj(a.y1, b.y1, -g_ch, ga[1], gb[1]);
+            } else if (kind == 2 || kind == 3) { g_iou = -g; g_pen = g; }
+            else g_pen = g;
+            if (g_pen != 0.f) {   // pen = cd2 / c2 (ops/boxes.py:79-103; no clamp on the enclosing box there)
+                const float c2 = cwr * cwr + chr_ * chr_;
+                const float dx = (a.x1 + a.x2) - (b.x1 + b.x2), dy = (a.y1 + a.y2) - (b.y1 + b.y2);
+                const float cd2 = (dx * dx + dy * dy) / 4.f;
+                const float g_cd2 = g_pen / c2, g_c2 = -g_pen * cd2 / (c2 * c2);
+                const float g_dx = g_cd2 * dx / 2.f, g_dy = g_cd2 * dy / 2.f;
+                ga[0] += g_dx; ga[2] += g_dx; gb[0] -= g_dx; gb[2] -= g_dx;
+                ga[1] += g_dy; ga[3] += g_dy; gb[1] -= g_dy; gb[3] -= g_dy;
+                const float g_cx = g_c2 * 2.f * cwr, g_cy = g_c2 * 2.f * chr_;
+                max_adj(a.x2, b.x2, g_cx, ga[2], gb[2]);
+                min_adj(a.x1, b.x1, -g_cx, ga[0], gb[0]);
+                max_adj(a.y2, b.y2, g_cy, ga[3], gb[3]);
+                min_adj(a.y1, b.y1, -g_cy, ga[1], gb[1]);
+            }
+            // iou = inter / uni
+            float g_inter = g_iou / uni;
+            g_uni += -g_iou * inter / (uni * uni);
+            const float g_area1 = g_uni, g_area2 = g_uni;
+            g_inter -= g_uni;
+            const float g_wr = wr >= 0.f ? g_inter * h : 0.f, g_hr = hr >= 0.f ? g_inter * w : 0.f;
+            min_adj(a.x2, b.x2, g_wr, ga[2], gb[2]);
+            max_adj(a.x1, b.x1, -g_wr, ga[0], gb[0]);
+            min_adj(a.y2, b.y2, g_hr, ga[3], gb[3]);
+            max_adj(a.y1, b.y1, -g_hr, ga[1], gb[1]);
+            const float aw = a.x2 - a.x1, ah = a.y2 - a.y1, bw = b.x2 - b.x1, bh = b.y2 - b.y1;
+            ga[2] += g_area1 * ah; ga[0] -= g_area1 * ah; ga[3] += g_area1 * aw; ga[1] -= g_area1 * aw;
+            gb[2] += g_area2 * bh; gb[0] -= g_area2 * bh; gb[3] += g_area2 * bw; gb[1] -= g_area2 * bw;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (ga[k] != 0.f) atomicAdd(db1 + 4 * i + k, ga[k]);
+            if (gb[k] != 0.f) atomicAdd(db2 + 4 * j + k, gb[k]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- NMS (torchvision.ops.nms semantics)
 // pass 1: mask[i][w] bit b set  <=>  j = 64*w + b > i  and  IoU(i, j) > thr
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr,
@@ -331,6 +417,14 @@ int hc_box_pairwise(const float* b1, const float* b2, float* out, int32_t M, int
     if (M == 0 || N == 0) return HC_OK;
     if (b1 == nullptr || b2 == nullptr || out == nullptr) return HC_ERR_ARG;
     hipLaunchKernelGGL(box_pairwise_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, (hipStream_t)stream, b1, b2, out, M, N, kind);
+    return hc_launch_status();
+}
+int hc_box_pairwise_bwd(const float* b1, const float* b2, const float* g, float* db1, float* db2, int32_t M, int32_t N, int32_t kind,
+                        hc_stream_t stream) {
+    if (M < 0 || N < 0 || kind < 0 || kind > 5) return HC_ERR_ARG;
+    if (M == 0 || N == 0) return HC_OK;
+    hipLaunchKernelGGL(box_pairwise_bwd_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, (hipStream_t)stream, b1, b2, g, db1, db2, M, N,
+                       kind);
     return hc_launch_status();
 }
 

@@ -1,3 +1,3 @@
-from . import detection, utils  # noqa: F401
+from . import detection, presets, utils  # noqa: F401
 from .classification import *  # noqa: F401,F403
 from . import classification  # noqa: F401

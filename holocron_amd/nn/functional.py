@@ -11,7 +11,8 @@ from torch import Tensor
 from .. import _lib
 from .._lib import check, ptr, stream
 
-__all__ = ["hard_mish", "focal_loss", "dice_loss", "poly_loss", "dropblock2d", "global_avg_pool2d", "concat_downsample2d"]
+__all__ = ["hard_mish", "focal_loss", "dice_loss", "poly_loss", "dropblock2d", "global_avg_pool2d", "concat_downsample2d",
+           "norm_conv2d"]
 
 
 class _HardMishFn(torch.autograd.Function):
@@ -447,3 +448,36 @@ def concat_downsample2d(x: Tensor, scale_factor: int) -> Tensor:
     out = concat_downsample2d_cl(_PadChannelsFn.apply(x, cp), scale_factor)
     s2 = scale_factor * scale_factor
     return torch.cat([out[:, k * cp:k * cp + c] for k in range(s2)], dim=1)
+
+
+class _NormConvState:
+    """Host state of the functional form, keyed on the weight tensor (packed-weight cache + descriptors)."""
+    cache = {}
+
+
+def norm_conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, stride=1, padding=0, dilation=1, groups: int = 1,
+                eps: float = 1e-14) -> Tensor:
+    """Normalised convolution, functional form (holocron/nn/functional.py:366-413): every input patch is normalised by its own
+    mean / biased variance over its Cin*KH*KW entries before the filters are applied.  Same kernels as ``nn.NormConv2d``
+    (nn/normconv_op.py: no unfold - patch statistics + a normalising conv epilogue); square stride / padding, dilation 1.
+    Like the reference (in-place normalisation of the unfolded input) it has no gradient w.r.t. ``x``."""
+    from .convbn_op import ConvState
+    from .normconv_op import NormConv2dFn
+    _lib.require_gpu(x, weight)
+
+    def pair(v):
+        return (v, v) if isinstance(v, int) else tuple(v)
+    stride, padding, dilation = pair(stride), pair(padding), pair(dilation)
+    if dilation != (1, 1) or stride[0] != stride[1] or padding[0] != padding[1] \
+            or weight.shape[2] * weight.shape[3] > _lib.HC_MAX_TAPS:
+        raise NotImplementedError("norm_conv2d on the HIP path: square stride / padding, dilation 1, at most 12 taps")
+    if groups != 1:   # the reference ignores `groups` (functional.py:322-363) and then fails on the matmul shapes
+        raise RuntimeError("norm_conv2d: the reference ignores `groups` and fails on the matmul shapes for groups != 1")
+    key = id(weight)
+    ent = _NormConvState.cache.get(key)
+    if ent is None or ent[0]() is not weight:
+        import weakref
+        if len(_NormConvState.cache) > 64:
+            _NormConvState.cache.clear()
+        ent = _NormConvState.cache[key] = (weakref.ref(weight), ConvState())
+    return NormConv2dFn.apply(x, weight, bias, ent[1], (stride[0], padding[0], float(eps)))

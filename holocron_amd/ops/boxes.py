@@ -1,7 +1,9 @@
 """Pairwise box operators (reference: holocron/ops/boxes.py:16-211) on the HIP kernels.
 
 ``ciou_loss`` reproduces the reference numerically, including its quirk that the aspect-ratio
-term is added to a temporary copy and therefore never reaches the result.
+term is added to a temporary copy and therefore never reaches the result.  Like the
+reference's torch expressions every operator is differentiable w.r.t. both box sets
+(``hc_box_pairwise_bwd``: analytic gradients with autograd's tie / clamp conventions).
 """
 import torch
 from torch import Tensor
@@ -15,14 +17,37 @@ __all__ = ["box_iou", "box_giou", "diou_loss", "ciou_loss", "iou_penalty", "aspe
 _KINDS = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3, "penalty": 4, "arc": 5}
 
 
+class _PairwiseFn(torch.autograd.Function):
+    """out[M, N] = op(boxes1[i], boxes2[j]) with the analytic gradient of the reference's torch expression (same sub-gradient
+    conventions: tied max / min split evenly, clamp(min=0) passes the gradient at 0)."""
+
+    @staticmethod
+    def forward(ctx, boxes1, boxes2, kind):
+        b1 = boxes1.detach().float().contiguous()
+        b2 = boxes2.detach().float().contiguous()
+        M, N = b1.shape[0], b2.shape[0]
+        out = torch.empty((M, N), dtype=torch.float32, device=b1.device)
+        check(_lib.load().hc_box_pairwise(ptr(b1), ptr(b2), ptr(out), M, N, kind, stream()), "hc_box_pairwise")
+        ctx.save_for_backward(b1, b2)
+        ctx.kind = kind
+        ctx.dtypes = (boxes1.dtype, boxes2.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b1, b2 = ctx.saved_tensors
+        M, N = b1.shape[0], b2.shape[0]
+        db1, db2 = torch.zeros_like(b1), torch.zeros_like(b2)
+        gc = g.float().contiguous()
+        check(_lib.load().hc_box_pairwise_bwd(ptr(b1), ptr(b2), ptr(gc), ptr(db1), ptr(db2), M, N, ctx.kind, stream()),
+              "hc_box_pairwise_bwd")
+        return (db1.to(ctx.dtypes[0]) if ctx.needs_input_grad[0] else None,
+                db2.to(ctx.dtypes[1]) if ctx.needs_input_grad[1] else None, None)
+
+
 def _pairwise(boxes1: Tensor, boxes2: Tensor, kind: str) -> Tensor:
     _lib.require_gpu(boxes1, boxes2)
-    b1 = boxes1.detach().float().contiguous()
-    b2 = boxes2.detach().float().contiguous()
-    M, N = b1.shape[0], b2.shape[0]
-    out = torch.empty((M, N), dtype=torch.float32, device=b1.device)
-    check(_lib.load().hc_box_pairwise(ptr(b1), ptr(b2), ptr(out), M, N, _KINDS[kind], stream()), "hc_box_pairwise")
-    return out
+    return _PairwiseFn.apply(boxes1, boxes2, _KINDS[kind])
 
 
 def box_iou(boxes1: Tensor, boxes2: Tensor) -> Tensor:

@@ -505,7 +505,7 @@ def launch_conv_small_fwd(d, x, wp3, wp1, y3, y1, stats3=None, stats1=None):
     d.srcA, d.srcB, d.w3, d.w1 = ptr(x), None, ptr(wp3), ptr(wp1)
     d.w3_rstride, d.w1_rstride = 9 * d.C, d.C
     d.out3, d.out1, d.resid, d.stats3, d.stats1 = ptr(y3), ptr(y1), None, ptr(stats3), ptr(stats1)
-    _launch_small(d, 2.0 * d.N * d.H * d.W * d.Cout * 10 * d.C)
+    _launch_small(d, 2.0 * d.N * d.H * d.W * d.Cout * 10 * d.C, 2.0 * d.N * d.H * d.W * (d.C + 2 * d.Cout))
 
 
 def launch_conv_small_dgrad(d, dy3, dy1, wpd, dx, resid=None):
@@ -515,15 +515,16 @@ def launch_conv_small_dgrad(d, dy3, dy1, wpd, dx, resid=None):
     d.w1 = ptr(wpd) + 9 * d.C * 2
     d.w3_rstride, d.w1_rstride = 10 * d.C, 10 * d.C
     d.out3, d.out1, d.resid, d.stats3, d.stats1 = ptr(dx), None, ptr(resid), None, None
-    _launch_small(d, 2.0 * d.N * d.H * d.W * d.Cout * 10 * d.C)
+    _launch_small(d, 2.0 * d.N * d.H * d.W * d.Cout * 10 * d.C,
+                  2.0 * d.N * d.H * d.W * (2 * d.C + d.Cout * (2 if resid is not None else 1)))
 
 
-def _launch_small(d, flops):
+def _launch_small(d, flops, nbytes=0):
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(_lib.load().hc_conv_small(C.byref(d), stream()), "hc_conv_small")
         e1.record()
-        PROFILE.append(("conv_small", flops, e0, e1, 0))
+        PROFILE.append(("conv_small", flops, e0, e1, nbytes))
         return
     check(_lib.load().hc_conv_small(C.byref(d), stream()), "hc_conv_small")

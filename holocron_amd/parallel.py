@@ -88,8 +88,16 @@ class GradReducer:
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_mb: float = 32.0,
                  comm_dtype: torch.dtype = torch.float32, group=None, overlap: bool = True,
-                 force: bool = False, new_bucket_at: Optional[Iterable[torch.nn.Parameter]] = None) -> None:
+                 force: bool = False, new_bucket_at: Optional[Iterable[torch.nn.Parameter]] = None,
+                 materialize_missing: bool = True) -> None:
         self.group = group
+        self._sync = True                    # False inside no_sync(): hooks do not count, nothing is launched
+        # A parameter without a gradient on this rank may have one on another: after the all-reduce every rank must hold the
+        # same (averaged) gradient or the replicas drift apart, so by default missing gradients are created from the reduced
+        # buffer.  The price: a parameter that is unused on EVERY rank gets a zero gradient where a single process would leave
+        # it None, and an optimizer then applies weight decay / momentum to it.  Pass materialize_missing=False when unused
+        # parameters are unused on all ranks (they then stay None, single-process semantics).
+        self.materialize_missing = materialize_missing
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
         self.comm_dtype = comm_dtype
@@ -165,19 +173,47 @@ class GradReducer:
         _copy_all(dst, src)
 
     def _unpack_bucket(self, b: _Bucket) -> None:
-        for p in b.params:
+        grads, views = [], []
+        for p, v in zip(b.params, b.views):
             if p.grad is None:
+                if not self.materialize_missing:
+                    continue
                 p.grad = torch.empty_like(p)
-        grads = [p.grad for p in b.params]
-        _copy_all(grads, b.views)
+            grads.append(p.grad)
+            views.append(v)
+        if not grads:
+            return
+        _copy_all(grads, views)
         torch._foreach_mul_(grads, 1.0 / self.world)
 
     def _launch(self, b: _Bucket) -> None:
         self._pack_bucket(b)
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def no_sync(self):
+        """Context manager for gradient accumulation: backward passes inside it only accumulate into ``p.grad`` (no hook
+        counts, no collective); the first backward outside it - or ``finalize()`` - reduces the accumulated gradients."""
+        red = self
+
+        class _NoSync:
+            def __enter__(self_inner):
+                self_inner.prev = red._sync
+                red._sync = False
+
+            def __exit__(self_inner, *exc):
+                red._sync = self_inner.prev
+                return False
+        return _NoSync()
+
     def _on_grad(self, p: torch.nn.Parameter) -> None:
+        if not self._sync:
+            return
         b, _ = self._of[p]
+        if b.work is not None or b.pending <= 0:
+            # a second backward before finalize(): the bucket's collective already ran on the first micro-batch's gradients and
+            # finalize() would overwrite the accumulated ones with it (ADVICE r1)
+            raise RuntimeError("GradReducer (overlap mode) saw a second backward pass before finalize(): wrap the accumulation "
+                               "micro-steps in `with reducer.no_sync():` (all but the last), or build it with overlap=False")
         b.pending -= 1
         if b.pending == 0:
             b.ready = True

@@ -1,0 +1,335 @@
+"""Training loop behind ``references/classification`` / ``references/detection`` (reference: holocron/trainer/core.py).
+
+Same class, constructor, attributes and method names as the reference's ``Trainer`` so that its scripts run unchanged
+(`references/classification/train.py:216-227`), with what the MI355X path needs folded in:
+
+* **data parallelism**: when ``torch.distributed`` is initialised with more than one rank (one process per GPU, RCCL over xGMI),
+  ``_backprop_step`` drives a ``parallel.GradReducer`` - bucketed all-reduce overlapped with backward, gradient-accumulation
+  micro-steps under ``no_sync`` - before the optimizer step.  The reference has no distributed path at all.
+* **no per-batch host synchronisation**: the reference formats ``batch_loss.item()`` into the progress bar every step
+  (core.py:162), a device->host wait per iteration; here the loss stays on the device and is read every ``log_every`` steps.
+* **bf16 is the storage type of the kernels**, so ``amp=True`` needs no ``GradScaler`` (bf16 has fp32's exponent range): the flag
+  is accepted and recorded, ``scaler`` stays ``None``.
+* ``save`` can include the optimizer state (``with_optimizer=True``), ``load`` restores it when present.
+"""
+import math
+from collections import defaultdict
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import Tensor, nn
+from torch.optim.lr_scheduler import CosineAnnealingLR, MultiplicativeLR, OneCycleLR
+
+from .utils import freeze_bn, freeze_model, split_normalization_params
+
+__all__ = ["Trainer"]
+
+ParamSeq = Sequence[nn.Parameter]
+
+
+class _Bar:
+    """Stand-in for fastprogress' bars (not installed on the training image): iterates, carries ``comment``."""
+
+    def __init__(self, it, parent=None):
+        self.it, self.parent, self.comment = it, parent, ""
+        self.main_bar = self
+
+    def __iter__(self):
+        return iter(self.it)
+
+    def __len__(self):
+        return len(self.it)
+
+    def write(self, msg):
+        print(msg)
+
+
+def _bars():
+    try:
+        from fastprogress import master_bar, progress_bar
+        return master_bar, progress_bar
+    except Exception:      # noqa: BLE001 - optional dependency
+        return _Bar, _Bar
+
+
+class Trainer:
+    """Baseline trainer (core.py:26-104).  Arguments as in the reference; ``log_every``: how often the running loss is read back."""
+
+    def __init__(self, model: nn.Module, train_loader, val_loader, criterion: nn.Module, optimizer: torch.optim.Optimizer,
+                 gpu: Optional[int] = None, output_file: str = "./checkpoint.pth", amp: bool = False,
+                 skip_nan_loss: bool = False, nan_tolerance: int = 5, gradient_acc: int = 1,
+                 gradient_clip: Optional[float] = None, on_epoch_end: Optional[Callable[[Dict[str, float]], Any]] = None,
+                 log_every: int = 50) -> None:
+        self.model = model
+        self.train_loader = train_loader
+        self.val_loader = val_loader
+        self.criterion = criterion
+        self.optimizer = optimizer
+        self.amp = amp
+        self.scaler = None
+        self.on_epoch_end = on_epoch_end
+        self.skip_nan_loss = skip_nan_loss
+        self.nan_tolerance = nan_tolerance
+        self.gradient_acc = gradient_acc
+        self.grad_clip = gradient_clip
+        self.output_file = output_file
+        self.log_every = max(1, int(log_every))
+
+        self.step = 0
+        self.start_epoch = 0
+        self.epoch = 0
+        self._grad_count = 0
+        self.min_loss = math.inf
+        self.gpu = gpu
+        self._params: Tuple[ParamSeq, ParamSeq] = ([], [])
+        self.lr_recorder: List[float] = []
+        self.loss_recorder: List[float] = []
+        self._reducer = None
+        self._reducer_key = None
+        self.set_device(gpu)
+        self._reset_opt(self.optimizer.defaults["lr"])
+
+    # ---------------------------------------------------------------- device / checkpoint
+    def set_device(self, gpu: Optional[int] = None) -> None:
+        """core.py:90-104"""
+        if isinstance(gpu, int):
+            if not torch.cuda.is_available():
+                raise AssertionError("PyTorch cannot access your GPU. Please investigate!")
+            if gpu >= torch.cuda.device_count():
+                raise ValueError("Invalid device index")
+            torch.cuda.set_device(gpu)
+            self.model = self.model.cuda()
+            if isinstance(self.criterion, nn.Module):
+                self.criterion = self.criterion.cuda()
+
+    def save(self, output_file: str, with_optimizer: bool = False) -> None:
+        """Checkpoint with the reference's keys (core.py:106-121); ``with_optimizer`` adds the optimizer state."""
+        state = {"epoch": self.epoch, "step": self.step, "min_loss": self.min_loss, "model": self.model.state_dict()}
+        if with_optimizer:
+            state["optimizer"] = self.optimizer.state_dict()
+        torch.save(state, output_file)
+
+    def load(self, state: Dict[str, Any]) -> None:
+        """core.py:123-133 (+ the optimizer state when the checkpoint has one)"""
+        self.start_epoch = state["epoch"]
+        self.epoch = self.start_epoch
+        self.step = state["step"]
+        self.min_loss = state["min_loss"]
+        self.model.load_state_dict(state["model"])
+        if "optimizer" in state:
+            self.optimizer.load_state_dict(state["optimizer"])
+
+    # ---------------------------------------------------------------- one epoch
+    def _fit_epoch(self, mb) -> None:
+        """core.py:135-165"""
+        freeze_bn(self.model.train())
+        _, progress_bar = _bars()
+        nan_cnt = 0
+        pb = progress_bar(self.train_loader, parent=mb)
+        for x, target in pb:
+            x, target = self.to_cuda(x, target)
+            batch_loss = self._get_loss(x, target)
+            # `skip_nan_loss` needs the value on the host; without it nothing here waits for the device
+            if not self.skip_nan_loss or bool(torch.isfinite(batch_loss)):
+                nan_cnt = 0
+                self._backprop_step(batch_loss)
+            else:
+                nan_cnt += 1
+                if nan_cnt > self.nan_tolerance:
+                    raise ValueError(f"loss value has been NaN or inf for more than {self.nan_tolerance} steps.")
+            self.scheduler.step()
+            if self.step % self.log_every == 0:
+                pb.comment = f"Training loss: {float(batch_loss.detach()):.4}"
+            self.step += 1
+        self.epoch += 1
+
+    def to_cuda(self, x, target):
+        if isinstance(self.gpu, int):
+            if self.gpu >= torch.cuda.device_count():
+                raise ValueError("Invalid device index")
+            return self._to_cuda(x, target)
+        return x, target
+
+    @staticmethod
+    def _to_cuda(x: Tensor, target: Tensor) -> Tuple[Tensor, Tensor]:
+        return x.cuda(non_blocking=True), target.cuda(non_blocking=True)
+
+    # ---------------------------------------------------------------- data parallelism
+    def _grad_reducer(self):
+        """The GradReducer over the parameters currently being optimised, or None on a single rank."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() <= 1:
+            return None
+        params = [p for g in self.optimizer.param_groups for p in g["params"] if p.requires_grad]
+        key = tuple(id(p) for p in params)
+        if self._reducer is None or self._reducer_key != key:
+            from ..parallel import GradReducer
+            if self._reducer is not None:
+                self._reducer.remove()
+            self._reducer = GradReducer(params, overlap=True)
+            self._reducer_key = key
+        return self._reducer
+
+    def _backprop_step(self, loss: Tensor) -> None:
+        """core.py:185-212: backward; every ``gradient_acc`` calls clip, (all-reduce,) step and zero the gradients."""
+        self._grad_count += 1
+        last = self._grad_count == self.gradient_acc
+        red = self._grad_reducer()
+        if red is not None and not last:
+            with red.no_sync():
+                loss.backward()
+        else:
+            loss.backward()
+        if last:
+            if red is not None:
+                red.finalize()
+            if isinstance(self.grad_clip, float):
+                nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_clip)
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+            self._grad_count = 0
+
+    def _get_loss(self, x: Tensor, target: Tensor, return_logits: bool = False) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+        """core.py:214-233"""
+        out = self.model(x)
+        loss = self.criterion(out if out.dtype == torch.float32 else out.float(), target)
+        return (loss, out) if return_logits else loss
+
+    # ---------------------------------------------------------------- optimizer / scheduler plumbing
+    def _set_params(self, norm_weight_decay: Optional[float] = None) -> None:
+        if not any(p.requires_grad for p in self.model.parameters()):
+            raise AssertionError("All parameters are frozen")
+        if norm_weight_decay is None:
+            self._params = [p for p in self.model.parameters() if p.requires_grad], []
+        else:
+            self._params = split_normalization_params(self.model)
+
+    def _reset_opt(self, lr: float, norm_weight_decay: Optional[float] = None) -> None:
+        """Point the optimizer at the currently trainable parameters with a fresh state (core.py:246-261)."""
+        self.optimizer.defaults["lr"] = lr
+        self.optimizer.state = defaultdict(dict)
+        self.optimizer.param_groups = []
+        self._set_params(norm_weight_decay)
+        if norm_weight_decay is None:
+            self.optimizer.add_param_group({"params": self._params[0]})
+        else:
+            decays = [norm_weight_decay, self.optimizer.defaults.get("weight_decay", 0)]
+            for group, wd in zip(self._params, decays):
+                if len(group) > 0:
+                    self.optimizer.add_param_group({"params": group, "weight_decay": wd})
+        self.optimizer.zero_grad()
+
+    @torch.inference_mode()
+    def evaluate(self):
+        raise NotImplementedError
+
+    @staticmethod
+    def _eval_metrics_str(eval_metrics) -> str:
+        raise NotImplementedError
+
+    def _reset_scheduler(self, lr: float, num_epochs: int, sched_type: str = "onecycle", **kwargs: Any) -> None:
+        total = num_epochs * len(self.train_loader)
+        if sched_type == "onecycle":
+            self.scheduler = OneCycleLR(self.optimizer, lr, total, **kwargs)
+        elif sched_type == "cosine":
+            self.scheduler = CosineAnnealingLR(self.optimizer, total, **kwargs)
+        else:
+            raise ValueError(f"The following scheduler type is not supported: {sched_type}")
+
+    # ---------------------------------------------------------------- public loops
+    def fit_n_epochs(self, num_epochs: int, lr: float, freeze_until: Optional[str] = None, sched_type: str = "onecycle",
+                     norm_weight_decay: Optional[float] = None, **kwargs: Any) -> None:
+        """core.py:277-324"""
+        freeze_model(self.model.train(), freeze_until)
+        self._reset_opt(lr, norm_weight_decay)
+        self._reset_scheduler(lr, num_epochs, sched_type, **kwargs)
+        master_bar, _ = _bars()
+        mb = master_bar(range(num_epochs))
+        for _ in mb:
+            self._fit_epoch(mb)
+            eval_metrics = self.evaluate()
+            mb.main_bar.comment = f"Epoch {self.epoch}/{self.start_epoch + num_epochs}"
+            mb.write(f"Epoch {self.epoch}/{self.start_epoch + num_epochs} - {self._eval_metrics_str(eval_metrics)}")
+            if eval_metrics["val_loss"] < self.min_loss:
+                print(f"Validation loss decreased {self.min_loss:.4} --> {eval_metrics['val_loss']:.4}: saving state...")
+                self.min_loss = eval_metrics["val_loss"]
+                self.save(self.output_file)
+            if self.on_epoch_end is not None:
+                self.on_epoch_end(eval_metrics)
+
+    def find_lr(self, freeze_until: Optional[str] = None, start_lr: float = 1e-7, end_lr: float = 1,
+                norm_weight_decay: Optional[float] = None, num_it: int = 100) -> None:
+        """Learning-rate range test (core.py:326-381): exponential sweep, losses in ``loss_recorder``."""
+        if num_it > len(self.train_loader):
+            raise ValueError("the value of `num_it` needs to be lower than the number of available batches")
+        freeze_model(self.model.train(), freeze_until)
+        self._reset_opt(start_lr, norm_weight_decay)
+        gamma = (end_lr / start_lr) ** (1 / (num_it - 1))
+        scheduler = MultiplicativeLR(self.optimizer, lambda step: gamma)
+        self.lr_recorder = [start_lr * gamma ** idx for idx in range(num_it)]
+        self.loss_recorder = []
+        for batch_idx, (x, target) in enumerate(self.train_loader):
+            x, target = self.to_cuda(x, target)
+            batch_loss = self._get_loss(x, target)
+            self._backprop_step(batch_loss)
+            scheduler.step()
+            value = float(batch_loss.detach())
+            if not math.isfinite(value):
+                if batch_idx == 0:
+                    raise ValueError("loss value is NaN or inf.")
+                break
+            self.loss_recorder.append(value)
+            if batch_idx + 1 == num_it:
+                break
+        self.lr_recorder = self.lr_recorder[: len(self.loss_recorder)]
+
+    def plot_recorder(self, beta: float = 0.95, **kwargs: Any) -> None:
+        """core.py:383-418 (needs matplotlib)"""
+        if len(self.lr_recorder) != len(self.loss_recorder) or len(self.lr_recorder) == 0:
+            raise AssertionError("Please run the `lr_find` method first")
+        import matplotlib.pyplot as plt
+        import numpy as np
+        smoothed, avg = [], 0.0
+        for idx, loss in enumerate(self.loss_recorder):
+            avg = beta * avg + (1 - beta) * loss
+            smoothed.append(avg / (1 - beta ** (idx + 1)))
+        n = len(self.loss_recorder)
+        sl = slice(min(n // 10, 10), -min(n // 20, 5) if n >= 20 else n)
+        vals = np.array(smoothed[sl])
+        lo = int(vals.argmin())
+        hi = vals[: lo + 1].max()
+        delta = hi - vals[lo]
+        plt.plot(self.lr_recorder[sl], smoothed[sl])
+        plt.xscale("log")
+        plt.xlabel("Learning Rate")
+        plt.ylabel("Training loss")
+        plt.ylim(vals[lo] - 0.1 * delta, hi + 0.2 * delta)
+        plt.grid(True, linestyle="--", axis="x")
+        plt.show(**kwargs)
+
+    def check_setup(self, freeze_until: Optional[str] = None, lr: float = 3e-4, norm_weight_decay: Optional[float] = None,
+                    num_it: int = 100, plot: bool = True, **kwargs: Any) -> List[float]:
+        """Overfit one batch (core.py:420-451); returns the losses (and plots them when matplotlib is there)."""
+        freeze_model(self.model.train(), freeze_until)
+        self._reset_opt(lr, norm_weight_decay)
+        x, target = next(iter(self.train_loader))
+        x, target = self.to_cuda(x, target)
+        losses = []
+        for _ in range(num_it):
+            batch_loss = self._get_loss(x, target)
+            self._backprop_step(batch_loss)
+            value = float(batch_loss.detach())
+            if not math.isfinite(value):
+                raise ValueError("loss value is NaN or inf.")
+            losses.append(value)
+        if plot:
+            try:
+                import matplotlib.pyplot as plt
+                plt.plot(range(len(losses)), losses)
+                plt.xlabel("Optimization steps")
+                plt.ylabel("Training loss")
+                plt.grid(True, linestyle="--", axis="x")
+                plt.show(**kwargs)
+            except ImportError:
+                pass
+        return losses

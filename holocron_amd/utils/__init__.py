@@ -1,1 +1,1 @@
-from . import data, metrics  # noqa: F401
+from . import data, metrics, misc  # noqa: F401

@@ -338,6 +338,11 @@ int hc_hard_mish_bwd(const float* x, const float* dy, float* dx, int64_t n, hc_s
  * 5 aspect_ratio_consistency */
 int hc_box_pairwise(const float* b1, const float* b2, float* out, int32_t M, int32_t N, int32_t kind,
                     hc_stream_t stream);
+/* Gradient of the same (the reference's functions are plain differentiable torch expressions, boxes.py:16-211; ciou_loss is the
+ * training loss at yolov4.py:403): db1 [M][4] += sum_j g[i][j] d out[i][j] / d b1[i], db2 [N][4] likewise; the caller zeroes db1 / db2.
+ * Ties of max / min split the gradient evenly, clamp(min=0) passes it at 0 - torch autograd's conventions. */
+int hc_box_pairwise_bwd(const float* b1, const float* b2, const float* g, float* db1, float* db2, int32_t M, int32_t N, int32_t kind,
+                        hc_stream_t stream);
 
 /* Greedy NMS with torchvision.ops.nms semantics (yolov4.py:329): boxes [n][4] fp32 already
  * sorted by descending score (stable); ws scratch of hc_nms_ws_bytes(n); keep out: int32 [n]
