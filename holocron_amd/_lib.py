@@ -71,7 +71,7 @@ class RepBnDesc(C.Structure):
 class RepBnBwdDesc(C.Structure):
     _fields_ = [("red", c_void_p), ("save", c_void_p), ("gamma", c_void_p * 3), ("dgamma", c_void_p * 3),
                 ("dbeta", c_void_p * 3), ("bcoef", c_void_p), ("C", c_int32), ("count", c_int64),
-                ("has_identity", c_int32), ("accumulate", c_int32), ("c_valid", c_int32)]
+                ("has_identity", c_int32), ("accumulate", c_int32), ("c_valid", c_int32), ("frozen", c_int32)]
 
 
 class MtChunk(C.Structure):

@@ -250,8 +250,10 @@ __global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_b
             const float dgamma = invstd * (sdzy - mean * sdz);
             const float a = d.gamma[b][c] * invstd;
             A = a;
-            B = -a * invstd * dgamma / cnt;
-            Cc = -a * sdz / cnt - B * mean;
+            if (!d.frozen) {            // batch statistics: the two centring terms of BatchNorm's backward
+                B = -a * invstd * dgamma / cnt;
+                Cc = -a * sdz / cnt - B * mean;
+            }
             if (d.dgamma[b] != nullptr) d.dgamma[b][c] = d.accumulate ? d.dgamma[b][c] + dgamma : dgamma;
             if (d.dbeta[b] != nullptr) d.dbeta[b][c] = d.accumulate ? d.dbeta[b][c] + sdz : sdz;
         }

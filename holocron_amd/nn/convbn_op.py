@@ -148,8 +148,6 @@ class ConvBnActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         stride, pad, act, slope, im2col, training = ctx.meta2
-        if not training:
-            raise NotImplementedError("conv_bn_act backward in eval mode (running statistics) is not implemented")
         lib = _lib.load()
         st = ctx.st
         src, y, coef, save, gamma, w = ctx.saved_tensors
@@ -171,6 +169,7 @@ class ConvBnActFn(torch.autograd.Function):
             d.gamma[b] = d.dgamma[b] = d.dbeta[b] = None
         d.gamma[0], d.dgamma[0], d.dbeta[0] = ptr(gamma), ptr(dgam), ptr(dbet)
         d.C, d.count, d.has_identity, d.accumulate = Cout, npix, 0, 0
+        d.frozen = 0 if training else 1               # eval mode / freeze_bn: running statistics, dy = a * dz
         check(lib.hc_rep_bn_bwd_finalize(C.byref(d), stream()), "hc_rep_bn_bwd_finalize")
         dy = torch.empty_like(y)
         check(lib.hc_bn_act_bwd_apply(ptr(g), g_ld, ptr(y), ptr(coef), ptr(bcoef), ptr(keep), ptr(count), ptr(dy), npix, Cout, act,

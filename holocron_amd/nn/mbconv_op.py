@@ -150,8 +150,6 @@ class PadConvBnActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         stride, pad, act, slope, training, depthwise, res_C = ctx.meta2
-        if not training:
-            raise NotImplementedError("conv_bn_act backward in eval mode (running statistics) is not implemented")
         lib = _lib.load()
         st = ctx.st
         x, y, coef, save, gamma, w = ctx.saved_tensors
@@ -170,6 +168,7 @@ class PadConvBnActFn(torch.autograd.Function):
         d.red, d.save, d.bcoef = ptr(red), ptr(save), ptr(bcoef)
         d.gamma[0], d.dgamma[0], d.dbeta[0] = ptr(gamma), ptr(dgam), ptr(dbet)
         d.C, d.count, d.has_identity, d.accumulate, d.c_valid = Cout_p, npix, 0, 0, Cout
+        d.frozen = 0 if training else 1               # eval mode / freeze_bn: running statistics, dy = a * dz
         check(lib.hc_rep_bn_bwd_finalize(C.byref(d), stream()), "hc_rep_bn_bwd_finalize")
         dy = torch.empty_like(y)
         check(lib.hc_bn_act_bwd_apply(ptr(g), g_ld, ptr(y), ptr(coef), ptr(bcoef), None, None, ptr(dy), npix, Cout_p, act, slope,

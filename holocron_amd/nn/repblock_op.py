@@ -296,8 +296,6 @@ class RepBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        if not ctx.was_training:
-            raise NotImplementedError("RepBlock backward in eval mode (running statistics) is not implemented")
         lib = _lib.load()
         st = ctx.st
         src, y3, y1, out, save, g3, g1, g0, w3, w1 = ctx.saved_tensors
@@ -325,6 +323,7 @@ class RepBlockFn(torch.autograd.Function):
             d.dgamma[b] = ptr(dgam[b]) if live else None
             d.dbeta[b] = ptr(dbet[b]) if live else None
         d.C, d.count, d.has_identity, d.accumulate = Cout, npix, 1 if st.identity else 0, 0
+        d.frozen = 0 if ctx.was_training else 1       # eval mode / freeze_bn: running statistics, dy = a * dz
         check(lib.hc_rep_bn_bwd_finalize(C.byref(d), stream()), "hc_rep_bn_bwd_finalize")
 
         dy3 = torch.empty_like(y3)
@@ -355,6 +354,9 @@ def rep_block_forward(x, w3, w1, bn3, bn1, bn0, st, relu=True):
     st.eps = bn3.eps
     st.momentum = 0.1 if bn3.momentum is None else bn3.momentum
     st.training = bn3.training
+    if bn1.training != bn3.training or (bn0 is not None and bn0.training != bn3.training):
+        raise NotImplementedError("RepBlock (HIP): the BatchNorm layers of one block must all be in the same mode (freeze the "
+                                  "whole block, e.g. freeze_model(model, 'features.2.1'), not a single branch)")
     out = RepBlockFn.apply(x, w3, w1, bn3.weight, bn3.bias, bn1.weight, bn1.bias,
                            bn0.weight if bn0 is not None else None, bn0.bias if bn0 is not None else None, st, relu)
     if st.last_out_stats is not None:

@@ -196,6 +196,8 @@ typedef struct {
     int32_t has_identity;
     int32_t accumulate;        /* 1: dgamma/dbeta += */
     int32_t c_valid;           /* > 0: channels >= c_valid are layout padding (A = B = C = 0, nothing written) */
+    int32_t frozen;            /* 1: the forward normalised with the RUNNING statistics (eval mode / freeze_bn, trainer/utils.py:14-30): they
+                                * do not depend on the batch, so dy = a * dz (B = C = 0); dgamma / dbeta as in training mode */
 } hc_rep_bn_bwd_desc;
 int hc_rep_bn_bwd_finalize(const hc_rep_bn_bwd_desc* d, hc_stream_t stream);
 int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void* y1, const void* x,
