@@ -1,7 +1,9 @@
-"""Secondary measurement: YOLOv4 (CSP-Darknet-53 + PAN/SPP neck + head, nc=80) training step
-at 608 x 608 on one MI355X: forward + four-part loss + backward + AdaBelief, synthetic data.  Prints one JSON line.
+"""BASELINE.json configs[3]: darknet53-CSP + YOLOv4 head (nc = 80), CIoU loss, synthetic 608 x 608, 16 images per GPU (128 over the
+8 GPUs the config names), data parallel over RCCL: forward + four-part loss + backward + AdaBelief.  `--eval` times forward +
+decode + NMS on one GPU instead.  Prints one JSON line (rank 0).
 
-    python scripts/bench_yolov4.py --batch 16 --steps 5 --warmup 2 [--eval]
+    python scripts/bench_yolov4.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29512 scripts/bench_yolov4.py --gpus 8
 """
 import argparse
 import json
@@ -9,68 +11,105 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch  # noqa: E402
 
-import holocron_amd as h  # noqa: E402
+import _train_bench as tb  # noqa: E402
 
 TRAIN_GFLOP_PER_IMG = 385.0   # 3 x 2 x 64.195 GMAC (fwd + dgrad + wgrad) at 608^2, nc=80
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--size", type=int, default=608)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--eval", action="store_true")
-    a = ap.parse_args()
-    dev = torch.device("cuda:0")
-    torch.manual_seed(0)
-    m = h.models.detection.yolov4(pretrained_backbone=False, num_classes=80).to(dev)
-    g = torch.Generator().manual_seed(1)
-    x = torch.rand((a.batch, 3, a.size, a.size), generator=g).to(dev)
-    target = []
-    for i in range(a.batch):
+def targets(batch, g, dev):
+    out = []
+    for i in range(batch):       # the reference's own recipe (tests/test_models_detection.py:40-42), 1..8 boxes per image
         k = 1 + i % 8
         b = torch.rand((k, 4), generator=g)
         b[:, :2] *= b[:, 2:]
         b[:, 2:] = torch.maximum(b[:, 2:], b[:, :2] + 0.02).clamp(max=0.999)
-        target.append({"boxes": b.to(dev), "labels": torch.randint(0, 80, (k,), generator=g).to(dev)})
+        out.append({"boxes": b.to(dev), "labels": torch.randint(0, 80, (k,), generator=g).to(dev)})
+    return out
+
+
+def main():
+    ap = tb.add_common_args(argparse.ArgumentParser())
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (configs[3]: 128 over 8 GPUs)")
+    ap.add_argument("--size", type=int, default=608)
+    ap.add_argument("--eval", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    a = ap.parse_args()
+    # The YOLOv4 step is NOT replayed from a hipGraph: every forward packs the ragged ground truth and the DropBlock plan on the host
+    # and uploads them (pageable memcpy nodes would re-read freed host buffers on replay - a memory fault on the MI355X box).
+    a.no_graph = True
+    import holocron_amd as h
+
     if a.eval:
-        m.eval()
+        dev = torch.device("cuda:0")
+        torch.manual_seed(0)
+        m = h.models.detection.yolov4(pretrained_backbone=False, num_classes=80).to(dev).eval()
+        x = torch.rand((a.batch, 3, a.size, a.size), generator=torch.Generator().manual_seed(1)).to(dev)
+        with torch.no_grad():
+            for _ in range(a.warmup):
+                out = m(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                out = m(x)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        print(json.dumps({"metric": "images/sec eval fwd+decode+NMS, YOLOv4 608^2 nc=80", "value": a.batch / dt, "unit": "images/sec",
+                          "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": f"yolov4 {a.size}^2 bs{a.batch} eval"}, "detections_img0": int(out[0]["boxes"].shape[0])}))
+        return
 
-        def step():
+    def build():
+        return h.models.detection.yolov4(pretrained_backbone=False, num_classes=80)
+
+    def make_batch(rank, dev):
+        g = torch.Generator().manual_seed(1 + rank)
+        return torch.rand((a.batch, 3, a.size, a.size), generator=g).to(dev), targets(a.batch, g, dev)
+
+    def loss_of(model, x, t):
+        return sum(v.sum() for v in model(x, t).values())
+
+    def cpu_baseline():
+        """oracle.yolov4.train_losses (the reference's YOLOv4 restated on torch-CPU fp32) + autograd + the oracle's AdaBelief."""
+        from oracle import yolov4 as ov
+        from oracle.optim import adabelief_step
+        torch.manual_seed(0)
+        sd = {k: v.detach().clone() for k, v in build().state_dict().items()}
+        keys = [k for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+        g = torch.Generator().manual_seed(0)
+        x = torch.rand((a.cpu_batch, 3, a.size, a.size), generator=g)
+        t = targets(a.cpu_batch, g, "cpu")
+        state = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in keys}
+        step = [0]
+
+        def one():
+            work = dict(sd)
+            params = {k: sd[k].detach().requires_grad_(True) for k in keys}
+            work.update(params)
+            losses, _ = ov.train_losses(work, x, t, ov.CSP53, 80, ov.Cfg(act="mish", drop=(0.1, 7), training=True))
+            grads = torch.autograd.grad(sum(v.sum() for v in losses.values()), [params[k] for k in keys], allow_unused=True)
+            step[0] += 1
             with torch.no_grad():
-                return m(x)
-    else:
-        m.train()
-        opt = h.optim.AdaBelief(m.parameters(), lr=1e-3, betas=(0.95, 0.99), eps=1e-6, weight_decay=0)
+                for k, gr in zip(keys, grads):
+                    if gr is not None:
+                        adabelief_step(sd[k], gr, state[k][0], state[k][1], step[0], 1e-3, 0.95, 0.99, 1e-6, 0.0)
+            return a.cpu_batch
+        torch.set_flush_denormal(True)
+        best, trial, host, default = tb.best_threads_run(one, counts=(16, 32, 64))
+        t0 = time.perf_counter()
+        n = sum(one() for _ in range(2))
+        dt = time.perf_counter() - t0
+        torch.set_num_threads(default)
+        return {"value": n / dt, "unit": "images/sec", "cores": best, "host_threads": host, "kind": "port",
+                "threads_tried": {str(k): round(v, 3) for k, v in trial.items()},
+                "sample": f"oracle yolov4 608^2 train step (torch-CPU fp32), batch {a.cpu_batch}, 2 timed iterations"}
 
-        def step():
-            opt.zero_grad(set_to_none=True)
-            losses = m(x, target)
-            sum(v.sum() for v in losses.values()).backward()
-            opt.step()
-            return losses
-    for _ in range(a.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.steps
-    rec = {"metric": "images/sec " + ("eval fwd+decode+NMS" if a.eval else "train step (fwd+loss+bwd+AdaBelief)") + ", YOLOv4 608^2 nc=80",
-           "value": a.batch / dt, "unit": "img/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3,
-           "dtype": "bf16", "data": "synthetic", "config": {"workload": f"yolov4 {a.size}^2 bs{a.batch}"},
-           "peak_mem_GB": torch.cuda.max_memory_allocated() / 2**30}
-    if not a.eval:
-        rec["mfma_frac"] = TRAIN_GFLOP_PER_IMG * 1e9 * a.batch / dt / 2.5e15 if a.size == 608 else None
-        rec["losses"] = {k: float(v.sum()) for k, v in out.items()}
-    else:
-        rec["detections_img0"] = int(out[0]["boxes"].shape[0])
-    print(json.dumps(rec))
+    tb.run(a, build, make_batch, loss_of, "images/sec fwd+loss+bwd+AdaBelief, YOLOv4 (CSP-darknet53) bs16/GPU 608^2 nc=80",
+           f"yolov4 bf16 train step (fwd + 4 losses + bwd + AdaBelief), synthetic {a.size}^2, bs={a.batch} per MI355X "
+           "(BASELINE.json configs[3]), random-init weights, 80 classes", train_gflop_per_img=TRAIN_GFLOP_PER_IMG if a.size == 608 else None,
+           cpu_baseline=cpu_baseline)
 
 
 if __name__ == "__main__":
