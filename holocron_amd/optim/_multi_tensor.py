@@ -65,3 +65,26 @@ class Staging:
             ev.record()
             self.events[i] = ev
         return self.dev
+
+
+class DeviceTables:
+    """Device-resident copies of an optimizer's small host tables (chunk table, group block, per-tensor arrays), keyed by name and
+    re-uploaded only when their BYTES change.  The chunk table of a model is a pure function of the parameter / gradient / state
+    addresses, which a training loop keeps from step to step, so after the first step nothing crosses PCIe for it - and a step
+    whose tables did not change records no copy node under hipGraph capture.  Uploads go through pinned staging rings (async,
+    no host synchronisation)."""
+
+    def __init__(self):
+        self.slots = {}
+
+    def get(self, name, raw, device):
+        raw = np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+        key = raw.tobytes()
+        slot = self.slots.get(name)
+        if slot is not None and slot[0] == key and slot[1].dev.device == device:
+            return slot[1].dev
+        n = max(raw.size, 16)
+        stage = slot[1] if (slot is not None and slot[1].dev.numel() == n and slot[1].dev.device == device) else Staging(n, device)
+        stage.upload(raw)
+        self.slots[name] = (key, stage)
+        return stage.dev

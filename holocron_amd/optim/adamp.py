@@ -16,7 +16,7 @@ from torch.optim.optimizer import Optimizer
 from .. import _lib
 from .._lib import AdamxGroup, check, ptr, stream
 from ..ops.conv import bump_weights_epoch
-from ._multi_tensor import build_chunks
+from ._multi_tensor import DeviceTables, chunk_rows
 
 __all__ = ["AdamP", "AdEMAMix"]
 
@@ -74,10 +74,14 @@ class AdamP(Adam):
         if not entries:
             return loss
         dev = entries[0]["p"].device
-        host, n = build_chunks(entries)
-        chunks, gdev = host.to(dev), _upload(gbuf, dev)
+        tabs = getattr(self, "_hc_tabs", None)
+        if tabs is None:
+            tabs = self._hc_tabs = DeviceTables()
+        raw, n = chunk_rows(entries)       # device-resident tables: re-uploaded only when an address / hyper-parameter / step changed
+        chunks = tabs.get("chunks", raw, dev)
+        gdev = tabs.get("groups", np.frombuffer(bytes(gbuf), dtype=np.uint8), dev)
         sums = torch.empty((len(entries), 4), dtype=torch.float32, device=dev)
-        nel = torch.tensor(numel, dtype=torch.int32).to(dev)
+        nel = tabs.get("numel", np.asarray(numel, dtype=np.int32), dev)
         check(_lib.load().hc_adamp_step(ptr(chunks), n, ptr(gdev), ptr(sums), ptr(nel), len(entries), stream()), "hc_adamp_step")
         self._hc_keep = (chunks, gdev, sums, nel)      # alive until the stream has consumed them
         bump_weights_epoch()
@@ -130,8 +134,12 @@ class AdEMAMix(Optimizer):
         if not entries:
             return loss
         dev = entries[0]["p"].device
-        host, n = build_chunks(entries)
-        chunks, gdev = host.to(dev), _upload(gbuf, dev)
+        tabs = getattr(self, "_hc_tabs", None)
+        if tabs is None:
+            tabs = self._hc_tabs = DeviceTables()
+        raw, n = chunk_rows(entries)
+        chunks = tabs.get("chunks", raw, dev)
+        gdev = tabs.get("groups", np.frombuffer(bytes(gbuf), dtype=np.uint8), dev)
         check(_lib.load().hc_ademamix_step(ptr(chunks), n, ptr(gdev), stream()), "hc_ademamix_step")
         self._hc_keep = (chunks, gdev)
         bump_weights_epoch()

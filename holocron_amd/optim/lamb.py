@@ -8,13 +8,14 @@ update with the ratio taken on the device.
 import math
 from typing import Callable, Iterable, Optional, Tuple
 
+import numpy as np
 import torch
 from torch.optim.optimizer import Optimizer
 
 from .. import _lib
 from .._lib import LambGroup, check, ptr, stream
 from ..ops.conv import bump_weights_epoch
-from ._multi_tensor import build_chunks
+from ._multi_tensor import DeviceTables, chunk_rows
 from .adamp import _check_param, _upload
 
 __all__ = ["LAMB", "RaLars"]
@@ -75,8 +76,12 @@ class _TrustRatioAdam(Optimizer):
         if not entries:
             return loss
         dev = entries[0]["p"].device
-        host, n = build_chunks(entries)
-        chunks, gdev = host.to(dev), _upload(gbuf, dev)
+        tabs = getattr(self, "_hc_tabs", None)
+        if tabs is None:
+            tabs = self._hc_tabs = DeviceTables()
+        raw, n = chunk_rows(entries)       # device-resident tables: re-uploaded only when an address / hyper-parameter / step changed
+        chunks = tabs.get("chunks", raw, dev)
+        gdev = tabs.get("groups", np.frombuffer(bytes(gbuf), dtype=np.uint8), dev)
         norms = torch.empty((len(entries), 2), dtype=torch.float32, device=dev)
         local = torch.empty((len(entries),), dtype=torch.float32, device=dev)
         check(_lib.load().hc_lamb_step(ptr(chunks), n, ptr(gdev), ptr(norms), ptr(local), len(entries), stream()), "hc_lamb_step")

@@ -14,7 +14,7 @@ from torch.optim.optimizer import Optimizer
 from .. import _lib
 from .._lib import LarsGroup, check, ptr, stream
 from ..ops.conv import bump_weights_epoch
-from ._multi_tensor import build_chunks
+from ._multi_tensor import DeviceTables, chunk_rows
 
 __all__ = ["LARS"]
 
@@ -73,12 +73,17 @@ class LARS(Optimizer):
         if not entries:
             return loss
         dev = entries[0]["p"].device
-        host, n = build_chunks(entries)
-        chunks = host.to(dev)
-        gdev = torch.from_numpy(np.frombuffer(bytes(gbuf), dtype=np.uint8).copy()).to(dev)
-        norms = torch.empty((len(entries), 2), dtype=torch.float32, device=dev)
+        # device-resident tables, re-uploaded only when an address or a hyper-parameter changed: no per-step H2D copy, and the step
+        # can be captured in a hipGraph (LARS has no step-dependent scalar)
+        tabs = getattr(self, "_hc_tabs", None)
+        if tabs is None:
+            tabs = self._hc_tabs = DeviceTables()
+        raw, n = chunk_rows(entries)
+        chunks = tabs.get("chunks", raw, dev)
+        gdev = tabs.get("groups", np.frombuffer(bytes(gbuf), dtype=np.uint8), dev)
+        norms = getattr(self, "_hc_norms", None)
+        if norms is None or norms.shape[0] != len(entries) or norms.device != dev:
+            norms = self._hc_norms = torch.empty((len(entries), 2), dtype=torch.float32, device=dev)
         check(_lib.load().hc_lars_step(ptr(chunks), n, ptr(gdev), ptr(norms), len(entries), stream()), "hc_lars_step")
-        # keep the tables alive until the stream has consumed them
-        self._hc_keep = (chunks, gdev, norms)
         bump_weights_epoch()
         return loss

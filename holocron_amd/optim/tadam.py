@@ -15,7 +15,7 @@ from torch.optim.optimizer import Optimizer
 from .. import _lib
 from .._lib import AdamxGroup, check, ptr, stream
 from ..ops.conv import bump_weights_epoch
-from ._multi_tensor import build_chunks
+from ._multi_tensor import DeviceTables, chunk_rows
 from .adamp import _check_param, _upload
 
 __all__ = ["TAdam", "Adan"]
@@ -81,17 +81,21 @@ class TAdam(Optimizer):
         if not entries:
             return loss
         dev = entries[0]["p"].device
-        host, n = build_chunks(entries)
-        chunks, gdev = host.to(dev), _upload(gbuf, dev)
+        tabs = getattr(self, "_hc_tabs", None)
+        if tabs is None:
+            tabs = self._hc_tabs = DeviceTables()
+        raw, n = chunk_rows(entries)       # device-resident tables: re-uploaded only when an address / hyper-parameter / step changed
+        chunks = tabs.get("chunks", raw, dev)
+        gdev = tabs.get("groups", np.frombuffer(bytes(gbuf), dtype=np.uint8), dev)
         T = len(entries)
         scratch = torch.empty((3 * T,), dtype=torch.float32, device=dev)
         # one staging buffer for the three per-tensor tables: numel | group | dof | W_t pointers
         tab = np.zeros((T,), dtype=[("numel", "<i4"), ("group", "<i4"), ("dof", "<f4"), ("pad", "<i4"), ("w", "<u8")])
         tab["numel"], tab["group"], tab["dof"], tab["w"] = numel, tgroup, dofs, wptr
-        nel = torch.from_numpy(np.ascontiguousarray(tab["numel"])).to(dev)
-        grp = torch.from_numpy(np.ascontiguousarray(tab["group"])).to(dev)
-        dof = torch.from_numpy(np.ascontiguousarray(tab["dof"])).to(dev)
-        wts = torch.from_numpy(np.ascontiguousarray(tab["w"]).view(np.int64)).to(dev)
+        nel = tabs.get("numel", np.ascontiguousarray(tab["numel"]), dev)
+        grp = tabs.get("group", np.ascontiguousarray(tab["group"]), dev)
+        dof = tabs.get("dof", np.ascontiguousarray(tab["dof"]), dev)
+        wts = tabs.get("w", np.ascontiguousarray(tab["w"]), dev)
         check(_lib.load().hc_tadam_step(ptr(chunks), n, ptr(gdev), ptr(scratch), ptr(dof), ptr(nel), ptr(grp), ptr(wts), T, stream()),
               "hc_tadam_step")
         self._hc_keep = (chunks, gdev, scratch, nel, grp, dof, wts)
@@ -144,10 +148,14 @@ class Adan(Adam):
         if not entries:
             return loss
         dev = entries[0]["p"].device
-        host, n = build_chunks(entries)
-        host2, n2 = build_chunks(extra)
+        tabs = getattr(self, "_hc_tabs", None)
+        if tabs is None:
+            tabs = self._hc_tabs = DeviceTables()
+        raw, n = chunk_rows(entries)
+        raw2, n2 = chunk_rows(extra)
         assert n == n2
-        chunks, chunks2, gdev = host.to(dev), host2.to(dev), _upload(gbuf, dev)
+        chunks, chunks2 = tabs.get("chunks", raw, dev), tabs.get("chunks2", raw2, dev)
+        gdev = tabs.get("groups", np.frombuffer(bytes(gbuf), dtype=np.uint8), dev)
         check(_lib.load().hc_adan_step(ptr(chunks), ptr(chunks2), n, ptr(gdev), stream()), "hc_adan_step")
         self._hc_keep = (chunks, chunks2, gdev)
         bump_weights_epoch()

@@ -13,7 +13,7 @@ from torch.optim.optimizer import Optimizer
 from .. import _lib
 from .._lib import check, ptr, stream
 from ..ops.conv import bump_weights_epoch
-from ._multi_tensor import build_chunks
+from ._multi_tensor import DeviceTables, chunk_rows
 
 __all__ = ["Lookahead", "Scout"]
 
@@ -98,8 +98,11 @@ class Lookahead(Optimizer):
         if not entries:
             return
         dev = entries[0]["p"].device
-        host, n = build_chunks(entries)
-        chunks = host.to(dev)
+        tabs = getattr(self, "_hc_tabs", None)
+        if tabs is None:
+            tabs = self._hc_tabs = DeviceTables()
+        raw, n = chunk_rows(entries)
+        chunks = tabs.get("chunks", raw, dev)
         check(_lib.load().hc_lookahead_sync(ptr(chunks), n, float(sync_rate), stream()), "hc_lookahead_sync")
         self._hc_keep = chunks
         bump_weights_epoch()
