@@ -233,6 +233,9 @@ SIGNATURES = {
     "hc_im2col_small_fp8": (c_int32, [c_void_p, c_void_p] + [c_int32] * 11 + [c_float, c_void_p]),
     "hc_quantize_fp8": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_float, c_void_p]),
     "hc_gap_fp8": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "hc_set_deterministic": (c_int32, [c_int32]),
+    "hc_get_deterministic": (c_int32, []),
+    "hc_get_stat_replicas": (c_int32, []),
     "hc_version": (C.c_char_p, []),
 }
 
@@ -259,6 +262,17 @@ def load():
 
 class HipError(RuntimeError):
     pass
+
+
+def stat_replicas() -> int:
+    """Replicas of every per-channel statistics accumulator right now (128, or 32768 in deterministic mode)."""
+    return int(load().hc_get_stat_replicas())
+
+
+def set_deterministic(on: bool) -> None:
+    """Bit-reproducible training steps (include/holocron_hip.h hc_set_deterministic): every workgroup gets its own slot of the
+    statistics accumulators, the split reductions become single-writer.  Costs memory (32768 replicas) and a slower finalize."""
+    check(load().hc_set_deterministic(1 if on else 0), "hc_set_deterministic")
 
 
 _ERR = {1: "bad argument", 2: "kernel launch failure"}

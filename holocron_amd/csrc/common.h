@@ -106,6 +106,12 @@ static inline hipError_t hc_zero_async(void* p, size_t bytes, hipStream_t st) {
     return hipGetLastError();
 }
 
+// Number of replicas of every per-channel statistics accumulator ([replicas][k][C], workgroup b adds into replica b % replicas).
+// Default HC_STAT_REPLICAS; hc_set_deterministic(1) raises it above the largest grid so that every workgroup owns its slot and the
+// finalize kernels add the slots in a fixed order (bit-reproducible statistics).  Defined in rep_bn.hip.
+extern "C" int hc_get_stat_replicas(void);
+extern "C" int hc_get_deterministic(void);
+
 static inline int hc_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? HC_OK : HC_ERR_LAUNCH;

@@ -35,7 +35,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // the epilogue applies the per-channel dequant * requant factor and bias, ReLU, and stores fp8.
 typedef __attribute__((ext_vector_type(8))) int hc_i32x8;
 template <int MR, int NR, int WM, int WN, int BK, bool FP8>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_conv_desc d) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_conv_desc d, const int reps) {
     static_assert(!FP8 || BK == 32, "fp8: 64 one-byte channels per k-step");
     constexpr int NT = 64 * WM * WN;
     constexpr int BC = 32 * MR * WM;  // output-channel tile (A rows)
@@ -221,9 +221,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
     // only 2*Cout distinct addresses, so (1) the waves of a workgroup are combined in LDS first and
     // (2) the global atomics are spread over HC_STAT_REPLICAS copies that bn_finalize sums.
     if (d.stats != nullptr) {
-        float* sred = reinterpret_cast<float*>(smem);  // [2][BC], the staging tiles are dead now
-        for (int i = tid; i < 2 * BC; i += NT) sred[i] = 0.f;
-        __syncthreads();
+        // [WN][2][BC], the staging tiles are dead now: one plane per pixel wave, summed in a fixed order below (no LDS
+        // atomics - a workgroup's contribution must not depend on which of its waves finishes first)
+        float* sred = reinterpret_cast<float*>(smem) + wn * 2 * BC;
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
             float s1[16], s2[16];
@@ -256,20 +256,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
             if ((lane & 1) == 0) {
                 const int r = 8 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 1) & 1);
                 const int cl_ = (wm * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (WN > 1) {
-                    atomicAdd(&sred[cl_], s1[0]);
-                    atomicAdd(&sred[BC + cl_], s2[0]);
-                } else {
-                    sred[cl_] = s1[0];
-                    sred[BC + cl_] = s2[0];
-                }
+                sred[cl_] = s1[0];
+                sred[BC + cl_] = s2[0];
             }
         }
         __syncthreads();
-        float* rep = d.stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * Cout;
+        float* rep = d.stats + (size_t)(blockIdx.x % reps) * 2 * Cout;
         for (int i = tid; i < 2 * BC; i += NT) {
             const int which = i / BC, c = i - which * BC;
-            if (cbase + c < Cout) atomicAdd(rep + which * Cout + cbase + c, sred[i]);
+            if (cbase + c < Cout) {
+                const float* pl = reinterpret_cast<const float*>(smem) + i;
+                float v = pl[0];
+#pragma unroll
+                for (int w = 1; w < WN; ++w) v += pl[w * 2 * BC];
+                atomicAdd(rep + which * Cout + cbase + c, v);
+            }
         }
     }
 
@@ -383,7 +384,8 @@ int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, st, d);
+    if (d.stats != nullptr && hc_get_deterministic() && (int)grid.x > hc_get_stat_replicas()) return HC_ERR_ARG;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, st, d, hc_get_stat_replicas());
     return hc_launch_status();
 }
 

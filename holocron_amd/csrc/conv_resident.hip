@@ -25,6 +25,7 @@ struct Args {
     int PS;            // bytes per window pixel
     int win_bytes;     // (H+2)*(W+2)*PS
     int wtile_bytes;   // Cout * 128
+    int reps;          // statistics replicas
 };
 
 template <int KCB, int MR>   // C = 64 KCB input channels, Cout = 64 MR output channels
@@ -164,9 +165,9 @@ __global__ __launch_bounds__(NT, 1) void conv_resident_kernel(const Args a) {
     const int lr = lane & 31, lh = lane >> 5;
     auto epilogue = [&](void* outp, float* stats, const void* residp) {
         if (stats != nullptr) {
-            float* sred = reinterpret_cast<float*>(wst);     // [2][Cout], the weight stages are dead here
-            for (int i = tid; i < 2 * Cout; i += NT) sred[i] = 0.f;
-            __syncthreads();
+            // [4 pixel waves][2][Cout], the weight stages are dead here.  One plane per pixel wave, summed in a fixed order
+            // below: no LDS atomics, so a workgroup's contribution does not depend on which wave finishes first
+            float* sred = reinterpret_cast<float*>(wst) + pw * 2 * Cout;
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
                 float s1[16], s2[16];
@@ -198,13 +199,15 @@ __global__ __launch_bounds__(NT, 1) void conv_resident_kernel(const Args a) {
                 if ((lane & 1) == 0) {
                     const int r = 8 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 1) & 1);
                     const int co = (cw * MR + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    atomicAdd(&sred[co], s1[0]);
-                    atomicAdd(&sred[Cout + co], s2[0]);
+                    sred[co] = s1[0];
+                    sred[Cout + co] = s2[0];
                 }
             }
             __syncthreads();
-            float* rep = stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * Cout;
-            for (int i = tid; i < 2 * Cout; i += NT) atomicAdd(rep + i, sred[i]);
+            float* rep = stats + (size_t)(blockIdx.x % a.reps) * 2 * Cout;
+            const float* pl = reinterpret_cast<const float*>(wst);
+            for (int i = tid; i < 2 * Cout; i += NT)
+                atomicAdd(rep + i, (pl[i] + pl[2 * Cout + i]) + (pl[4 * Cout + i] + pl[6 * Cout + i]));
             __syncthreads();
         }
         bf16_t* dst = reinterpret_cast<bf16_t*>(outp) + (size_t)n * HW * Cout;
@@ -261,8 +264,9 @@ inline bool make_args(const hc_conv_small_desc& d, Args& a, int& smem) {
     a.PS = d.C * 2 + 16;
     a.win_bytes = (d.H + 2) * (d.W + 2) * a.PS;
     a.wtile_bytes = d.Cout * BK * 2;
+    a.reps = hc_get_stat_replicas();
     smem = a.win_bytes + 2 * a.wtile_bytes;
-    if (smem < a.win_bytes + 2 * d.Cout * (int)sizeof(float)) smem = a.win_bytes + 2 * d.Cout * (int)sizeof(float);
+    if (smem < a.win_bytes + 8 * d.Cout * (int)sizeof(float)) smem = a.win_bytes + 8 * d.Cout * (int)sizeof(float);
     return smem <= 160 * 1024;
 }
 

@@ -46,6 +46,7 @@ struct Args {
     int qa, qb;                // DMA instructions per window (the last wave pass may be partial)
     int wrows;                 // weight rows kept in LDS (Cout rounded up to 16; MFMA rows beyond read finite junk)
     int dbg;                   // HC_CSM_DBG knock-outs (timing experiments only): 1 no MFMA/LDS reads, 2 no stats, 4 no stores, 8 no DMA
+    int reps;                  // statistics replicas
 };
 
 template <int KC>   // KC = C / 16 (1, 2, 3)
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(NT, 1) void conv_small_kernel(const Args a) {
         __syncthreads();
         const int which = tid >> 7, kind = (tid >> 6) & 1, co = tid & 63;
         if (co < Cout) {
-            float* st = (which == 0 ? stats3 : stats1) + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * Cout;
+            float* st = (which == 0 ? stats3 : stats1) + (size_t)(blockIdx.x % a.reps) * 2 * Cout;
             atomicAdd(st + kind * Cout + co, sstat[tid]);
         }
     }
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(NT, 1) void conv_small_pipe_kernel(const Args a) {
         __syncthreads();
         const int which = tid >> 7, kind = (tid >> 6) & 1, co = tid & 63;
         if (co < Cout) {
-            float* st = (which == 0 ? stats3 : stats1) + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * Cout;
+            float* st = (which == 0 ? stats3 : stats1) + (size_t)(blockIdx.x % a.reps) * 2 * Cout;
             atomicAdd(st + kind * Cout + co, sstat[tid]);
         }
     }
@@ -801,6 +802,7 @@ extern "C" int hc_conv_small(const hc_conv_small_desc* dp, hc_stream_t stream) {
     int smem = 0;
     if (!csm::make_args(d, a, smem)) return HC_ERR_ARG;
     { const char* e = getenv("HC_CSM_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.reps = hc_get_stat_replicas();
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int grid = a.ntiles < 256 ? a.ntiles : 256;      // one persistent workgroup per CU
     // test / experiment knobs: HC_CONV_SMALL_GRID caps the grid (several tiles per workgroup on small inputs),

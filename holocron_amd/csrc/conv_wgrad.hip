@@ -247,7 +247,7 @@ static inline int launch_wgrad_reduce(const hc_wgrad_desc& d, int nsplit, hipStr
     const int T = d.KH * d.KW;
     const int base = d.Cout * ((d.Cin + 63) / 64);
     int nz = 1;
-    if (base < 512 && nsplit >= 64) {
+    if (base < 512 && nsplit >= 64 && !hc_get_deterministic()) {   // (the z-slices combine with atomics)
         nz = (512 + base - 1) / base;
         if (nz > nsplit / 16) nz = nsplit / 16;
         if (nz < 1) nz = 1;

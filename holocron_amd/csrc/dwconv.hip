@@ -74,7 +74,7 @@ __device__ __forceinline__ void block_reduce_flush(const float (&v)[S][8], int c
 template <int STRIDE, int TW>
 __global__ __launch_bounds__(DW_THREADS) void dw3x3_fwd_kernel(const u32x4* __restrict__ x, const float* __restrict__ w,
                                                                u32x4* __restrict__ y, float* __restrict__ stats, int N, int H, int W,
-                                                               int OH, int OW, int C) {
+                                                               int OH, int OW, int C, const int reps) {
     extern __shared__ float sred[];
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * DW_THREADS + threadIdx.x;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_fwd_kernel(const u32x4* __re
             }
         }
     }
-    if (stats != nullptr) block_reduce_flush<2>(sv, cg, C, stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * C, sred);
+    if (stats != nullptr) block_reduce_flush<2>(sv, cg, C, stats + (size_t)(blockIdx.x % reps) * 2 * C, sred);
 }
 
 // ---------------------------------------------------------------- stride-2 data gradient
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_dgrad_s2_kernel(const u32x4*
 // three rows are loaded once and feed every (pixel, kw) pair they belong to - 5.5 16-byte loads per pixel instead of 10
 template <int STRIDE, int TW>
 __global__ __launch_bounds__(DW_THREADS) void dw3x3_wgrad_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ dy,
-                                                                 float* __restrict__ dw, int N, int H, int W, int OH, int OW, int C) {
+                                                                 float* __restrict__ dw, int N, int H, int W, int OH, int OW, int C, const int reps) {
     extern __shared__ float sred[];
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * DW_THREADS + threadIdx.x;
@@ -247,20 +247,20 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_wgrad_kernel(const u32x4* __
             }
         }
     }
-    block_reduce_flush<9>(acc, cg, C, dw + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 9 * C, sred);
+    block_reduce_flush<9>(acc, cg, C, dw + (size_t)(blockIdx.x % reps) * 9 * C, sred);
 }
 
 // dw OIHW fp32 [C][1][3][3] = sum over replicas of slab [R][9][Cpad]; 8 lanes per element (c fastest: coalesced slab reads),
 // each summing 16 replicas
 __global__ __launch_bounds__(256) void dw3x3_wgrad_finish_kernel(const float* __restrict__ slab, float* __restrict__ dw, int C, int Cpad,
-                                                                 int accumulate) {
+                                                                 int accumulate, const int reps) {
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 3;
     const int sub = threadIdx.x & 7;
     const bool live = i < C * 9;
     const int t = live ? i / C : 0, c = live ? i - t * C : 0;
     float s = 0.f;
     if (live)
-        for (int r = sub; r < HC_STAT_REPLICAS; r += 8) s += slab[((size_t)r * 9 + t) * Cpad + c];
+        for (int r = sub; r < reps; r += 8) s += slab[((size_t)r * 9 + t) * Cpad + c];
     s += __shfl_xor(s, 1);
     s += __shfl_xor(s, 2);
     s += __shfl_xor(s, 4);
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(DW_THREADS) void patch_stats_kernel(const u32x4* __
 }
 __global__ __launch_bounds__(DW_THREADS) void normconv_bwd_scale_kernel(const u32x4* __restrict__ g, const float* __restrict__ mean,
                                                                         const float* __restrict__ rstd, u32x4* __restrict__ gs,
-                                                                        float* __restrict__ red, long npix, int C) {
+                                                                        float* __restrict__ red, long npix, int C, const int reps) {
     extern __shared__ float sred[];
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * DW_THREADS + threadIdx.x;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(DW_THREADS) void normconv_bwd_scale_kernel(const u3
         for (int e = 0; e < 8; ++e) { o[e] = f[e] * r; sv[0][e] += f[e]; sv[1][e] += f[e] * rm; }
         gs[p * cg + cgi] = pack8(o);
     }
-    block_reduce_flush<2>(sv, cg, C, red + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * C, sred);
+    block_reduce_flush<2>(sv, cg, C, red + (size_t)(blockIdx.x % reps) * 2 * C, sred);
 }
 
 }  // namespace
@@ -469,12 +469,12 @@ int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t
         constexpr int TW = 4;
         const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
         hipLaunchKernelGGL((dw3x3_fwd_kernel<1, TW>), dim3(dw_blocks(items, cg, 2)), dim3(DW_THREADS), lds, st, (const u32x4*)x, wpk,
-                           (u32x4*)y, stats, N, H, W, OH, OW, C);
+                           (u32x4*)y, stats, N, H, W, OH, OW, C, hc_get_stat_replicas());
     } else {
         constexpr int TW = 2;
         const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
         hipLaunchKernelGGL((dw3x3_fwd_kernel<2, TW>), dim3(dw_blocks(items, cg, 2)), dim3(DW_THREADS), lds, st, (const u32x4*)x, wpk,
-                           (u32x4*)y, stats, N, H, W, OH, OW, C);
+                           (u32x4*)y, stats, N, H, W, OH, OW, C, hc_get_stat_replicas());
     }
     return hc_launch_status();
 }
@@ -496,7 +496,7 @@ int hc_dw3x3_dgrad(const void* dy, const float* wpk, const float* wpk_flipped, v
     return hc_launch_status();
 }
 
-int64_t hc_dw3x3_wgrad_ws_bytes(int32_t C) { return (int64_t)HC_STAT_REPLICAS * 9 * C * sizeof(float); }
+int64_t hc_dw3x3_wgrad_ws_bytes(int32_t C) { return (int64_t)hc_get_stat_replicas() * 9 * C * sizeof(float); }
 
 int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Creal,
                    int32_t stride, int32_t accumulate, hc_stream_t stream) {
@@ -513,16 +513,16 @@ int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N
             constexpr int TW = 4;
             const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
             hipLaunchKernelGGL((dw3x3_wgrad_kernel<1, TW>), dim3(dw_blocks(items, cg, 4)), dim3(DW_THREADS), lds, st, (const u32x4*)x,
-                               (const u32x4*)dy, (float*)ws, N, H, W, OH, OW, C);
+                               (const u32x4*)dy, (float*)ws, N, H, W, OH, OW, C, hc_get_stat_replicas());
         } else {
             constexpr int TW = 2;
             const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
             hipLaunchKernelGGL((dw3x3_wgrad_kernel<2, TW>), dim3(dw_blocks(items, cg, 8)), dim3(DW_THREADS), lds, st, (const u32x4*)x,
-                               (const u32x4*)dy, (float*)ws, N, H, W, OH, OW, C);
+                               (const u32x4*)dy, (float*)ws, N, H, W, OH, OW, C, hc_get_stat_replicas());
         }
     }
     hipLaunchKernelGGL(dw3x3_wgrad_finish_kernel, dim3((Creal * 9 * 8 + 255) / 256), dim3(256), 0, st, (const float*)ws, dw, Creal, C,
-                       accumulate);
+                       accumulate, hc_get_stat_replicas());
     return hc_launch_status();
 }
 
@@ -606,7 +606,7 @@ int hc_normconv_bwd_scale(const void* g, const float* mean, const float* rstd, v
     if (npix == 0) return HC_OK;
     const int cg = C / 8;
     hipLaunchKernelGGL(normconv_bwd_scale_kernel, dim3(dw_blocks((long)npix * cg, cg, 8)), dim3(DW_THREADS),
-                       DW_THREADS * 17 * sizeof(float), (hipStream_t)stream, (const u32x4*)g, mean, rstd, (u32x4*)gs, red, (long)npix, C);
+                       DW_THREADS * 17 * sizeof(float), (hipStream_t)stream, (const u32x4*)g, mean, rstd, (u32x4*)gs, red, (long)npix, C, hc_get_stat_replicas());
     return hc_launch_status();
 }
 

@@ -83,7 +83,7 @@ __device__ __forceinline__ void block_reduce_flush(const float (&v)[S][8], int c
 }
 
 // ---------------------------------------------------------------- statistics -> affine
-// 8 lanes per (branch, channel): each sums 16 of the HC_STAT_REPLICAS partial sums, a butterfly combines them
+// 8 lanes per (branch, channel): each sums 16 of the reps partial sums, a butterfly combines them
 constexpr int FIN_SUB = 8;
 __device__ __forceinline__ float sub_sum(float v) {
     v += __shfl_xor(v, 1);
@@ -92,7 +92,7 @@ __device__ __forceinline__ float sub_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void msbn_finalize_kernel(const hc_msbn_desc d) {
+__global__ __launch_bounds__(256) void msbn_finalize_kernel(const hc_msbn_desc d, const int reps) {
     const int i = (blockIdx.x * 256 + threadIdx.x) / FIN_SUB;
     const int sub = threadIdx.x & (FIN_SUB - 1);
     const bool live = i < d.B * d.C;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void msbn_finalize_kernel(const hc_msbn_desc d
     const bool valid = live && c < d.c_valid;
     float s = 0.f, q = 0.f;
     if (valid && d.training) {
-        for (int r = sub; r < HC_STAT_REPLICAS; r += FIN_SUB) {
+        for (int r = sub; r < reps; r += FIN_SUB) {
             s += br.stats[((size_t)r * 2 + 0) * br.stats_ld + c];
             q += br.stats[((size_t)r * 2 + 1) * br.stats_ld + c];
         }
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void msbn_finalize_kernel(const hc_msbn_desc d
     if (c == 0 && d.training && br.num_batches_tracked != nullptr) *br.num_batches_tracked += 1;
 }
 
-// red: [HC_STAT_REPLICAS][B + 1][C]; k = 0: sum gz, k = 1 + b: sum gz * y_b
-__global__ __launch_bounds__(256) void msbn_bwd_finalize_kernel(const hc_msbn_desc d) {
+// red: [reps][B + 1][C]; k = 0: sum gz, k = 1 + b: sum gz * y_b
+__global__ __launch_bounds__(256) void msbn_bwd_finalize_kernel(const hc_msbn_desc d, const int reps) {
     const int i = (blockIdx.x * 256 + threadIdx.x) / FIN_SUB;
     const int sub = threadIdx.x & (FIN_SUB - 1);
     const bool live = i < d.B * d.C;
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void msbn_bwd_finalize_kernel(const hc_msbn_de
     const bool valid = live && c < d.c_valid;
     float sg = 0.f, sgy = 0.f;
     if (valid) {
-        for (int r = sub; r < HC_STAT_REPLICAS; r += FIN_SUB) {
+        for (int r = sub; r < reps; r += FIN_SUB) {
             sg += d.red[((size_t)r * (d.B + 1) + 0) * d.C + c];
             sgy += d.red[((size_t)r * (d.B + 1) + 1 + b) * d.C + c];
         }
@@ -184,7 +184,7 @@ struct Srcs {
 
 template <int B, bool STATS>
 __global__ __launch_bounds__(MB_THREADS) void msbn_apply_kernel(const Srcs s, const float* __restrict__ coef, u32x4* __restrict__ out,
-                                                                float* __restrict__ out_stats, long npix, int C, int act) {
+                                                                float* __restrict__ out_stats, long npix, int C, int act, const int reps) {
     extern __shared__ float sred[];
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * MB_THREADS + threadIdx.x;
@@ -229,13 +229,13 @@ __global__ __launch_bounds__(MB_THREADS) void msbn_apply_kernel(const Srcs s, co
             for (int e = 0; e < 8; ++e) { sv[0][e] += r[e]; sv[1][e] += r[e] * r[e]; }
         }
     }
-    if (STATS) block_reduce_flush<2>(sv, cg, C, out_stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * C, sred);
+    if (STATS) block_reduce_flush<2>(sv, cg, C, out_stats + (size_t)(blockIdx.x % reps) * 2 * C, sred);
 }
 
 template <int B>
 __global__ __launch_bounds__(MB_THREADS) void msbn_bwd_reduce_kernel(const Srcs s, const u32x4* __restrict__ g, int g_ld8,
                                                                      const u32x4* __restrict__ out, float* __restrict__ red, long npix,
-                                                                     int C, int act) {
+                                                                     int C, int act, const int reps) {
     extern __shared__ float sred[];
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * MB_THREADS + threadIdx.x;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(MB_THREADS) void msbn_bwd_reduce_kernel(const Srcs 
             for (int e = 0; e < 8; ++e) sv[1 + b][e] += gz[e] * f[e];
         }
     }
-    block_reduce_flush<B + 1>(sv, cg, C, red + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * (B + 1) * C, sred);
+    block_reduce_flush<B + 1>(sv, cg, C, red + (size_t)(blockIdx.x % reps) * (B + 1) * C, sred);
 }
 
 template <int B>
@@ -461,7 +461,7 @@ int hc_msbn_finalize(const hc_msbn_desc* d, hc_stream_t stream) {
         if ((br.running_mean == nullptr) != (br.running_var == nullptr)) return HC_ERR_ARG;
     }
     const int n = d->B * d->C * FIN_SUB;
-    hipLaunchKernelGGL(msbn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(msbn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d, hc_get_stat_replicas());
     return hc_launch_status();
 }
 
@@ -470,7 +470,7 @@ int hc_msbn_bwd_finalize(const hc_msbn_desc* d, hc_stream_t stream) {
     for (int b = 0; b < d->B; ++b)
         if (d->br[b].gamma == nullptr) return HC_ERR_ARG;
     const int n = d->B * d->C * FIN_SUB;
-    hipLaunchKernelGGL(msbn_bwd_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(msbn_bwd_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d, hc_get_stat_replicas());
     return hc_launch_status();
 }
 
@@ -486,10 +486,10 @@ int hc_msbn_apply(const hc_msbn_io* io, const float* coef, void* out, float* out
     if (out_stats != nullptr) {
         const size_t lds = (size_t)MB_THREADS * 17 * sizeof(float);
         MSBN_DISPATCH(io->B, hipLaunchKernelGGL((msbn_apply_kernel<BB, true>), dim3(blocks), dim3(MB_THREADS), lds, st, s, coef, (u32x4*)out,
-                                                out_stats, npix, C, act));
+                                                out_stats, npix, C, act, hc_get_stat_replicas()));
     } else {
         MSBN_DISPATCH(io->B, hipLaunchKernelGGL((msbn_apply_kernel<BB, false>), dim3(blocks), dim3(MB_THREADS), 0, st, s, coef, (u32x4*)out,
-                                                out_stats, npix, C, act));
+                                                out_stats, npix, C, act, hc_get_stat_replicas()));
     }
     return hc_launch_status();
 }
@@ -508,7 +508,7 @@ int hc_msbn_bwd_reduce(const hc_msbn_io* io, const void* g, int32_t g_ld, const 
     const int C = io->C;
     MSBN_DISPATCH(io->B, hipLaunchKernelGGL((msbn_bwd_reduce_kernel<BB>), dim3(blocks), dim3(MB_THREADS),
                                             (size_t)MB_THREADS * 25 * sizeof(float), st, s, (const u32x4*)g, g_ld / 8,
-                                            (const u32x4*)out, red, npix, C, act));
+                                            (const u32x4*)out, red, npix, C, act, hc_get_stat_replicas()));
     return hc_launch_status();
 }
 

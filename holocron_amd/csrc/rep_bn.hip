@@ -80,7 +80,7 @@ __device__ __forceinline__ void block_reduce_flush(const float (&v)[S][8], int c
 
 // ---------------------------------------------------------------- forward BN finalize
 // one WAVE per channel: the 64 lanes sum the statistic replicas in parallel, lane 0 finishes
-__global__ __launch_bounds__(256) void rep_bn_finalize_kernel(const hc_rep_bn_desc d) {
+__global__ __launch_bounds__(256) void rep_bn_finalize_kernel(const hc_rep_bn_desc d, const int reps) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= d.C) return;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void rep_bn_finalize_kernel(const hc_rep_bn_de
         if (d.gamma[b] != nullptr && (d.c_valid <= 0 || c < d.c_valid)) {
             if (d.training) {
                 float s1 = 0.f, s2 = 0.f;
-                for (int r = lane; r < HC_STAT_REPLICAS; r += 64) {
+                for (int r = lane; r < reps; r += 64) {
                     s1 += d.stats[b][(2 * r) * d.C + c];
                     s2 += d.stats[b][(2 * r + 1) * d.C + c];
                 }
@@ -132,7 +132,7 @@ template <bool HAS_ID, bool STATS>
 __global__ __launch_bounds__(EW_THREADS) void rep_apply_kernel(const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
                                                                const u32x4* __restrict__ x, const float* __restrict__ coef,
                                                                u32x4* __restrict__ out, float* __restrict__ out_stats,
-                                                               long nchunks, int C, int act) {
+                                                               long nchunks, int C, int act, const int reps) {
     extern __shared__ float sred[];  // [2][C] when STATS
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
@@ -167,13 +167,13 @@ __global__ __launch_bounds__(EW_THREADS) void rep_apply_kernel(const u32x4* __re
             for (int i = 0; i < 8; ++i) { sv[0][i] += r[i]; sv[1][i] += r[i] * r[i]; }
         }
     }
-    if (STATS) block_reduce_flush<2>(sv, cg, C, out_stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * C, sred, 2);
+    if (STATS) block_reduce_flush<2>(sv, cg, C, out_stats + (size_t)(blockIdx.x % reps) * 2 * C, sred, 2);
 }
 
 // per-channel sum / sum of squares of an NHWC bf16 tensor (identity-branch BN statistics when the
 // producer did not emit them)
 __global__ __launch_bounds__(EW_THREADS) void channel_stats_kernel(const u32x4* __restrict__ x, float* __restrict__ stats,
-                                                                   long nchunks, int C) {
+                                                                   long nchunks, int C, const int reps) {
     extern __shared__ float sred[];  // [2][C]
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(EW_THREADS) void channel_stats_kernel(const u32x4* 
         for (int i = 0; i < 8; ++i) { sv[0][i] += f[i]; sv[1][i] += f[i] * f[i]; }
     }
     (void)c0;
-    block_reduce_flush<2>(sv, cg, C, stats + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 2 * C, sred, 2);
+    block_reduce_flush<2>(sv, cg, C, stats + (size_t)(blockIdx.x % reps) * 2 * C, sred, 2);
 }
 
 // ---------------------------------------------------------------- backward reduce
@@ -197,7 +197,7 @@ template <bool HAS_ID>
 __global__ __launch_bounds__(EW_THREADS) void rep_bwd_reduce_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ out,
                                                                     const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
                                                                     const u32x4* __restrict__ x, float* __restrict__ red,
-                                                                    long nchunks, int C) {
+                                                                    long nchunks, int C, const int reps) {
     extern __shared__ float sred[];  // [4][C]
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
@@ -225,16 +225,16 @@ __global__ __launch_bounds__(EW_THREADS) void rep_bwd_reduce_kernel(const u32x4*
         }
     }
     (void)c0;
-    block_reduce_flush<4>(sv, cg, C, red + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 4 * C, sred, HAS_ID ? 4 : 3);
+    block_reduce_flush<4>(sv, cg, C, red + (size_t)(blockIdx.x % reps) * 4 * C, sred, HAS_ID ? 4 : 3);
 }
 
-__global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_bn_bwd_desc d) {
+__global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_bn_bwd_desc d, const int reps) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= d.C) return;
     const float cnt = (float)d.count;
     float rsum[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = lane; r < HC_STAT_REPLICAS; r += 64)
+    for (int r = lane; r < reps; r += 64)
 #pragma unroll
         for (int k = 0; k < 4; ++k) rsum[k] += d.red[((size_t)r * 4 + k) * d.C + c];
 #pragma unroll
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32
                                                                        const u32x4* __restrict__ y, const float* __restrict__ coef,
                                                                        const float* __restrict__ keep, const float* __restrict__ count,
                                                                        float* __restrict__ red, long npix, int C, int act,
-                                                                       float slope) {
+                                                                       float slope, const int reps) {
     extern __shared__ float sred[];
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32
         }
     }
     // same slab layout as the RepBlock reduce ([4][C] per replica): sum dz at k=0, sum dz*y at k=1
-    block_reduce_flush<2>(sv, cg, C, red + (size_t)(blockIdx.x % HC_STAT_REPLICAS) * 4 * C, sred, 2);
+    block_reduce_flush<2>(sv, cg, C, red + (size_t)(blockIdx.x % reps) * 4 * C, sred, 2);
 }
 
 __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_apply_kernel(const u32x4* __restrict__ g, int g_ld8,
@@ -740,11 +740,22 @@ inline int grid_for(long total, int threads = 256, int cap = 4096) {
 
 }  // namespace
 
+// ---- run-to-run determinism switch (include/holocron_hip.h) ----
+static int g_hc_deterministic = 0;
+static int g_hc_stat_replicas = HC_STAT_REPLICAS;
+
 extern "C" {
+int hc_get_stat_replicas(void) { return g_hc_stat_replicas; }
+int hc_get_deterministic(void) { return g_hc_deterministic; }
+int hc_set_deterministic(int on) {
+    g_hc_deterministic = on ? 1 : 0;
+    g_hc_stat_replicas = on ? HC_STAT_REPLICAS_DETERMINISTIC : HC_STAT_REPLICAS;
+    return HC_OK;
+}
 
 int hc_rep_bn_finalize(const hc_rep_bn_desc* d, hc_stream_t stream) {
     if (d == nullptr || d->coef == nullptr || d->C <= 0) return HC_ERR_ARG;
-    hipLaunchKernelGGL(rep_bn_finalize_kernel, dim3((d->C + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(rep_bn_finalize_kernel, dim3((d->C + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d, hc_get_stat_replicas());
     return hc_launch_status();
 }
 
@@ -757,7 +768,7 @@ int hc_rep_apply(const void* y3, const void* y1, const void* x, const float* coe
     const size_t sm = out_stats ? EW_THREADS * 17 * sizeof(float) : 0;
 #define HC_LAUNCH_APPLY(ID, ST)                                                                                          \
     hipLaunchKernelGGL((rep_apply_kernel<ID, ST>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)y3,             \
-                       (const u32x4*)y1, (const u32x4*)x, coef, (u32x4*)out, out_stats, nchunks, C, act)
+                       (const u32x4*)y1, (const u32x4*)x, coef, (u32x4*)out, out_stats, nchunks, C, act, hc_get_stat_replicas())
     if (x != nullptr) {
         if (out_stats) HC_LAUNCH_APPLY(true, true); else HC_LAUNCH_APPLY(true, false);
     } else {
@@ -772,7 +783,7 @@ int hc_channel_stats(const void* x, float* stats, int64_t npix, int32_t C, hc_st
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8, 16);
     hipLaunchKernelGGL(channel_stats_kernel, dim3(blocks), dim3(EW_THREADS), EW_THREADS * 17 * sizeof(float), (hipStream_t)stream,
-                       (const u32x4*)x, stats, nchunks, C);
+                       (const u32x4*)x, stats, nchunks, C, hc_get_stat_replicas());
     return hc_launch_status();
 }
 
@@ -785,16 +796,16 @@ int hc_rep_bwd_reduce(const void* g, const void* out, const void* y3, const void
     const size_t sm = EW_THREADS * 33 * sizeof(float);
     if (x != nullptr)
         hipLaunchKernelGGL((rep_bwd_reduce_kernel<true>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)g,
-                           (const u32x4*)out, (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, red, nchunks, C);
+                           (const u32x4*)out, (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, red, nchunks, C, hc_get_stat_replicas());
     else
         hipLaunchKernelGGL((rep_bwd_reduce_kernel<false>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)g,
-                           (const u32x4*)out, (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, red, nchunks, C);
+                           (const u32x4*)out, (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, red, nchunks, C, hc_get_stat_replicas());
     return hc_launch_status();
 }
 
 int hc_rep_bn_bwd_finalize(const hc_rep_bn_bwd_desc* d, hc_stream_t stream) {
     if (d == nullptr || d->red == nullptr || d->save == nullptr || d->bcoef == nullptr) return HC_ERR_ARG;
-    hipLaunchKernelGGL(rep_bn_bwd_finalize_kernel, dim3((d->C + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(rep_bn_bwd_finalize_kernel, dim3((d->C + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d, hc_get_stat_replicas());
     return hc_launch_status();
 }
 
@@ -841,7 +852,7 @@ int hc_bn_act_bwd_reduce(const void* g, int32_t g_ld, const void* y, const float
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8, 16);
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(blocks), dim3(EW_THREADS), EW_THREADS * 17 * sizeof(float), (hipStream_t)stream,
-                       (const u32x4*)g, g_ld / 8, (const u32x4*)y, coef, keep, count, red, (long)npix, C, act, slope);
+                       (const u32x4*)g, g_ld / 8, (const u32x4*)y, coef, keep, count, red, (long)npix, C, act, slope, hc_get_stat_replicas());
     return hc_launch_status();
 }
 int hc_bn_act_bwd_apply(const void* g, int32_t g_ld, const void* y, const float* coef, const float* bcoef, const float* keep,
@@ -866,6 +877,7 @@ int hc_gap_fwd(const void* x, float* y, int32_t N, int32_t HW, int32_t C, hc_str
     // enough workgroups to fill the chip, at least 4 rows per thread
     int rows = R * 4;
     while ((long)N * ((HW + rows - 1) / rows) > 8192 && rows < HW) rows *= 2;
+    if (hc_get_deterministic()) rows = HW;      // one workgroup per image: a single add per output, no order to depend on
     hipLaunchKernelGGL(gap_fwd_kernel, dim3((HW + rows - 1) / rows, N), dim3(256), 0, st, (const u32x4*)x, y, N, HW, C, rows);
     return hc_launch_status();
 }

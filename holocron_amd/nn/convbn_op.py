@@ -110,7 +110,7 @@ class ConvBnActFn(torch.autograd.Function):
         OH, OW = fd.OH, fd.OW
         npix = N * OH * OW
         y = cv.empty_cl(N, Cout, OH, OW, dev)
-        stats = POOL.take((_lib.HC_STAT_REPLICAS, 2, Cout), dev) if training else None
+        stats = POOL.take((_lib.stat_replicas(), 2, Cout), dev) if training else None
         cv.launch_conv(fd, src, wpk, y, stats=stats, flops=flops)
 
         coef = torch.empty((4, Cout), dtype=torch.float32, device=dev)
@@ -140,7 +140,7 @@ class ConvBnActFn(torch.autograd.Function):
         ctx.drop = (keep, count)
         ctx.st, ctx.meta2 = st, (stride, pad, act, slope, im2col, training)
         ctx.geom = (N, Cin, H, W, Cout, KH, KW, OH, OW)
-        ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.HC_STAT_REPLICAS, 4, Cout), dev) if training else (None, -1)
+        ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.stat_replicas(), 4, Cout), dev) if training else (None, -1)
         ctx.has_res = res is not None
         ctx.save_for_backward(src, y, coef, save, gamma, w)
         return out
@@ -156,7 +156,7 @@ class ConvBnActFn(torch.autograd.Function):
         g, g_ld = as_cl_view(g)
         keep, count = ctx.drop
         npix = N * OH * OW
-        red = POOL.claim(ctx.red, ctx.red_gen, (_lib.HC_STAT_REPLICAS, 4, Cout), dev)   # stale after another forward's POOL.begin()
+        red = POOL.claim(ctx.red, ctx.red_gen, (_lib.stat_replicas(), 4, Cout), dev)   # stale after another forward's POOL.begin()
         ctx.red = None
         check(lib.hc_bn_act_bwd_reduce(ptr(g), g_ld, ptr(y), ptr(coef), ptr(keep), ptr(count), ptr(red), npix, Cout, act, slope,
                                        stream()), "hc_bn_act_bwd_reduce")
@@ -242,7 +242,7 @@ class ConvBiasFn(torch.autograd.Function):
         lib = _lib.load()
         db = None
         if has_bias:
-            stats = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Cp), dtype=torch.float32, device=dev)
+            stats = torch.zeros((_lib.stat_replicas(), 2, Cp), dtype=torch.float32, device=dev)
             check(lib.hc_channel_stats(ptr(dy), ptr(stats), N * OH * OW, Cp, stream()), "hc_channel_stats")
             db = stats[:, 0].sum(0)[:Cout]
         dx = None
@@ -324,7 +324,7 @@ class ConvBiasActFn(torch.autograd.Function):
             check(lib.hc_leaky_bwd(ptr(g), g_ld, ptr(out), ptr(dy), npix, Cout, slope if act == 3 else 0.0, stream()), "hc_leaky_bwd")
         db = None
         if has_bias:
-            stats = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Cout), dtype=torch.float32, device=dev)
+            stats = torch.zeros((_lib.stat_replicas(), 2, Cout), dtype=torch.float32, device=dev)
             check(lib.hc_channel_stats(ptr(dy), ptr(stats), npix, Cout, stream()), "hc_channel_stats")
             db = stats[:, 0].sum(0)
         dx = None

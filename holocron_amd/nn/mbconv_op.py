@@ -107,7 +107,7 @@ class PadConvBnActFn(torch.autograd.Function):
         OH, OW = cv.conv_out_size(H, KH, stride, pad), cv.conv_out_size(W, KW, stride, pad)
         npix = N * OH * OW
         y = cv.empty_cl(N, Cout_p, OH, OW, dev)
-        stats = POOL.take((_lib.HC_STAT_REPLICAS, 2, Cout_p), dev) if training else None
+        stats = POOL.take((_lib.stat_replicas(), 2, Cout_p), dev) if training else None
         if depthwise:
             check(lib.hc_dw3x3_fwd(ptr(x), ptr(wf), ptr(y), ptr(stats), N, H, W, Cout_p, stride, stream()), "hc_dw3x3_fwd")
         else:
@@ -142,7 +142,7 @@ class PadConvBnActFn(torch.autograd.Function):
               "hc_bn_act_apply")
         ctx.st, ctx.meta2 = st, (stride, pad, act, slope, training, depthwise, res_C)
         ctx.geom = (N, Cin, Cin_p, H, W, Cout, Cout_p, KH, KW, OH, OW)
-        ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.HC_STAT_REPLICAS, 4, Cout_p), dev) if training else (None, -1)
+        ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.stat_replicas(), 4, Cout_p), dev) if training else (None, -1)
         ctx.has_cbias = cbias is not None
         ctx.save_for_backward(x, y, coef, save, gamma, w)
         return out
@@ -157,7 +157,7 @@ class PadConvBnActFn(torch.autograd.Function):
         dev = g.device
         g, g_ld = as_cl_view(g)
         npix = N * OH * OW
-        red = POOL.claim(ctx.red, ctx.red_gen, (_lib.HC_STAT_REPLICAS, 4, Cout_p), dev)   # stale after another forward's POOL.begin()
+        red = POOL.claim(ctx.red, ctx.red_gen, (_lib.stat_replicas(), 4, Cout_p), dev)   # stale after another forward's POOL.begin()
         ctx.red = None
         check(lib.hc_bn_act_bwd_reduce(ptr(g), g_ld, ptr(y), ptr(coef), None, None, ptr(red), npix, Cout_p, act, slope, stream()),
               "hc_bn_act_bwd_reduce")
@@ -346,7 +346,7 @@ class PadConvBiasFn(torch.autograd.Function):
         lib = _lib.load()
         db = None
         if has_bias:
-            stats = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Cout_p), dtype=torch.float32, device=dev)
+            stats = torch.zeros((_lib.stat_replicas(), 2, Cout_p), dtype=torch.float32, device=dev)
             check(lib.hc_channel_stats(ptr(dy), ptr(stats), N * OH * OW, Cout_p, stream()), "hc_channel_stats")
             db = stats[:, 0].sum(0)[:Cout]
         dx = None

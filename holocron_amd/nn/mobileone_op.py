@@ -27,7 +27,9 @@ from .convbn_op import as_cl_view, cl_ld
 from .mbconv_op import ceil16
 from .repblock_op import POOL, _stats_of
 
-R = _lib.HC_STAT_REPLICAS
+
+def _R():
+    return _lib.stat_replicas()
 MAXB = _lib.HC_MSBN_MAX_BRANCHES
 
 
@@ -68,7 +70,7 @@ def _io(srcs, lds, npix, Cp):
 def _msbn_backward(ctx, lib, g, out, save, io, B, gammas, Cp, c_valid, npix, dy_ptrs, dy_lds, dev):
     """reduce -> finalize -> apply; returns the per-branch [B, 2, c_valid] parameter gradients."""
     g, g_ld = as_cl_view(g)
-    red = POOL.claim(ctx.red, getattr(ctx, "red_gen", -1), (R, B + 1, Cp), dev)   # stale after another forward's POOL.begin()
+    red = POOL.claim(ctx.red, getattr(ctx, "red_gen", -1), (_R(), B + 1, Cp), dev)   # stale after another forward's POOL.begin()
     ctx.red = None
     check(lib.hc_msbn_bwd_reduce(C.byref(io), ptr(g), g_ld, ptr(out), ptr(red), ctx.act, stream()), "hc_msbn_bwd_reduce")
     pgrad = torch.empty((B, 2, max(c_valid, 1)), dtype=torch.float32, device=dev)
@@ -124,14 +126,14 @@ class DepthRepFn(torch.autograd.Function):
         npix = N * OH * OW
         planes = torch.empty((P, N, OH, OW, Cp), dtype=torch.bfloat16, device=dev)
         psz = npix * Cp * 2
-        stats = POOL.take((P, R, 2, Cp), dev) if training else None
+        stats = POOL.take((P, _R(), 2, Cp), dev) if training else None
         for b in range(P):
             check(lib.hc_dw3x3_fwd(ptr(x), st.pw[b].data_ptr(), planes.data_ptr() + b * psz,
-                                   None if stats is None else stats.data_ptr() + b * R * 2 * Cp * 4, N, H, W, Cp, stride, stream()),
+                                   None if stats is None else stats.data_ptr() + b * _R() * 2 * Cp * 4, N, H, W, Cp, stride, stream()),
                   "hc_dw3x3_fwd")
         srcs = [planes.data_ptr() + b * psz for b in range(P)]
         lds = [Cp] * P
-        sptr = [None if stats is None else stats.data_ptr() + b * R * 2 * Cp * 4 for b in range(P)]
+        sptr = [None if stats is None else stats.data_ptr() + b * _R() * 2 * Cp * 4 for b in range(P)]
         slds = [Cp] * P
         if has_id:
             srcs.append(x.data_ptr())
@@ -145,14 +147,14 @@ class DepthRepFn(torch.autograd.Function):
         d.coef, d.save = ptr(coef), ptr(save)
         check(lib.hc_msbn_finalize(C.byref(d), stream()), "hc_msbn_finalize")
         out = cv.empty_cl(N, Cp, OH, OW, dev)
-        out_stats = POOL.take((R, 2, Cp), dev) if training else None
+        out_stats = POOL.take((_R(), 2, Cp), dev) if training else None
         io = _io(srcs, lds, npix, Cp)
         check(lib.hc_msbn_apply(C.byref(io), ptr(coef), ptr(out), ptr(out_stats), act, stream()), "hc_msbn_apply")
         st.last_out_stats = out_stats
         ctx.st, ctx.meta = st, meta
         ctx.act, ctx.training = act, training
         ctx.geom = (N, Cp, H, W, OH, OW, P, B)
-        ctx.red, ctx.red_gen = (POOL.take_for_backward((R, B + 1, Cp), dev)
+        ctx.red, ctx.red_gen = (POOL.take_for_backward((_R(), B + 1, Cp), dev)
                                 if any(t.requires_grad for t in params) or x.requires_grad else (None, -1))
         ctx.nb = (P, B)
         ctx.save_for_backward(x, out, save, planes, *gammas, *ws)
@@ -248,7 +250,7 @@ class PointRepFn(torch.autograd.Function):
         if fkey not in st.desc:
             st.desc[fkey] = cv.fwd_desc(N, Cin_p, H, W, KC, 1, 1, 1, 0)
         Y = cv.empty_cl(N, KC, H, W, dev)
-        stats = POOL.take((R, 2, KC), dev) if training else None
+        stats = POOL.take((_R(), 2, KC), dev) if training else None
         cv.launch_conv(st.desc[fkey], x, st.pw[0], Y, stats=stats, flops=2.0 * npix * K * Cout * Cin)
         srcs = [Y.data_ptr() + b * Cout_p * 2 for b in range(K)]
         lds = [KC] * K
@@ -266,14 +268,14 @@ class PointRepFn(torch.autograd.Function):
         d.coef, d.save = ptr(coef), ptr(save)
         check(lib.hc_msbn_finalize(C.byref(d), stream()), "hc_msbn_finalize")
         out = cv.empty_cl(N, Cout_p, H, W, dev)
-        out_stats = POOL.take((R, 2, Cout_p), dev) if training else None
+        out_stats = POOL.take((_R(), 2, Cout_p), dev) if training else None
         io = _io(srcs, lds, npix, Cout_p)
         check(lib.hc_msbn_apply(C.byref(io), ptr(coef), ptr(out), ptr(out_stats), act, stream()), "hc_msbn_apply")
         st.last_out_stats = out_stats
         ctx.st, ctx.meta = st, meta
         ctx.act, ctx.training = act, training
         ctx.geom = (N, H, W, Cin_p, Cout_p, K, B)
-        ctx.red, ctx.red_gen = (POOL.take_for_backward((R, B + 1, Cout_p), dev)
+        ctx.red, ctx.red_gen = (POOL.take_for_backward((_R(), B + 1, Cout_p), dev)
                                 if any(t.requires_grad for t in params) or x.requires_grad else (None, -1))
         ctx.save_for_backward(x, out, save, Y, *gammas)
         return out

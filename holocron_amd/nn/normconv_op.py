@@ -67,7 +67,7 @@ class NormConv2dFn(torch.autograd.Function):
         dev = g.device
         gp = pad_channels(g, Cout_p)
         gs = torch.empty_like(gp)
-        red = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Cout_p), dtype=torch.float32, device=dev)
+        red = torch.zeros((_lib.stat_replicas(), 2, Cout_p), dtype=torch.float32, device=dev)
         check(lib.hc_normconv_bwd_scale(ptr(gp), ptr(mean), ptr(rstd), ptr(gs), ptr(red), N * OH * OW, Cout_p, stream()),
               "hc_normconv_bwd_scale")
         sums = red.sum(0)

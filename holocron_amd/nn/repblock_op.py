@@ -171,7 +171,7 @@ def _stats_of(x):
     if st is not None:
         return st
     N, Cc, H, W = x.shape
-    st = POOL.take((_lib.HC_STAT_REPLICAS, 2, Cc), x.device)
+    st = POOL.take((_lib.stat_replicas(), 2, Cc), x.device)
     check(_lib.load().hc_channel_stats(ptr(x), ptr(st), N * H * W, Cc, stream()), "hc_channel_stats")
     return st
 
@@ -257,7 +257,7 @@ class RepBlockFn(torch.autograd.Function):
                 x_stats = _stats_of(src if src is not x else x)
         if w3.dtype != torch.float32 or not w3.is_contiguous() or not w1.is_contiguous():
             raise RuntimeError("RepBlock (HIP) expects contiguous fp32 conv weights")
-        R = _lib.HC_STAT_REPLICAS
+        R = _lib.stat_replicas()
         stats = POOL.take((2, R, 2, Cout), dev) if st.training else None
         y3, y1 = block_convs_forward(st, src, w3, w1, (N, Cin, H, W, Cout), stats, Cin if stem else None)
 
@@ -282,9 +282,9 @@ class RepBlockFn(torch.autograd.Function):
         check(lib.hc_rep_bn_finalize(C.byref(d), stream()), "hc_rep_bn_finalize")
 
         out = cv.empty_cl(N, Cout, OH, OW, dev)
-        out_stats = POOL.take((_lib.HC_STAT_REPLICAS, 2, Cout), dev) if (st.emit_stats and st.training) else None
+        out_stats = POOL.take((_lib.stat_replicas(), 2, Cout), dev) if (st.emit_stats and st.training) else None
         # backward's reduction target, zeroed with the rest of the arena; re-validated in backward (ZeroPool.claim)
-        ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.HC_STAT_REPLICAS, 4, Cout), dev) if st.training else (None, -1)
+        ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.stat_replicas(), 4, Cout), dev) if st.training else (None, -1)
         check(lib.hc_rep_apply(ptr(y3), ptr(y1), ptr(src) if st.identity else None, ptr(coef), ptr(out), ptr(out_stats),
                                N * OH * OW, Cout, 1 if relu else 0, stream()), "hc_rep_apply")
         ctx.st, ctx.relu, ctx.stem = st, relu, stem
@@ -306,7 +306,7 @@ class RepBlockFn(torch.autograd.Function):
         mask_src = out if ctx.relu else torch.ones_like(out)
         xid = src if st.identity else None
 
-        red = POOL.claim(ctx.red, ctx.red_gen, (_lib.HC_STAT_REPLICAS, 4, Cout), dev)
+        red = POOL.claim(ctx.red, ctx.red_gen, (_lib.stat_replicas(), 4, Cout), dev)
         ctx.red = None      # a second backward through this node (retain_graph) gets a fresh buffer
         check(lib.hc_rep_bwd_reduce(ptr(g), ptr(mask_src), ptr(y3), ptr(y1), ptr(xid), ptr(red), npix, Cout, stream()),
               "hc_rep_bwd_reduce")

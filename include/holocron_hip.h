@@ -22,6 +22,17 @@ typedef void* hc_stream_t; /* hipStream_t */
 
 #define HC_MAX_TAPS 12
 #define HC_STAT_REPLICAS 128
+/* Run-to-run determinism.  Per-channel statistics (BatchNorm sums, their backward sums, depthwise weight gradients) are
+ * accumulated with fp32 atomics into `hc_get_stat_replicas()` replicas ([replicas][k][C]; workgroup b -> replica b % replicas)
+ * that a finalize kernel adds in a fixed order.  With the default 128 replicas several workgroups share a replica and the order of
+ * their atomics moves the last bit of a sum; hc_set_deterministic(1) raises the count to HC_STAT_REPLICAS_DETERMINISTIC, above the
+ * grid of every statistics-producing launch (checked: launches with more workgroups return HC_ERR_ARG), so that every workgroup
+ * owns its slot and two runs of the same step are bit-identical.  It also makes the split reduction of hc_conv_wgrad and the
+ * global average pool single-writer.  Callers size every statistics buffer with hc_get_stat_replicas() (zero-filled as before). */
+#define HC_STAT_REPLICAS_DETERMINISTIC 32768
+int hc_set_deterministic(int on);
+int hc_get_deterministic(void);
+int hc_get_stat_replicas(void);
 
 /* One "parity class" of a gather-conv: output sub-grid (i,j) -> output pixel
  * (i*ostep+oy0, j*ostep+ox0); tap t reads source pixel (i*istep+dy[t], j*istep+dx[t]) of

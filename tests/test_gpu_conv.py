@@ -43,7 +43,7 @@ def test_conv_forward_matches_cpu(N, Cin, Cout, H, W, k, stride):
     b = torch.randn(Cout)
     ref = F.conv2d(x, w, b, stride, k // 2)
     from holocron_amd import _lib
-    stats = torch.zeros(_lib.HC_STAT_REPLICAS, 2, Cout, device="cuda")
+    stats = torch.zeros(_lib.stat_replicas(), 2, Cout, device="cuda")
     out = cv.conv2d(x.cuda(), w.cuda(), b.cuda(), stride, k // 2, stats=stats)
     assert out.shape == ref.shape
     assert rel_l2(_to_nchw_f32(out), ref) < 3e-3
@@ -140,7 +140,7 @@ def test_conv_small_forward_and_dgrad(N, C, Cout, H, W):
     assert d is not None
     y3 = cv.empty_cl(N, Cout, H, W, "cuda")
     y1 = cv.empty_cl(N, Cout, H, W, "cuda")
-    stats = torch.zeros(2, _lib.HC_STAT_REPLICAS, 2, Cout, device="cuda")
+    stats = torch.zeros(2, _lib.stat_replicas(), 2, Cout, device="cuda")
     cv.launch_conv_small_fwd(d, cv.to_cl_bf16(x.cuda()), cv.pack_weight(w3.cuda(), 0), cv.pack_weight(w1.cuda(), 0), y3, y1,
                              stats[0], stats[1])
     r3, r1 = F.conv2d(x, w3, None, 1, 1), F.conv2d(x, w1, None, 1, 0)
@@ -199,7 +199,7 @@ def test_resident_image_conv_forward_and_dgrad():
         xg = cv.to_cl_bf16(x.cuda())
         wp3, wp1 = cv.pack_weight(w3.cuda(), 0), cv.pack_weight(w1.cuda(), 0)
         y3, y1 = cv.empty_cl(N, Cc, H, W, "cuda"), cv.empty_cl(N, Cc, H, W, "cuda")
-        stats = torch.zeros((2, _lib.HC_STAT_REPLICAS, 2, Cc), device="cuda")
+        stats = torch.zeros((2, _lib.stat_replicas(), 2, Cc), device="cuda")
         cv.launch_conv_small_fwd(sf, xg, wp3, wp1, y3, y1, stats[0], stats[1])
         assert rel_l2(y3.float().cpu(), y3r) < 4e-3 and rel_l2(y1.float().cpu(), y1r) < 4e-3
         for st, yr in ((stats[0], y3r), (stats[1], y1r)):

@@ -68,9 +68,14 @@ def test_repvgg_a0_bs256_properties():
         e, f = _rel(grp[n], gr0[n]), max(_rel(gr1[n], gr0[n]), 1e-3)
         report.append((n, f, e))
         print(f"{n}: floor {f:.3e} permuted {e:.3e}")
+    # only tensors that are stable run to run can say anything about the permutation: for the others (floor ~0.5: every conv
+    # gradient in front of the last block) a bound of "3 x floor" passes a zero or an uncorrelated gradient, so none is asserted -
+    # those kernels are compared with the fp32 reference layer by layer at this size in test_gpu_fullsize_layers.py, and the whole
+    # step is checked for bit-reproducibility in test_repvgg_a0_bs256_deterministic_mode below
     for n, f, e in report:
-        assert e < 3 * f + 5e-2, (n, e, f)
-        checked += f < 0.1
+        if f < 0.1:
+            assert e < 3 * f + 1e-2, (n, e, f)
+            checked += 1
     assert checked >= 2, report
 
     # eval: images are independent
@@ -90,3 +95,43 @@ def test_repvgg_a0_bs256_properties():
         rep = m2(x).float()
     print(f"re-parametrised vs three-branch: {_rel(rep, full):.3e}")
     assert _rel(rep, full) < 5e-2, _rel(rep, full)
+
+
+def test_repvgg_a0_bs256_deterministic_mode():
+    """hc_set_deterministic(1): every workgroup owns its slot of the statistics accumulators (32768 replicas instead of 128, added in
+    a fixed order by the finalize kernels), the split reductions are single-writer.  Two training steps from the same state on the
+    same input are then BIT-identical - loss, logits, every gradient, every updated parameter and running statistic - at the
+    benchmark's size, i.e. with the launch geometries of the bench (SURVEY.md hard-part 3, VERDICT r1 weak #3)."""
+    import holocron_amd as h
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.rand((256, 3, 224, 224), device=dev, generator=g)
+    t = torch.randint(0, 10, (256,), device=dev, generator=g)
+    h.set_deterministic(True)
+    try:
+        runs = []
+        for _ in range(2):
+            torch.manual_seed(0)
+            m = h.models.repvgg_a0(num_classes=10).to(dev).train()
+            opt = h.optim.AdaBelief(m.parameters(), lr=1e-3, betas=(0.95, 0.99), eps=1e-6)
+            out = []
+            for _step in range(2):
+                opt.zero_grad(set_to_none=True)
+                logits = m(x)
+                loss = torch.nn.functional.cross_entropy(logits, t, label_smoothing=0.1)
+                loss.backward()
+                grads = [p.grad.detach().clone() for p in m.parameters()]
+                opt.step()
+                out.append((loss.detach().clone(), logits.detach().clone(), grads))
+            torch.cuda.synchronize()
+            runs.append((out, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+        (o0, s0), (o1, s1) = runs
+        for (l0, lg0, g0), (l1, lg1, g1) in zip(o0, o1):
+            assert torch.equal(l0, l1) and torch.equal(lg0, lg1)
+            for a, b in zip(g0, g1):
+                assert torch.equal(a, b)
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), k
+        assert torch.isfinite(o0[1][0])
+    finally:
+        h.set_deterministic(False)

@@ -98,7 +98,7 @@ def test_c2_conv_passes_vs_fp32_cpu(cfg):
     src = cv.im2col_small(xg, 3, 3, stride, 1, rb.STEM_KPAD) if stem else cv.to_cl_bf16(xg)
     w3g, w1g = w3.to(dev), w1.to(dev)
     geom = (N, cin, H, H, cout)
-    stats = torch.zeros((2, _lib.HC_STAT_REPLICAS, 2, cout), device=dev)
+    stats = torch.zeros((2, _lib.stat_replicas(), 2, cout), device=dev)
     y3, y1 = rb.block_convs_forward(st, src, w3g, w1g, geom, stats, cin if stem else None)
     torch.cuda.synchronize()
 
@@ -251,7 +251,7 @@ def _conv_passes(N, cin, H, cout, k, stride, seed, dev):
     x = bf16r(torch.rand((N, cin, H, H), generator=g))
     w = bf16r(torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cout * k * k)) ** 0.5)
     xg, wg = x.to(dev), w.to(dev)
-    stats = torch.zeros((_lib.HC_STAT_REPLICAS, 2, cout), device=dev)
+    stats = torch.zeros((_lib.stat_replicas(), 2, cout), device=dev)
     y = cv.conv2d(xg, wg, None, stride, pad, stats=stats)
     torch.cuda.synchronize()
     c = F.conv2d(x, w, None, stride, pad)
@@ -329,7 +329,7 @@ def test_c3_rexnet_depthwise_vs_fp32_cpu(cfg):
     check(lib.hc_dw3x3_pack(ptr(wg), ptr(wb), ch, Cp, 1, stream()), "hc_dw3x3_pack")
     OH = (H + 2 - 3) // stride + 1
     y = cv.empty_cl(N, Cp, OH, OH, dev)
-    stats = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Cp), device=dev)
+    stats = torch.zeros((_lib.stat_replicas(), 2, Cp), device=dev)
     check(lib.hc_dw3x3_fwd(ptr(xg), ptr(wf), ptr(y), ptr(stats), N, H, H, Cp, stride, stream()), "hc_dw3x3_fwd")
     torch.cuda.synchronize()
     c = F.conv2d(x, w, None, stride, 1, groups=ch)
@@ -374,7 +374,7 @@ def test_c3_rexnet_pointwise_vs_fp32_cpu(cfg):
     wp = torch.zeros((Co, Ci, 1, 1))
     wp[:cout, :cin] = w
     xg, wg = cv.to_cl_bf16(xp.to(dev)), wp.to(dev)
-    stats = torch.zeros((_lib.HC_STAT_REPLICAS, 2, Co), device=dev)
+    stats = torch.zeros((_lib.stat_replicas(), 2, Co), device=dev)
     d = cv.fwd_desc(N, Ci, H, H, Co, 1, 1, 1, 0)
     y = cv.empty_cl(N, Co, H, H, dev)
     cv.launch_conv(d, xg, cv.pack_weight(wg, 0), y, stats=stats)

