@@ -23,6 +23,7 @@ SOURCES = {
     "conv_wgrad_tr.hip": [],
     "conv_wgrad_dma.hip": [],
     "conv_wgrad_rep.hip": [],
+    "conv_rows.hip": [],
     "rep_bn.hip": [],
     "optim.hip": [],
     "nhwc_ops.hip": [],

@@ -63,6 +63,9 @@ __device__ __forceinline__ unsigned hc_lds_addr(const void* p) { return (unsigne
 __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned int voff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
 }
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned int voff, unsigned int soff) {   // + scalar offset
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
 
 // LDS tile [rows][BK] bf16 with a 16-byte-chunk XOR swizzle so that the ds_read_b128 fragment
 // reads (lane = row, fixed chunk) and the ds_write_b128 staging writes (lane = chunk within a

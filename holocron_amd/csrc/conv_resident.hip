@@ -28,7 +28,9 @@ struct Args {
     int reps;          // statistics replicas
 };
 
-template <int KCB, int MR>   // C = 64 KCB input channels, Cout = 64 MR output channels
+// DBG (timing knock-outs, HC_CRS_DBG; results are wrong): 1 no MFMA, 2 no fragment reads, 4 no weight DMA, 8 no window staging,
+// 16 no epilogue
+template <int KCB, int MR, int DBG = 0>   // C = 64 KCB input channels, Cout = 64 MR output channels
 __global__ __launch_bounds__(NT, 1) void conv_resident_kernel(const Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(NT, 1) void conv_resident_kernel(const Args a) {
     auto stage_window = [&](const void* srcp) {
         const u32x4* src = reinterpret_cast<const u32x4*>(srcp) + (size_t)n * HW * CP;
         const int nchunks = (H + 2) * WW * (CP + 1);
+        if (DBG & 8) return;
         for (int j = tid; j < nchunks; j += NT) {
             const int slot = j / (CP + 1), c = j - slot * (CP + 1);
             const int ih = slot / WW - 1, iw = slot - (ih + 1) * WW - 1;
@@ -114,6 +117,7 @@ __global__ __launch_bounds__(NT, 1) void conv_resident_kernel(const Args a) {
         auto issue = [&](int stage, int t, int ck) {
             char* sw = wst + stage * a.wtile_bytes;
             const unsigned wk = (unsigned)((wtap0 + t) * C + ck * BK) * 2u;
+            if (DBG & 4) return;
 #pragma unroll
             for (int j = 0; j < WJ; ++j) {
                 if (WQ % NW == 0 || wid + j * NW < WQ) {
@@ -140,6 +144,15 @@ __global__ __launch_bounds__(NT, 1) void conv_resident_kernel(const Args a) {
             // reading, then both multiplying
             bf16x8 af[2][MR], bfr[2][NR];
             auto load_frags = [&](int kk, int buf) {
+                if (DBG & 2) {
+                    if (s == 0 && kk < 2) {
+#pragma unroll
+                        for (int m = 0; m < MR; ++m) af[buf][m] = *reinterpret_cast<const bf16x8*>(sw + frag_off[kk] + m * 32 * BK * 2);
+#pragma unroll
+                        for (int b = 0; b < NR; ++b) bfr[buf][b] = *reinterpret_cast<const bf16x8*>(win + b_base[b] + kk * 32);
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int m = 0; m < MR; ++m) af[buf][m] = *reinterpret_cast<const bf16x8*>(sw + frag_off[kk] + m * 32 * BK * 2);
 #pragma unroll
@@ -153,8 +166,10 @@ __global__ __launch_bounds__(NT, 1) void conv_resident_kernel(const Args a) {
 #pragma unroll
                 for (int m = 0; m < MR; ++m)
 #pragma unroll
-                    for (int b = 0; b < NR; ++b)
-                        acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][m], bfr[kk & 1][b], acc[m][b], 0, 0, 0);
+                    for (int b = 0; b < NR; ++b) {
+                        if (DBG & 1) acc[m][b][0] += (float)af[kk & 1][m][0] * (float)bfr[kk & 1][b][0];
+                        else acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][m], bfr[kk & 1][b], acc[m][b], 0, 0, 0);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -164,6 +179,17 @@ __global__ __launch_bounds__(NT, 1) void conv_resident_kernel(const Args a) {
     // ---- epilogue: optional BN statistics of the fp32 result, then bf16 NHWC stores (+ residual) ---------------------------
     const int lr = lane & 31, lh = lane >> 5;
     auto epilogue = [&](void* outp, float* stats, const void* residp) {
+        if (DBG & 16) {
+            float t = 0.f;
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int b = 0; b < NR; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += acc[m][b][r];
+            if (t == 123.456f) reinterpret_cast<float*>(outp)[tid] = t;
+            return;
+        }
         if (stats != nullptr) {
             // [4 pixel waves][2][Cout], the weight stages are dead here.  One plane per pixel wave, summed in a fixed order
             // below: no LDS atomics, so a workgroup's contribution does not depend on which wave finishes first
@@ -270,9 +296,9 @@ inline bool make_args(const hc_conv_small_desc& d, Args& a, int& smem) {
     return smem <= 160 * 1024;
 }
 
-template <int K>
+template <int K, int DBG = 0>
 void launch(const Args& a, int smem, hipStream_t st) {
-    auto kern = conv_resident_kernel<K, K>;
+    auto kern = conv_resident_kernel<K, K, DBG>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -299,7 +325,23 @@ int hc_conv_resident_launch(const hc_conv_small_desc& d, hipStream_t st) {
     switch (d.C / 64) {
         case 1: crs::launch<1>(a, smem, st); break;
         case 2: crs::launch<2>(a, smem, st); break;
-        case 3: crs::launch<3>(a, smem, st); break;
+        case 3: {
+            static const int dbg = getenv("HC_CRS_DBG") ? atoi(getenv("HC_CRS_DBG")) : 0;
+            switch (dbg) {
+                case 1: crs::launch<3, 1>(a, smem, st); break;
+                case 2: crs::launch<3, 2>(a, smem, st); break;
+                case 3: crs::launch<3, 3>(a, smem, st); break;
+                case 4: crs::launch<3, 4>(a, smem, st); break;
+                case 6: crs::launch<3, 6>(a, smem, st); break;
+                case 7: crs::launch<3, 7>(a, smem, st); break;
+                case 8: crs::launch<3, 8>(a, smem, st); break;
+                case 16: crs::launch<3, 16>(a, smem, st); break;
+                case 24: crs::launch<3, 24>(a, smem, st); break;
+                case 31: crs::launch<3, 31>(a, smem, st); break;
+                default: crs::launch<3>(a, smem, st); break;
+            }
+            break;
+        }
         default: crs::launch<4>(a, smem, st); break;
     }
     return hc_launch_status();

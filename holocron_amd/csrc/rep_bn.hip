@@ -538,6 +538,18 @@ __global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ x, float* __restr
 // mode 0: wpk[co][tap0 + kh*KW+kw][ci]            (forward)
 // mode 1: wpk[ci][tap0 + flipped(kh,kw)][co]      (data gradient)
 // mode 2: wpk[co][0][(kh*KW+kw)*Cin + ci], K padded to T*? (im2col order; T = padded K)
+// modes 3 / 4: the row-unit image of conv_rows.hip (forward / data gradient), C = Cout = Cin, a multiple of 48:
+//   wpk[step = tap * C/32 + kc/32][row r(rc)][j(kc % 32)], rc = the conv's OUTPUT channel (mode 3: co, mode 4: ci), kc its input
+//   channel, tap = tap0 + kh*KW+kw (mode 4: spatially flipped).  r() puts the 16 rows of an MFMA A fragment next to each other
+//   (a wave's fragment f, row m is channel 48 w + 12 (m >> 2) + 4 f + (m & 3): a lane of the D tile ends up with 12 consecutive
+//   channels), j() puts a lane's eight k values (4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3) into one 16-byte piece.
+__device__ __forceinline__ long rows_image_index(int rc, int kc, int tap, int Cc) {
+    const int w = rc / 48, rem = rc - 48 * w, q = rem / 12, rem2 = rem - 12 * q, f = rem2 >> 2, i = rem2 & 3;
+    const int r = 48 * w + 16 * f + 4 * q + i;
+    const int t = kc >> 5, kk = kc & 31, hi = kk >> 4, g = (kk & 15) >> 2, e = kk & 3;
+    const int j = 8 * g + 4 * hi + e;
+    return ((long)(tap * (Cc >> 5) + t) * Cc + r) * 32 + j;
+}
 __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wpk, int Cout, int Cin, int KH, int KW,
                                    int mode, int tap0, int T) {
     const long total = (long)Cout * Cin * KH * KW;
@@ -554,6 +566,10 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
         } else if (mode == 1) {
             const int t = (KH - 1 - kh) * KW + (KW - 1 - kw);
             wpk[((long)ci * T + tap0 + t) * Cout + co] = v;
+        } else if (mode == 3) {
+            wpk[rows_image_index(co, ci, tap0 + kh * KW + kw, Cout)] = v;
+        } else if (mode == 4) {
+            wpk[rows_image_index(ci, co, tap0 + (KH - 1 - kh) * KW + (KW - 1 - kw), Cout)] = v;
         } else {
             wpk[(long)co * T + tap0 + (kh * KW + kw) * Cin + ci] = v;
         }
@@ -607,6 +623,18 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const hc_pack_it
     const hc_pack_item it = items[blockIdx.y];
     const int KK = it.KH * it.KW;
     bf16_t* wpk = reinterpret_cast<bf16_t*>(it.dst);
+    if (it.mode >= 3) {                              // row-unit images: walk the source (small tensors, 16-byte runs on both sides)
+        const long total = (long)it.Cout * it.Cin * KK;
+        for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+            const int t = (int)(o % KK);
+            const long r = o / KK;
+            const int ci = (int)(r % it.Cin), co = (int)(r / it.Cin);
+            const bf16_t v = f32_to_bf16(it.w[o]);
+            if (it.mode == 3) wpk[rows_image_index(co, ci, it.tap0 + t, it.Cout)] = v;
+            else wpk[rows_image_index(ci, co, it.tap0 + KK - 1 - t, it.Cout)] = v;
+        }
+        return;
+    }
     if (it.mode == 2 || KK > PK_MAXKK) {            // im2col order / large kernels: element-wise walk
         const long total = (long)it.Cout * it.Cin * KK;
         for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
@@ -904,7 +932,8 @@ int hc_nhwc_bf16_to_nchw(const void* x, float* y, int32_t N, int32_t C, int32_t 
 }
 int hc_pack_conv_weight(const float* w, void* wpk, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t mode, int32_t tap0,
                         int32_t T, hc_stream_t stream) {
-    if (w == nullptr || wpk == nullptr || mode < 0 || mode > 2) return HC_ERR_ARG;
+    if (w == nullptr || wpk == nullptr || mode < 0 || mode > 4) return HC_ERR_ARG;
+    if (mode >= 3 && (Cout != Cin || Cout % 48 != 0 || Cin % 32 != 0)) return HC_ERR_ARG;
     const long total = (long)Cout * Cin * KH * KW;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wpk, Cout, Cin, KH,
                        KW, mode, tap0, T);

@@ -109,6 +109,7 @@ class RepState:
         self.last_out_stats = None
         self.packed = None          # persistent packed-weight buffers (wp3, wp1, wpd)
         self.packed_key = None
+        self.rows_image = False     # set by descs(): the block's convs run on the row-unit kernel, which reads its own weight image
 
     # ---- packed weights (persistent buffers; refreshed by one multi-tensor launch per model) ----
     @staticmethod
@@ -121,7 +122,9 @@ class RepState:
         dev = w3.device
         stem = (Cin % 16) != 0
         if self.packed is None or self.packed[0].device != dev:
-            if stem:
+            if self.rows_image:     # (forward image, -, data-gradient image), each shared by the 3x3 and the 1x1 kernel
+                self.packed = (cv.rows_image(Cout, dev), None, cv.rows_image(Cout, dev))
+            elif stem:
                 self.packed = (torch.zeros((Cout, 1, STEM_KPAD), dtype=torch.bfloat16, device=dev),
                                torch.zeros((Cout, 1, STEM_KPAD), dtype=torch.bfloat16, device=dev), None)
             else:
@@ -130,6 +133,9 @@ class RepState:
                                torch.empty((Cin, 10, Cout), dtype=torch.bfloat16, device=dev))
             self.packed_key = None
         wp3, wp1, wpd = self.packed
+        if self.rows_image:
+            return [(w3, wp3, Cout, Cin, 3, 3, 3, 0, 10), (w1, wp3, Cout, Cin, 1, 1, 3, 9, 10),
+                    (w3, wpd, Cout, Cin, 3, 3, 4, 0, 10), (w1, wpd, Cout, Cin, 1, 1, 4, 9, 10)]
         if stem:
             return [(w3, wp3, Cout, Cin, 3, 3, 2, 0, STEM_KPAD), (w1, wp1, Cout, Cin, 1, 1, 2, 4 * Cin, STEM_KPAD)]
         return [(w3, wp3, Cout, Cin, 3, 3, 0, 0, 9), (w1, wp1, Cout, Cin, 1, 1, 0, 0, 1),
@@ -159,11 +165,19 @@ class RepState:
                 f1 = cv.fwd_desc(N, STEM_KPAD, OH, OW, Cout, 1, 1, 1, 0)
                 dg = None
             sf = sd = None
-            if Cin % 16 == 0 and s == 1:   # small-channel persistent kernel (fused 3x3+1x1, LDS-resident weights)
-                sf = cv.conv_small_desc(N, H, W, Cin, Cout, 0)
-                sd = cv.conv_small_desc(N, H, W, Cout, Cin, 1)
-            self.desc[key] = (f3, f1, dg, sf, sd)
-        return self.desc[key]
+            rows = False
+            if Cin % 16 == 0 and s == 1:   # fused 3x3 + 1x1 kernels: row-unit (own weight image), small-channel persistent, image-resident
+                sf = cv.conv_small_desc(N, H, W, Cin, Cout, cv.ROWS_IMAGE)
+                sd = cv.conv_small_desc(N, H, W, Cout, Cin, cv.ROWS_IMAGE | 1)
+                rows = sf is not None and sd is not None
+                if not rows:
+                    sf = cv.conv_small_desc(N, H, W, Cin, Cout, 0)
+                    sd = cv.conv_small_desc(N, H, W, Cout, Cin, 1)
+            self.desc[key] = (f3, f1, dg, sf, sd, rows)
+        rows = self.desc[key][5]
+        if rows != self.rows_image:    # this geometry reads the other weight-image format: drop the images, ensure_packed() rebuilds
+            self.rows_image, self.packed, self.packed_key = rows, None, None
+        return self.desc[key][:5]
 
 
 def _stats_of(x):

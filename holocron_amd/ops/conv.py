@@ -140,11 +140,22 @@ def launch_conv(d, src0, wpk, dst, src1=None, resid=None, stats=None, bias=None,
 
 
 # ------------------------------------------------------------------ weight packing
+ROWS_IMAGE = 4   # HC_CONV_SMALL_ROWS_IMAGE: hc_conv_small reads the row-unit weight image (pack modes 3 / 4)
+
+
+def rows_image(Cc, device):
+    """Destination of pack modes 3 / 4: [10 * C/32 k32-steps][C rows][32] bf16 (3x3 taps at tap0 = 0, the 1x1 at tap0 = 9)."""
+    return torch.empty((10 * (Cc // 32), Cc, 32), dtype=torch.bfloat16, device=device)
+
+
 def pack_weight(w, mode, out=None, tap0=0, T=None):
-    """fp32 OIHW -> packed bf16 (mode 0 fwd [Cout][T][Cin], mode 1 dgrad [Cin][T][Cout])."""
+    """fp32 OIHW -> packed bf16 (mode 0 fwd [Cout][T][Cin], mode 1 dgrad [Cin][T][Cout], modes 3 / 4: forward / data-gradient
+    row-unit image, ``out`` = rows_image(C))."""
     Cout, Cin, KH, KW = w.shape
     T = KH * KW if T is None else T
     if out is None:
+        if mode >= 3:
+            raise ValueError("pack modes 3 / 4 write into a rows_image() shared by the 3x3 and the 1x1 kernel: pass out=")
         shape = (Cout, T, Cin) if mode == 0 else (Cin, T, Cout)
         out = torch.empty(shape, dtype=torch.bfloat16, device=w.device)
     wc = w.detach()
