@@ -79,42 +79,64 @@ __device__ __forceinline__ void block_reduce_flush(const float (&v)[S][8], int c
 }
 
 // ---------------------------------------------------------------- forward BN finalize
-// one WAVE per channel: the 64 lanes sum the statistic replicas in parallel, lane 0 finishes
+// one WAVE per channel: the 64 lanes sum the statistic replicas in parallel, lane 0 finishes.  Every load of the three branches - the
+// replicas, the affine parameters, the running statistics - is requested before the first one is used: the kernel is one memory
+// round trip long instead of three per branch (it is pure latency: 9.5 -> ~4 us, 27 launches per step).
 __global__ __launch_bounds__(256) void rep_bn_finalize_kernel(const hc_rep_bn_desc d, const int reps) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= d.C) return;
     const float cnt = (float)d.count;
+    // channels >= c_valid are layout padding: zero affine, no parameters / running statistics behind them
+    const bool chan_ok = d.c_valid <= 0 || c < d.c_valid;
+    bool on[3];
+    float gam[3], bet[3], rm[3], rv[3], s1[3], s2[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        on[b] = d.gamma[b] != nullptr && chan_ok;
+        gam[b] = bet[b] = rm[b] = rv[b] = s1[b] = s2[b] = 0.f;
+        if (on[b]) {
+            gam[b] = d.gamma[b][c];
+            bet[b] = d.beta[b][c];
+            if (d.running_mean[b] != nullptr) {
+                rm[b] = d.running_mean[b][c];
+                rv[b] = d.running_var[b][c];
+            }
+        }
+    }
+    if (d.training) {
+        for (int r = lane; r < reps; r += 64) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                if (on[b]) {
+                    s1[b] += d.stats[b][(2 * r) * d.C + c];
+                    s2[b] += d.stats[b][(2 * r + 1) * d.C + c];
+                }
+        }
+    }
     float shift = 0.f;
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         float a = 0.f, mean = 0.f, invstd = 0.f;
-        // channels >= c_valid are layout padding: zero affine, no parameters / running statistics behind them
-        if (d.gamma[b] != nullptr && (d.c_valid <= 0 || c < d.c_valid)) {
+        if (on[b]) {
             if (d.training) {
-                float s1 = 0.f, s2 = 0.f;
-                for (int r = lane; r < reps; r += 64) {
-                    s1 += d.stats[b][(2 * r) * d.C + c];
-                    s2 += d.stats[b][(2 * r + 1) * d.C + c];
-                }
-                s1 = wave_sum(s1);
-                s2 = wave_sum(s2);
-                mean = s1 / cnt;
-                float var = s2 / cnt - mean * mean;
+                const float t1 = wave_sum(s1[b]), t2 = wave_sum(s2[b]);
+                mean = t1 / cnt;
+                float var = t2 / cnt - mean * mean;
                 var = var > 0.f ? var : 0.f;
                 invstd = rsqrtf(var + d.eps);
                 if (lane == 0 && d.running_mean[b] != nullptr) {
                     const float unb = d.count > 1 ? var * (cnt / (cnt - 1.f)) : var;
-                    d.running_mean[b][c] = (1.f - d.momentum) * d.running_mean[b][c] + d.momentum * mean;
-                    d.running_var[b][c] = (1.f - d.momentum) * d.running_var[b][c] + d.momentum * unb;
+                    d.running_mean[b][c] = (1.f - d.momentum) * rm[b] + d.momentum * mean;
+                    d.running_var[b][c] = (1.f - d.momentum) * rv[b] + d.momentum * unb;
                 }
                 if (lane == 0 && c == 0 && d.num_batches_tracked[b] != nullptr) d.num_batches_tracked[b][0] += 1;
             } else {
-                mean = d.running_mean[b][c];
-                invstd = rsqrtf(d.running_var[b][c] + d.eps);
+                mean = rm[b];
+                invstd = rsqrtf(rv[b] + d.eps);
             }
-            a = d.gamma[b][c] * invstd;
-            shift += d.beta[b][c] - a * mean;
+            a = gam[b] * invstd;
+            shift += bet[b] - a * mean;
         }
         if (lane == 0) {
             d.coef[b * d.C + c] = a;
@@ -128,6 +150,15 @@ __global__ __launch_bounds__(256) void rep_bn_finalize_kernel(const hc_rep_bn_de
 }
 
 // ---------------------------------------------------------------- forward apply
+// pre-activation of the fused block output.  ONE explicit fma chain used by the forward apply and by the backward kernels that
+// recompute the ReLU mask from it (hc_rep_bwd_*_z): the same inputs give the same bits, so (z > 0) there IS (out > 0) here
+// (out = bf16(relu(z)) > 0 exactly when z > 0: a positive fp32 never rounds to a bf16 zero above 2^-134).
+template <bool HAS_ID>
+__device__ __forceinline__ float rep_preact(float a3, float f3, float a1, float f1, float a0, float f0, float sh) {
+    float z = __builtin_fmaf(a1, f1, sh);
+    if (HAS_ID) z = __builtin_fmaf(a0, f0, z);
+    return __builtin_fmaf(a3, f3, z);
+}
 template <bool HAS_ID, bool STATS>
 __global__ __launch_bounds__(EW_THREADS) void rep_apply_kernel(const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
                                                                const u32x4* __restrict__ x, const float* __restrict__ coef,
@@ -153,8 +184,7 @@ __global__ __launch_bounds__(EW_THREADS) void rep_apply_kernel(const u32x4* __re
         if (HAS_ID) unpack8(x[q], f0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float z = a3[i] * f3[i] + a1[i] * f1[i] + sh[i];
-            if (HAS_ID) z += a0[i] * f0[i];
+            float z = rep_preact<HAS_ID>(a3[i], f3[i], a1[i], f1[i], HAS_ID ? a0[i] : 0.f, HAS_ID ? f0[i] : 0.f, sh[i]);
             if (act == 1) z = z > 0.f ? z : 0.f;
             o[i] = z;
         }
@@ -193,16 +223,26 @@ __global__ __launch_bounds__(EW_THREADS) void channel_stats_kernel(const u32x4* 
 }
 
 // ---------------------------------------------------------------- backward reduce
-template <bool HAS_ID>
+// ZMASK: the ReLU mask is recomputed from the pre-activation (coef = the forward's [4][C] affine; act 0 = no activation) instead of
+// read from `out` - one tensor less per pass (2 of the 13 tensor passes of a block's BatchNorm backward)
+template <bool HAS_ID, bool ZMASK>
 __global__ __launch_bounds__(EW_THREADS) void rep_bwd_reduce_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ out,
                                                                     const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
-                                                                    const u32x4* __restrict__ x, float* __restrict__ red,
+                                                                    const u32x4* __restrict__ x, const float* __restrict__ coef,
+                                                                    const int act, float* __restrict__ red,
                                                                     long nchunks, int C, const int reps) {
     extern __shared__ float sred[];  // [4][C]
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
     const long stride = (long)gridDim.x * EW_THREADS;
     const int c0 = (int)(gtid % cg) * 8;
+    float a3[8], a1[8], a0[8], sh[8];
+    if (ZMASK) {
+        load8f(coef + c0, a3);
+        load8f(coef + C + c0, a1);
+        if (HAS_ID) load8f(coef + 2 * C + c0, a0);
+        load8f(coef + 3 * C + c0, sh);
+    }
     float sv[4][8];   // dz, dz*y3, dz*y1, dz*x
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -211,12 +251,13 @@ __global__ __launch_bounds__(EW_THREADS) void rep_bwd_reduce_kernel(const u32x4*
     for (long q = gtid; q < nchunks; q += stride) {
         float fg[8], fo[8], f3[8], f1[8], f0[8];
         unpack8(g[q], fg);
-        unpack8(out[q], fo);
+        if (!ZMASK) unpack8(out[q], fo);
         unpack8(y3[q], f3);
         unpack8(y1[q], f1);
         if (HAS_ID) unpack8(x[q], f0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+            if (ZMASK) fo[i] = act == 1 ? rep_preact<HAS_ID>(a3[i], f3[i], a1[i], f1[i], HAS_ID ? a0[i] : 0.f, HAS_ID ? f0[i] : 0.f, sh[i]) : 1.f;
             const float dz = fo[i] > 0.f ? fg[i] : 0.f;
             sv[0][i] += dz;
             sv[1][i] += dz * f3[i];
@@ -233,6 +274,24 @@ __global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_b
     const int lane = threadIdx.x & 63;
     if (c >= d.C) return;
     const float cnt = (float)d.count;
+    const int nb = d.has_identity ? 3 : 2;
+    // like the forward finalize: everything is requested before anything is used (one round trip)
+    bool on[3];
+    float gam[3], mean_[3], inv_[3], dg0[3], db0[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        on[b] = b < nb && d.gamma[b] != nullptr && (d.c_valid <= 0 || c < d.c_valid);
+        gam[b] = mean_[b] = inv_[b] = dg0[b] = db0[b] = 0.f;
+        if (on[b]) {
+            gam[b] = d.gamma[b][c];
+            mean_[b] = d.save[(2 * b) * d.C + c];
+            inv_[b] = d.save[(2 * b + 1) * d.C + c];
+            if (d.accumulate) {
+                if (d.dgamma[b] != nullptr) dg0[b] = d.dgamma[b][c];
+                if (d.dbeta[b] != nullptr) db0[b] = d.dbeta[b][c];
+            }
+        }
+    }
     float rsum[4] = {0.f, 0.f, 0.f, 0.f};
     for (int r = lane; r < reps; r += 64)
 #pragma unroll
@@ -241,21 +300,20 @@ __global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_b
     for (int k = 0; k < 4; ++k) rsum[k] = wave_sum(rsum[k]);
     if (lane != 0) return;
     const float sdz = rsum[0];
-    const int nb = d.has_identity ? 3 : 2;
     for (int b = 0; b < 3; ++b) {
         float A = 0.f, B = 0.f, Cc = 0.f;
-        if (b < nb && d.gamma[b] != nullptr && (d.c_valid <= 0 || c < d.c_valid)) {
-            const float mean = d.save[(2 * b) * d.C + c], invstd = d.save[(2 * b + 1) * d.C + c];
+        if (on[b]) {
+            const float mean = mean_[b], invstd = inv_[b];
             const float sdzy = rsum[b + 1];
             const float dgamma = invstd * (sdzy - mean * sdz);
-            const float a = d.gamma[b][c] * invstd;
+            const float a = gam[b] * invstd;
             A = a;
             if (!d.frozen) {            // batch statistics: the two centring terms of BatchNorm's backward
                 B = -a * invstd * dgamma / cnt;
                 Cc = -a * sdz / cnt - B * mean;
             }
-            if (d.dgamma[b] != nullptr) d.dgamma[b][c] = d.accumulate ? d.dgamma[b][c] + dgamma : dgamma;
-            if (d.dbeta[b] != nullptr) d.dbeta[b][c] = d.accumulate ? d.dbeta[b][c] + sdz : sdz;
+            if (d.dgamma[b] != nullptr) d.dgamma[b][c] = d.accumulate ? dg0[b] + dgamma : dgamma;
+            if (d.dbeta[b] != nullptr) d.dbeta[b][c] = d.accumulate ? db0[b] + sdz : sdz;
         }
         d.bcoef[(3 * b) * d.C + c] = A;
         d.bcoef[(3 * b + 1) * d.C + c] = B;
@@ -263,16 +321,24 @@ __global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_b
     }
 }
 
-template <bool HAS_ID>
+template <bool HAS_ID, bool ZMASK>
 __global__ __launch_bounds__(EW_THREADS) void rep_bwd_apply_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ out,
                                                                    const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
-                                                                   const u32x4* __restrict__ x, const float* __restrict__ bc,
+                                                                   const u32x4* __restrict__ x, const float* __restrict__ coef,
+                                                                   const int act, const float* __restrict__ bc,
                                                                    u32x4* __restrict__ dy3, u32x4* __restrict__ dy1,
                                                                    u32x4* __restrict__ dxid, long nchunks, int C) {
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
     const long stride = (long)gridDim.x * EW_THREADS;
     const int c0 = (int)(gtid % cg) * 8;
+    float a3[8], a1[8], a0[8], sh[8];
+    if (ZMASK) {
+        load8f(coef + c0, a3);
+        load8f(coef + C + c0, a1);
+        if (HAS_ID) load8f(coef + 2 * C + c0, a0);
+        load8f(coef + 3 * C + c0, sh);
+    }
     float A3[8], B3[8], C3[8], A1[8], B1[8], C1[8], A0[8], B0[8], C0[8];
     load8f(bc + 0 * C + c0, A3); load8f(bc + 1 * C + c0, B3); load8f(bc + 2 * C + c0, C3);
     load8f(bc + 3 * C + c0, A1); load8f(bc + 4 * C + c0, B1); load8f(bc + 5 * C + c0, C1);
@@ -280,16 +346,17 @@ __global__ __launch_bounds__(EW_THREADS) void rep_bwd_apply_kernel(const u32x4* 
     for (long q = gtid; q < nchunks; q += stride) {
         float fg[8], fo[8], f3[8], f1[8], f0[8], o3[8], o1[8], o0[8];
         unpack8(g[q], fg);
-        unpack8(out[q], fo);
+        if (!ZMASK) unpack8(out[q], fo);
         unpack8(y3[q], f3);
         unpack8(y1[q], f1);
         if (HAS_ID) unpack8(x[q], f0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+            if (ZMASK) fo[i] = act == 1 ? rep_preact<HAS_ID>(a3[i], f3[i], a1[i], f1[i], HAS_ID ? a0[i] : 0.f, HAS_ID ? f0[i] : 0.f, sh[i]) : 1.f;
             const float dz = fo[i] > 0.f ? fg[i] : 0.f;
-            o3[i] = A3[i] * dz + B3[i] * f3[i] + C3[i];
-            o1[i] = A1[i] * dz + B1[i] * f1[i] + C1[i];
-            if (HAS_ID) o0[i] = A0[i] * dz + B0[i] * f0[i] + C0[i];
+            o3[i] = __builtin_fmaf(A3[i], dz, __builtin_fmaf(B3[i], f3[i], C3[i]));   // explicit chains: every instantiation rounds alike
+            o1[i] = __builtin_fmaf(A1[i], dz, __builtin_fmaf(B1[i], f1[i], C1[i]));
+            if (HAS_ID) o0[i] = __builtin_fmaf(A0[i], dz, __builtin_fmaf(B0[i], f0[i], C0[i]));
         }
         dy3[q] = pack8(o3);
         dy1[q] = pack8(o1);
@@ -815,20 +882,36 @@ int hc_channel_stats(const void* x, float* stats, int64_t npix, int32_t C, hc_st
     return hc_launch_status();
 }
 
-int hc_rep_bwd_reduce(const void* g, const void* out, const void* y3, const void* y1, const void* x, float* red, int64_t npix,
-                      int32_t C, hc_stream_t stream) {
-    if (g == nullptr || out == nullptr || y3 == nullptr || y1 == nullptr || red == nullptr || (C % 8) != 0) return HC_ERR_ARG;
+static int rep_bwd_reduce_launch(const void* g, const void* out, const float* coef, int act, const void* y3, const void* y1,
+                                 const void* x, float* red, int64_t npix, int32_t C, hc_stream_t stream) {
+    if (g == nullptr || (out == nullptr && coef == nullptr) || y3 == nullptr || y1 == nullptr || red == nullptr || (C % 8) != 0)
+        return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8, 16);
     hipStream_t st = (hipStream_t)stream;
     const size_t sm = EW_THREADS * 33 * sizeof(float);
-    if (x != nullptr)
-        hipLaunchKernelGGL((rep_bwd_reduce_kernel<true>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)g,
-                           (const u32x4*)out, (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, red, nchunks, C, hc_get_stat_replicas());
-    else
-        hipLaunchKernelGGL((rep_bwd_reduce_kernel<false>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)g,
-                           (const u32x4*)out, (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, red, nchunks, C, hc_get_stat_replicas());
+#define HC_RBR(ID, ZM)                                                                                                              \
+    hipLaunchKernelGGL((rep_bwd_reduce_kernel<ID, ZM>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)g, (const u32x4*)out, \
+                       (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, coef, act, red, nchunks, C, hc_get_stat_replicas())
+    if (coef != nullptr) {
+        if (x != nullptr) HC_RBR(true, true);
+        else HC_RBR(false, true);
+    } else {
+        if (x != nullptr) HC_RBR(true, false);
+        else HC_RBR(false, false);
+    }
+#undef HC_RBR
     return hc_launch_status();
+}
+int hc_rep_bwd_reduce(const void* g, const void* out, const void* y3, const void* y1, const void* x, float* red, int64_t npix,
+                      int32_t C, hc_stream_t stream) {
+    if (out == nullptr) return HC_ERR_ARG;
+    return rep_bwd_reduce_launch(g, out, nullptr, 1, y3, y1, x, red, npix, C, stream);
+}
+int hc_rep_bwd_reduce_z(const void* g, const float* coef, int32_t act, const void* y3, const void* y1, const void* x, float* red,
+                        int64_t npix, int32_t C, hc_stream_t stream) {
+    if (coef == nullptr || (act != 0 && act != 1)) return HC_ERR_ARG;
+    return rep_bwd_reduce_launch(g, nullptr, coef, act, y3, y1, x, red, npix, C, stream);
 }
 
 int hc_rep_bn_bwd_finalize(const hc_rep_bn_bwd_desc* d, hc_stream_t stream) {
@@ -837,24 +920,39 @@ int hc_rep_bn_bwd_finalize(const hc_rep_bn_bwd_desc* d, hc_stream_t stream) {
     return hc_launch_status();
 }
 
-int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void* y1, const void* x, const float* bcoef, void* dy3,
-                     void* dy1, void* dxid, int64_t npix, int32_t C, hc_stream_t stream) {
-    if (g == nullptr || out == nullptr || y3 == nullptr || y1 == nullptr || bcoef == nullptr || dy3 == nullptr || dy1 == nullptr ||
-        (C % 8) != 0)
+static int rep_bwd_apply_launch(const void* g, const void* out, const float* coef, int act, const void* y3, const void* y1,
+                                const void* x, const float* bcoef, void* dy3, void* dy1, void* dxid, int64_t npix, int32_t C,
+                                hc_stream_t stream) {
+    if (g == nullptr || (out == nullptr && coef == nullptr) || y3 == nullptr || y1 == nullptr || bcoef == nullptr || dy3 == nullptr ||
+        dy1 == nullptr || (C % 8) != 0)
         return HC_ERR_ARG;
     if ((x == nullptr) != (dxid == nullptr)) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8);
     hipStream_t st = (hipStream_t)stream;
-    if (x != nullptr)
-        hipLaunchKernelGGL((rep_bwd_apply_kernel<true>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)g, (const u32x4*)out,
-                           (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, bcoef, (u32x4*)dy3, (u32x4*)dy1, (u32x4*)dxid,
-                           nchunks, C);
-    else
-        hipLaunchKernelGGL((rep_bwd_apply_kernel<false>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)g, (const u32x4*)out,
-                           (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, bcoef, (u32x4*)dy3, (u32x4*)dy1, (u32x4*)dxid,
-                           nchunks, C);
+#define HC_RBA(ID, ZM)                                                                                                              \
+    hipLaunchKernelGGL((rep_bwd_apply_kernel<ID, ZM>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)g, (const u32x4*)out,    \
+                       (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, coef, act, bcoef, (u32x4*)dy3, (u32x4*)dy1,             \
+                       (u32x4*)dxid, nchunks, C)
+    if (coef != nullptr) {
+        if (x != nullptr) HC_RBA(true, true);
+        else HC_RBA(false, true);
+    } else {
+        if (x != nullptr) HC_RBA(true, false);
+        else HC_RBA(false, false);
+    }
+#undef HC_RBA
     return hc_launch_status();
+}
+int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void* y1, const void* x, const float* bcoef, void* dy3,
+                     void* dy1, void* dxid, int64_t npix, int32_t C, hc_stream_t stream) {
+    if (out == nullptr) return HC_ERR_ARG;
+    return rep_bwd_apply_launch(g, out, nullptr, 1, y3, y1, x, bcoef, dy3, dy1, dxid, npix, C, stream);
+}
+int hc_rep_bwd_apply_z(const void* g, const float* coef, int32_t act, const void* y3, const void* y1, const void* x,
+                       const float* bcoef, void* dy3, void* dy1, void* dxid, int64_t npix, int32_t C, hc_stream_t stream) {
+    if (coef == nullptr || (act != 0 && act != 1)) return HC_ERR_ARG;
+    return rep_bwd_apply_launch(g, nullptr, coef, act, y3, y1, x, bcoef, dy3, dy1, dxid, npix, C, stream);
 }
 
 int hc_bn_act_apply(const void* y, const float* coef, const void* res, int32_t res_C, const float* keep, const float* count,

@@ -304,7 +304,8 @@ class RepBlockFn(torch.autograd.Function):
         ctx.st, ctx.relu, ctx.stem = st, relu, stem
         ctx.geom = (N, Cin, H, W, Cout, OH, OW)
         ctx.was_training = st.training
-        ctx.save_for_backward(src, y3, y1, out, save, g3, g1, g0 if st.identity else None, w3, w1)
+        # `out` is not kept for the backward: its ReLU mask is recomputed from (y3, y1, src, coef) by the *_z kernels
+        ctx.save_for_backward(src, y3, y1, coef, save, g3, g1, g0 if st.identity else None, w3, w1)
         st.last_out_stats = out_stats
         return out
 
@@ -312,18 +313,18 @@ class RepBlockFn(torch.autograd.Function):
     def backward(ctx, g):
         lib = _lib.load()
         st = ctx.st
-        src, y3, y1, out, save, g3, g1, g0, w3, w1 = ctx.saved_tensors
+        src, y3, y1, coef, save, g3, g1, g0, w3, w1 = ctx.saved_tensors
         N, Cin, H, W, Cout, OH, OW = ctx.geom
         dev = g.device
         g = cv.to_cl_bf16(g)
         npix = N * OH * OW
-        mask_src = out if ctx.relu else torch.ones_like(out)
+        act = 1 if ctx.relu else 0
         xid = src if st.identity else None
 
         red = POOL.claim(ctx.red, ctx.red_gen, (_lib.stat_replicas(), 4, Cout), dev)
         ctx.red = None      # a second backward through this node (retain_graph) gets a fresh buffer
-        check(lib.hc_rep_bwd_reduce(ptr(g), ptr(mask_src), ptr(y3), ptr(y1), ptr(xid), ptr(red), npix, Cout, stream()),
-              "hc_rep_bwd_reduce")
+        check(lib.hc_rep_bwd_reduce_z(ptr(g), ptr(coef), act, ptr(y3), ptr(y1), ptr(xid), ptr(red), npix, Cout, stream()),
+              "hc_rep_bwd_reduce_z")
         nb = 3 if st.identity else 2
         dgam = torch.empty((3, Cout), dtype=torch.float32, device=dev)
         dbet = torch.empty((3, Cout), dtype=torch.float32, device=dev)
@@ -343,8 +344,8 @@ class RepBlockFn(torch.autograd.Function):
         dy3 = torch.empty_like(y3)
         dy1 = torch.empty_like(y1)
         dxid = torch.empty_like(src) if st.identity else None
-        check(lib.hc_rep_bwd_apply(ptr(g), ptr(mask_src), ptr(y3), ptr(y1), ptr(xid), ptr(bcoef), ptr(dy3), ptr(dy1),
-                                   ptr(dxid), npix, Cout, stream()), "hc_rep_bwd_apply")
+        check(lib.hc_rep_bwd_apply_z(ptr(g), ptr(coef), act, ptr(y3), ptr(y1), ptr(xid), ptr(bcoef), ptr(dy3), ptr(dy1),
+                                     ptr(dxid), npix, Cout, stream()), "hc_rep_bwd_apply_z")
 
         dx = None
         geom = (N, Cin, H, W, Cout)

@@ -202,6 +202,13 @@ int hc_channel_stats(const void* x, float* stats, int64_t npix, int32_t C, hc_st
  * dz*y1, dz*x into red[HC_STAT_REPLICAS][4][C] (replicas spread the atomics).  Pass 2 (after hc_rep_bn_bwd_finalize): dy3, dy1, dx_id. */
 int hc_rep_bwd_reduce(const void* g, const void* out, const void* y3, const void* y1, const void* x, float* red,
                       int64_t npix, int32_t C, hc_stream_t stream);
+/* The same two passes without reading `out`: the mask is (z > 0) of the pre-activation z = a3*y3 + a1*y1 + a0*x + b recomputed from
+ * the forward's `coef` (hc_rep_bn_finalize) with the very fma chain hc_rep_apply uses - bit-identical results, one tensor less per
+ * pass.  act: 1 = ReLU, 0 = no activation (dz = g). */
+int hc_rep_bwd_reduce_z(const void* g, const float* coef, int32_t act, const void* y3, const void* y1, const void* x, float* red,
+                        int64_t npix, int32_t C, hc_stream_t stream);
+int hc_rep_bwd_apply_z(const void* g, const float* coef, int32_t act, const void* y3, const void* y1, const void* x,
+                       const float* bcoef, void* dy3, void* dy1, void* dxid, int64_t npix, int32_t C, hc_stream_t stream);
 typedef struct {
     const float* red;          /* [HC_STAT_REPLICAS][4][C] */
     const float* save;         /* [6][C] from forward */
