@@ -341,6 +341,12 @@ class _RepWgradQueue:
         self.armed = False
         self.support = {}
         self.enabled = os.environ.get("HC_WREP_DEFER", "1") != "0"
+        # HC_WREP_SIDE=1: a group is launched on a second HIP stream as soon as the backward pass moves on to another block shape, so
+        # that it runs next to the BatchNorm passes / data gradients of the following blocks; joined at the end of the pass
+        self.side_on = os.environ.get("HC_WREP_SIDE", "0") == "1"
+        self.side = None
+        self.inflight = []          # inputs of launches on the side stream: referenced until the join
+        self.side_params = set()
         self.arena = None           # zero-filled fp32 buffer of this backward pass (sized by the previous pass)
         self.arena_used = 0
         self.arena_want = 0
@@ -408,6 +414,11 @@ class _RepWgradQueue:
         dw1 = self._zeros((Cout, Cin, 1, 1), x.device)
         # The queue must not hold the gradient TENSORS: AccumulateGrad only adopts a gradient it holds the sole reference to
         # (otherwise it clones it on the spot).  The storages keep the memory alive instead.
+        if self.side_on and PROFILE is None:
+            if id(w3) in self.side_params or id(w1) in self.side_params:
+                self.join()             # a weight shared by two nodes: autograd will accumulate into a gradient the side stream writes
+            elif self.jobs and self.jobs[-1][0] != key:
+                self._launch_on_side()  # the pass moved on to another shape: the finished group goes to the side stream now
         self.jobs.append((key, x, dy3, dy1, dw3.untyped_storage(), dw3.data_ptr(), dw3.storage_offset(),
                           dw1.untyped_storage(), dw1.data_ptr(), dw1.storage_offset(), w3, w1))
         if not self.armed:
@@ -415,25 +426,60 @@ class _RepWgradQueue:
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
         return dw3, dw1
 
-    def flush(self):
-        self.armed = False
+    def _launch_on_side(self):
         jobs, self.jobs = self.jobs, []
-        self.arena, self.arena_used = None, 0          # the views handed out keep the buffer alive
-        self.arena_high, self.arena_want = max(self.arena_high, self.arena_want), 0
         if not jobs:
             return
+        cur = torch.cuda.current_stream()
+        if self.side is None or self.side.device != cur.device:
+            self.side = torch.cuda.Stream(cur.device)
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            self._launch_groups(jobs)
+        self.inflight.append(jobs)
+        for j in jobs:
+            self.side_params.add(id(j[10]))
+            self.side_params.add(id(j[11]))
+
+    def join(self):
+        """Everything launched on the side stream is ordered before what the caller's stream does next."""
+        if self.inflight:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._fix_clones(self.inflight)
+            self.inflight = []
+            self.side_params = set()
+
+    def _launch_groups(self, jobs):
         groups = {}
         for job in jobs:
             groups.setdefault(job[0], []).append(job)
         for key, grp in groups.items():
             self.launch(key, [(j[1], j[2], j[3], j[5], j[8]) for j in grp], accumulate=True)
-            # a gradient that autograd cloned instead of adopting (create_graph, a hook that kept a reference): the clone was
-            # taken before the launch - add what the launch produced
-            for (_, x, _, _, s3, p3, o3, s1, p1, o1, w3, w1) in grp:
+
+    @staticmethod
+    def _fix_clones(job_lists):
+        # a gradient that autograd cloned instead of adopting (create_graph, a hook that kept a reference): the clone was
+        # taken before the launch - add what the launch produced
+        for jobs in job_lists:
+            for (_, x, _, _, s3, p3, o3, s1, p1, o1, w3, w1) in jobs:
                 for w, st, p, off in ((w3, s3, p3, o3), (w1, s1, p1, o1)):
                     g = w.grad
                     if g is not None and g.data_ptr() != p:
                         g.add_(torch.empty(0, dtype=torch.float32, device=x.device).set_(st, off, g.shape))
+
+    def flush(self):
+        self.armed = False
+        jobs, self.jobs = self.jobs, []
+        self.arena, self.arena_used = None, 0          # the views handed out keep the buffer alive
+        self.arena_high, self.arena_want = max(self.arena_high, self.arena_want), 0
+        if jobs and self.inflight:          # side-stream mode: the last groups go there too, then everything is joined
+            self.jobs = jobs
+            self._launch_on_side()
+            jobs = []
+        if jobs:
+            self._launch_groups(jobs)
+            self._fix_clones([jobs])
+        self.join()
 
 
 _WREP = _RepWgradQueue()
@@ -441,7 +487,7 @@ _WREP = _RepWgradQueue()
 
 def flush_deferred_wgrads() -> None:
     """Launch every weight gradient that is still queued (call before reading ``.grad`` from inside a backward pass)."""
-    if _WREP.jobs:
+    if _WREP.jobs or _WREP.inflight:
         jobs, _WREP.jobs = _WREP.jobs, []
         arena = (_WREP.arena, _WREP.arena_used, _WREP.arena_want)
         _WREP.jobs = jobs

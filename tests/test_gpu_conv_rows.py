@@ -1,0 +1,98 @@
+"""Row-unit convolution kernel (csrc/conv_rows.hip: the 192 @ 14x14 and 96 @ 28x28 RepVGG-A0 stages) and its weight image
+(hc_pack_conv_weight modes 3 / 4) against fp32 torch convolutions of the same bf16 operands.
+
+Reference semantics: RepBlock.forward (holocron/models/classification/repvgg.py:71-73: conv3x3 + conv1x1 of one input) and
+aten::convolution_backward's data gradient of both.  Bounds: one bf16 rounding of an fp32 result is 1.65e-3 rel-L2 on these
+distributions (tests/test_gpu_fullsize_layers.py); the statistics are fp32 sums of fp32 accumulators (1e-5)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-3
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-30)).item()
+
+
+def rows_index(rc, kc, tap, C):
+    """The layout hc_pack_conv_weight modes 3 / 4 document (rows_image_index, csrc/rep_bn.hip), restated."""
+    w, rem = divmod(rc, 48)
+    q, rem2 = divmod(rem, 12)
+    f, i = divmod(rem2, 4)
+    r = 48 * w + 16 * f + 4 * q + i
+    t, kk = divmod(kc, 32)
+    hi, g, e = kk >> 4, (kk & 15) >> 2, kk & 3
+    j = 8 * g + 4 * hi + e
+    return ((tap * (C // 32) + t) * C + r) * 32 + j
+
+
+@pytest.mark.parametrize("C", [96, 192])
+def test_rows_image_layout(C):
+    from holocron_amd.ops import conv as cv
+    g = torch.Generator(device="cuda").manual_seed(0)
+    w3 = torch.randn(C, C, 3, 3, device="cuda", generator=g)
+    w1 = torch.randn(C, C, 1, 1, device="cuda", generator=g)
+    for mode in (3, 4):
+        img = cv.rows_image(C, "cuda")
+        img.zero_()
+        cv.pack_weight(w3, mode, out=img, tap0=0, T=10)
+        cv.pack_weight(w1, mode, out=img, tap0=9, T=10)
+        got = img.float().cpu().numpy().ravel()
+        w3b, w1b = w3.bfloat16().float().cpu().numpy(), w1.bfloat16().float().cpu().numpy()
+        rs = np.random.RandomState(1)
+        for _ in range(400):
+            co, ci, kh, kw = rs.randint(C), rs.randint(C), rs.randint(3), rs.randint(3)
+            if mode == 3:
+                assert got[rows_index(co, ci, kh * 3 + kw, C)] == w3b[co, ci, kh, kw]
+                assert got[rows_index(co, ci, 9, C)] == w1b[co, ci, 0, 0]
+            else:   # data gradient: rows = input channels, k = output channels, taps flipped
+                assert got[rows_index(ci, co, (2 - kh) * 3 + (2 - kw), C)] == w3b[co, ci, kh, kw]
+                assert got[rows_index(ci, co, 9, C)] == w1b[co, ci, 0, 0]
+
+
+@pytest.mark.parametrize("N,C,H", [(2, 192, 14), (256, 192, 14), (3, 96, 28), (256, 96, 28), (5, 192, 28), (2, 96, 56)])
+def test_conv_rows_vs_fp32(N, C, H):
+    """forward (3x3 + 1x1 + statistics) and data gradient (+ residual); W is the template size, H any multiple of 14"""
+    from holocron_amd import _lib
+    from holocron_amd.ops import conv as cv
+    W = 14 if C == 192 else 28
+    bf = lambda t: t.to(torch.bfloat16).float()
+    g = torch.Generator(device="cuda").manual_seed(N + C)
+    x = bf(torch.randn(N, C, H, W, device="cuda", generator=g))
+    dy3 = bf(torch.randn(N, C, H, W, device="cuda", generator=g))
+    dy1 = bf(torch.randn(N, C, H, W, device="cuda", generator=g))
+    w3 = bf(torch.randn(C, C, 3, 3, device="cuda", generator=g) * 0.05)
+    w1 = bf(torch.randn(C, C, 1, 1, device="cuda", generator=g) * 0.1)
+    xc, d3c, d1c = cv.to_cl_bf16(x), cv.to_cl_bf16(dy3), cv.to_cl_bf16(dy1)
+    wf, wd = cv.rows_image(C, "cuda"), cv.rows_image(C, "cuda")
+    cv.pack_weight(w3, 3, out=wf, tap0=0, T=10); cv.pack_weight(w1, 3, out=wf, tap0=9, T=10)
+    cv.pack_weight(w3, 4, out=wd, tap0=0, T=10); cv.pack_weight(w1, 4, out=wd, tap0=9, T=10)
+    d = cv.conv_small_desc(N, H, W, C, C, cv.ROWS_IMAGE)
+    dd = cv.conv_small_desc(N, H, W, C, C, cv.ROWS_IMAGE | 1)
+    assert d is not None and dd is not None
+    R = _lib.stat_replicas()
+    y3, y1 = cv.empty_cl(N, C, H, W, "cuda"), cv.empty_cl(N, C, H, W, "cuda")
+    stats = torch.zeros(2, R, 2, C, device="cuda")
+    cv.launch_conv_small_fwd(d, xc, wf, None, y3, y1, stats[0], stats[1])
+    dx = cv.empty_cl(N, C, H, W, "cuda")
+    cv.launch_conv_small_dgrad(dd, d3c, d1c, wd, dx, resid=xc)
+    dx0 = cv.empty_cl(N, C, H, W, "cuda")
+    cv.launch_conv_small_dgrad(dd, d3c, d1c, wd, dx0, resid=None)
+    torch.cuda.synchronize()
+    r3, r1 = F.conv2d(x, w3, padding=1), F.conv2d(x, w1)
+    assert rel(y3, r3) < TOL and rel(y1, r1) < TOL
+    s3, s1 = stats[0].sum(0), stats[1].sum(0)
+    for got, ref in ((s3[0], r3.sum((0, 2, 3))), (s3[1], (r3 * r3).sum((0, 2, 3))), (s1[0], r1.sum((0, 2, 3))), (s1[1], (r1 * r1).sum((0, 2, 3)))):
+        assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    rdx = F.conv_transpose2d(dy3, w3, padding=1) + F.conv_transpose2d(dy1, w1)
+    assert rel(dx0, rdx) < TOL
+    assert rel(dx, rdx + x) < TOL
+
+
+def test_conv_rows_unsupported_shapes():
+    from holocron_amd.ops import conv as cv
+    for (N, H, W, C) in [(4, 14, 14, 96), (4, 28, 28, 192), (4, 21, 14, 192), (4, 14, 14, 128), (4, 7, 14, 192)]:
+        assert cv.conv_small_desc(N, H, W, C, C, cv.ROWS_IMAGE) is None
