@@ -269,7 +269,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
                 float v = pl[0];
 #pragma unroll
                 for (int w = 1; w < WN; ++w) v += pl[w * 2 * BC];
-                atomicAdd(rep + which * Cout + cbase + c, v);
+                const int cg_ = cbase + c;
+                if (d.co_split > 0) {      // stacked convolutions: each has its own statistics array
+                    const int C1 = d.co_split, C2 = Cout - d.co_split;
+                    if (cg_ < C1) atomicAdd(d.stats + (size_t)(blockIdx.x % reps) * 2 * C1 + which * C1 + cg_, v);
+                    else atomicAdd(d.stats2 + (size_t)(blockIdx.x % reps) * 2 * C2 + which * C2 + (cg_ - C1), v);
+                } else {
+                    atomicAdd(rep + which * Cout + cbase + c, v);
+                }
             }
         }
     }
@@ -338,7 +345,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
                     for (int e = 0; e < 4; ++e)
                         if (co + e < Cout) v[e] += d.bias[co + e];
                 }
-                if ((Cout & 3) == 0) {
+                if (d.co_split > 0) {         // stacked convolutions: two destinations with their own channel counts
+                    const bool second = co >= d.co_split;
+                    bf16_t* dp = second ? reinterpret_cast<bf16_t*>(d.dst2) + pix * (Cout - d.co_split) + (co - d.co_split)
+                                        : dst + pix * d.co_split + co;
+                    u32x2 o;
+                    o[0] = pack_bf16x2(v[0], v[1]);
+                    o[1] = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(dp) = o;
+                } else if ((Cout & 3) == 0) {
                     if (resid != nullptr) {
                         const u32x2 rv = *reinterpret_cast<const u32x2*>(resid + pofs + co);
                         v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]);
@@ -425,6 +440,11 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
         if (d.cls[c].ntaps < 0 || d.cls[c].ntaps > HC_MAX_TAPS) return HC_ERR_ARG;
         for (int t = 0; t < d.cls[c].ntaps; ++t)
             if (((d.cls[c].tap[t] >> 16) & 0xff) != 0 && d.src1 == nullptr) return HC_ERR_ARG;
+    }
+    if (d.co_split != 0) {        // stacked convolutions
+        if (d.co_split < 0 || d.co_split >= d.Cout || (d.co_split % 4) != 0 || (d.Cout % 4) != 0 || d.dst2 == nullptr) return HC_ERR_ARG;
+        if ((d.stats == nullptr) != (d.stats2 == nullptr)) return HC_ERR_ARG;
+        if (d.resid != nullptr || d.bias != nullptr || d.act != 0 || d.pix_scale != nullptr || d.ch_mult != nullptr) return HC_ERR_ARG;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d.ch_mult != nullptr) {   // fp8 inference path

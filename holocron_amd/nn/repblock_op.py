@@ -14,6 +14,8 @@ Kernel sequence (DESIGN.md "RepBlock step"):
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from .. import _lib
@@ -110,6 +112,7 @@ class RepState:
         self.packed = None          # persistent packed-weight buffers (wp3, wp1, wpd)
         self.packed_key = None
         self.rows_image = False     # set by descs(): the block's convs run on the row-unit kernel, which reads its own weight image
+        self.stack_fwd = False      # set by pack_items(): 3x3 + 1x1 forward as ONE gather-conv over stacked weight rows
 
     # ---- packed weights (persistent buffers; refreshed by one multi-tensor launch per model) ----
     @staticmethod
@@ -121,8 +124,14 @@ class RepState:
         Cout, Cin = w3.shape[0], w3.shape[1]
         dev = w3.device
         stem = (Cin % 16) != 0
+        # small-channel stride-2 blocks and the stem read their input twice (3x3, then 1x1) in HBM-bound launches: stack the two
+        # kernels as 2 * Cout weight rows (the 1x1 at the centre tap resp. at its im2col columns) and gather the input once
+        self.stack_fwd = (stem or (self.stride == 2 and Cin <= 48)) and Cout % 4 == 0 and os.environ.get("HC_STACK_FWD", "1") != "0"
         if self.packed is None or self.packed[0].device != dev:
-            if self.rows_image:     # (forward image, -, data-gradient image), each shared by the 3x3 and the 1x1 kernel
+            if self.stack_fwd:
+                self.packed = (torch.zeros((2 * Cout, 1, STEM_KPAD) if stem else (2 * Cout, 9, Cin), dtype=torch.bfloat16, device=dev),
+                               None, None if stem else torch.empty((Cin, 10, Cout), dtype=torch.bfloat16, device=dev))
+            elif self.rows_image:     # (forward image, -, data-gradient image), each shared by the 3x3 and the 1x1 kernel
                 self.packed = (cv.rows_image(Cout, dev), None, cv.rows_image(Cout, dev))
             elif stem:
                 self.packed = (torch.zeros((Cout, 1, STEM_KPAD), dtype=torch.bfloat16, device=dev),
@@ -133,6 +142,11 @@ class RepState:
                                torch.empty((Cin, 10, Cout), dtype=torch.bfloat16, device=dev))
             self.packed_key = None
         wp3, wp1, wpd = self.packed
+        if self.stack_fwd:
+            if stem:
+                return [(w3, wp3, Cout, Cin, 3, 3, 2, 0, STEM_KPAD), (w1, wp3[Cout:], Cout, Cin, 1, 1, 2, 4 * Cin, STEM_KPAD)]
+            return [(w3, wp3, Cout, Cin, 3, 3, 0, 0, 9), (w1, wp3[Cout:], Cout, Cin, 1, 1, 0, 4, 9),
+                    (w3, wpd, Cout, Cin, 3, 3, 1, 0, 10), (w1, wpd, Cout, Cin, 1, 1, 1, 9, 10)]
         if self.rows_image:
             return [(w3, wp3, Cout, Cin, 3, 3, 3, 0, 10), (w1, wp3, Cout, Cin, 1, 1, 3, 9, 10),
                     (w3, wpd, Cout, Cin, 3, 3, 4, 0, 10), (w1, wpd, Cout, Cin, 1, 1, 4, 9, 10)]
@@ -150,6 +164,18 @@ class RepState:
                       "hc_pack_conv_weight")
             self.packed_key = key
         return self.packed
+
+    def stacked_desc(self, N, Cin, H, W, Cout):
+        """forward descriptor of the stacked 3x3 + 1x1 launch (2 * Cout output channels)"""
+        key = ("stack", N, Cin, H, W, Cout)
+        if key not in self.desc:
+            s = self.stride
+            if Cin % 16 == 0:
+                self.desc[key] = cv.fwd_desc(N, Cin, H, W, 2 * Cout, 3, 3, s, 1)
+            else:
+                OH, OW = cv.conv_out_size(H, 3, s, 1), cv.conv_out_size(W, 3, s, 1)
+                self.desc[key] = cv.fwd_desc(N, STEM_KPAD, OH, OW, 2 * Cout, 1, 1, 1, 0)
+        return self.desc[key]
 
     def descs(self, N, Cin, H, W, Cout):
         key = (N, Cin, H, W, Cout)
@@ -209,6 +235,10 @@ def block_convs_forward(st, src, w3, w1, geom, stats=None, stem_cin=None):
     s1 = None if stats is None else stats[1]
     if sf is not None:
         cv.launch_conv_small_fwd(sf, src, wp3, wp1, y3, y1, s3, s1)
+    elif st.stack_fwd:
+        f31 = st.stacked_desc(N, Cin, H, W, Cout)
+        cv.launch_conv(f31, src, wp3, y3, stats=s3, dst2=y1, stats2=s1, co_split=Cout,
+                       flops=None if fl3 is None else fl3 + fl1)
     else:
         cv.launch_conv(f3, src, wp3, y3, stats=s3, flops=fl3)
         cv.launch_conv(f1, src, wp1, y1, stats=s1, flops=fl1)

@@ -125,15 +125,18 @@ def _desc_flops(d):
     return 2.0 * macs * d.srcC * d.Cout
 
 
-def launch_conv(d, src0, wpk, dst, src1=None, resid=None, stats=None, bias=None, act=0, flops=None):
+def launch_conv(d, src0, wpk, dst, src1=None, resid=None, stats=None, bias=None, act=0, flops=None, dst2=None, stats2=None,
+                co_split=0):
+    """``dst2`` / ``stats2`` / ``co_split``: two convolutions of ``src0`` in one launch (stacked weight rows, hc_conv_desc.co_split)."""
     d.src0, d.src1, d.wpk, d.dst = ptr(src0), ptr(src1), ptr(wpk), ptr(dst)
     d.resid, d.stats, d.bias, d.act = ptr(resid), ptr(stats), ptr(bias), act
+    d.dst2, d.stats2, d.co_split = ptr(dst2), ptr(stats2), co_split
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         check(_lib.load().hc_conv_gather(C.byref(d), stream()), "hc_conv_gather")
         e1.record()
-        nbytes = sum(t.numel() * t.element_size() for t in (src0, src1, wpk, dst, resid) if t is not None)
+        nbytes = sum(t.numel() * t.element_size() for t in (src0, src1, wpk, dst, resid, dst2) if t is not None)
         PROFILE.append(("conv_gather", _desc_flops(d) if flops is None else flops, e0, e1, nbytes))
         return
     check(_lib.load().hc_conv_gather(C.byref(d), stream()), "hc_conv_gather")

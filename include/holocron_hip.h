@@ -74,6 +74,14 @@ typedef struct {
      * v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales and dst = fp8(act(acc * ch_mult[co] + bias[co])), i.e.
      * ch_mult = weight_scale[co] * input_scale / output_scale and bias is pre-divided by the output scale. */
     const float* ch_mult;    /* fp32 [Cout] */
+    /* two convolutions of the same source in one launch (stacked weight rows): when co_split > 0, output channels
+     * [co_split, Cout) go to dst2 (NHWC with Cout - co_split channels) and their statistics to stats2, channels [0, co_split) to
+     * dst / stats with co_split channels per pixel.  co_split % 4 == 0; no resid / bias / act / normalisation with it.  Used for the
+     * 3x3 + 1x1 branches of the small-channel stride-2 RepBlocks and the stem (the 1x1 kernel sits at the centre tap of a second
+     * set of rows): the source is gathered once instead of twice. */
+    void* dst2;
+    float* stats2;
+    int32_t co_split;
 } hc_conv_desc;
 int hc_conv_gather(const hc_conv_desc* d, hc_stream_t stream);
 
