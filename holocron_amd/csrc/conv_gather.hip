@@ -35,7 +35,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // the epilogue applies the per-channel dequant * requant factor and bias, ReLU, and stores fp8.
 typedef __attribute__((ext_vector_type(8))) int hc_i32x8;
 template <int MR, int NR, int WM, int WN, int BK, bool FP8>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_conv_desc d, const int reps) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_conv_desc d, const int reps, const int flags) {
     static_assert(!FP8 || BK == 32, "fp8: 64 one-byte channels per k-step");
     constexpr int NT = 64 * WM * WN;
     constexpr int BC = 32 * MR * WM;  // output-channel tile (A rows)
@@ -316,6 +316,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
     }
     bf16_t* dst = reinterpret_cast<bf16_t*>(d.dst);
     const bf16_t* resid = reinterpret_cast<const bf16_t*>(d.resid);
+    // Coalesced stores: a lane of the D tile holds 4 channels (8 bytes) of ONE pixel and its neighbours hold other pixels, so
+    // direct stores touch 32 cache lines per instruction.  When whole 16-byte channel chunks exist (Cout % 8 == 0) the tile goes
+    // through LDS instead ([pixel][channel] bf16, pitch BC * 2 + 8 bytes: conflict-free 8-byte writes) and leaves as 16-byte
+    // stores whose consecutive lanes walk a pixel's channels - full rows of the NHWC destination.
+    constexpr int OPITCH = BC * 2 + 8;
+    const bool staged = (flags & 1) != 0 && (Cout & 7) == 0 && (d.co_split & 7) == 0;
+    char* ost = smem;
+    if (staged) __syncthreads();        // the statistics scratch / the last staging tiles are dead
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int m = pbase + (wn * NR + nr) * 32 + lr;
@@ -345,7 +353,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
                     for (int e = 0; e < 4; ++e)
                         if (co + e < Cout) v[e] += d.bias[co + e];
                 }
-                if (d.co_split > 0) {         // stacked convolutions: two destinations with their own channel counts
+                if (staged) {
+                    if (resid != nullptr) {
+                        const u32x2 rv = *reinterpret_cast<const u32x2*>(resid + pofs + co);
+                        v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]);
+                        v[2] += bf16lo(rv[1]); v[3] += bf16hi(rv[1]);
+                    }
+                    if (d.act != 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], d.act);
+                    }
+                    u32x2 o;
+                    o[0] = pack_bf16x2(v[0], v[1]);
+                    o[1] = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(ost + ((wn * NR + nr) * 32 + lr) * OPITCH + (co - cbase) * 2) = o;
+                } else if (d.co_split > 0) {         // stacked convolutions: two destinations with their own channel counts
                     const bool second = co >= d.co_split;
                     bf16_t* dp = second ? reinterpret_cast<bf16_t*>(d.dst2) + pix * (Cout - d.co_split) + (co - d.co_split)
                                         : dst + pix * d.co_split + co;
@@ -380,12 +402,36 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
             }
         }
     }
+    if (staged) {
+        __syncthreads();
+        constexpr int CPR = BC / 8;      // 16-byte chunks per staged pixel row
+        for (int i = tid; i < BP * CPR; i += NT) {
+            const int pl = i / CPR, ch = i - pl * CPR;
+            const int m = pbase + pl, co = cbase + ch * 8;
+            if (m >= M || co >= Cout) continue;
+            const int n = m / (OHg * OWg);
+            const int rem = m - n * (OHg * OWg);
+            const int oi = rem / OWg, oj = rem - oi * OWg;
+            const long pix = ((long)n * d.OH + (oi * cl.ostep + cl.oy0)) * d.OW + (oj * cl.ostep + cl.ox0);
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(ost + pl * OPITCH + ch * 16);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(ost + pl * OPITCH + ch * 16 + 8);
+            const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+            if (d.co_split > 0) {
+                if (co >= d.co_split) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(d.dst2) + pix * (Cout - d.co_split) + (co - d.co_split)) = v;
+                else *reinterpret_cast<u32x4*>(dst + pix * d.co_split + co) = v;
+            } else {
+                *reinterpret_cast<u32x4*>(dst + pix * Cout + co) = v;
+            }
+        }
+    }
 }
 
 template <int MR, int NR, int WM, int WN, int BK, bool FP8 = false>
 int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
     constexpr int BC = 32 * MR * WM, BP = 32 * NR * WN;
-    constexpr int smem = 2 * (BC + BP) * BK * 2;
+    constexpr int smem_k = 2 * (BC + BP) * BK * 2, smem_o = BP * (BC * 2 + 8);    // k-loop stages / output staging
+    constexpr int smem = smem_k > smem_o ? smem_k : smem_o;
+    static const int flags = [] { const char* e = getenv("HC_CONV_STAGED_STORES"); return (e == nullptr || atoi(e) != 0) ? 1 : 0; }();
     int maxM = 0;
     for (int c = 0; c < d.nclass; ++c) {
         const int m = d.N * d.cls[c].OHg * d.cls[c].OWg;
@@ -400,7 +446,7 @@ int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
         attr_set = true;
     }
     if (d.stats != nullptr && hc_get_deterministic() && (int)grid.x > hc_get_stat_replicas()) return HC_ERR_ARG;
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, st, d, hc_get_stat_replicas());
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), smem, st, d, hc_get_stat_replicas(), FP8 ? 0 : flags);
     return hc_launch_status();
 }
 
