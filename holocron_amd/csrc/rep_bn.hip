@@ -52,6 +52,24 @@ __device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
     for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
 }
 
+// Streaming accesses of the elementwise passes.  NT: tensors far larger than the 256 MB last-level cache (the 112x112 and 56x56
+// stages at batch 256: 77-308 MB each, 4-7 of them per pass) are read and written with the non-temporal hint - nothing of them
+// survives until its next use anyway, and not allocating them sped those passes up by 8-12 %; on the small stages the same hint
+// costs 3-18 % (their operands ARE still in cache from the producing kernel), so the host picks per launch.
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16(const u32x4* p) {
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16(u32x4* p, const u32x4 v) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+static inline bool ew_streaming(long nchunks) {      // one tensor >= 48 MB
+    static const long thr = getenv("HC_EW_NT_MB") ? atol(getenv("HC_EW_NT_MB")) : 48;
+    return thr >= 0 && nchunks * 16 >= thr * 1000000L;
+}
+
 // Per-workgroup reduction of per-thread partial sums v[S][8] (8 channels of the thread's channel
 // group) WITHOUT LDS atomics (contended ds_add_f32 costs ~8 us per workgroup here): partials go to
 // LDS [thread][S*8 (+1 pad)], then each output (sum k, channel c) adds the ~256/cg threads that own
@@ -159,7 +177,7 @@ __device__ __forceinline__ float rep_preact(float a3, float f3, float a1, float 
     if (HAS_ID) z = __builtin_fmaf(a0, f0, z);
     return __builtin_fmaf(a3, f3, z);
 }
-template <bool HAS_ID, bool STATS>
+template <bool HAS_ID, bool STATS, bool NT>
 __global__ __launch_bounds__(EW_THREADS) void rep_apply_kernel(const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
                                                                const u32x4* __restrict__ x, const float* __restrict__ coef,
                                                                u32x4* __restrict__ out, float* __restrict__ out_stats,
@@ -179,9 +197,9 @@ __global__ __launch_bounds__(EW_THREADS) void rep_apply_kernel(const u32x4* __re
     for (int i = 0; i < 8; ++i) sv[0][i] = sv[1][i] = 0.f;
     for (long q = gtid; q < nchunks; q += stride) {
         float f3[8], f1[8], f0[8], o[8];
-        unpack8(y3[q], f3);
-        unpack8(y1[q], f1);
-        if (HAS_ID) unpack8(x[q], f0);
+        unpack8(ld16<NT>(y3 + q), f3);
+        unpack8(ld16<NT>(y1 + q), f1);
+        if (HAS_ID) unpack8(ld16<NT>(x + q), f0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float z = rep_preact<HAS_ID>(a3[i], f3[i], a1[i], f1[i], HAS_ID ? a0[i] : 0.f, HAS_ID ? f0[i] : 0.f, sh[i]);
@@ -189,7 +207,7 @@ __global__ __launch_bounds__(EW_THREADS) void rep_apply_kernel(const u32x4* __re
             o[i] = z;
         }
         const u32x4 pk = pack8(o);
-        out[q] = pk;
+        st16<NT>(out + q, pk);
         if (STATS) {  // statistics of what the next block will actually read (bf16-rounded)
             float r[8];
             unpack8(pk, r);
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(EW_THREADS) void channel_stats_kernel(const u32x4* 
 // ---------------------------------------------------------------- backward reduce
 // ZMASK: the ReLU mask is recomputed from the pre-activation (coef = the forward's [4][C] affine; act 0 = no activation) instead of
 // read from `out` - one tensor less per pass (2 of the 13 tensor passes of a block's BatchNorm backward)
-template <bool HAS_ID, bool ZMASK>
+template <bool HAS_ID, bool ZMASK, bool NT>
 __global__ __launch_bounds__(EW_THREADS) void rep_bwd_reduce_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ out,
                                                                     const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
                                                                     const u32x4* __restrict__ x, const float* __restrict__ coef,
@@ -250,11 +268,11 @@ __global__ __launch_bounds__(EW_THREADS) void rep_bwd_reduce_kernel(const u32x4*
         for (int i = 0; i < 8; ++i) sv[k][i] = 0.f;
     for (long q = gtid; q < nchunks; q += stride) {
         float fg[8], fo[8], f3[8], f1[8], f0[8];
-        unpack8(g[q], fg);
-        if (!ZMASK) unpack8(out[q], fo);
-        unpack8(y3[q], f3);
-        unpack8(y1[q], f1);
-        if (HAS_ID) unpack8(x[q], f0);
+        unpack8(ld16<NT>(g + q), fg);
+        if (!ZMASK) unpack8(ld16<NT>(out + q), fo);
+        unpack8(ld16<NT>(y3 + q), f3);
+        unpack8(ld16<NT>(y1 + q), f1);
+        if (HAS_ID) unpack8(ld16<NT>(x + q), f0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (ZMASK) fo[i] = act == 1 ? rep_preact<HAS_ID>(a3[i], f3[i], a1[i], f1[i], HAS_ID ? a0[i] : 0.f, HAS_ID ? f0[i] : 0.f, sh[i]) : 1.f;
@@ -321,7 +339,7 @@ __global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_b
     }
 }
 
-template <bool HAS_ID, bool ZMASK>
+template <bool HAS_ID, bool ZMASK, bool NT>
 __global__ __launch_bounds__(EW_THREADS) void rep_bwd_apply_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ out,
                                                                    const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
                                                                    const u32x4* __restrict__ x, const float* __restrict__ coef,
@@ -345,11 +363,11 @@ __global__ __launch_bounds__(EW_THREADS) void rep_bwd_apply_kernel(const u32x4* 
     if (HAS_ID) { load8f(bc + 6 * C + c0, A0); load8f(bc + 7 * C + c0, B0); load8f(bc + 8 * C + c0, C0); }
     for (long q = gtid; q < nchunks; q += stride) {
         float fg[8], fo[8], f3[8], f1[8], f0[8], o3[8], o1[8], o0[8];
-        unpack8(g[q], fg);
-        if (!ZMASK) unpack8(out[q], fo);
-        unpack8(y3[q], f3);
-        unpack8(y1[q], f1);
-        if (HAS_ID) unpack8(x[q], f0);
+        unpack8(ld16<NT>(g + q), fg);
+        if (!ZMASK) unpack8(ld16<NT>(out + q), fo);
+        unpack8(ld16<NT>(y3 + q), f3);
+        unpack8(ld16<NT>(y1 + q), f1);
+        if (HAS_ID) unpack8(ld16<NT>(x + q), f0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (ZMASK) fo[i] = act == 1 ? rep_preact<HAS_ID>(a3[i], f3[i], a1[i], f1[i], HAS_ID ? a0[i] : 0.f, HAS_ID ? f0[i] : 0.f, sh[i]) : 1.f;
@@ -358,9 +376,9 @@ __global__ __launch_bounds__(EW_THREADS) void rep_bwd_apply_kernel(const u32x4* 
             o1[i] = __builtin_fmaf(A1[i], dz, __builtin_fmaf(B1[i], f1[i], C1[i]));
             if (HAS_ID) o0[i] = __builtin_fmaf(A0[i], dz, __builtin_fmaf(B0[i], f0[i], C0[i]));
         }
-        dy3[q] = pack8(o3);
-        dy1[q] = pack8(o1);
-        if (HAS_ID) dxid[q] = pack8(o0);
+        st16<NT>(dy3 + q, pack8(o3));
+        st16<NT>(dy1 + q, pack8(o1));
+        if (HAS_ID) st16<NT>(dxid + q, pack8(o0));
     }
 }
 
@@ -861,15 +879,21 @@ int hc_rep_apply(const void* y3, const void* y1, const void* x, const float* coe
     const int blocks = ew_blocks(nchunks, C / 8, out_stats ? 16 : 8);
     hipStream_t st = (hipStream_t)stream;
     const size_t sm = out_stats ? EW_THREADS * 17 * sizeof(float) : 0;
-#define HC_LAUNCH_APPLY(ID, ST)                                                                                          \
-    hipLaunchKernelGGL((rep_apply_kernel<ID, ST>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)y3,             \
+#define HC_LAUNCH_APPLY1(ID, ST, NTM)                                                                                    \
+    hipLaunchKernelGGL((rep_apply_kernel<ID, ST, NTM>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)y3,        \
                        (const u32x4*)y1, (const u32x4*)x, coef, (u32x4*)out, out_stats, nchunks, C, act, hc_get_stat_replicas())
+#define HC_LAUNCH_APPLY(ID, ST)                                   \
+    do {                                                          \
+        if (ew_streaming(nchunks)) HC_LAUNCH_APPLY1(ID, ST, true); \
+        else HC_LAUNCH_APPLY1(ID, ST, false);                     \
+    } while (0)
     if (x != nullptr) {
         if (out_stats) HC_LAUNCH_APPLY(true, true); else HC_LAUNCH_APPLY(true, false);
     } else {
         if (out_stats) HC_LAUNCH_APPLY(false, true); else HC_LAUNCH_APPLY(false, false);
     }
 #undef HC_LAUNCH_APPLY
+#undef HC_LAUNCH_APPLY1
     return hc_launch_status();
 }
 
@@ -890,9 +914,15 @@ static int rep_bwd_reduce_launch(const void* g, const void* out, const float* co
     const int blocks = ew_blocks(nchunks, C / 8, 16);
     hipStream_t st = (hipStream_t)stream;
     const size_t sm = EW_THREADS * 33 * sizeof(float);
-#define HC_RBR(ID, ZM)                                                                                                              \
-    hipLaunchKernelGGL((rep_bwd_reduce_kernel<ID, ZM>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)g, (const u32x4*)out, \
-                       (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, coef, act, red, nchunks, C, hc_get_stat_replicas())
+#define HC_RBR1(ID, ZM, NTM)                                                                                                             \
+    hipLaunchKernelGGL((rep_bwd_reduce_kernel<ID, ZM, NTM>), dim3(blocks), dim3(EW_THREADS), sm, st, (const u32x4*)g,                   \
+                       (const u32x4*)out, (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, coef, act, red, nchunks, C,             \
+                       hc_get_stat_replicas())
+#define HC_RBR(ID, ZM)                \
+    do {                              \
+        if (ew_streaming(nchunks)) HC_RBR1(ID, ZM, true); \
+        else HC_RBR1(ID, ZM, false);  \
+    } while (0)
     if (coef != nullptr) {
         if (x != nullptr) HC_RBR(true, true);
         else HC_RBR(false, true);
@@ -901,6 +931,7 @@ static int rep_bwd_reduce_launch(const void* g, const void* out, const float* co
         else HC_RBR(false, false);
     }
 #undef HC_RBR
+#undef HC_RBR1
     return hc_launch_status();
 }
 int hc_rep_bwd_reduce(const void* g, const void* out, const void* y3, const void* y1, const void* x, float* red, int64_t npix,
@@ -930,10 +961,15 @@ static int rep_bwd_apply_launch(const void* g, const void* out, const float* coe
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8);
     hipStream_t st = (hipStream_t)stream;
-#define HC_RBA(ID, ZM)                                                                                                              \
-    hipLaunchKernelGGL((rep_bwd_apply_kernel<ID, ZM>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)g, (const u32x4*)out,    \
+#define HC_RBA1(ID, ZM, NTM)                                                                                                         \
+    hipLaunchKernelGGL((rep_bwd_apply_kernel<ID, ZM, NTM>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)g, (const u32x4*)out, \
                        (const u32x4*)y3, (const u32x4*)y1, (const u32x4*)x, coef, act, bcoef, (u32x4*)dy3, (u32x4*)dy1,             \
                        (u32x4*)dxid, nchunks, C)
+#define HC_RBA(ID, ZM)                \
+    do {                              \
+        if (ew_streaming(nchunks)) HC_RBA1(ID, ZM, true); \
+        else HC_RBA1(ID, ZM, false);  \
+    } while (0)
     if (coef != nullptr) {
         if (x != nullptr) HC_RBA(true, true);
         else HC_RBA(false, true);
@@ -942,6 +978,7 @@ static int rep_bwd_apply_launch(const void* g, const void* out, const float* coe
         else HC_RBA(false, false);
     }
 #undef HC_RBA
+#undef HC_RBA1
     return hc_launch_status();
 }
 int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void* y1, const void* x, const float* bcoef, void* dy3,
