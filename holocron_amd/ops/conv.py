@@ -585,6 +585,6 @@ def _launch_small(d, flops, nbytes=0):
         e0.record()
         check(_lib.load().hc_conv_small(C.byref(d), stream()), "hc_conv_small")
         e1.record()
-        PROFILE.append(("conv_small", flops, e0, e1, nbytes))
+        PROFILE.append(("conv_rows" if (d.mode & ROWS_IMAGE) else "conv_small", flops, e0, e1, nbytes))
         return
     check(_lib.load().hc_conv_small(C.byref(d), stream()), "hc_conv_small")
