@@ -79,14 +79,19 @@ constexpr int DJW = 4;   // dy DMA instructions per tensor and wave (stages up t
 
 // HV = 2: eight waves, the ci tile split over two groups of four waves (two waves per SIMD at <= 256 registers: while one waits for
 // LDS or issues DMA the other feeds the matrix pipe - with one wave per SIMD nothing overlaps unless the instruction stream says so)
-template <int MR, int NR, int HV>
-__global__ __launch_bounds__(256 * HV, (HV == 2 || MR * NR <= 9) ? 2 : 1) void wrep_kernel(const Args a) {
-    constexpr int NW = 4 * HV, NT_ = 256 * HV, MH = MR / HV;
+// PV = 2 (the 48 x 48 tile, whose ci blocks do not split evenly): eight waves, the two groups take alternate halves of the 32-pixel
+// k-steps of every step and write their own partial slab (the reduction kernel adds twice as many) - same reason as HV = 2.
+template <int MR, int NR, int HV, int PV = 1>
+__global__ __launch_bounds__(256 * HV * PV, (PV == 1 && (HV == 2 || MR * NR <= 9)) ? 2 : 1) void wrep_kernel(const Args a) {
+    constexpr int NW = 4 * HV * PV, NT_ = 256 * HV * PV, MH = MR / HV;
+    static_assert(HV == 1 || PV == 1, "one kind of wave-group split at a time");
     static_assert(MR % HV == 0, "ci tile must split evenly over the wave groups");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int role = wid & 3, half = wid >> 2;             // role 0..2: kernel row, 3: the 1x1; half: which MH ci blocks of the tile
+    const int role = wid & 3;                              // role 0..2: kernel row, 3: the 1x1
+    const int half = HV == 2 ? wid >> 2 : 0;               // which MH ci blocks of the tile
+    const int pz = PV == 2 ? wid >> 2 : 0;                 // which k-steps of a step
 
     // ---- blockIdx -> (job, split, tile): the tiles of one (job, split) - same pixels, different channels - share an XCD's L2
     const int NT = a.n_ci * a.n_co;
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256 * HV, (HV == 2 || MR * NR <= 9) ? 2 : 1) void w
                 issue_dy();
             }
             const char* dyb = smem + a.off_dy + cstage * a.DSLOT + dywave;
-            for (int g = 0; g < nk; ++g) {
+            for (int g = (pz * nk) / PV; g < ((pz + 1) * nk) / PV; ++g) {
                 const int p0 = 32 * g + prow;
                 const int r0 = tab[2 * p0], c0 = tab[2 * p0 + 1], r1 = tab[2 * p0 + 32], c1 = tab[2 * p0 + 33];
                 int s0 = base + r0 + khw, s1 = base + r1 + khw;
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256 * HV, (HV == 2 || MR * NR <= 9) ? 2 : 1) void w
         wait_vm(0);                                        // drain the run-ahead DMA before the workgroup retires
 
         // ---- slab[job][split][co][10][ci]: lane = co column, the 4 accumulator values = 4 consecutive ci -------------
-        float* ws = a.ws + (size_t)(job * a.nsplit + split) * (size_t)a.Cout * 10u * (size_t)a.Cin;
+        float* ws = a.ws + (size_t)((job * a.nsplit + split) * PV + pz) * (size_t)a.Cout * 10u * (size_t)a.Cin;
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             const int co = co0 + 16 * q + la;
@@ -361,7 +366,7 @@ inline int round_stride(int bytes, int stride) {
 struct Plan {
     bool ok;
     Args a;
-    int MR, NR, HV, smem, grid;
+    int MR, NR, HV, PV, smem, grid;
 };
 
 inline Plan make_plan(const hc_rep_wgrad_desc& d) {
@@ -455,19 +460,22 @@ inline Plan make_plan(const hc_rep_wgrad_desc& d) {
     pl.NR = NR;
     static const int hv_env = getenv("HC_WREP_HV") ? atoi(getenv("HC_WREP_HV")) : 0;
     pl.HV = (MR % 2 == 0 && hv_env != 1) ? 2 : 1;
+    // the 48 x 48 tile: when the LDS footprint leaves room for one workgroup per CU only, run it with eight waves (pixel split)
+    static const int pv_env = getenv("HC_WREP_PV") ? atoi(getenv("HC_WREP_PV")) : 0;
+    pl.PV = (pl.HV == 1 && MR == 3 && (a.P32 >> 5) >= 2 && (pv_env == 2 || (pv_env == 0 && per_cu == 1))) ? 2 : 1;
     pl.ok = true;
     return pl;
 }
 
-template <int MR, int NR, int HV>
+template <int MR, int NR, int HV, int PV = 1>
 int launch(const Plan& pl, hipStream_t st) {
-    auto kern = wrep_kernel<MR, NR, HV>;
+    auto kern = wrep_kernel<MR, NR, HV, PV>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256 * HV), pl.smem, st, pl.a);
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256 * HV * PV), pl.smem, st, pl.a);
     return hc_launch_status();
 }
 
@@ -482,7 +490,7 @@ extern "C" int64_t hc_rep_wgrad_ws_bytes(const hc_rep_wgrad_desc* d) {
     if (d == nullptr) return -1;
     const wrep::Plan pl = wrep::make_plan(*d);
     if (!pl.ok) return -1;
-    return (int64_t)d->njobs * pl.a.nsplit * d->Cout * 10 * d->Cin * 4;
+    return (int64_t)d->njobs * pl.a.nsplit * pl.PV * d->Cout * 10 * d->Cin * 4;
 }
 
 extern "C" int hc_rep_wgrad_plan(const hc_rep_wgrad_desc* d, int32_t* out8) {
@@ -506,9 +514,9 @@ extern "C" int hc_rep_wgrad(const hc_rep_wgrad_desc* dp, hc_stream_t stream) {
     int rc;
     if (pl.MR == 6) rc = pl.HV == 2 ? wrep::launch<6, 3, 2>(pl, st) : wrep::launch<6, 3, 1>(pl, st);
     else if (pl.MR == 4) rc = pl.HV == 2 ? wrep::launch<4, 4, 2>(pl, st) : wrep::launch<4, 4, 1>(pl, st);
-    else rc = wrep::launch<3, 3, 1>(pl, st);
+    else rc = pl.PV == 2 ? wrep::launch<3, 3, 1, 2>(pl, st) : wrep::launch<3, 3, 1>(pl, st);
     if (rc != HC_OK) return rc;
-    const int ns = pl.a.nsplit;
+    const int ns = pl.a.nsplit * pl.PV;
     if (ns <= 32) {
         hipLaunchKernelGGL(wrep::wrep_reduce_kernel<1>, dim3(d.Cout, (d.Cin + 63) / 64, d.njobs), dim3(640), 0, st, pl.a.ws, d, ns);
     } else if (ns <= 128) {
