@@ -115,7 +115,7 @@ def main():
     if distributed:
         parallel.broadcast_parameters(model)
     opt = h.optim.AdaBelief(model.parameters(), lr=1e-3, betas=(0.95, 0.99), eps=1e-6, weight_decay=0.0)
-    reducer, cut = None, None
+    reducer, cut, cut2 = None, None, None
     if distributed:
         # Backward in two pieces: the last block + head hold 66 % of the parameters (the 1280 x 1280 x 3 x 3 conv) and their
         # gradients come first; their bucket ends exactly at the cut, so its all-reduce runs behind the rest of backward.
@@ -123,9 +123,17 @@ def main():
         rear = {id(p) for p in rear_mod.parameters()} | {id(p) for p in model.head.parameters()}
         front_last = next(p for p in reversed(list(model.parameters())) if id(p) not in rear)
         comm = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32
-        reducer = parallel.GradReducer(model.parameters(), bucket_mb=128.0 if comm == torch.float32 else 64.0, comm_dtype=comm,
-                                       force=force_dist, new_bucket_at=[front_last])
+        # ... and in three: a second cut in front of the 192-channel stage.  The middle bucket (that stage + the first 1280-channel
+        # block, 8 M parameters) is then reduced behind the backward of the 48 / 96-channel stages (the HBM-bound third of the pass),
+        # and what stays exposed is their own 0.55 M parameters (2.2 MB in fp32) instead of a third of the model.
+        mid_mod = model.features[3][0]
+        mid = {id(p) for st in model.features[3:] for p in st.parameters()} | rear
+        early_last = next((p for p in reversed(list(model.parameters())) if id(p) not in mid), None)
+        bounds = [front_last] + ([early_last] if early_last is not None and os.environ.get("HC_BENCH_CUTS", "2") == "2" else [])
+        reducer = parallel.GradReducer(model.parameters(), bucket_mb=256.0, comm_dtype=comm, force=force_dist, new_bucket_at=bounds)
         cut = parallel.BackwardCut(rear_mod)
+        if len(bounds) == 2:
+            cut2 = parallel.BackwardCut(mid_mod)
 
     g = torch.Generator(device=dev).manual_seed(rank)
     x = torch.rand((args.batch, 3, 224, 224), device=dev, generator=g)
@@ -139,7 +147,7 @@ def main():
         loss.backward()
         loss_buf.copy_(loss.detach())
 
-    segments = [seg_fwd_bwd] if cut is None else [seg_fwd_bwd, cut.continue_backward]
+    segments = [seg_fwd_bwd] if cut is None else [seg_fwd_bwd, cut.continue_backward] + ([cut2.continue_backward] if cut2 is not None else [])
 
     def fwd_bwd():
         for seg in segments:
@@ -183,10 +191,11 @@ def main():
             if ok and not int(flag.item()):
                 ok, why = 0, "capture failed on another rank"
         if ok:
+            mb = [sum(t.numel() * t.element_size() for t in sp) / 1e6 for sp in gstep.spans] if distributed else []
             graph_note = ("weight gradients on a second stream; " if wgrad_side else "") + ("hipGraph replay of the full step" if not distributed else
                           f"hipGraphs with eager RCCL all-reduces of the {args.comm_dtype} gradient between them (fwd + bwd of last block/head | "
-                          f"all-reduce {sum(t.numel() * t.element_size() for t in gstep.spans[0]) / 1e6:.1f} MB behind: rest of bwd | all-reduce "
-                          f"{sum(t.numel() * t.element_size() for t in gstep.spans[-1]) / 1e6:.1f} MB | unpack + AdaBelief)")
+                          + " | ".join(f"all-reduce {m:.1f} MB" + (" behind: next part of bwd" if i + 1 < len(mb) else " (exposed)")
+                                       for i, m in enumerate(mb)) + " | unpack + AdaBelief)")
         else:
             if gstep is not None:
                 gstep.release()
