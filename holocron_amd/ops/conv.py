@@ -17,6 +17,12 @@ _WEIGHTS_EPOCH = [0]  # bumped by holocron_amd.optim after every raw-pointer par
 
 
 def bump_weights_epoch():
+    """Invalidate every cached packed-weight image (public as ``holocron_amd.bump_weights_epoch``).
+
+    The conv units cache the bf16 images of their fp32 master weights keyed on ``Parameter._version`` and on this epoch.  torch's own
+    in-place ops on a parameter bump ``_version``; the HIP optimizers write through raw pointers and call this after every step.
+    Code that writes through ``p.data`` (``p.data.add_``, ``.data.copy_``, ``.data.clamp_``: older third-party optimizers, EMA weight
+    swaps, weight clipping) does neither - call this after such an update, or the next forward multiplies with the old weights."""
     _WEIGHTS_EPOCH[0] += 1
 
 

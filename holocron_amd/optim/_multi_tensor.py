@@ -26,6 +26,28 @@ def chunk_rows(entries):
     return arr.view(np.uint8).copy(), len(rows)
 
 
+class VGroups:
+    """Launch groups keyed by (param_group index, step count).  The kernels keep one step counter (bias corrections) per group;
+    the reference keeps ``state['step']`` per parameter (e.g. holocron/optim/adabelief.py:120-128), and the two only differ when a
+    parameter skipped iterations (``grad is None``: conditional branches, layers unfrozen mid-run).  Such parameters simply land in
+    a launch group of their own with the same hyper-parameters."""
+
+    def __init__(self):
+        self.keys = []
+        self._of = {}
+
+    def index(self, gi, step):
+        k = (gi, int(step))
+        v = self._of.get(k)
+        if v is None:
+            v = self._of[k] = len(self.keys)
+            self.keys.append(k)
+        return v
+
+    def __len__(self):
+        return len(self.keys)
+
+
 def build_chunks(entries):
     raw, n = chunk_rows(entries)
     return torch.from_numpy(raw), n

@@ -20,7 +20,7 @@ from torch.optim import Adam
 from .. import _lib
 from .._lib import AdaBeliefGroup, check, ptr, stream
 from ..ops.conv import bump_weights_epoch
-from ._multi_tensor import Staging, chunk_rows
+from ._multi_tensor import Staging, VGroups, chunk_rows
 
 __all__ = ["AdaBelief"]
 
@@ -30,9 +30,8 @@ class AdaBelief(Adam):
 
     # ---- host bookkeeping -----------------------------------------------------------------
     def _collect(self, advance_state: bool):
-        plist, hyper, steps = [], [], []
+        plist, vg = [], VGroups()
         for gi, group in enumerate(self.param_groups):
-            gstep = None
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -50,15 +49,14 @@ class AdaBelief(Adam):
                         state["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 if advance_state:
                     state["step"] += 1
-                if gstep is None:
-                    gstep = state["step"]
-                elif gstep != state["step"]:
-                    raise RuntimeError("AdaBelief (HIP): parameters of one group must share the step count")
-                plist.append((p, gi))
+                plist.append((p, vg.index(gi, state["step"])))      # one launch group per (param group, step count)
+        hyper, steps = [], []
+        for gi, st in vg.keys:
+            group = self.param_groups[gi]
             beta1, beta2 = group["betas"]
             hyper.append((float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
                           float(group["weight_decay"]), int(bool(group["amsgrad"]))))
-            steps.append(int(gstep or 0))
+            steps.append(st)
         return plist, hyper, steps
 
     def _sync_groups(self, dev, hyper, steps_after):

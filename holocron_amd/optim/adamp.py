@@ -16,7 +16,7 @@ from torch.optim.optimizer import Optimizer
 from .. import _lib
 from .._lib import AdamxGroup, check, ptr, stream
 from ..ops.conv import bump_weights_epoch
-from ._multi_tensor import DeviceTables, chunk_rows
+from ._multi_tensor import DeviceTables, chunk_rows, VGroups
 
 __all__ = ["AdamP", "AdEMAMix"]
 
@@ -45,10 +45,8 @@ class AdamP(Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        entries, numel = [], []
-        gbuf = (AdamxGroup * max(len(self.param_groups), 1))()
+        entries, numel, vg = [], [], VGroups()
         for gi, group in enumerate(self.param_groups):
-            gstep = None
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -61,16 +59,14 @@ class AdamP(Adam):
                     if group["amsgrad"]:
                         state["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["step"] += 1
-                if gstep is None:
-                    gstep = state["step"]
-                elif gstep != state["step"]:
-                    raise RuntimeError("AdamP (HIP): parameters of one group must share the step count")
                 entries.append({"p": p.data, "g": p.grad, "m": state["exp_avg"], "s": state["exp_avg_sq"],
-                                "smax": state.get("max_exp_avg_sq"), "group": gi, "tensor": len(entries)})
+                                "smax": state.get("max_exp_avg_sq"), "group": vg.index(gi, state["step"]), "tensor": len(entries)})
                 numel.append(p.numel())
-            g = gbuf[gi]
+        gbuf = (AdamxGroup * max(len(vg), 1))()
+        for g, (gi, st) in zip(gbuf, vg.keys):      # one launch group per (param group, step count)
+            group = self.param_groups[gi]
             g.lr, g.beta1, g.beta2, g.eps = float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"])
-            g.weight_decay, g.delta, g.step, g.amsgrad = float(group["weight_decay"]), float(self.delta), int(gstep or 0), int(bool(group["amsgrad"]))
+            g.weight_decay, g.delta, g.step, g.amsgrad = float(group["weight_decay"]), float(self.delta), st, int(bool(group["amsgrad"]))
         if not entries:
             return loss
         dev = entries[0]["p"].device
@@ -106,10 +102,8 @@ class AdEMAMix(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        entries = []
-        gbuf = (AdamxGroup * max(len(self.param_groups), 1))()
+        entries, vg = [], VGroups()
         for gi, group in enumerate(self.param_groups):
-            gstep = None
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -121,16 +115,14 @@ class AdEMAMix(Optimizer):
                     state["exp_avg_slow"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["step"] += 1
-                if gstep is None:
-                    gstep = state["step"]
-                elif gstep != state["step"]:
-                    raise RuntimeError("AdEMAMix (HIP): parameters of one group must share the step count")
                 entries.append({"p": p.data, "g": p.grad, "m": state["exp_avg"], "s": state["exp_avg_sq"],
-                                "smax": state["exp_avg_slow"], "group": gi, "tensor": len(entries)})
-            g = gbuf[gi]
+                                "smax": state["exp_avg_slow"], "group": vg.index(gi, state["step"]), "tensor": len(entries)})
+        gbuf = (AdamxGroup * max(len(vg), 1))()
+        for g, (gi, st) in zip(gbuf, vg.keys):
+            group = self.param_groups[gi]
             b1, b2, b3 = group["betas"]
             g.lr, g.beta1, g.beta2, g.beta3, g.alpha = float(group["lr"]), float(b1), float(b2), float(b3), float(group["alpha"])
-            g.eps, g.weight_decay, g.step = float(group["eps"]), float(group["weight_decay"]), int(gstep or 0)
+            g.eps, g.weight_decay, g.step = float(group["eps"]), float(group["weight_decay"]), st
         if not entries:
             return loss
         dev = entries[0]["p"].device

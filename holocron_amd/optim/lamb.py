@@ -15,7 +15,7 @@ from torch.optim.optimizer import Optimizer
 from .. import _lib
 from .._lib import LambGroup, check, ptr, stream
 from ..ops.conv import bump_weights_epoch
-from ._multi_tensor import DeviceTables, chunk_rows
+from ._multi_tensor import DeviceTables, chunk_rows, VGroups
 from .adamp import _check_param, _upload
 
 __all__ = ["LAMB", "RaLars"]
@@ -47,10 +47,8 @@ class _TrustRatioAdam(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        entries, owners = [], []
-        gbuf = (LambGroup * max(len(self.param_groups), 1))()
+        entries, owners, vg = [], [], VGroups()
         for gi, group in enumerate(self.param_groups):
-            gstep = None
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -61,17 +59,15 @@ class _TrustRatioAdam(Optimizer):
                     state["exp_avg"] = torch.zeros_like(p.data)
                     state["exp_avg_sq"] = torch.zeros_like(p.data)
                 state["step"] += 1
-                if gstep is None:
-                    gstep = state["step"]
-                elif gstep != state["step"]:
-                    raise RuntimeError(f"{self._name} (HIP): parameters of one group must share the step count")
                 entries.append({"p": p.data, "g": p.grad, "m": state["exp_avg"], "s": state["exp_avg_sq"], "smax": None,
-                                "group": gi, "tensor": len(entries)})
+                                "group": vg.index(gi, state["step"]), "tensor": len(entries)})
                 owners.append(state)
-            g = gbuf[gi]
+        gbuf = (LambGroup * max(len(vg), 1))()
+        for g, (gi, st) in zip(gbuf, vg.keys):      # one launch group per (param group, step count)
+            group = self.param_groups[gi]
             g.lr, g.beta1, g.beta2, g.eps = float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"])
             g.weight_decay, g.clip_lo, g.clip_hi = float(group["weight_decay"]), float(self.scale_clip[0]), float(self.scale_clip[1])
-            g.step = int(gstep or 0)
+            g.step = st
             g.mode, g.rect = self._mode(group, g.step)
         if not entries:
             return loss

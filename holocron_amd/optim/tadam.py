@@ -15,7 +15,7 @@ from torch.optim.optimizer import Optimizer
 from .. import _lib
 from .._lib import AdamxGroup, check, ptr, stream
 from ..ops.conv import bump_weights_epoch
-from ._multi_tensor import DeviceTables, chunk_rows
+from ._multi_tensor import DeviceTables, chunk_rows, VGroups
 from .adamp import _check_param, _upload
 
 __all__ = ["TAdam", "Adan"]
@@ -47,10 +47,8 @@ class TAdam(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        entries, numel, dofs, tgroup, wptr = [], [], [], [], []
-        gbuf = (AdamxGroup * max(len(self.param_groups), 1))()
+        entries, numel, dofs, tgroup, wptr, vg = [], [], [], [], [], VGroups()
         for gi, group in enumerate(self.param_groups):
-            gstep = None
             beta1, beta2 = group["betas"]
             for p in group["params"]:
                 if p.grad is None:
@@ -65,19 +63,18 @@ class TAdam(Optimizer):
                         state["max_exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["W_t"] = beta1 / (1 - beta1) * torch.ones(1, dtype=p.data.dtype, device=p.data.device)
                 state["step"] += 1
-                if gstep is None:
-                    gstep = state["step"]
-                elif gstep != state["step"]:
-                    raise RuntimeError("TAdam (HIP): parameters of one group must share the step count")
+                v = vg.index(gi, state["step"])         # one launch group per (param group, step count)
                 entries.append({"p": p.data, "g": p.grad, "m": state["exp_avg"], "s": state["exp_avg_sq"],
-                                "smax": state.get("max_exp_avg_sq"), "group": gi, "tensor": len(entries)})
+                                "smax": state.get("max_exp_avg_sq"), "group": v, "tensor": len(entries)})
                 numel.append(p.numel())
                 dofs.append(float(p.numel()) if group["dof"] is None else float(group["dof"]))
-                tgroup.append(gi)
+                tgroup.append(v)
                 wptr.append(state["W_t"].data_ptr())
-            g = gbuf[gi]
-            g.lr, g.beta1, g.beta2, g.eps = float(group["lr"]), float(beta1), float(beta2), float(group["eps"])
-            g.weight_decay, g.step, g.amsgrad = float(group["weight_decay"]), int(gstep or 0), int(bool(group["amsgrad"]))
+        gbuf = (AdamxGroup * max(len(vg), 1))()
+        for g, (gi, st) in zip(gbuf, vg.keys):
+            group = self.param_groups[gi]
+            g.lr, g.beta1, g.beta2, g.eps = float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"])
+            g.weight_decay, g.step, g.amsgrad = float(group["weight_decay"]), st, int(bool(group["amsgrad"]))
         if not entries:
             return loss
         dev = entries[0]["p"].device
@@ -115,9 +112,8 @@ class Adan(Adam):
             with torch.enable_grad():
                 loss = closure()
         entries, extra = [], []
-        gbuf = (AdamxGroup * max(len(self.param_groups), 1))()
+        vg = VGroups()
         for gi, group in enumerate(self.param_groups):
-            gstep = None
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -132,19 +128,17 @@ class Adan(Adam):
                         state["max_exp_avg_delta"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["prev_grad"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["step"] += 1
-                if gstep is None:
-                    gstep = state["step"]
-                elif gstep != state["step"]:
-                    raise RuntimeError("Adan (HIP): parameters of one group must share the step count")
-                t = len(entries)
+                t, v = len(entries), vg.index(gi, state["step"])
                 entries.append({"p": p.data, "g": p.grad, "m": state["exp_avg"], "s": state["exp_avg_sq"],
-                                "smax": state["exp_avg_delta"], "group": gi, "tensor": t})
+                                "smax": state["exp_avg_delta"], "group": v, "tensor": t})
                 extra.append({"p": p.data, "g": None, "m": state.get("max_exp_avg_delta"), "s": state["prev_grad"], "smax": None,
-                              "group": gi, "tensor": t})
-            g = gbuf[gi]
+                              "group": v, "tensor": t})
+        gbuf = (AdamxGroup * max(len(vg), 1))()
+        for g, (gi, st) in zip(gbuf, vg.keys):
+            group = self.param_groups[gi]
             b1, b2, b3 = group["betas"]
             g.lr, g.beta1, g.beta2, g.beta3, g.eps = float(group["lr"]), float(b1), float(b2), float(b3), float(group["eps"])
-            g.weight_decay, g.step, g.amsgrad = float(group["weight_decay"]), int(gstep or 0), int(bool(group["amsgrad"]))
+            g.weight_decay, g.step, g.amsgrad = float(group["weight_decay"]), st, int(bool(group["amsgrad"]))
         if not entries:
             return loss
         dev = entries[0]["p"].device

@@ -134,6 +134,8 @@ class Scout(Lookahead):
                 update_similarity.append((torch.std(update, dim=0) / max_dev).mean().item())
             update_coherence = sum(update_similarity) / len(update_similarity)
             sync_rate = max(1 - update_coherence, self.defaults["sync_rate"])
+            if sync_rate != sync_rate:      # NaN coherence (a parameter that did not move: 0 / 0): the reference's `if sync_rate > 0`
+                sync_rate = 0.0             # (wrapper.py:270-283) is then false - no outer update, the fast weights go back to the slow ones
             self.sync_params(sync_rate)
             self.buffer = []
             for group in self.param_groups:

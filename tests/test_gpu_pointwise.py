@@ -414,3 +414,44 @@ def test_lars_step_is_graph_capturable_and_uploads_tables_once():
     torch.cuda.synchronize()
     for a, b in zip(ps_e, ps_g):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["AdaBelief", "LAMB", "RaLars", "TAdam", "AdamP", "AdEMAMix", "Adan"])
+def test_optimizers_with_a_parameter_that_skips_steps(name):
+    """A parameter whose ``grad is None`` on some iterations keeps its own step count in the reference (per-parameter
+    ``state['step']``, e.g. holocron/optim/adabelief.py:120-128): here it moves into a launch group of its own.  Checked against
+    two single-parameter optimizers of the same class stepped only when their parameter has a gradient."""
+    import holocron_amd as h
+    cls = getattr(h.optim, name)
+    torch.manual_seed(0)
+    a0, b0 = torch.randn(300, device="cuda"), torch.randn(17, 5, device="cuda")
+    pa, pb = a0.clone().requires_grad_(), b0.clone().requires_grad_()
+    qa, qb = a0.clone().requires_grad_(), b0.clone().requires_grad_()
+    joint = cls([pa, pb], lr=1e-2)
+    sa, sb = cls([qa], lr=1e-2), cls([qb], lr=1e-2)
+    for it in range(6):
+        ga, gb = torch.randn_like(a0), torch.randn_like(b0)
+        skip_b = it in (1, 2, 4)
+        pa.grad, qa.grad = ga.clone(), ga.clone()
+        pb.grad, qb.grad = (None, None) if skip_b else (gb.clone(), gb.clone())
+        joint.step()
+        sa.step()
+        if not skip_b:
+            sb.step()
+    torch.cuda.synchronize()
+    assert joint.state[pa]["step"] == 6 and joint.state[pb]["step"] == 3
+    assert torch.allclose(pa, qa, rtol=1e-6, atol=1e-7) and torch.allclose(pb, qb, rtol=1e-6, atol=1e-7)
+
+
+def test_scout_nan_coherence_skips_outer_update():
+    import holocron_amd as h
+    w = torch.randn(64, device="cuda").requires_grad_()
+    frozen = torch.randn(8, device="cuda").requires_grad_()      # zero gradient: its updates are all 0 -> std / max_dev = 0 / 0
+    base = torch.optim.SGD([w, frozen], lr=0.1)
+    opt = h.optim.Scout(base, sync_rate=0.5, sync_period=3)
+    for _ in range(3):
+        w.grad = torch.randn_like(w)
+        frozen.grad = torch.zeros_like(frozen)
+        opt.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(w).all() and torch.isfinite(frozen).all()
