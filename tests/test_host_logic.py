@@ -112,8 +112,8 @@ def test_struct_sizes_match_header_layout(tmp_path):
              "hc_wgrad_desc": _lib.WgradDesc, "hc_pack_item": _lib.PackItem, "hc_rep_bn_desc": _lib.RepBnDesc,
              "hc_rep_bn_bwd_desc": _lib.RepBnBwdDesc, "hc_mt_chunk": _lib.MtChunk, "hc_adabelief_group": _lib.AdaBeliefGroup,
              "hc_lars_group": _lib.LarsGroup, "hc_drop_item": _lib.DropItem, "hc_adamx_group": _lib.AdamxGroup, "hc_lamb_group": _lib.LambGroup, "hc_msbn_branch": _lib.MsbnBranch,
-             "hc_msbn_desc": _lib.MsbnDesc, "hc_msbn_io": _lib.MsbnIo}
-    last = {"hc_conv_desc": "ch_mult", "hc_pack_item": "ld", "hc_rep_bn_desc": "c_valid", "hc_rep_bn_bwd_desc": "c_valid",
+             "hc_msbn_desc": _lib.MsbnDesc, "hc_msbn_io": _lib.MsbnIo, "hc_rep_wgrad_desc": _lib.RepWgradDesc}
+    last = {"hc_conv_desc": "co_split", "hc_rep_wgrad_desc": "accumulate", "hc_pack_item": "ld", "hc_rep_bn_desc": "c_valid", "hc_rep_bn_bwd_desc": "frozen",
             "hc_conv_small_desc": "mode", "hc_wgrad_desc": "beta", "hc_lamb_group": "mode", "hc_msbn_branch": "momentum", "hc_msbn_desc": "accumulate", "hc_msbn_io": "C"}
     src = tmp_path / "sz.c"
     lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{os.path.join(ROOT, "include", "holocron_hip.h")}"', "int main(void) {"]
@@ -209,3 +209,93 @@ def test_weight_gradient_workspace_planner():
         assert b < 64 * slab + (1 << 20) or b < (1 << 31), (b, slab)       # bounded: never more than a few dozen slabs
     # more images -> at least as many splits for the same layer
     assert ws(256, 192, 14, 192, 3, 1) >= ws(8, 192, 14, 192, 3, 1)
+
+
+def test_row_unit_conv_planner_accepts_and_rejects():
+    """hc_conv_small_supported with HC_CONV_SMALL_ROWS_IMAGE (host code): the row-unit kernel takes exactly 192 channels on 14-wide and
+    96 channels on 28-wide maps whose height is a whole number of unit pairs (two 4-wave teams x 7 rows), forward and data gradient;
+    without the flag the same shapes still resolve to the older kernels (or to the gather-conv)."""
+    from holocron_amd.ops import conv as cv
+    R = cv.ROWS_IMAGE
+    for a in [(256, 14, 14, 192, 192, R), (256, 14, 14, 192, 192, R | 1), (256, 28, 28, 96, 96, R), (3, 28, 28, 96, 96, R | 1),
+              (5, 28, 14, 192, 192, R), (2, 56, 28, 96, 96, R)]:
+        d = cv.conv_small_desc(*a)
+        assert d is not None and d.mode == a[5], a
+    for a in [(4, 14, 14, 96, 96, R), (4, 28, 28, 192, 192, R), (4, 21, 14, 192, 192, R), (4, 7, 14, 192, 192, R), (4, 14, 14, 128, 128, R),
+              (4, 70, 14, 192, 192, R), (4, 14, 14, 192, 96, R), (4, 14, 14, 192, 192, R | 2), (4, 112, 112, 48, 48, R)]:
+        assert cv.conv_small_desc(*a) is None, a
+    assert cv.conv_small_desc(256, 14, 14, 192, 192, 0) is not None        # image-resident kernel, its own weight format
+    assert cv.rows_image(192, "cpu").shape == (60, 192, 32) and cv.rows_image(96, "cpu").shape == (30, 96, 32)
+
+
+def test_fused_weight_gradient_planner():
+    """hc_rep_wgrad_supported / _plan / _ws_bytes (host code): tile choice by channel counts, the rows-per-step and prefetch depth
+    fit the LDS, grouping more blocks into a launch lowers the pixel split, the workspace is whole fp32 slabs, wide layers are left to
+    the k-pipelined kernel."""
+    import ctypes as C
+    from holocron_amd.ops.conv import _WREP
+    lib = _lib.load()
+
+    def plan(N, cin, H, cout, s, jobs):
+        d = _WREP._desc((N, cin, H, H, cout, s), jobs)
+        out = (C.c_int32 * 8)()
+        if not lib.hc_rep_wgrad_supported(C.byref(d)):
+            return None
+        assert lib.hc_rep_wgrad_plan(C.byref(d), out) == 0
+        return list(out), int(lib.hc_rep_wgrad_ws_bytes(C.byref(d)))
+
+    p192, ws192 = plan(256, 192, 14, 192, 1, 14)
+    assert p192[0:2] == [6, 3] and p192[6] <= 160 * 1024 and p192[2] * 14 <= 128
+    p1, ws1 = plan(256, 192, 14, 192, 1, 1)
+    assert p1[4] > p192[4]                                   # one block alone needs a deeper pixel split than 14 grouped ones
+    assert ws192 % (4 * 192 * 10 * 192) == 0 and ws1 % (4 * 192 * 10 * 192) == 0
+    p48, ws48 = plan(256, 48, 112, 48, 1, 1)
+    assert p48[0:2] == [3, 3] and p48[6] <= 160 * 1024 and ws48 % (4 * 48 * 10 * 48) == 0
+    assert plan(256, 96, 28, 192, 2, 1)[0][0:2] == [6, 3] and plan(256, 64, 16, 64, 1, 2)[0][0:2] == [4, 4]
+    assert plan(256, 1280, 7, 1280, 1, 1) is None and plan(256, 40, 14, 48, 1, 1) is None and plan(4, 48, 14, 48, 3, 1) is None
+    assert _WREP._desc((4, 48, 14, 14, 48, 1), 17).njobs == 17 and plan(4, 48, 14, 48, 1, 17) is None     # more than 16 blocks per launch
+
+
+def test_pack_and_stacked_conv_argument_checks():
+    """argument validation that runs on the host before anything is launched"""
+    import ctypes as C
+    lib = _lib.load()
+    w = torch.zeros(8)
+    # row-unit images need Cout == Cin, a multiple of 48 (rows) and of 32 (k blocks)
+    assert lib.hc_pack_conv_weight(w.data_ptr(), w.data_ptr(), 40, 40, 3, 3, 3, 0, 10, None) == 1
+    assert lib.hc_pack_conv_weight(w.data_ptr(), w.data_ptr(), 96, 48, 3, 3, 4, 0, 10, None) == 1
+    assert lib.hc_pack_conv_weight(w.data_ptr(), w.data_ptr(), 48, 48, 3, 3, 5, 0, 10, None) == 1
+    # stacked convolutions: split on a 4-channel boundary, second destination required, no epilogue extras
+    d = _lib.ConvDesc()
+    d.src0 = d.wpk = d.dst = w.data_ptr()
+    d.N, d.IH, d.IW, d.srcC, d.OH, d.OW, d.Cout, d.T, d.nclass = 1, 4, 4, 16, 4, 4, 96, 9, 1
+    d.co_split = 48
+    assert lib.hc_conv_gather(C.byref(d), None) == 1          # dst2 missing
+    d.dst2 = w.data_ptr()
+    d.co_split = 46
+    assert lib.hc_conv_gather(C.byref(d), None) == 1          # not a multiple of 4
+    d.co_split = 48
+    d.bias = w.data_ptr()
+    assert lib.hc_conv_gather(C.byref(d), None) == 1          # bias with a split
+    # the z-mask BN backward wants the forward coefficients and a known activation code
+    assert lib.hc_rep_bwd_reduce_z(w.data_ptr(), None, 1, w.data_ptr(), w.data_ptr(), None, w.data_ptr(), 8, 8, None) == 1
+    assert lib.hc_rep_bwd_apply_z(w.data_ptr(), w.data_ptr(), 2, w.data_ptr(), w.data_ptr(), None, w.data_ptr(), w.data_ptr(), w.data_ptr(),
+                                  None, 8, 8, None) == 1
+
+
+def test_deterministic_switch_resizes_the_replica_count():
+    lib = _lib.load()
+    assert _lib.stat_replicas() == 128 and lib.hc_get_deterministic() == 0
+    _lib.set_deterministic(True)
+    try:
+        assert _lib.stat_replicas() == 32768 and lib.hc_get_deterministic() == 1
+    finally:
+        _lib.set_deterministic(False)
+    assert _lib.stat_replicas() == 128
+
+
+def test_optimizer_launch_groups_by_step_count():
+    from holocron_amd.optim._multi_tensor import VGroups
+    vg = VGroups()
+    assert [vg.index(0, 5), vg.index(0, 5), vg.index(1, 5), vg.index(0, 3), vg.index(1, 5)] == [0, 0, 1, 2, 1]
+    assert vg.keys == [(0, 5), (1, 5), (0, 3)] and len(vg) == 3
