@@ -24,6 +24,7 @@ SOURCES = {
     "conv_wgrad_dma.hip": [],
     "conv_wgrad_rep.hip": [],
     "conv_rows.hip": [],
+    "conv_rows48.hip": [],
     "rep_bn.hip": [],
     "optim.hip": [],
     "nhwc_ops.hip": [],

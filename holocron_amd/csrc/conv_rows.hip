@@ -26,8 +26,9 @@
 // and B alike, i.e. two pieces 32 bytes apart; with a pixel pitch of 2 x odd 8-byte units (400 B for 192 channels, 208 B for 96) the 16
 // pixels x 2 k-groups of a half wave fall into 32 distinct 8-byte bank pairs.  (ds_read_b128 services lanes {0-3,12-15,20-27}
 // together, which mixes two k-groups in one bank cycle and cannot be made conflict-free for this fragment shape.)
-// Output channels are permuted inside a wave's 48 so that a lane ends up with 12 CONSECUTIVE channels of its pixel (24-byte runs,
-// 96 contiguous bytes per pixel and wave) instead of three 8-byte pieces 32 bytes apart.
+// Output channels are permuted inside a wave's 48 so that lane group g ends up with channels 8 g .. 8 g + 7 and 32 + 4 g .. 32 + 4 g + 3
+// of its pixel: one 16-byte and one 8-byte store, 64 + 32 contiguous bytes per pixel over the four groups, instead of three 8-byte
+// pieces 32 bytes apart.
 // MI355X, batch 256 (scripts/check_rows.py): 192 @ 14x14 forward + statistics 42.6 us (868 TFLOP/s; image-resident kernel 62.7),
 // data gradient 44.9 us (62.7); 96 @ 28x28 54.8 / 54.5 us (gather-conv: 3 launches, 195 us).
 #include <type_traits>
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
     };
 
     // ---- epilogue of one unit and one output: lane (px, g) holds channels 48 cw + 12 g + 4 f + e of pixel (row0 + i, col)
-    const int cbase = 48 * cw + 12 * g;
+    const int cbase = 48 * cw + 8 * g;       // first channel of this lane's 16-byte piece (see rows_image_index, rep_bn.hip)
     auto epilogue = [&](void* outp, float* stats, const void* residp, int row0) __attribute__((always_inline)) {
         if (DBG & 16) {
             float t = 0.f;
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
             return;
         }
         const size_t img = (size_t)n * H * W * C;
+        __builtin_amdgcn_sched_barrier(0);     // the residual loads below stay below: hoisted into the last k-steps they spill the accumulators
         float st[2][12];
 #pragma unroll
         for (int k = 0; k < 2; ++k)
@@ -212,9 +214,14 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
             const size_t e0 = img + (size_t)((row0 + i) * W + (col_ok ? col : 0)) * C + cbase;
             bf16_t* op = reinterpret_cast<bf16_t*>(outp) + e0;
             const bf16_t* rp = residp != nullptr ? reinterpret_cast<const bf16_t*>(residp) + e0 : nullptr;
+            // channel pieces of this lane: 8 g + 4 f (f = 0, 1) and 32 + 4 g (f = 2).  Forward: one 16-byte + one 8-byte store; the data
+            // gradient (residual loads, a staging loop and both sources in the same scheduling region) keeps three 8-byte accesses:
+            // the 16-byte form there costs the register allocator 120 spilled accumulator registers
+            u32x2 pk[3];
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
                 f32x4 v = acc[f][i];
+                const int cofs = f < 2 ? 4 * f : 32 - 4 * g;
                 if (stats != nullptr) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -223,14 +230,16 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
                         st[1][f * 4 + e] += x * x;
                     }
                 }
-                if (rp != nullptr && col_ok) {
-                    const u32x2 rv = *reinterpret_cast<const u32x2*>(rp + 4 * f);
+                if (MODE == 1 && rp != nullptr && col_ok) {
+                    const u32x2 rv = *reinterpret_cast<const u32x2*>(rp + cofs);
                     v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]); v[2] += bf16lo(rv[1]); v[3] += bf16hi(rv[1]);
                 }
-                if (col_ok) {
-                    const u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                    *reinterpret_cast<u32x2*>(op + 4 * f) = p;
-                }
+                pk[f] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                if (MODE == 1 && col_ok) *reinterpret_cast<u32x2*>(op + cofs) = pk[f];
+            }
+            if (MODE == 0 && col_ok) {
+                *reinterpret_cast<u32x4*>(op) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
+                *reinterpret_cast<u32x2*>(op + 32 - 4 * g) = pk[2];
             }
         }
         // BN statistics of the fp32 results: fold the 16 pixel lanes of every k-group (DPP rotations: every lane gets the total), let
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
                     const float x = row16_sum(st[k][e]);
                     mine = px == e ? x : mine;
                 }
-                if (px < 12) atomicAdd(rep + k * C + px, mine);
+                if (px < 12) atomicAdd(rep + k * C + (px < 8 ? px : 24 - 4 * g + px), mine);    // slot e -> channel 8 g + e | 32 + 4 g + e - 8
             }
         }
     };

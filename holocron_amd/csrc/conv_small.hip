@@ -785,6 +785,9 @@ int hc_conv_resident_launch(const hc_conv_small_desc& d, hipStream_t st);
 // row-unit kernel for 192 @ 14x14 and 96 @ 28x28 (conv_rows.hip); HC_CONV_ROWS=0 disables it
 bool hc_conv_rows_supported(const hc_conv_small_desc& d);
 int hc_conv_rows_launch(const hc_conv_small_desc& d, hipStream_t st);
+// streaming row-unit kernel for 48 channels @ 112 / 56 (conv_rows48.hip); HC_CONV_ROWS48=0 disables it
+bool hc_conv_rows48_supported(const hc_conv_small_desc& d);
+int hc_conv_rows48_launch(const hc_conv_small_desc& d, hipStream_t st);
 static bool resident_enabled() {
     static const bool on = [] { const char* e = getenv("HC_CONV_RESIDENT"); return e == nullptr || atoi(e) != 0; }();
     return on;
@@ -793,8 +796,10 @@ static bool resident_enabled() {
 extern "C" int hc_conv_small(const hc_conv_small_desc* dp, hc_stream_t stream) {
     if (dp == nullptr) return HC_ERR_ARG;
     const hc_conv_small_desc& d = *dp;
+    if (d.mode & HC_CONV_SMALL_ROWS_IMAGE)
+        return d.C >= 64 ? hc_conv_rows_launch(d, reinterpret_cast<hipStream_t>(stream))
+                         : hc_conv_rows48_launch(d, reinterpret_cast<hipStream_t>(stream));
     if (d.C >= 64) {
-        if (d.mode & HC_CONV_SMALL_ROWS_IMAGE) return hc_conv_rows_launch(d, reinterpret_cast<hipStream_t>(stream));
         if (!resident_enabled() || !hc_conv_resident_supported(d)) return HC_ERR_ARG;
         return hc_conv_resident_launch(d, reinterpret_cast<hipStream_t>(stream));
     }
@@ -839,7 +844,7 @@ extern "C" int hc_conv_small_trace(unsigned long long* out) {
 
 extern "C" int hc_conv_small_supported(const hc_conv_small_desc* dp) {
     if (dp == nullptr) return 0;
-    if (dp->mode & HC_CONV_SMALL_ROWS_IMAGE) return hc_conv_rows_supported(*dp) ? 1 : 0;
+    if (dp->mode & HC_CONV_SMALL_ROWS_IMAGE) return (hc_conv_rows_supported(*dp) || hc_conv_rows48_supported(*dp)) ? 1 : 0;
     if (dp->C >= 64) return (resident_enabled() && hc_conv_resident_supported(*dp)) ? 1 : 0;
     csm::Args a;
     int smem = 0;

@@ -626,14 +626,16 @@ __global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ x, float* __restr
 // modes 3 / 4: the row-unit image of conv_rows.hip (forward / data gradient), C = Cout = Cin, a multiple of 48:
 //   wpk[step = tap * C/32 + kc/32][row r(rc)][j(kc % 32)], rc = the conv's OUTPUT channel (mode 3: co, mode 4: ci), kc its input
 //   channel, tap = tap0 + kh*KW+kw (mode 4: spatially flipped).  r() puts the 16 rows of an MFMA A fragment next to each other
-//   (a wave's fragment f, row m is channel 48 w + 12 (m >> 2) + 4 f + (m & 3): a lane of the D tile ends up with 12 consecutive
-//   channels), j() puts a lane's eight k values (4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3) into one 16-byte piece.
+//   (a lane group g of the D tile ends up with channels 8 g .. 8 g + 7 and 32 + 4 g .. 32 + 4 g + 3 of the wave's 48), j() puts a lane's eight k values (4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3) into one 16-byte piece.
 __device__ __forceinline__ long rows_image_index(int rc, int kc, int tap, int Cc) {
-    const int w = rc / 48, rem = rc - 48 * w, q = rem / 12, rem2 = rem - 12 * q, f = rem2 >> 2, i = rem2 & 3;
-    const int r = 48 * w + 16 * f + 4 * q + i;
+    // channel c of a wave's 48 -> (fragment f, MFMA row 4 g + i): lane group g of the D tile then holds channels 8 g .. 8 g + 7
+    // (fragments 0, 1) and 32 + 4 g .. 32 + 4 g + 3 (fragment 2): one 16-byte and one 8-byte piece per pixel, contiguous over g
+    const int w = rc / 48, c = rc - 48 * w;
+    const int f = c < 32 ? (c >> 2) & 1 : 2, gq = c < 32 ? c >> 3 : (c - 32) >> 2, i = c & 3;
+    const int r = 48 * w + 16 * f + 4 * gq + i;
     const int t = kc >> 5, kk = kc & 31, hi = kk >> 4, g = (kk & 15) >> 2, e = kk & 3;
     const int j = 8 * g + 4 * hi + e;
-    return ((long)(tap * (Cc >> 5) + t) * Cc + r) * 32 + j;
+    return ((long)(tap * ((Cc + 31) >> 5) + t) * Cc + r) * 32 + j;       // a tap's channels are padded to whole k32 steps (C = 48: two)
 }
 __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wpk, int Cout, int Cin, int KH, int KW,
                                    int mode, int tap0, int T) {
@@ -1068,7 +1070,7 @@ int hc_nhwc_bf16_to_nchw(const void* x, float* y, int32_t N, int32_t C, int32_t 
 int hc_pack_conv_weight(const float* w, void* wpk, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t mode, int32_t tap0,
                         int32_t T, hc_stream_t stream) {
     if (w == nullptr || wpk == nullptr || mode < 0 || mode > 4) return HC_ERR_ARG;
-    if (mode >= 3 && (Cout != Cin || Cout % 48 != 0 || Cin % 32 != 0)) return HC_ERR_ARG;
+    if (mode >= 3 && (Cout != Cin || Cout % 48 != 0)) return HC_ERR_ARG;
     const long total = (long)Cout * Cin * KH * KW;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wpk, Cout, Cin, KH,
                        KW, mode, tap0, T);

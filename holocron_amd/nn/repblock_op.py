@@ -111,7 +111,7 @@ class RepState:
         self.last_out_stats = None
         self.packed = None          # persistent packed-weight buffers (wp3, wp1, wpd)
         self.packed_key = None
-        self.rows_image = False     # set by descs(): the block's convs run on the row-unit kernel, which reads its own weight image
+        self.rows_image = (False, False)   # set by descs(): (forward, data gradient) run on a row-unit kernel, which reads its own weight image
         self.stack_fwd = False      # set by pack_items(): 3x3 + 1x1 forward as ONE gather-conv over stacked weight rows
 
     # ---- packed weights (persistent buffers; refreshed by one multi-tensor launch per model) ----
@@ -131,8 +131,11 @@ class RepState:
             if self.stack_fwd:
                 self.packed = (torch.zeros((2 * Cout, 1, STEM_KPAD) if stem else (2 * Cout, 9, Cin), dtype=torch.bfloat16, device=dev),
                                None, None if stem else torch.empty((Cin, 10, Cout), dtype=torch.bfloat16, device=dev))
-            elif self.rows_image:     # (forward image, -, data-gradient image), each shared by the 3x3 and the 1x1 kernel
-                self.packed = (cv.rows_image(Cout, dev), None, cv.rows_image(Cout, dev))
+            elif any(self.rows_image):     # a row-unit image is shared by the 3x3 and the 1x1 kernel
+                rf, rb = self.rows_image
+                self.packed = (cv.rows_image(Cout, dev) if rf else torch.empty((Cout, 9, Cin), dtype=torch.bfloat16, device=dev),
+                               None if rf else torch.empty((Cout, 1, Cin), dtype=torch.bfloat16, device=dev),
+                               cv.rows_image(Cout, dev) if rb else torch.empty((Cin, 10, Cout), dtype=torch.bfloat16, device=dev))
             elif stem:
                 self.packed = (torch.zeros((Cout, 1, STEM_KPAD), dtype=torch.bfloat16, device=dev),
                                torch.zeros((Cout, 1, STEM_KPAD), dtype=torch.bfloat16, device=dev), None)
@@ -147,9 +150,13 @@ class RepState:
                 return [(w3, wp3, Cout, Cin, 3, 3, 2, 0, STEM_KPAD), (w1, wp3[Cout:], Cout, Cin, 1, 1, 2, 4 * Cin, STEM_KPAD)]
             return [(w3, wp3, Cout, Cin, 3, 3, 0, 0, 9), (w1, wp3[Cout:], Cout, Cin, 1, 1, 0, 4, 9),
                     (w3, wpd, Cout, Cin, 3, 3, 1, 0, 10), (w1, wpd, Cout, Cin, 1, 1, 1, 9, 10)]
-        if self.rows_image:
-            return [(w3, wp3, Cout, Cin, 3, 3, 3, 0, 10), (w1, wp3, Cout, Cin, 1, 1, 3, 9, 10),
-                    (w3, wpd, Cout, Cin, 3, 3, 4, 0, 10), (w1, wpd, Cout, Cin, 1, 1, 4, 9, 10)]
+        if any(self.rows_image):
+            rf, rb = self.rows_image
+            fwd = ([(w3, wp3, Cout, Cin, 3, 3, 3, 0, 10), (w1, wp3, Cout, Cin, 1, 1, 3, 9, 10)] if rf else
+                   [(w3, wp3, Cout, Cin, 3, 3, 0, 0, 9), (w1, wp1, Cout, Cin, 1, 1, 0, 0, 1)])
+            bwd = ([(w3, wpd, Cout, Cin, 3, 3, 4, 0, 10), (w1, wpd, Cout, Cin, 1, 1, 4, 9, 10)] if rb else
+                   [(w3, wpd, Cout, Cin, 3, 3, 1, 0, 10), (w1, wpd, Cout, Cin, 1, 1, 1, 9, 10)])
+            return fwd + bwd
         if stem:
             return [(w3, wp3, Cout, Cin, 3, 3, 2, 0, STEM_KPAD), (w1, wp1, Cout, Cin, 1, 1, 2, 4 * Cin, STEM_KPAD)]
         return [(w3, wp3, Cout, Cin, 3, 3, 0, 0, 9), (w1, wp1, Cout, Cin, 1, 1, 0, 0, 1),
@@ -191,13 +198,14 @@ class RepState:
                 f1 = cv.fwd_desc(N, STEM_KPAD, OH, OW, Cout, 1, 1, 1, 0)
                 dg = None
             sf = sd = None
-            rows = False
+            rows = (False, False)
             if Cin % 16 == 0 and s == 1:   # fused 3x3 + 1x1 kernels: row-unit (own weight image), small-channel persistent, image-resident
                 sf = cv.conv_small_desc(N, H, W, Cin, Cout, cv.ROWS_IMAGE)
                 sd = cv.conv_small_desc(N, H, W, Cout, Cin, cv.ROWS_IMAGE | 1)
-                rows = sf is not None and sd is not None
-                if not rows:
+                rows = (sf is not None, sd is not None)
+                if sf is None:
                     sf = cv.conv_small_desc(N, H, W, Cin, Cout, 0)
+                if sd is None:
                     sd = cv.conv_small_desc(N, H, W, Cout, Cin, 1)
             self.desc[key] = (f3, f1, dg, sf, sd, rows)
         rows = self.desc[key][5]

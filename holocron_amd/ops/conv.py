@@ -153,8 +153,9 @@ ROWS_IMAGE = 4   # HC_CONV_SMALL_ROWS_IMAGE: hc_conv_small reads the row-unit we
 
 
 def rows_image(Cc, device):
-    """Destination of pack modes 3 / 4: [10 * C/32 k32-steps][C rows][32] bf16 (3x3 taps at tap0 = 0, the 1x1 at tap0 = 9)."""
-    return torch.empty((10 * (Cc // 32), Cc, 32), dtype=torch.bfloat16, device=device)
+    """Destination of pack modes 3 / 4: [10 * ceil(C / 32) k32-steps][C rows][32] bf16 (3x3 taps at tap0 = 0, the 1x1 at tap0 = 9),
+    zero-filled: with C = 48 the second k32 step of every tap is half padding."""
+    return torch.zeros((10 * ((Cc + 31) // 32), Cc, 32), dtype=torch.bfloat16, device=device)
 
 
 def pack_weight(w, mode, out=None, tap0=0, T=None):

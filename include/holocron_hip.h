@@ -93,7 +93,8 @@ int hc_conv_gather(const hc_conv_desc* d, hc_stream_t stream);
  * mode 1: out3 = W3 (*) srcA + W1 . srcB + resid  (RepBlock data gradient; srcA = dy3, srcB = dy1).
  * w3/w1 are packed bf16 rows [out channel][tap][C] with the given row strides (elements).
  * mode | HC_CONV_SMALL_ROWS_IMAGE: w3 is the row-unit image of BOTH kernels (hc_pack_conv_weight modes 3 / 4; w1 and the strides
- * are ignored) - the format of the row-unit kernel for 192 channels @ 14x14 and 96 channels @ 28x28 (conv_rows.hip); supported()
+ * are ignored) - the format of the row-unit kernels for 192 channels @ 14x14, 96 @ 28x28 (conv_rows.hip) and 48 @ 112x112 / 56x56
+ * (conv_rows48.hip); supported()
  * says whether a shape has it. */
 #define HC_CONV_SMALL_ROWS_IMAGE 4
 typedef struct {
@@ -154,7 +155,7 @@ int hc_rep_wgrad(const hc_rep_wgrad_desc* d, hc_stream_t stream);
  * mode 1: data-gradient [Cin][KH*KW (spatially flipped)][Cout]; mode 2: im2col order (see below).  `tap0`/`T` let several
  * kernels (3x3 + 1x1) share one packed tensor: taps are written at [tap0, tap0+KH*KW).
  * modes 3 / 4: the row-unit image read by hc_conv_small with HC_CONV_SMALL_ROWS_IMAGE (forward / data gradient; Cout == Cin == C,
- * C % 48 == 0): bf16 [10 * C/32 k32-steps][C rows][32] (20 C^2 bytes), 3x3 taps at tap0 = 0, the 1x1 at tap0 = 9; rows and
+ * C % 48 == 0): bf16 [10 * ceil(C/32) k32-steps][C rows][32], zero where C = 48 pads a tap to two steps; 3x3 taps at tap0 = 0, the 1x1 at tap0 = 9; rows and
  * k values are permuted so that an MFMA A fragment of a wave is 1 KB of consecutive bytes (layout: rows_image_index, rep_bn.hip). */
 int hc_pack_conv_weight(const float* w, void* wpk, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
                         int32_t mode, int32_t tap0, int32_t T, hc_stream_t stream);

@@ -19,17 +19,16 @@ def rel(a, b):
 
 def rows_index(rc, kc, tap, C):
     """The layout hc_pack_conv_weight modes 3 / 4 document (rows_image_index, csrc/rep_bn.hip), restated."""
-    w, rem = divmod(rc, 48)
-    q, rem2 = divmod(rem, 12)
-    f, i = divmod(rem2, 4)
-    r = 48 * w + 16 * f + 4 * q + i
+    w, c = divmod(rc, 48)
+    f, gq, i = ((c >> 2) & 1, c >> 3, c & 3) if c < 32 else (2, (c - 32) >> 2, c & 3)
+    r = 48 * w + 16 * f + 4 * gq + i
     t, kk = divmod(kc, 32)
     hi, g, e = kk >> 4, (kk & 15) >> 2, kk & 3
     j = 8 * g + 4 * hi + e
-    return ((tap * (C // 32) + t) * C + r) * 32 + j
+    return ((tap * ((C + 31) // 32) + t) * C + r) * 32 + j
 
 
-@pytest.mark.parametrize("C", [96, 192])
+@pytest.mark.parametrize("C", [48, 96, 192])
 def test_rows_image_layout(C):
     from holocron_amd.ops import conv as cv
     g = torch.Generator(device="cuda").manual_seed(0)
