@@ -672,23 +672,26 @@ constexpr int PK_TILE = 16 * 64 * PK_MAXKK;      // floats: 16 x 64 (co x ci or 
 // mode 1: tiles of 64 co x 16 ci, written [ci][flipped tap][co]
 // KKC: compile-time tap count (1 | 9; 0 = run time) - the index arithmetic is all divisions, which must be by constants
 template <int MODE, int KKC>
-__device__ __forceinline__ void pack_tiles(const hc_pack_item& it, bf16_t* __restrict__ wpk, float* __restrict__ tile) {
+__device__ __forceinline__ void pack_tiles(const hc_pack_item& it, bf16_t* __restrict__ wpk, float* __restrict__ tile, const int tl) {
     const int KK = KKC ? KKC : it.KH * it.KW;
     constexpr int TCO = MODE == 0 ? 16 : 64, TCI = MODE == 0 ? 64 : 16;
     const int nco = (it.Cout + TCO - 1) / TCO, nci = (it.Cin + TCI - 1) / TCI;
     const int run = TCI * KK;                       // contiguous source floats per co row of a tile
     const int lrun = run + 1;                       // LDS row stride (odd: the transposing reads spread over the banks)
-    for (int tl = blockIdx.x; tl < nco * nci; tl += gridDim.x) {
+    {
+        (void)nco;
         const int co0 = (tl / nci) * TCO, ci0 = (tl % nci) * TCI;
         const int cw = min(TCI, it.Cin - ci0) * KK;   // valid floats of a row
         __syncthreads();
-        for (int e = threadIdx.x; e < TCO * run; e += 256) {
+#pragma unroll 6
+        for (int e = threadIdx.x; e < TCO * run; e += 256) {      // unrolled: six independent loads in flight per thread
             const int r = e / run, c = e - r * run;
             if (co0 + r < it.Cout && c < cw) tile[r * lrun + c] = it.w[((long)(co0 + r) * it.Cin + ci0) * KK + c];
         }
         __syncthreads();
         if (MODE == 0) {
             const int ld = it.ld > 0 ? it.ld : it.Cin;
+#pragma unroll 4
             for (int e = threadIdx.x; e < TCO * KK * TCI; e += 256) {
                 const int ci = e % TCI, q = e / TCI, t = q % KK, r = q / KK;
                 if (co0 + r < it.Cout && ci0 + ci < it.Cin)
@@ -696,6 +699,7 @@ __device__ __forceinline__ void pack_tiles(const hc_pack_item& it, bf16_t* __res
             }
         } else {
             const int ld = it.ld > 0 ? it.ld : it.Cout;
+#pragma unroll 4
             for (int e = threadIdx.x; e < TCI * KK * TCO; e += 256) {
                 const int r = e % TCO, q = e / TCO, tf = q % KK, ci = q / KK;
                 if (co0 + r < it.Cout && ci0 + ci < it.Cin)
@@ -705,60 +709,83 @@ __device__ __forceinline__ void pack_tiles(const hc_pack_item& it, bf16_t* __res
     }
 }
 
-__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const hc_pack_item* __restrict__ items) {
-    __shared__ float tile[PK_TILE + 64];
-    const hc_pack_item it = items[blockIdx.y];
+// Work units of an item: its LDS tiles (modes 0 / 1, kernels up to 3x3) or chunks of PK_CHUNK source elements (element-wise modes).
+// The grid is ONE dimension of a few thousand workgroups that walk the flat unit list (the former (tiles, items) grid launched
+// 512 x 108 workgroups of which 50 000 had nothing to do; removing them did not change the 175 us of the RepVGG-A0 pack, whose time
+// is in the two 59 MB passes over the 1280 x 1280 x 3 x 3 tensor).
+constexpr int PK_CHUNK = 8192;
+__device__ __forceinline__ int pack_units(const hc_pack_item& it) {
     const int KK = it.KH * it.KW;
-    bf16_t* wpk = reinterpret_cast<bf16_t*>(it.dst);
-    if (it.mode >= 3) {                              // row-unit images: walk the source (small tensors, 16-byte runs on both sides)
-        const long total = (long)it.Cout * it.Cin * KK;
-        for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
-            const int t = (int)(o % KK);
-            const long r = o / KK;
-            const int ci = (int)(r % it.Cin), co = (int)(r / it.Cin);
-            const bf16_t v = f32_to_bf16(it.w[o]);
-            if (it.mode == 3) wpk[rows_image_index(co, ci, it.tap0 + t, it.Cout)] = v;
-            else wpk[rows_image_index(ci, co, it.tap0 + KK - 1 - t, it.Cout)] = v;
-        }
-        return;
+    if (it.mode >= 2 || KK > PK_MAXKK) return (int)(((long)it.Cout * it.Cin * KK + PK_CHUNK - 1) / PK_CHUNK);
+    return it.mode == 0 ? ((it.Cout + 15) / 16) * ((it.Cin + 63) / 64) : ((it.Cout + 63) / 64) * ((it.Cin + 15) / 16);
+}
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const hc_pack_item* __restrict__ items, const int nitems) {
+    __shared__ float tile[PK_TILE + 64];
+    extern __shared__ int pref[];                    // [nitems + 1] exclusive prefix of the unit counts
+    for (int i = threadIdx.x; i < nitems; i += 256) pref[i + 1] = pack_units(items[i]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pref[0] = 0;
+        for (int i = 0; i < nitems; ++i) pref[i + 1] += pref[i];
     }
-    if (it.mode == 2 || KK > PK_MAXKK) {            // im2col order / large kernels: element-wise walk
+    __syncthreads();
+    const int total_units = pref[nitems];
+    for (int flat = blockIdx.x; flat < total_units; flat += gridDim.x) {
+        int lo = 0, hi = nitems;                     // largest item index with pref[item] <= flat
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pref[mid] <= flat) lo = mid; else hi = mid;
+        }
+        const hc_pack_item it = items[lo];
+        const int tl = flat - pref[lo];
+        const int KK = it.KH * it.KW;
+        bf16_t* wpk = reinterpret_cast<bf16_t*>(it.dst);
         const long total = (long)it.Cout * it.Cin * KK;
-        for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
-            int co, ci, t;
-            long dst;
-            if (it.mode == 0) {
-                ci = (int)(o % it.Cin);
-                const long r = o / it.Cin;
-                t = (int)(r % KK);
-                co = (int)(r / KK);
-                dst = ((long)co * it.T + it.tap0 + t) * (it.ld > 0 ? it.ld : it.Cin) + ci;
-            } else if (it.mode == 1) {
-                co = (int)(o % it.Cout);
-                const long r = o / it.Cout;
-                const int tf = (int)(r % KK);
-                ci = (int)(r / KK);
-                t = KK - 1 - tf;
-                dst = ((long)ci * it.T + it.tap0 + tf) * (it.ld > 0 ? it.ld : it.Cout) + co;
-            } else {                     // [co][tap0 + tap*Cin + ci]
-                ci = (int)(o % it.Cin);
-                const long r = o / it.Cin;
-                t = (int)(r % KK);
-                co = (int)(r / KK);
-                dst = (long)co * it.T + it.tap0 + t * it.Cin + ci;
+        const long o0 = (long)tl * PK_CHUNK, o1 = o0 + PK_CHUNK < total ? o0 + PK_CHUNK : total;
+        if (it.mode >= 3) {                          // row-unit images: walk the source (16-byte runs on both sides)
+            for (long o = o0 + threadIdx.x; o < o1; o += 256) {
+                const int t = (int)(o % KK);
+                const long r = o / KK;
+                const int ci = (int)(r % it.Cin), co = (int)(r / it.Cin);
+                const bf16_t v = f32_to_bf16(it.w[o]);
+                if (it.mode == 3) wpk[rows_image_index(co, ci, it.tap0 + t, it.Cout)] = v;
+                else wpk[rows_image_index(ci, co, it.tap0 + KK - 1 - t, it.Cout)] = v;
             }
-            wpk[dst] = f32_to_bf16(it.w[((long)co * it.Cin + ci) * KK + t]);
+        } else if (it.mode == 2 || KK > PK_MAXKK) {  // im2col order / large kernels: element-wise walk
+            for (long o = o0 + threadIdx.x; o < o1; o += 256) {
+                int co, ci, t;
+                long dst;
+                if (it.mode == 0) {
+                    ci = (int)(o % it.Cin);
+                    const long r = o / it.Cin;
+                    t = (int)(r % KK);
+                    co = (int)(r / KK);
+                    dst = ((long)co * it.T + it.tap0 + t) * (it.ld > 0 ? it.ld : it.Cin) + ci;
+                } else if (it.mode == 1) {
+                    co = (int)(o % it.Cout);
+                    const long r = o / it.Cout;
+                    const int tf = (int)(r % KK);
+                    ci = (int)(r / KK);
+                    t = KK - 1 - tf;
+                    dst = ((long)ci * it.T + it.tap0 + tf) * (it.ld > 0 ? it.ld : it.Cout) + co;
+                } else {                     // [co][tap0 + tap*Cin + ci]
+                    ci = (int)(o % it.Cin);
+                    const long r = o / it.Cin;
+                    t = (int)(r % KK);
+                    co = (int)(r / KK);
+                    dst = (long)co * it.T + it.tap0 + t * it.Cin + ci;
+                }
+                wpk[dst] = f32_to_bf16(it.w[((long)co * it.Cin + ci) * KK + t]);
+            }
+        } else if (it.mode == 0) {
+            if (KK == 9) pack_tiles<0, 9>(it, wpk, tile, tl);
+            else if (KK == 1) pack_tiles<0, 1>(it, wpk, tile, tl);
+            else pack_tiles<0, 0>(it, wpk, tile, tl);
+        } else {
+            if (KK == 9) pack_tiles<1, 9>(it, wpk, tile, tl);
+            else if (KK == 1) pack_tiles<1, 1>(it, wpk, tile, tl);
+            else pack_tiles<1, 0>(it, wpk, tile, tl);
         }
-        return;
-    }
-    if (it.mode == 0) {
-        if (KK == 9) pack_tiles<0, 9>(it, wpk, tile);
-        else if (KK == 1) pack_tiles<0, 1>(it, wpk, tile);
-        else pack_tiles<0, 0>(it, wpk, tile);
-    } else {
-        if (KK == 9) pack_tiles<1, 9>(it, wpk, tile);
-        else if (KK == 1) pack_tiles<1, 1>(it, wpk, tile);
-        else pack_tiles<1, 0>(it, wpk, tile);
     }
 }
 
@@ -1079,10 +1106,12 @@ int hc_pack_conv_weight(const float* w, void* wpk, int32_t Cout, int32_t Cin, in
 int hc_pack_conv_weights_multi(const hc_pack_item* items, int32_t nitems, int64_t max_elems, hc_stream_t stream) {
     if (items == nullptr || nitems < 0) return HC_ERR_ARG;
     if (nitems == 0) return HC_OK;
-    int bx = (int)((max_elems + 1023) / 1024);      // a 1x1 tile is 16 x 64 elements; workgroups beyond an item's tile count exit
-    if (bx > 512) bx = 512;
+    // a flat list of work units (LDS tiles / element chunks) walked by a fixed-size grid; max_elems bounds the units of one item
+    long units = (long)nitems * ((max_elems + 1023) / 1024);
+    int bx = units > 4096 ? 4096 : (int)units;
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(bx, nitems), dim3(256), 0, (hipStream_t)stream, items);
+    if (nitems > 8000) return HC_ERR_ARG;            // the prefix array lives in LDS
+    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(bx), dim3(256), (nitems + 1) * sizeof(int), (hipStream_t)stream, items, nitems);
     return hc_launch_status();
 }
 int hc_im2col_small(const float* x, void* col, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t KH,
