@@ -218,14 +218,18 @@ def test_row_unit_conv_planner_accepts_and_rejects():
     from holocron_amd.ops import conv as cv
     R = cv.ROWS_IMAGE
     for a in [(256, 14, 14, 192, 192, R), (256, 14, 14, 192, 192, R | 1), (256, 28, 28, 96, 96, R), (3, 28, 28, 96, 96, R | 1),
-              (5, 28, 14, 192, 192, R), (2, 56, 28, 96, 96, R)]:
+              (5, 28, 14, 192, 192, R), (2, 56, 28, 96, 96, R),
+              (256, 112, 112, 48, 48, R), (256, 56, 56, 48, 48, R), (2, 8, 112, 48, 48, R)]:   # streaming 48-channel kernel: forward
         d = cv.conv_small_desc(*a)
         assert d is not None and d.mode == a[5], a
     for a in [(4, 14, 14, 96, 96, R), (4, 28, 28, 192, 192, R), (4, 21, 14, 192, 192, R), (4, 7, 14, 192, 192, R), (4, 14, 14, 128, 128, R),
-              (4, 70, 14, 192, 192, R), (4, 14, 14, 192, 96, R), (4, 14, 14, 192, 192, R | 2), (4, 112, 112, 48, 48, R)]:
+              (4, 70, 14, 192, 192, R), (4, 14, 14, 192, 96, R), (4, 14, 14, 192, 192, R | 2),
+              (4, 112, 112, 48, 48, R | 1),     # its data gradient stays on the persistent kernel unless HC_CONV_ROWS48=2
+              (4, 110, 112, 48, 48, R), (4, 28, 28, 48, 48, R), (4, 60, 56, 48, 48, R)]:
         assert cv.conv_small_desc(*a) is None, a
     assert cv.conv_small_desc(256, 14, 14, 192, 192, 0) is not None        # image-resident kernel, its own weight format
     assert cv.rows_image(192, "cpu").shape == (60, 192, 32) and cv.rows_image(96, "cpu").shape == (30, 96, 32)
+    assert cv.rows_image(48, "cpu").shape == (20, 48, 32) and float(cv.rows_image(48, "cpu").abs().sum()) == 0.0   # zero-filled K padding
 
 
 def test_fused_weight_gradient_planner():
@@ -264,6 +268,7 @@ def test_pack_and_stacked_conv_argument_checks():
     # row-unit images need Cout == Cin, a multiple of 48 (rows) and of 32 (k blocks)
     assert lib.hc_pack_conv_weight(w.data_ptr(), w.data_ptr(), 40, 40, 3, 3, 3, 0, 10, None) == 1
     assert lib.hc_pack_conv_weight(w.data_ptr(), w.data_ptr(), 96, 48, 3, 3, 4, 0, 10, None) == 1
+    assert lib.hc_pack_conv_weight(w.data_ptr(), w.data_ptr(), 64, 64, 3, 3, 3, 0, 10, None) == 1
     assert lib.hc_pack_conv_weight(w.data_ptr(), w.data_ptr(), 48, 48, 3, 3, 5, 0, 10, None) == 1
     # stacked convolutions: split on a 4-channel boundary, second destination required, no epilogue extras
     d = _lib.ConvDesc()
