@@ -42,6 +42,7 @@ constexpr int NT = 512, UR = 7;
 struct Args {
     hc_conv_small_desc d;
     int reps;          // statistics replicas
+    int delay;         // start-up delay of the second team (s_sleep rounds): de-phases the two teams of a workgroup
 };
 
 template <int C, int W>
@@ -55,7 +56,7 @@ struct Geo {
     static constexpr int WIN = NDMA * 1024;
     static constexpr int SEGW = (W + 15) / 16;             // 16-pixel segments per row = pixel waves of a team
     static constexpr int CWN = 4 / SEGW;                   // channel waves of a team
-    static constexpr int SMEM = 2 * WIN;                   // one window per team
+    static constexpr int SMEM = 2 * WIN + 64;              // one window per team + the two team counters
     static constexpr int S3 = 9 * CK, S1 = CK, S = S3 + S1;
     static_assert(C == 48 * CWN, "one wave = 48 output channels");
     static_assert(CK % 3 == 0, "three rotating weight register sets per tap");
@@ -109,6 +110,21 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
     const int col = 16 * pw + px;
     const bool col_ok = col < W;
     const int region = team * G::WIN;
+    // The two teams synchronise only among themselves (an LDS arrival counter per team instead of s_barrier) and the second one starts
+    // late: one team's window wait / re-staging / store drain then runs under the other team's MFMAs instead of next to its own
+    int* cnt = reinterpret_cast<int*>(smem + 2 * G::WIN) + team * 8;
+    int gen = 0;
+    if (tid < 16) reinterpret_cast<int*>(smem + 2 * G::WIN)[tid] = 0;
+    __syncthreads();
+    auto team_sync = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        gen += 4;
+        if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    if (team == 1)
+        for (int i = 0; i < a.delay; ++i) __builtin_amdgcn_s_sleep(64);
 
     const unsigned act_bytes = (unsigned)d.N * H * W * C * 2u;
     const u32x4 rsA = uniform_rsrc(d.srcA, act_bytes);
@@ -263,10 +279,9 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
     // ---- the image: the units of this team, one after the other (both teams walk the same number of units)
     for (int u = team; u < UPI; u += 2) {
         const int row0 = u * UR;
-        if (u >= 2) __builtin_amdgcn_s_barrier();           // every wave is done reading the previous unit's window
+        if (u >= 2) team_sync();                            // every wave of the team is done reading the previous unit's window
         stage_window(rsA, row0, 0, G::NDMA);
-        hc_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
+        team_sync();                                        // the window has landed
         load_a(0, 0);
         load_a(1, 1);
         zero_acc();
@@ -288,10 +303,9 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
             zero_acc();
         } else {
             // second source through the same window: only the unit's own rows (slots WW .. 8 WW) are read by the centre tap
-            __builtin_amdgcn_s_barrier();
+            team_sync();
             stage_window(rsB, row0, (WW * PS) / 1024, (8 * WW * PS + PS + 1023) / 1024);
-            hc_wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
+            team_sync();
             load_b(S3 & 1, 0);
         }
         tap_block(std::integral_constant<int, (S3 & 1)>{}, S3, S, 0, 0, false);
@@ -349,6 +363,8 @@ int hc_conv_rows_launch(const hc_conv_small_desc& d, hipStream_t st) {
     crw::Args a;
     a.d = d;
     a.reps = hc_get_stat_replicas();
+    static const int delay = getenv("HC_CRW_DELAY") ? atoi(getenv("HC_CRW_DELAY")) : 0;
+    a.delay = delay;
     if (d.C == 192) crw::launch<192, 14>(a, st);
     else crw::launch<96, 28>(a, st);
     return hc_launch_status();
