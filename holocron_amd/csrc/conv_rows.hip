@@ -11,7 +11,7 @@
 //   * the unit of work is 7 output rows of one image (two units per 14x14 image, four per 28x28 image); its 9-row input window
 //     (zero halo, natural NHWC + one 16-byte pad chunk per pixel) is DMA'd into LDS.  A workgroup owns an image; its eight waves
 //     form two TEAMS of four, each team walks every other unit with its own window (two waves per SIMD: one team's LDS / VMEM issue
-//     runs under the other team's MFMAs);
+//     runs under the other team's MFMAs) and synchronises only with itself (LDS arrival counter, no workgroup barrier);
 //   * the MFMA is v_mfma_f32_16x16x32_bf16 with D[co][pixel]: one 16-pixel ROW SEGMENT per B fragment (14/16 resp. 28/32 columns
 //     valid = 87.5 %, no idle tiles), 3 x 16 output channels per wave -> 21 MFMAs per k32 step against 3 weight loads + 14 ds_read_b64;
 //   * every wave owns its 48 output channels, so nobody shares its weights: they go straight from L2 into registers, two k32 steps
@@ -29,8 +29,8 @@
 // Output channels are permuted inside a wave's 48 so that lane group g ends up with channels 8 g .. 8 g + 7 and 32 + 4 g .. 32 + 4 g + 3
 // of its pixel: one 16-byte and one 8-byte store, 64 + 32 contiguous bytes per pixel over the four groups, instead of three 8-byte
 // pieces 32 bytes apart.
-// MI355X, batch 256 (scripts/check_rows.py): 192 @ 14x14 forward + statistics 42.6 us (868 TFLOP/s; image-resident kernel 62.7),
-// data gradient 44.9 us (62.7); 96 @ 28x28 54.8 / 54.5 us (gather-conv: 3 launches, 195 us).
+// MI355X, batch 256 (scripts/check_rows.py, profiles/r02_final_conv_rows_shapes.txt): 192 @ 14x14 forward + statistics 40 us
+// (920 TFLOP/s; image-resident kernel 62.7), data gradient 44 us (62.7); 96 @ 28x28 46 / 56 us (gather-conv: 3 launches, 195 us).
 #include <type_traits>
 #include "common.h"
 #include "../../include/holocron_hip.h"
