@@ -56,7 +56,8 @@ struct Geo {
     static constexpr int WIN = NDMA * 1024;
     static constexpr int SEGW = (W + 15) / 16;             // 16-pixel segments per row = pixel waves of a team
     static constexpr int CWN = 4 / SEGW;                   // channel waves of a team
-    static constexpr int SMEM = 2 * WIN + 64;              // one window per team + the two team counters
+    static constexpr int SMEM = 2 * WIN + 64 + 1024;       // one window per team + the two team counters + slack: the fragment reads of
+                                                           // discarded columns run up to a few hundred bytes past the second window
     static constexpr int S3 = 9 * CK, S1 = CK, S = S3 + S1;
     static_assert(C == 48 * CWN, "one wave = 48 output channels");
     static_assert(CK % 3 == 0, "three rotating weight register sets per tap");

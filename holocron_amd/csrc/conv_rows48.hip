@@ -38,7 +38,8 @@ struct Geo {
     static constexpr int NSLOT = (UR + 2) * WW + 1;
     static constexpr int NDMA = (NSLOT * PS + 1023) / 1024;
     static constexpr int WIN = NDMA * 1024;
-    static constexpr int SMEM = 2 * WIN + 64;              // one window per team + the two team counters
+    static constexpr int SMEM = 2 * WIN + 64 + 1024;       // one window per team + the two team counters + slack: the fragment reads of
+                                                           // discarded columns run up to a few hundred bytes past the second window
     static_assert(SMEM <= 160 * 1024, "LDS budget");
 };
 
