@@ -10,10 +10,11 @@
 // Why one kernel.  The separate kernels (conv_wgrad_tr.hip) launch 3x3 and 1x1 apart (x staged twice), stage through
 // registers (no load / MFMA overlap with one workgroup per CU), and need a ~40-way split-K on the 14 x 14 layers whose fp32
 // slabs double the HBM traffic of the layer.  Here:
-//   * a workgroup owns a (16*MR ci) x (16*NR co) tile of ALL TEN taps.  Its four waves split the taps, not the tile: wave kh
-//     (0..2) accumulates kernel row kh (3 taps) against dy3, wave 3 the 1x1 against dy1 (the 1x1 input pixel is tap (1,1)).
-//     A wave's three taps share their dy fragments, and nobody re-reads a neighbour's x fragments: 2*(3*MR + NR) transposing
-//     LDS reads per 3*MR*NR MFMAs instead of 2*(9*MR + NR) per 9*MR*NR/WAVES.
+//   * a workgroup owns a (16*MR ci) x (16*NR co) tile of ALL TEN taps.  Its four wave ROLES split the taps, not the tile, 3 + 3 + 2 + 2:
+//     kernel row 0, kernel row 1, taps (2,0) (2,1), and tap (2,2) together with the 1x1 against dy1 (the 1x1 input pixel is tap
+//     (1,1)).  A wave's taps share their dy fragments, and nobody re-reads a neighbour's x fragments: 2*(3*MR + NR) transposing
+//     LDS reads per 3*MR*NR MFMAs instead of 2*(9*MR + NR) per 9*MR*NR/WAVES.  Eight-wave variants (two ci halves or two pixel
+//     halves) rotate the roles of the second group by two so that every SIMD carries one 3-tap and one 2-tap wave.
 //   * operands stream HBM/L2 -> LDS by DMA (buffer_load ... lds) in their natural NHWC layout, one step (R output rows)
 //     ahead of the MFMAs, no staging registers.  The batch is walked as ONE tall image: image n owns virtual input rows
 //     [n*PI, (n+1)*PI), PI = s*(OH+1), row 0 = the zero halo row (out-of-range DMA -> zeros), and virtual output rows
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256 * HV * PV, (PV == 1 && (HV == 2 || MR * NR <= 9
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int role = wid & 3;                              // role 0..2: kernel row, 3: the 1x1
+    const int role = (wid + ((NW == 8 && (wid & 4)) ? 2 : 0)) & 3;   // which taps (see `run`); the second wave group is rotated by two
     const int half = HV == 2 ? wid >> 2 : 0;               // which MH ci blocks of the tile
     const int pz = PV == 2 ? wid >> 2 : 0;                 // which k-steps of a step
 
@@ -235,11 +236,15 @@ __global__ __launch_bounds__(256 * HV * PV, (PV == 1 && (HV == 2 || MR * NR <= 9
         issue_dy();
     }
 
-    // The step loop, once per wave ROLE (TAPS = 3: a kernel row against dy3; TAPS = 1: the 1x1 against dy1).  Two instantiations
-    // instead of a branch inside the loop: with one accumulator array live across `if (role)` the register allocator copied the
-    // accumulators at every join (438 v_accvgpr_mov per k-step, 5 VALU per MFMA in the PMC counters).
-    auto run = [&](auto taps_c) {
-        constexpr int TAPS = decltype(taps_c)::value;
+    // The step loop, once per wave ROLE.  The ten taps are dealt 3 + 3 + 2 + 2: role 0 = kernel row 0, role 1 = kernel row 1,
+    // role 2 = taps (2,0), (2,1), role 3 = tap (2,2) against dy3 plus the 1x1 against dy1 - and the second wave group takes the roles
+    // rotated by two, so that every SIMD hosts one 3-tap and one 2-tap wave (45 MFMAs per k-step each; with a 3 + 3 + 3 + 1 deal the
+    // two 1-tap waves shared one SIMD and the other three carried 54).  One instantiation per role instead of a branch inside the
+    // loop: with one accumulator array live across `if (role)` the register allocator copied the accumulators at every join
+    // (438 v_accvgpr_mov per k-step, 5 VALU per MFMA in the PMC counters).
+    auto run = [&](auto kh_c, auto kw0_c, auto n3_c, auto has1_c) {
+        constexpr int KH = decltype(kh_c)::value, KW0 = decltype(kw0_c)::value, N3 = decltype(n3_c)::value, HAS1 = decltype(has1_c)::value;
+        constexpr int TAPS = N3 + HAS1;
         f32x4 acc[TAPS][MH][NR];
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
@@ -247,9 +252,7 @@ __global__ __launch_bounds__(256 * HV * PV, (PV == 1 && (HV == 2 || MR * NR <= 9
             for (int m = 0; m < MH; ++m)
 #pragma unroll
                 for (int q = 0; q < NR; ++q) acc[t][m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int khw = TAPS == 3 ? role : 1;              // kernel row of this wave (the 1x1 reads the centre row ...
-        const int kwoff = (TAPS == 3 ? 0 : a.SX) + 32 * MH * half;   // ... and the centre column); first ci block of this wave
-        const int dywave = TAPS == 3 ? 0 : a.DHALF;        // dy3 for the kernel-row waves, dy1 for the 1x1 wave
+        const int kwoff = 32 * MH * half;                  // first ci block of this wave
         int base = (s * Ua) % a.NSLOT;                     // ring slot of the first input row of the current step
         int cstage = 0;
         for (int t = 0; t < nsteps; ++t) {
@@ -259,27 +262,45 @@ __global__ __launch_bounds__(256 * HV * PV, (PV == 1 && (HV == 2 || MR * NR <= 9
                 issue_x_rows(RS);                          // step t + PF (past the end of the split: harmless real / zero rows)
                 issue_dy();
             }
-            const char* dyb = smem + a.off_dy + cstage * a.DSLOT + dywave;
+            const char* dyb = smem + a.off_dy + cstage * a.DSLOT;
             for (int g = (pz * nk) / PV; g < ((pz + 1) * nk) / PV; ++g) {
                 const int p0 = 32 * g + prow;
                 const int r0 = tab[2 * p0], c0 = tab[2 * p0 + 1], r1 = tab[2 * p0 + 32], c1 = tab[2 * p0 + 33];
-                int s0 = base + r0 + khw, s1 = base + r1 + khw;
-                if (s0 >= a.NSLOT) s0 -= a.NSLOT;
-                if (s1 >= a.NSLOT) s1 -= a.NSLOT;
-                const int xa0 = s0 * a.ROWB + c0 + cq2 + kwoff, xa1 = s1 * a.ROWB + c1 + cq2 + kwoff;
                 const int d0 = p0 * a.SD + cq2;
-                bf16x8 fb[NR];
+                if (N3 > 0) {                              // taps (KH, KW0 .. KW0 + N3 - 1) against dy3
+                    int s0 = base + r0 + KH, s1 = base + r1 + KH;
+                    if (s0 >= a.NSLOT) s0 -= a.NSLOT;
+                    if (s1 >= a.NSLOT) s1 -= a.NSLOT;
+                    const int xa0 = s0 * a.ROWB + c0 + cq2 + kwoff, xa1 = s1 * a.ROWB + c1 + cq2 + kwoff;
+                    bf16x8 fb[NR];
 #pragma unroll
-                for (int q = 0; q < NR; ++q) fb[q] = tr_pair(dyb, d0 + 32 * q, d0 + SD16B + 32 * q);
+                    for (int q = 0; q < NR; ++q) fb[q] = tr_pair(dyb, d0 + 32 * q, d0 + SD16B + 32 * q);
 #pragma unroll
-                for (int kw = 0; kw < TAPS; ++kw) {
-                    const int ko = kw == 0 ? 0 : (kw == 1 ? SX1 : SX2);
+                    for (int kw = 0; kw < N3; ++kw) {
+                        const int ko = (KW0 + kw) == 0 ? 0 : ((KW0 + kw) == 1 ? SX1 : SX2);
+#pragma unroll
+                        for (int m = 0; m < MH; ++m) {
+                            const bf16x8 fa = tr_pair(smem, xa0 + ko + 32 * m, xa1 + ko + 32 * m);
+#pragma unroll
+                            for (int q = 0; q < NR; ++q)
+                                acc[kw][m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[q], acc[kw][m][q], 0, 0, 0);
+                        }
+                    }
+                }
+                if (HAS1) {                                // the 1x1: centre row, centre column, against dy1
+                    int s0 = base + r0 + 1, s1 = base + r1 + 1;
+                    if (s0 >= a.NSLOT) s0 -= a.NSLOT;
+                    if (s1 >= a.NSLOT) s1 -= a.NSLOT;
+                    const int xa0 = s0 * a.ROWB + c0 + cq2 + kwoff + SX1, xa1 = s1 * a.ROWB + c1 + cq2 + kwoff + SX1;
+                    bf16x8 fb[NR];
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) fb[q] = tr_pair(dyb + a.DHALF, d0 + 32 * q, d0 + SD16B + 32 * q);
 #pragma unroll
                     for (int m = 0; m < MH; ++m) {
-                        const bf16x8 fa = tr_pair(smem, xa0 + ko + 32 * m, xa1 + ko + 32 * m);
+                        const bf16x8 fa = tr_pair(smem, xa0 + 32 * m, xa1 + 32 * m);
 #pragma unroll
                         for (int q = 0; q < NR; ++q)
-                            acc[kw][m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[q], acc[kw][m][q], 0, 0, 0);
+                            acc[N3][m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[q], acc[N3][m][q], 0, 0, 0);
                     }
                 }
             }
@@ -296,15 +317,21 @@ __global__ __launch_bounds__(256 * HV * PV, (PV == 1 && (HV == 2 || MR * NR <= 9
             const int co = co0 + 16 * q + la;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
-                const int tap = TAPS == 3 ? 3 * role + t : 9;
+                const int tap = t < N3 ? 3 * KH + KW0 + t : 9;
                 float* row = ws + ((size_t)co * 10 + tap) * a.Cin + ci0 + 16 * MH * half + 4 * kq;
 #pragma unroll
                 for (int m = 0; m < MH; ++m) *reinterpret_cast<f32x4*>(row + 16 * m) = acc[t][m][q];
             }
         }
     };
-    if (role < 3) run(std::integral_constant<int, 3>{});
-    else run(std::integral_constant<int, 1>{});
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    if (role == 0) run(I0{}, I0{}, I3{}, I0{});
+    else if (role == 1) run(I1{}, I0{}, I3{}, I0{});
+    else if (role == 2) run(I2{}, I0{}, I2{}, I0{});
+    else run(I2{}, I2{}, I1{}, I1{});
 }
 
 // dw3[co][ci][t] (t < 9), dw1[co][ci] = (accumulate ? old : 0) + sum_split slab[job][split][co][t][ci], splits added in a fixed
