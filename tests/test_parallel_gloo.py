@@ -226,6 +226,60 @@ def test_graphed_step_segments_world2_eager_form():
     mp.spawn(_worker_segments, args=(2, _free_port()), nprocs=2, join=True)
 
 
+def _worker_three_segments(rank, world, port):
+    """The N > 1 bench configuration (bench.py): backward cut in THREE by two BackwardCuts, three buckets aligned with the cuts -
+    after segment k exactly buckets 0..k are complete, and the result is serial full-batch training."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from holocron_amd.parallel import BackwardCut, GradReducer, GraphedStep
+
+    def make():
+        torch.manual_seed(101)
+        return torch.nn.Sequential(torch.nn.Linear(8, 12), torch.nn.Tanh(), torch.nn.Linear(12, 12), torch.nn.Tanh(),
+                                   torch.nn.Linear(12, 12), torch.nn.Tanh(), torch.nn.Linear(12, 3))
+    model = make()
+    # cuts sit at module INPUTS: segment 0 = model[6], segment 1 = model[2] .. model[5], segment 2 = model[0] .. model[1]
+    rear_cut, mid_cut = BackwardCut(model[6]), BackwardCut(model[2])
+    b1 = list(model[4].parameters())[-1]               # first parameter (backwards) in front of the rear cut
+    b2 = list(model[0].parameters())[-1]               # ... in front of the middle cut
+    red = GradReducer(model.parameters(), bucket_mb=32.0, new_bucket_at=[b1, b2], overlap=False)
+    assert [len(b.params) for b in red.buckets] == [2, 4, 2]
+    torch.manual_seed(9)
+    data, target = torch.randn(2 * world, 8), torch.randn(2 * world, 3)
+    x, t = data[rank * 2:(rank + 1) * 2], target[rank * 2:(rank + 1) * 2]
+    seen = []
+
+    def seg0():
+        for p in model.parameters():
+            p.grad = None
+        ((model(x) - t) ** 2).sum().backward()
+        seen.append(red.buckets_with_all_grads())
+
+    def seg1():
+        rear_cut.continue_backward()
+        seen.append(red.buckets_with_all_grads())
+
+    step = GraphedStep([seg0, seg1, mid_cut.continue_backward], _PlainSGD(model.parameters(), 0.01), red)
+    for _ in range(2):
+        step.run()
+    assert seen == [[0], [0, 1], [0], [0, 1]]
+    ref = make()
+    for _ in range(2):
+        for p in ref.parameters():
+            p.grad = None
+        (((ref(data) - target) ** 2).sum() / world).backward()
+        with torch.no_grad():
+            for p in ref.parameters():
+                p -= 0.01 * p.grad
+    for a, b in zip(model.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, atol=1e-5, rtol=1e-5), (a - b).abs().max()
+    dist.destroy_process_group()
+
+
+def test_graphed_step_three_segments_world2():
+    mp.spawn(_worker_three_segments, args=(2, _free_port()), nprocs=2, join=True)
+
+
 # ---------------------------------------------------------------- gradient accumulation, guard, comm dtype, Trainer
 def _worker_accum(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
