@@ -271,10 +271,23 @@ def stat_replicas() -> int:
     return int(load().hc_get_stat_replicas())
 
 
+_REPLICA_LISTENERS = []      # called after the replica count changed: arenas sized for the old count start over
+
+
+def on_replicas_changed(fn) -> None:
+    _REPLICA_LISTENERS.append(fn)
+
+
 def set_deterministic(on: bool) -> None:
     """Bit-reproducible training steps (include/holocron_hip.h hc_set_deterministic): every workgroup gets its own slot of the
-    statistics accumulators, the split reductions become single-writer.  Costs memory (32768 replicas) and a slower finalize."""
+    statistics accumulators, the split reductions become single-writer.  Costs memory (32768 replicas) and a slower finalize.
+    The per-step zero arenas are told (``on_replicas_changed``) and start over, so that LEAVING the mode also returns its 256x
+    larger zero-fill instead of clearing gigabytes on every later step."""
+    before = stat_replicas()
     check(load().hc_set_deterministic(1 if on else 0), "hc_set_deterministic")
+    if stat_replicas() != before:
+        for fn in _REPLICA_LISTENERS:
+            fn()
 
 
 _ERR = {1: "bad argument", 2: "kernel launch failure"}

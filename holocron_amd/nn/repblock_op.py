@@ -65,6 +65,14 @@ class ZeroPool:
     def end(self):
         self.depth = max(0, self.depth - 1)
 
+    def reset(self):
+        """Forget the high-water mark (the statistics replica count changed: deterministic mode sizes everything 256x larger and
+        `begin()` zeroes up to the mark on every step).  The old buffer is retired, not freed: a captured graph may still use it."""
+        if self.buf is not None:
+            self.retired.append(self.buf)
+        self.buf, self.used, self.high = None, 0, 0
+        self.gen += 1
+
     def take(self, shape, device):
         n = 1
         for v in shape:
@@ -92,6 +100,7 @@ class ZeroPool:
 
 
 POOL = ZeroPool()
+_lib.on_replicas_changed(POOL.reset)
 
 
 class RepState:

@@ -289,14 +289,22 @@ def test_pack_and_stacked_conv_argument_checks():
 
 
 def test_deterministic_switch_resizes_the_replica_count():
+    """... and the per-step zero arena forgets its high-water mark on every change of the replica count: sized for 32768 replicas it
+    would otherwise clear gigabytes per step for the rest of the process"""
+    from holocron_amd.nn.repblock_op import POOL
     lib = _lib.load()
     assert _lib.stat_replicas() == 128 and lib.hc_get_deterministic() == 0
+    POOL.high = 4096
     _lib.set_deterministic(True)
     try:
         assert _lib.stat_replicas() == 32768 and lib.hc_get_deterministic() == 1
+        assert POOL.high == 0 and POOL.buf is None
+        POOL.high = 1 << 30
+        _lib.set_deterministic(True)            # no change: nothing is reset
+        assert POOL.high == 1 << 30
     finally:
         _lib.set_deterministic(False)
-    assert _lib.stat_replicas() == 128
+    assert _lib.stat_replicas() == 128 and POOL.high == 0
 
 
 def test_optimizer_launch_groups_by_step_count():
