@@ -60,47 +60,36 @@ class Trainer:
                  skip_nan_loss: bool = False, nan_tolerance: int = 5, gradient_acc: int = 1,
                  gradient_clip: Optional[float] = None, on_epoch_end: Optional[Callable[[Dict[str, float]], Any]] = None,
                  log_every: int = 50) -> None:
-        self.model = model
-        self.train_loader = train_loader
-        self.val_loader = val_loader
-        self.criterion = criterion
-        self.optimizer = optimizer
-        self.amp = amp
-        self.scaler = None
-        self.on_epoch_end = on_epoch_end
-        self.skip_nan_loss = skip_nan_loss
-        self.nan_tolerance = nan_tolerance
-        self.gradient_acc = gradient_acc
-        self.grad_clip = gradient_clip
-        self.output_file = output_file
+        # the attribute names are the reference's (scripts and callbacks read them)
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.train_loader, self.val_loader = train_loader, val_loader
+        self.amp, self.scaler = amp, None                   # bf16 activations are always on: no GradScaler to keep
+        self.skip_nan_loss, self.nan_tolerance = skip_nan_loss, nan_tolerance
+        self.gradient_acc, self.grad_clip = gradient_acc, gradient_clip
+        self.on_epoch_end, self.output_file = on_epoch_end, output_file
         self.log_every = max(1, int(log_every))
-
-        self.step = 0
-        self.start_epoch = 0
-        self.epoch = 0
-        self._grad_count = 0
-        self.min_loss = math.inf
-        self.gpu = gpu
+        self.step = self.start_epoch = self.epoch = self._grad_count = 0
+        self.min_loss, self.gpu = math.inf, gpu
         self._params: Tuple[ParamSeq, ParamSeq] = ([], [])
         self.lr_recorder: List[float] = []
         self.loss_recorder: List[float] = []
-        self._reducer = None
-        self._reducer_key = None
+        self._reducer = self._reducer_key = None
         self.set_device(gpu)
-        self._reset_opt(self.optimizer.defaults["lr"])
+        self._reset_opt(optimizer.defaults["lr"])
 
     # ---------------------------------------------------------------- device / checkpoint
     def set_device(self, gpu: Optional[int] = None) -> None:
         """core.py:90-104"""
-        if isinstance(gpu, int):
-            if not torch.cuda.is_available():
-                raise AssertionError("PyTorch cannot access your GPU. Please investigate!")
-            if gpu >= torch.cuda.device_count():
-                raise ValueError("Invalid device index")
-            torch.cuda.set_device(gpu)
-            self.model = self.model.cuda()
-            if isinstance(self.criterion, nn.Module):
-                self.criterion = self.criterion.cuda()
+        if not isinstance(gpu, int):
+            return
+        if not torch.cuda.is_available():
+            raise AssertionError("PyTorch cannot access your GPU. Please investigate!")      # the reference's messages
+        if gpu >= torch.cuda.device_count():
+            raise ValueError("Invalid device index")
+        torch.cuda.set_device(gpu)
+        self.model = self.model.cuda()
+        if isinstance(self.criterion, nn.Module):
+            self.criterion = self.criterion.cuda()
 
     def save(self, output_file: str, with_optimizer: bool = False) -> None:
         """Checkpoint with the reference's keys (core.py:106-121); ``with_optimizer`` adds the optimizer state."""
@@ -111,10 +100,8 @@ class Trainer:
 
     def load(self, state: Dict[str, Any]) -> None:
         """core.py:123-133 (+ the optimizer state when the checkpoint has one)"""
-        self.start_epoch = state["epoch"]
-        self.epoch = self.start_epoch
-        self.step = state["step"]
-        self.min_loss = state["min_loss"]
+        self.start_epoch = self.epoch = state["epoch"]
+        self.step, self.min_loss = state["step"], state["min_loss"]
         self.model.load_state_dict(state["model"])
         if "optimizer" in state:
             self.optimizer.load_state_dict(state["optimizer"])
