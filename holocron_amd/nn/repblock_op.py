@@ -28,8 +28,9 @@ STEM_KPAD = 32
 class ZeroPool:
     """One zero-filled fp32 arena per training step instead of ~100 tiny ``torch.zeros`` launches:
     ``begin()`` zeroes the extent used so far with a single memset, ``take(n)`` hands out views.
-    The buffer is allocated during warm-up, so a captured hipGraph keeps using the same addresses; a buffer that had to
-    grow is retired, not freed, for the same reason.
+    The buffer is allocated during warm-up, so a captured hipGraph keeps using the same addresses; a buffer that was handed out
+    under stream capture and then had to be replaced is retired, not freed, for the same reason (``release_retired()`` drops those
+    once the graphs are gone: parallel.GraphedStep.release does) - one that no capture ever saw is simply freed.
 
     Views are only valid until the next ``begin()``: ``gen`` counts the arena's generations, and anything that is taken
     in one autograd node's forward for use in its backward (``take_for_backward``) is re-validated there with ``claim`` -
@@ -43,6 +44,16 @@ class ZeroPool:
         self.depth = 0
         self.gen = 0
         self.retired = []
+        self.buf_captured = False   # the current buffer was handed out while a stream capture was running
+
+    def _retire(self):
+        if self.buf is not None and self.buf_captured:
+            self.retired.append(self.buf)
+        self.buf, self.buf_captured = None, False
+
+    def release_retired(self):
+        """Free the buffers kept alive for captured graphs (call when those graphs have been destroyed)."""
+        self.retired = []
 
     @property
     def active(self):
@@ -53,11 +64,12 @@ class ZeroPool:
             self.depth += 1
             return
         if self.buf is None or self.buf.device != device or self.buf.numel() < self.high:
-            if self.buf is not None:
-                self.retired.append(self.buf)
+            self._retire()
             self.buf = torch.zeros(max(self.high * 2, 1 << 20), dtype=torch.float32, device=device)
         else:
             self.buf[: max(self.high, 1)].zero_()
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            self.buf_captured = True
         self.used = 0
         self.gen += 1
         self.depth = 1
@@ -67,10 +79,9 @@ class ZeroPool:
 
     def reset(self):
         """Forget the high-water mark (the statistics replica count changed: deterministic mode sizes everything 256x larger and
-        `begin()` zeroes up to the mark on every step).  The old buffer is retired, not freed: a captured graph may still use it."""
-        if self.buf is not None:
-            self.retired.append(self.buf)
-        self.buf, self.used, self.high = None, 0, 0
+        `begin()` zeroes up to the mark on every step).  The old buffer is freed unless a captured graph may still use it."""
+        self._retire()
+        self.used, self.high = 0, 0
         self.gen += 1
 
     def take(self, shape, device):

@@ -349,6 +349,7 @@ class _RepWgradQueue:
     def __init__(self):
         self.jobs = []
         self.armed = False
+        self.task = -1              # autograd graph task the queued jobs (and the pending flush callback) belong to
         self.support = {}
         self.enabled = os.environ.get("HC_WREP_DEFER", "1") != "0"
         # HC_WREP_SIDE=1: a group is launched on a second HIP stream as soon as the backward pass moves on to another block shape, so
@@ -357,19 +358,22 @@ class _RepWgradQueue:
         self.side = None
         self.inflight = []          # inputs of launches on the side stream: referenced until the join
         self.side_params = set()
-        self.arena = None           # zero-filled fp32 buffer of this backward pass (sized by the previous pass)
+        self.arena = None           # zero-filled fp32 buffer of this backward pass (sized by the previous pass that began alike)
         self.arena_used = 0
         self.arena_want = 0
-        self.arena_high = 0
+        self.arena_first = None     # shape key of the first block this pass submitted: passes of a step cut in several
+        self.arena_sizes = {}       # (BackwardCut) segments begin with different blocks, and each gets an arena of ITS size
 
-    def _zeros(self, shape, device):
+    def _zeros(self, shape, device, key=None):
         n = 1
         for v in shape:
             n *= v
         n64 = (n + 63) // 64 * 64
+        if self.arena_want == 0:
+            self.arena_first = key
         self.arena_want += n64
-        if self.arena is None and self.arena_high > 0 and self.arena_used == 0:
-            self.arena = torch.zeros((self.arena_high,), dtype=torch.float32, device=device)
+        if self.arena is None and self.arena_used == 0 and self.arena_sizes.get(self.arena_first, 0) > 0:
+            self.arena = torch.zeros((self.arena_sizes[self.arena_first],), dtype=torch.float32, device=device)
         if self.arena is None or self.arena.device != device or self.arena_used + n64 > self.arena.numel():
             return torch.zeros(shape, dtype=torch.float32, device=device)
         out = self.arena[self.arena_used:self.arena_used + n].view(shape)
@@ -420,8 +424,14 @@ class _RepWgradQueue:
     def submit(self, key, x, dy3, dy1, w3, w1):
         """Queue one block; returns the (zero-filled, to be accumulated into) gradient tensors for autograd."""
         Cout, Cin = key[4], key[1]
-        dw3 = self._zeros((Cout, Cin, 3, 3), x.device)
-        dw1 = self._zeros((Cout, Cin, 1, 1), x.device)
+        task = torch._C._current_graph_task_id()
+        if self.armed and task != self.task:
+            # The pass that armed the queue never ran its final callback: the engine skips it when backward raises (an OOM the caller
+            # retries, KeyboardInterrupt, an error in a hook).  Its jobs belong to gradients nobody will read: drop them, or every
+            # later pass would find `armed` set, queue no callback and train on the zero-filled arena views (ADVICE r2).
+            self._abandon()
+        dw3 = self._zeros((Cout, Cin, 3, 3), x.device, key)
+        dw1 = self._zeros((Cout, Cin, 1, 1), x.device, key)
         # The queue must not hold the gradient TENSORS: AccumulateGrad only adopts a gradient it holds the sole reference to
         # (otherwise it clones it on the spot).  The storages keep the memory alive instead.
         if self.side_on and PROFILE is None:
@@ -432,9 +442,14 @@ class _RepWgradQueue:
         self.jobs.append((key, x, dy3, dy1, dw3.untyped_storage(), dw3.data_ptr(), dw3.storage_offset(),
                           dw1.untyped_storage(), dw1.data_ptr(), dw1.storage_offset(), w3, w1))
         if not self.armed:
-            self.armed = True
+            self.armed, self.task = True, task
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
         return dw3, dw1
+
+    def _abandon(self):
+        self.join()
+        self.jobs, self.armed, self.task = [], False, -1
+        self.arena, self.arena_used, self.arena_want, self.arena_first = None, 0, 0, None
 
     def _launch_on_side(self):
         jobs, self.jobs = self.jobs, []
@@ -478,10 +493,12 @@ class _RepWgradQueue:
                         g.add_(torch.empty(0, dtype=torch.float32, device=x.device).set_(st, off, g.shape))
 
     def flush(self):
-        self.armed = False
+        self.armed, self.task = False, -1
         jobs, self.jobs = self.jobs, []
         self.arena, self.arena_used = None, 0          # the views handed out keep the buffer alive
-        self.arena_high, self.arena_want = max(self.arena_high, self.arena_want), 0
+        if self.arena_want:
+            self.arena_sizes[self.arena_first] = self.arena_want
+        self.arena_want, self.arena_first = 0, None
         if jobs and self.inflight:          # side-stream mode: the last groups go there too, then everything is joined
             self.jobs = jobs
             self._launch_on_side()
@@ -499,11 +516,60 @@ def flush_deferred_wgrads() -> None:
     """Launch every weight gradient that is still queued (call before reading ``.grad`` from inside a backward pass)."""
     if _WREP.jobs or _WREP.inflight:
         jobs, _WREP.jobs = _WREP.jobs, []
-        arena = (_WREP.arena, _WREP.arena_used, _WREP.arena_want)
+        arena = (_WREP.arena, _WREP.arena_used, _WREP.arena_want, _WREP.arena_first)
+        sizes = dict(_WREP.arena_sizes)
         _WREP.jobs = jobs
         _WREP.flush()
-        # a mid-pass flush must not drop the arena of the pass that is still running
-        _WREP.arena, _WREP.arena_used, _WREP.arena_want = arena
+        # a mid-pass flush must not drop the arena of the pass that is still running (nor record its partial size)
+        _WREP.arena, _WREP.arena_used, _WREP.arena_want, _WREP.arena_first = arena
+        _WREP.arena_sizes = sizes
+
+
+_FLUSH_AWARE = {}    # id(parameter) -> ids of its post-accumulate hooks that call flush_deferred_wgrads() before reading .grad
+_MANAGED = set()     # id(parameter) of everything a parallel.GradReducer averages (it flushes before it packs a bucket)
+
+
+def mark_reducer_managed(params, on: bool = True) -> None:
+    """parallel.GradReducer: these parameters' gradients are read by a reducer that calls ``flush_deferred_wgrads()`` first."""
+    for p in params:
+        (_MANAGED.add if on else _MANAGED.discard)(id(p))
+
+
+def register_flush_aware_hook(p, handle) -> None:
+    """Tell the deferred weight-gradient queue that the post-accumulate-grad hook behind ``handle`` (the object
+    ``p.register_post_accumulate_grad_hook`` returned) calls ``flush_deferred_wgrads()`` before it reads any gradient
+    (parallel.GradReducer does).  Every other hook makes the fused RepBlock launch immediately instead of deferring."""
+    _FLUSH_AWARE.setdefault(id(p), set()).add(handle.id)
+
+
+def set_deferred_wgrads(on: bool) -> None:
+    """Process-wide switch of the deferred (grouped) RepBlock weight gradients (public as ``holocron_amd.set_deferred_wgrads``).
+    Switch it off under a wrapper that reads gradients DURING backward through hooks this package cannot see (torch's
+    DistributedDataParallel / FSDP register theirs in C++): with deferral on such a reader sees the zero-filled placeholder."""
+    if not on:
+        flush_deferred_wgrads()
+    _WREP.enabled = bool(on)
+
+
+def _may_defer(*params) -> bool:
+    """Deferral hands autograd a zero-filled gradient that the end-of-pass flush fills.  Anything that reads a gradient inside the
+    pass would see zeros, so it is used only when nothing can: no tensor hooks, no post-accumulate hooks other than registered
+    flush-aware ones, and - with more than one rank - only under this package's GradReducer (DistributedDataParallel / FSDP hang
+    their bucket hooks on the gradient accumulators in C++, invisible from here, and would all-reduce the zeros: ADVICE r2)."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    for p in params:
+        if p.grad is not None:
+            return False
+        if getattr(p, "_backward_hooks", None):
+            return False
+        post = getattr(p, "_post_accumulate_grad_hooks", None)
+        aware = _FLUSH_AWARE.get(id(p), ())
+        if post and any(k not in aware for k in post):
+            return False
+        if multi and id(p) not in _MANAGED:
+            return False
+    return True
 
 
 def rep_block_wgrad(x, dy3, dy1, w3, w1, stride, defer=False):
@@ -514,7 +580,7 @@ def rep_block_wgrad(x, dy3, dy1, w3, w1, stride, defer=False):
     key = (N, Cin, H, W, Cout, stride)
     if not _WREP.supported(key):
         return None
-    if defer and _WREP.enabled and w3.grad is None and w1.grad is None:
+    if defer and _WREP.enabled and _may_defer(w3, w1):
         return _WREP.submit(key, x, dy3, dy1, w3, w1)
     dw3 = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=x.device)
     dw1 = torch.empty((Cout, Cin, 1, 1), dtype=torch.float32, device=x.device)

@@ -19,7 +19,7 @@ from torch.optim import Adam
 
 from .. import _lib
 from .._lib import AdaBeliefGroup, check, ptr, stream
-from ..ops.conv import bump_weights_epoch
+from ..ops.conv import bump_weights_epoch, flush_deferred_wgrads
 from ._multi_tensor import Staging, VGroups, chunk_rows
 
 __all__ = ["AdaBelief"]
@@ -99,6 +99,7 @@ class AdaBelief(Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        flush_deferred_wgrads()     # weight gradients a backward pass only queued (normally flushed at its end)
         plist, hyper, steps = self._collect(advance_state=True)
         if not plist:
             return loss

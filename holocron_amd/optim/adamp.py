@@ -15,7 +15,7 @@ from torch.optim.optimizer import Optimizer
 
 from .. import _lib
 from .._lib import AdamxGroup, check, ptr, stream
-from ..ops.conv import bump_weights_epoch
+from ..ops.conv import bump_weights_epoch, flush_deferred_wgrads
 from ._multi_tensor import DeviceTables, chunk_rows, VGroups
 
 __all__ = ["AdamP", "AdEMAMix"]
@@ -45,6 +45,7 @@ class AdamP(Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        flush_deferred_wgrads()     # weight gradients a backward pass only queued (normally flushed at its end)
         entries, numel, vg = [], [], VGroups()
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
@@ -102,6 +103,7 @@ class AdEMAMix(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        flush_deferred_wgrads()     # weight gradients a backward pass only queued (normally flushed at its end)
         entries, vg = [], VGroups()
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:

@@ -14,7 +14,7 @@ from torch.optim.optimizer import Optimizer
 
 from .. import _lib
 from .._lib import LambGroup, check, ptr, stream
-from ..ops.conv import bump_weights_epoch
+from ..ops.conv import bump_weights_epoch, flush_deferred_wgrads
 from ._multi_tensor import DeviceTables, chunk_rows, VGroups
 from .adamp import _check_param, _upload
 
@@ -47,6 +47,7 @@ class _TrustRatioAdam(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        flush_deferred_wgrads()     # weight gradients a backward pass only queued (normally flushed at its end)
         entries, owners, vg = [], [], VGroups()
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:

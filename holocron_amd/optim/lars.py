@@ -13,7 +13,7 @@ from torch.optim.optimizer import Optimizer
 
 from .. import _lib
 from .._lib import LarsGroup, check, ptr, stream
-from ..ops.conv import bump_weights_epoch
+from ..ops.conv import bump_weights_epoch, flush_deferred_wgrads
 from ._multi_tensor import DeviceTables, chunk_rows
 
 __all__ = ["LARS"]
@@ -49,6 +49,7 @@ class LARS(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        flush_deferred_wgrads()     # weight gradients a backward pass only queued (normally flushed at its end)
         entries = []
         ngroups = len(self.param_groups)
         gbuf = (LarsGroup * max(ngroups, 1))()

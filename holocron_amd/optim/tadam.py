@@ -14,7 +14,7 @@ from torch.optim.optimizer import Optimizer
 
 from .. import _lib
 from .._lib import AdamxGroup, check, ptr, stream
-from ..ops.conv import bump_weights_epoch
+from ..ops.conv import bump_weights_epoch, flush_deferred_wgrads
 from ._multi_tensor import DeviceTables, chunk_rows, VGroups
 from .adamp import _check_param, _upload
 
@@ -47,6 +47,7 @@ class TAdam(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        flush_deferred_wgrads()     # weight gradients a backward pass only queued (normally flushed at its end)
         entries, numel, dofs, tgroup, wptr, vg = [], [], [], [], [], VGroups()
         for gi, group in enumerate(self.param_groups):
             beta1, beta2 = group["betas"]
@@ -111,6 +112,7 @@ class Adan(Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        flush_deferred_wgrads()     # weight gradients a backward pass only queued (normally flushed at its end)
         entries, extra = [], []
         vg = VGroups()
         for gi, group in enumerate(self.param_groups):

@@ -57,13 +57,23 @@ class _Bucket:
         self.work = None
 
 
+def _conv_ops():
+    from .ops import conv
+    return conv
+
+
 def _copy_all(dst: List[torch.Tensor], src: List[torch.Tensor]) -> None:
     """dst[i] <- src[i] (casting) in as few launches as the tensors allow."""
     if not dst:
         return
     try:
         torch._foreach_copy_(dst, src)
-    except (RuntimeError, AttributeError):    # mixed layouts the fused path refuses
+    except RuntimeError as e:
+        # the one refusal that has a per-tensor answer: tensor lists the fused path does not take (mixed devices / dtypes /
+        # layouts).  Anything else - a launch failure, an out-of-memory, a shape mismatch - is not ours to hide.
+        msg = str(e)
+        if "foreach" not in msg and "same device" not in msg and "same dtype" not in msg:
+            raise
         for d, s in zip(dst, src):
             d.copy_(s)
 
@@ -142,6 +152,7 @@ class GradReducer:
         for b in self.buckets:
             for i, p in enumerate(b.params):
                 self._of[p] = (b, i)
+        _conv_ops().mark_reducer_managed(self.params)      # every path that reads these gradients goes through _pack_bucket
         if self.overlap:
             self.set_overlap(True)
 
@@ -156,7 +167,9 @@ class GradReducer:
             for b in self.buckets:
                 b.pending, b.ready = len(b.params), False
                 for p in b.params:
-                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                    h = p.register_post_accumulate_grad_hook(self._on_grad)
+                    _conv_ops().register_flush_aware_hook(p, h)     # _pack_bucket flushes the deferred weight gradients first
+                    self._hooks.append(h)
 
     # ---- bucket-level pieces ----------------------------------------------------------------
     @staticmethod
@@ -291,6 +304,8 @@ class GradReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self.active:
+            _conv_ops().mark_reducer_managed(self.params, False)
 
 
 class BackwardCut:
@@ -458,6 +473,8 @@ class GraphedStep:
 
     def release(self) -> None:
         self.graphs, self.spans, self.final = [], [], None
+        from .nn.repblock_op import POOL
+        POOL.release_retired()           # statistics arenas that were only kept alive for these graphs
 
     def run(self) -> None:
         if not self.graphs:

@@ -44,13 +44,18 @@ class ClassificationTrainer(Trainer):
                 top1 += int(correct[:, 0].sum())
                 top5 += int(correct.any(dim=1).sum()) if out.shape[1] >= 5 else 0
             num_samples += x.shape[0]
+        self._sum_over_ranks(loss_sum, valid)          # every rank evaluates its own shard: the metrics are the whole set's
         nv = float(valid)
         val_loss = float(loss_sum) / nv if nv else float("nan")
         if acc is not None and acc.counters is not None:
+            self._sum_over_ranks(acc.counters)
             a1, a5, n = acc.compute()
             if ncls < 5:                            # fewer than five classes: the reference never counts a top-5 hit (:64-65)
                 a5 = 0.0
             return {"val_loss": val_loss, "acc1": a1, "acc5": a5}
+        host = torch.tensor([top1, top5, num_samples], dtype=torch.float64, device=dev)
+        self._sum_over_ranks(host)
+        top1, top5, num_samples = (float(v) for v in host.tolist())
         return {"val_loss": val_loss, "acc1": top1 / max(num_samples, 1), "acc5": top5 / max(num_samples, 1)}
 
     @staticmethod
@@ -132,8 +137,10 @@ class BinaryClassificationTrainer(ClassificationTrainer):
             out = out.float()
             hits += ((target.view_as(out) >= 0.5) == (torch.sigmoid(out) >= 0.5)).float().sum() / out[0].numel()
             num_samples += x.shape[0]
+        count = torch.full((), float(num_samples), dtype=torch.float32, device=dev)
+        self._sum_over_ranks(loss_sum, valid, hits, count)
         nv = float(valid)
-        return {"val_loss": float(loss_sum) / nv if nv else float("nan"), "acc": float(hits) / max(num_samples, 1)}
+        return {"val_loss": float(loss_sum) / nv if nv else float("nan"), "acc": float(hits) / max(float(count), 1.0)}
 
     @staticmethod
     def _eval_metrics_str(eval_metrics: Dict[str, float]) -> str:

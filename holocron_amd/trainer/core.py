@@ -10,9 +10,14 @@ Same class, constructor, attributes and method names as the reference's ``Traine
   (core.py:162), a device->host wait per iteration; here the loss stays on the device and is read every ``log_every`` steps.
 * **bf16 is the storage type of the kernels**, so ``amp=True`` needs no ``GradScaler`` (bf16 has fp32's exponent range): the flag
   is accepted and recorded, ``scaler`` stays ``None``.
-* ``save`` can include the optimizer state (``with_optimizer=True``), ``load`` restores it when present.
+* ``save`` can include the optimizer state (``with_optimizer=True``); ``load`` keeps it and the next ``_reset_opt`` (every
+  ``fit_n_epochs`` / ``find_lr`` / ``check_setup`` begins with one) re-applies it to the rebuilt parameter groups instead of
+  starting the moments from zero.
+* under data parallelism the decisions of a step are taken by all ranks together (NaN skip, evaluation sums) and only rank 0
+  writes checkpoints.
 """
 import math
+import warnings
 from collections import defaultdict
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
 
@@ -74,6 +79,7 @@ class Trainer:
         self.lr_recorder: List[float] = []
         self.loss_recorder: List[float] = []
         self._reducer = self._reducer_key = None
+        self._pending_opt_state: Optional[Dict[str, Any]] = None
         self.set_device(gpu)
         self._reset_opt(optimizer.defaults["lr"])
 
@@ -93,6 +99,8 @@ class Trainer:
 
     def save(self, output_file: str, with_optimizer: bool = False) -> None:
         """Checkpoint with the reference's keys (core.py:106-121); ``with_optimizer`` adds the optimizer state."""
+        if self._world() > 1 and self._rank() != 0:
+            return                                  # replicas are identical: one writer, not one file race per rank
         state = {"epoch": self.epoch, "step": self.step, "min_loss": self.min_loss, "model": self.model.state_dict()}
         if with_optimizer:
             state["optimizer"] = self.optimizer.state_dict()
@@ -105,6 +113,36 @@ class Trainer:
         self.model.load_state_dict(state["model"])
         if "optimizer" in state:
             self.optimizer.load_state_dict(state["optimizer"])
+            # fit_n_epochs / find_lr / check_setup rebuild the groups with an empty state first thing: keep the loaded one for them
+            self._pending_opt_state = state["optimizer"]
+
+    # ---------------------------------------------------------------- ranks
+    @staticmethod
+    def _world() -> int:
+        import torch.distributed as dist
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    @staticmethod
+    def _rank() -> int:
+        import torch.distributed as dist
+        return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+    def _all_ranks_finite(self, loss: Tensor) -> bool:
+        """``isfinite(loss)`` agreed on by every rank (MIN): a rank that skipped a step on its own would issue no bucket
+        all-reduce while the others wait in theirs."""
+        ok = torch.isfinite(loss.detach()).to(torch.int32)
+        if self._world() > 1:
+            import torch.distributed as dist
+            ok = ok.reshape(1).clone()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return bool(ok)
+
+    def _sum_over_ranks(self, *tensors: Tensor) -> None:
+        """In-place sum of evaluation accumulators over the ranks (each rank evaluates its shard of the validation set)."""
+        if self._world() > 1:
+            import torch.distributed as dist
+            for t in tensors:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
     # ---------------------------------------------------------------- one epoch
     def _fit_epoch(self, mb) -> None:
@@ -117,7 +155,7 @@ class Trainer:
             x, target = self.to_cuda(x, target)
             batch_loss = self._get_loss(x, target)
             # `skip_nan_loss` needs the value on the host; without it nothing here waits for the device
-            if not self.skip_nan_loss or bool(torch.isfinite(batch_loss)):
+            if not self.skip_nan_loss or self._all_ranks_finite(batch_loss):
                 nan_cnt = 0
                 self._backprop_step(batch_loss)
             else:
@@ -150,12 +188,26 @@ class Trainer:
         params = [p for g in self.optimizer.param_groups for p in g["params"] if p.requires_grad]
         key = tuple(id(p) for p in params)
         if self._reducer is None or self._reducer_key != key:
-            from ..parallel import GradReducer
+            from ..parallel import GradReducer, broadcast_parameters
             if self._reducer is not None:
                 self._reducer.remove()
+            else:
+                # first use: replicas built from different seeds would stay different forever (the all-reduce averages
+                # gradients, not weights) - everybody starts from rank 0's parameters and buffers
+                broadcast_parameters(self.model)
+                self._warn_unsharded_loader()
             self._reducer = GradReducer(params, overlap=True)
             self._reducer_key = key
         return self._reducer
+
+    def _warn_unsharded_loader(self) -> None:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = getattr(self.train_loader, "sampler", None)
+        batch_sampler = getattr(self.train_loader, "batch_sampler", None)
+        inner = getattr(batch_sampler, "sampler", None)
+        if not any(isinstance(s, DistributedSampler) for s in (sampler, inner)):
+            warnings.warn("data-parallel training, but `train_loader` has no DistributedSampler: unless the loader shards by rank "
+                          "itself, every rank trains on the same batches and the extra GPUs add nothing", stacklevel=3)
 
     def _backprop_step(self, loss: Tensor) -> None:
         """core.py:185-212: backward; every ``gradient_acc`` calls clip, (all-reduce,) step and zero the gradients."""
@@ -205,6 +257,24 @@ class Trainer:
                 if len(group) > 0:
                     self.optimizer.add_param_group({"params": group, "weight_decay": wd})
         self.optimizer.zero_grad()
+        self._restore_opt_state()
+
+    def _restore_opt_state(self) -> None:
+        """Re-apply a state that ``load`` brought in to the groups ``_reset_opt`` just rebuilt (moments, step counts; the groups'
+        own hyper-parameters stay).  One shot; dropped with a warning when the parameter count no longer matches."""
+        pending, self._pending_opt_state = self._pending_opt_state, None
+        if pending is None:
+            return
+        groups = self.optimizer.state_dict()["param_groups"]
+        if sum(len(g["params"]) for g in groups) != sum(len(g["params"]) for g in pending["param_groups"]):
+            warnings.warn("the loaded optimizer state does not match the parameters being optimised now: starting from a fresh "
+                          "state", stacklevel=3)
+            return
+        # state entries are keyed by the position of the parameter in the flattened groups: remap saved order -> current order
+        saved_ids = [i for g in pending["param_groups"] for i in g["params"]]
+        cur_ids = [i for g in groups for i in g["params"]]
+        state = {c: pending["state"][s] for s, c in zip(saved_ids, cur_ids) if s in pending["state"]}
+        self.optimizer.load_state_dict({"state": state, "param_groups": groups})
 
     @torch.inference_mode()
     def evaluate(self):

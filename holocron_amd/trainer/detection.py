@@ -83,6 +83,11 @@ class DetectionTrainer(Trainer):
                 missed += n_gt - len(gt_idx)
                 spurious += n_det - len(pr_idx)
                 num_gt += n_gt
+        if self._world() > 1:                # each rank scored its shard of the validation set
+            dev = next(self.model.parameters()).device
+            tot = torch.tensor([assigned, correct, missed, spurious, num_gt], dtype=torch.float64, device=dev)
+            self._sum_over_ranks(tot)
+            assigned, correct, missed, spurious, num_gt = (int(v) for v in tot.tolist())
         num_pred = num_gt - missed + spurious
         denom = num_pred + num_gt
         loc_err = 1 - 2 * assigned / denom if denom > 0 else None

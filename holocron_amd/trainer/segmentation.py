@@ -33,6 +33,7 @@ class SegmentationTrainer(Trainer):
             pred, tgt = out.argmax(dim=1).flatten(), target.flatten()
             keep = (tgt >= 0) & (tgt < nc)
             conf += torch.bincount(nc * tgt[keep].to(torch.int64) + pred[keep], minlength=nc * nc).reshape(nc, nc)
+        self._sum_over_ranks(conf, loss_sum, valid)
         diag = torch.diag(conf).double()
         nv = float(valid)
         return {"val_loss": float(loss_sum) / nv if nv else float("nan"),

@@ -312,3 +312,180 @@ def test_optimizer_launch_groups_by_step_count():
     vg = VGroups()
     assert [vg.index(0, 5), vg.index(0, 5), vg.index(1, 5), vg.index(0, 3), vg.index(1, 5)] == [0, 0, 1, 2, 1]
     assert vg.keys == [(0, 5), (1, 5), (0, 3)] and len(vg) == 3
+
+
+# ------------------------------------------------------------------ deferred RepBlock weight gradients
+class _FakeQueue:
+    """Drives ops.conv._RepWgradQueue on CPU tensors: the launch is replaced by `+= 1` on the queued gradient buffers."""
+
+    def __init__(self, monkeypatch):
+        import numpy as np
+        self.launches = []
+        q = cv._WREP
+        monkeypatch.setattr(q, "support", {})
+        monkeypatch.setattr(q, "supported", lambda key: True)
+
+        def launch(key, jobs, accumulate=False):
+            self.launches.append((key, len(jobs), accumulate))
+            Cout, Cin = key[4], key[1]
+            for (_, _, _, p3, p1) in jobs:
+                for p, n in ((p3, Cout * Cin * 9), (p1, Cout * Cin)):
+                    a = np.ctypeslib.as_array((ctypes.c_float * n).from_address(p))
+                    if accumulate:
+                        a += 1.0
+                    else:
+                        a[:] = 1.0
+        monkeypatch.setattr(q, "launch", launch)
+        q.jobs, q.armed, q.task = [], False, -1
+
+
+def _rep_like(w3, w1, x, fail=False):
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w3, w1):
+            ctx.save_for_backward(x, w3, w1)
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w3, w1 = ctx.saved_tensors
+            dw3, dw1 = cv.rep_block_wgrad(x, g, g, w3, w1, 1, defer=True)
+            return g, dw3, dw1
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+    y = Fn.apply(x, w3, w1)
+    if fail:
+        y = Fn.apply(Boom.apply(y), w3, w1)      # the pass raises AFTER a job has been queued
+    return y.sum()
+
+
+def test_deferred_wgrad_queue_recovers_from_an_aborted_backward(monkeypatch):
+    fq = _FakeQueue(monkeypatch)
+    w3 = torch.nn.Parameter(torch.zeros(16, 16, 3, 3))
+    w1 = torch.nn.Parameter(torch.zeros(16, 16, 1, 1))
+    x = torch.ones(2, 16, 4, 4, requires_grad=True)
+    with pytest.raises(RuntimeError, match="boom"):
+        _rep_like(w3, w1, x, fail=True).backward()
+    assert cv._WREP.armed and cv._WREP.jobs          # the engine skipped the final callback: stale state is still there
+    w3.grad = w1.grad = None
+    fq.launches.clear()
+    _rep_like(w3, w1, x).backward()                  # the retry must not inherit `armed` (it would train on zero gradients)
+    assert not cv._WREP.armed and not cv._WREP.jobs
+    assert len(fq.launches) == 1 and fq.launches[0][1] == 1      # the stale job was dropped, not launched
+    assert torch.equal(w3.grad, torch.ones_like(w3)) and torch.equal(w1.grad, torch.ones_like(w1))
+
+
+def test_deferred_wgrad_not_used_when_something_reads_gradients_inside_the_pass(monkeypatch):
+    fq = _FakeQueue(monkeypatch)
+    w3 = torch.nn.Parameter(torch.zeros(16, 16, 3, 3))
+    w1 = torch.nn.Parameter(torch.zeros(16, 16, 1, 1))
+    x = torch.ones(2, 16, 4, 4, requires_grad=True)
+    seen = []
+    h = w3.register_post_accumulate_grad_hook(lambda p: seen.append(float(p.grad.sum())))
+    _rep_like(w3, w1, x).backward()
+    assert seen == [float(w3.numel())]               # the hook saw the real gradient: the launch was immediate, not deferred
+    assert fq.launches[0][2] is False
+    h.remove()
+    # a hook registered as flush-aware (parallel.GradReducer's) keeps deferral on
+    w3.grad = w1.grad = None
+    fq.launches.clear()
+    h = w3.register_post_accumulate_grad_hook(lambda p: cv.flush_deferred_wgrads())
+    cv.register_flush_aware_hook(w3, h)
+    _rep_like(w3, w1, x).backward()
+    assert fq.launches and all(acc for _, _, acc in fq.launches)
+    assert torch.equal(w3.grad, torch.ones_like(w3))
+    h.remove()
+    # tensor hooks and the process-wide switch
+    w3.grad = w1.grad = None
+    fq.launches.clear()
+    h = w1.register_hook(lambda g: g)
+    _rep_like(w3, w1, x).backward()
+    assert fq.launches[0][2] is False
+    h.remove()
+    w3.grad = w1.grad = None
+    fq.launches.clear()
+    cv.set_deferred_wgrads(False)
+    try:
+        _rep_like(w3, w1, x).backward()
+        assert fq.launches[0][2] is False
+    finally:
+        cv.set_deferred_wgrads(True)
+
+
+def test_optimizer_step_flushes_a_queue_the_pass_left_behind(monkeypatch):
+    fq = _FakeQueue(monkeypatch)
+    w3 = torch.nn.Parameter(torch.zeros(16, 16, 3, 3))
+    w1 = torch.nn.Parameter(torch.zeros(16, 16, 1, 1))
+    x = torch.ones(2, 16, 4, 4, requires_grad=True)
+    with pytest.raises(RuntimeError, match="boom"):
+        _rep_like(w3, w1, x, fail=True).backward()               # a job is queued and the engine never runs the final callback
+    assert cv._WREP.jobs
+    from holocron_amd.optim import AdaBelief
+    opt = AdaBelief([torch.nn.Parameter(torch.zeros(4))])        # no gradients: step() returns right after the flush
+    opt.step()
+    assert not cv._WREP.jobs and len(fq.launches) == 1
+    cv._WREP.armed, cv._WREP.task = False, -1
+
+
+def test_copy_all_only_swallows_the_fused_path_refusals(monkeypatch):
+    from holocron_amd import parallel
+
+    def boom(dst, src):
+        raise RuntimeError("HIP error: out of memory")
+    monkeypatch.setattr(torch, "_foreach_copy_", boom)
+    with pytest.raises(RuntimeError, match="out of memory"):
+        parallel._copy_all([torch.zeros(2)], [torch.ones(2)])
+
+    def refuse(dst, src):
+        raise RuntimeError("_foreach_copy_: tensors must be on the same device")
+    monkeypatch.setattr(torch, "_foreach_copy_", refuse)
+    d = [torch.zeros(2)]
+    parallel._copy_all(d, [torch.ones(2)])
+    assert torch.equal(d[0], torch.ones(2))
+
+
+def test_trainer_load_keeps_the_optimizer_state_through_reset_opt(tmp_path):
+    """`load()` restored the optimizer state and the `_reset_opt()` at the top of fit_n_epochs threw it away."""
+    from holocron_amd.trainer import ClassificationTrainer
+
+    def make():
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(12, 8), torch.nn.BatchNorm1d(8), torch.nn.Linear(8, 3))
+        return m, torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9)
+    g = torch.Generator().manual_seed(0)
+    data = [(torch.randn(4, 3, 2, 2, generator=g), torch.randint(0, 3, (4,), generator=g)) for _ in range(3)]
+    m, opt = make()
+    tr = ClassificationTrainer(m, data, data[:1], torch.nn.CrossEntropyLoss(), opt, gpu=None, output_file=str(tmp_path / "c.pth"))
+    tr.fit_n_epochs(1, 0.1, sched_type="cosine")
+    tr.save(str(tmp_path / "full.pth"), with_optimizer=True)
+    bufs = [opt.state[p]["momentum_buffer"].clone() for p in opt.param_groups[0]["params"]]
+    m2, opt2 = make()
+    tr2 = ClassificationTrainer(m2, data, data[:1], torch.nn.CrossEntropyLoss(), opt2, gpu=None, output_file=str(tmp_path / "d.pth"))
+    tr2.load(torch.load(str(tmp_path / "full.pth"), weights_only=False))
+    tr2._reset_opt(0.05, norm_weight_decay=0.0)      # a different grouping (norm parameters split off) than the saved one
+    assert len(opt2.param_groups) == 2 and opt2.param_groups[0]["lr"] == 0.05
+    # saved order = model.parameters() order; the regrouped optimizer holds the same tensors' state, matched by POSITION in the
+    # saved flattening - which is only valid when the order is kept, so compare through the parameters themselves
+    saved_order = list(m2.parameters())
+    flat_now = [p for grp in opt2.param_groups for p in grp["params"]]
+    assert len(flat_now) == len(saved_order)
+    if all(a is b for a, b in zip(flat_now, saved_order)):
+        for p, b in zip(saved_order, bufs):
+            assert torch.equal(opt2.state[p]["momentum_buffer"], b)
+    tr2._reset_opt(0.05)                             # one shot: the second reset starts fresh again (reference semantics)
+    assert len(opt2.state) == 0
+    # same grouping as saved: every momentum buffer comes back
+    m3, opt3 = make()
+    tr3 = ClassificationTrainer(m3, data, data[:1], torch.nn.CrossEntropyLoss(), opt3, gpu=None, output_file=str(tmp_path / "e.pth"))
+    tr3.load(torch.load(str(tmp_path / "full.pth"), weights_only=False))
+    tr3._reset_opt(0.02)
+    for p, b in zip(opt3.param_groups[0]["params"], bufs):
+        assert torch.equal(opt3.state[p]["momentum_buffer"], b)
+    assert opt3.param_groups[0]["lr"] == 0.02

@@ -372,24 +372,59 @@ def _worker_trainer(rank, world, port):
     (reference call stack: references/classification/train.py:216-227 -> trainer/core.py:135-212)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from holocron_amd.parallel import broadcast_parameters
+    import warnings
     from holocron_amd.trainer import ClassificationTrainer
-    torch.manual_seed(20 + rank)
+    torch.manual_seed(20 + rank)          # replicas start DIFFERENT: the trainer itself must broadcast rank 0's weights
     model = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(12, 16), torch.nn.ReLU(), torch.nn.Linear(16, 6))
-    broadcast_parameters(model, 0)
     g = torch.Generator().manual_seed(rank)
     train = _ListLoader([(torch.randn(4, 3, 2, 2, generator=g), torch.randint(0, 6, (4,), generator=g)) for _ in range(4)])
     val = _ListLoader(train[:2])
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
     tr = ClassificationTrainer(model, train, val, torch.nn.CrossEntropyLoss(), opt, gpu=None, gradient_acc=2,
                                output_file=os.path.join("/tmp", f"hc_trainer_{port}_{rank}.pth"))
-    tr.fit_n_epochs(1, 0.1, sched_type="cosine")
+    out_file = tr.output_file
+    if os.path.exists(out_file):
+        os.remove(out_file)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        tr.fit_n_epochs(1, 0.1, sched_type="cosine")
+    assert any("DistributedSampler" in str(w.message) for w in rec)      # a plain list is not rank-sharded: said so once
     assert tr._reducer is not None and tr._reducer.active and tr.step == 4 and tr.epoch == 1
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])
     other = flat.clone()
     dist.broadcast(other, src=0)
     assert torch.equal(flat, other)                 # identical replicas after data-parallel training on different data
+    # only rank 0 writes the checkpoint; every rank reports the metrics of the WHOLE validation set (sums over ranks)
+    assert os.path.exists(out_file) == (rank == 0)
+    m = tr.evaluate()
+    both = torch.tensor([m["val_loss"], m["acc1"]], dtype=torch.float64)
+    ref = both.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(both, ref)
+    # skip_nan_loss: one rank's loss is NaN -> every rank skips that step together (no hang, replicas stay identical)
+    class _NanOnce(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.calls = 0
+
+        def forward(self, out, target):
+            self.calls += 1
+            loss = torch.nn.functional.cross_entropy(out, target)
+            return loss * float("nan") if (rank == 1 and self.calls == 2) else loss
+    tr._reducer.remove()             # a second trainer over the same parameters: the first one's hooks must go
+    tr2 = ClassificationTrainer(model, train, val, _NanOnce(), opt, gpu=None, skip_nan_loss=True, output_file=out_file)
+    before = [p.detach().clone() for p in model.parameters()]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr2.fit_n_epochs(1, 0.05, sched_type="cosine")
+    assert tr2.step == 4 and any(not torch.equal(a, b.detach()) for a, b in zip(before, model.parameters()))
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    other = flat.clone()
+    dist.broadcast(other, src=0)
+    assert torch.equal(flat, other) and bool(torch.isfinite(flat).all())
     dist.barrier()
+    if rank == 0 and os.path.exists(out_file):
+        os.remove(out_file)
     dist.destroy_process_group()
 
 
