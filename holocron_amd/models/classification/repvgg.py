@@ -156,8 +156,10 @@ class RepVGG(nn.Sequential):
             host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
             cache = (sig, host.to(items[0][0].device), len(items), mx)
             self._hc_pack_table = cache
-        _lib.check(_lib.load().hc_pack_conv_weights_multi(cache[1].data_ptr(), cache[2], cache[3], _lib.stream()),
-                   "hc_pack_conv_weights_multi")
+        from ...ops.conv import profiled
+        with profiled("weight_pack", 0.0, sum(6.0 * w.numel() for (w, *_r) in items)):     # fp32 master read, bf16 image written
+            _lib.check(_lib.load().hc_pack_conv_weights_multi(cache[1].data_ptr(), cache[2], cache[3], _lib.stream()),
+                       "hc_pack_conv_weights_multi")
         for b, w3, w1 in stale:
             b._hc.packed_key = RepState.weights_key(w3, w1)
 

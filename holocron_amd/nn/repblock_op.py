@@ -240,7 +240,8 @@ def _stats_of(x):
         return st
     N, Cc, H, W = x.shape
     st = POOL.take((_lib.stat_replicas(), 2, Cc), x.device)
-    check(_lib.load().hc_channel_stats(ptr(x), ptr(st), N * H * W, Cc, stream()), "hc_channel_stats")
+    with cv.profiled("bn_elementwise", 0.0, N * H * W * Cc * 2.0):
+        check(_lib.load().hc_channel_stats(ptr(x), ptr(st), N * H * W, Cc, stream()), "hc_channel_stats")
     return st
 
 
@@ -351,14 +352,17 @@ class RepBlockFn(torch.autograd.Function):
                 d.stats[2] = ptr(x_stats)
         d.coef, d.save, d.C, d.count = ptr(coef), ptr(save), Cout, N * OH * OW
         d.eps, d.momentum, d.training = st.eps, st.momentum, 1 if st.training else 0
-        check(lib.hc_rep_bn_finalize(C.byref(d), stream()), "hc_rep_bn_finalize")
+        with cv.profiled("bn_finalize", 0.0, 0.0):
+            check(lib.hc_rep_bn_finalize(C.byref(d), stream()), "hc_rep_bn_finalize")
 
         out = cv.empty_cl(N, Cout, OH, OW, dev)
         out_stats = POOL.take((_lib.stat_replicas(), 2, Cout), dev) if (st.emit_stats and st.training) else None
         # backward's reduction target, zeroed with the rest of the arena; re-validated in backward (ZeroPool.claim)
         ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.stat_replicas(), 4, Cout), dev) if st.training else (None, -1)
-        check(lib.hc_rep_apply(ptr(y3), ptr(y1), ptr(src) if st.identity else None, ptr(coef), ptr(out), ptr(out_stats),
-                               N * OH * OW, Cout, 1 if relu else 0, stream()), "hc_rep_apply")
+        tb = N * OH * OW * Cout * 2.0            # bytes of one activation tensor of this block
+        with cv.profiled("bn_elementwise", 0.0, tb * (4 if st.identity else 3)):      # reads y3, y1 [, x], writes out
+            check(lib.hc_rep_apply(ptr(y3), ptr(y1), ptr(src) if st.identity else None, ptr(coef), ptr(out), ptr(out_stats),
+                                   N * OH * OW, Cout, 1 if relu else 0, stream()), "hc_rep_apply")
         ctx.st, ctx.relu, ctx.stem = st, relu, stem
         ctx.geom = (N, Cin, H, W, Cout, OH, OW)
         ctx.was_training = st.training
@@ -381,8 +385,10 @@ class RepBlockFn(torch.autograd.Function):
 
         red = POOL.claim(ctx.red, ctx.red_gen, (_lib.stat_replicas(), 4, Cout), dev)
         ctx.red = None      # a second backward through this node (retain_graph) gets a fresh buffer
-        check(lib.hc_rep_bwd_reduce_z(ptr(g), ptr(coef), act, ptr(y3), ptr(y1), ptr(xid), ptr(red), npix, Cout, stream()),
-              "hc_rep_bwd_reduce_z")
+        tb = npix * Cout * 2.0
+        with cv.profiled("bn_elementwise", 0.0, tb * (4 if st.identity else 3)):      # reads g, y3, y1 [, x]
+            check(lib.hc_rep_bwd_reduce_z(ptr(g), ptr(coef), act, ptr(y3), ptr(y1), ptr(xid), ptr(red), npix, Cout, stream()),
+                  "hc_rep_bwd_reduce_z")
         nb = 3 if st.identity else 2
         dgam = torch.empty((3, Cout), dtype=torch.float32, device=dev)
         dbet = torch.empty((3, Cout), dtype=torch.float32, device=dev)
@@ -397,13 +403,15 @@ class RepBlockFn(torch.autograd.Function):
             d.dbeta[b] = ptr(dbet[b]) if live else None
         d.C, d.count, d.has_identity, d.accumulate = Cout, npix, 1 if st.identity else 0, 0
         d.frozen = 0 if ctx.was_training else 1       # eval mode / freeze_bn: running statistics, dy = a * dz
-        check(lib.hc_rep_bn_bwd_finalize(C.byref(d), stream()), "hc_rep_bn_bwd_finalize")
+        with cv.profiled("bn_finalize", 0.0, 0.0):
+            check(lib.hc_rep_bn_bwd_finalize(C.byref(d), stream()), "hc_rep_bn_bwd_finalize")
 
         dy3 = torch.empty_like(y3)
         dy1 = torch.empty_like(y1)
         dxid = torch.empty_like(src) if st.identity else None
-        check(lib.hc_rep_bwd_apply_z(ptr(g), ptr(coef), act, ptr(y3), ptr(y1), ptr(xid), ptr(bcoef), ptr(dy3), ptr(dy1),
-                                     ptr(dxid), npix, Cout, stream()), "hc_rep_bwd_apply_z")
+        with cv.profiled("bn_elementwise", 0.0, tb * (7 if st.identity else 5)):      # reads g, y3, y1 [, x], writes dy3, dy1 [, dx_id]
+            check(lib.hc_rep_bwd_apply_z(ptr(g), ptr(coef), act, ptr(y3), ptr(y1), ptr(xid), ptr(bcoef), ptr(dy3), ptr(dy1),
+                                         ptr(dxid), npix, Cout, stream()), "hc_rep_bwd_apply_z")
 
         dx = None
         geom = (N, Cin, H, W, Cout)

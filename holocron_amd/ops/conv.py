@@ -123,6 +123,31 @@ def dgrad_desc(N, Cin, H, W, Cout, branches, stride):
 PROFILE = None  # bench.py sets this to a list: (family, algorithmic flops, start event, end event, algorithmic bytes)
 
 
+class profiled:
+    """``with profiled(family, flops, nbytes): <launches>`` - when bench.py's instrumented step is running (``PROFILE`` is a list),
+    brackets the launches with HIP events on the launch stream and books them under ``family`` with their ALGORITHMIC flops and
+    bytes; otherwise free.  Used for the launches the conv wrappers below do not time themselves (BatchNorm / elementwise passes,
+    packing, pooling, optimizer)."""
+
+    __slots__ = ("family", "flops", "nbytes", "e0")
+
+    def __init__(self, family, flops=0.0, nbytes=0.0):
+        self.family, self.flops, self.nbytes, self.e0 = family, flops, nbytes, None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.e0 is not None and PROFILE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE.append((self.family, self.flops, self.e0, e1, self.nbytes))
+        return False
+
+
 def _desc_flops(d):
     macs = 0
     for c in range(d.nclass):
@@ -596,8 +621,9 @@ def im2col_small(x, KH, KW, stride, pad, Kpad):
     if xc.dtype != torch.float32 or not xc.is_contiguous():
         xc = xc.float().contiguous()
     col = empty_cl(N, Kpad, OH, OW, x.device)
-    check(_lib.load().hc_im2col_small(ptr(xc), ptr(col), N, Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad, stream()),
-          "hc_im2col_small")
+    with profiled("stem_im2col", 0.0, xc.numel() * 4.0):     # algorithmically the stem reads its fp32 input once: the column tensor is overhead
+        check(_lib.load().hc_im2col_small(ptr(xc), ptr(col), N, Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad, stream()),
+              "hc_im2col_small")
     return col
 
 

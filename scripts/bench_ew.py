@@ -24,14 +24,14 @@ for (Cc, H) in [(48, 112), (48, 56), (96, 28), (192, 14), (1280, 7)]:
     st = torch.zeros(128, 2, Cc, device="cuda")
     p = lambda x: x.data_ptr()
     us = timeit(lambda: lib.hc_rep_bwd_reduce(p(t[0]), p(t[1]), p(t[2]), p(t[3]), p(t[4]), p(red), npix, Cc, S()))
-    print(f"C={Cc:4d} H={H:3d} tensor {mb:6.1f} MB | bwd_reduce {us:7.1f} us ({5*mb/us/1e3:5.2f} TB/s)", end="")
+    print(f"C={Cc:4d} H={H:3d} tensor {mb:6.1f} MB | bwd_reduce {us:7.1f} us ({5*mb/us:5.2f} TB/s)", end="")
     us = timeit(lambda: lib.hc_rep_bwd_apply(p(t[0]), p(t[1]), p(t[2]), p(t[3]), p(t[4]), p(bc), p(t[5]), p(t[6]), p(t[7]), npix, Cc, S()))
-    print(f" | bwd_apply {us:7.1f} us ({8*mb/us/1e3:5.2f} TB/s)", end="")
+    print(f" | bwd_apply {us:7.1f} us ({8*mb/us:5.2f} TB/s)", end="")
     us = timeit(lambda: lib.hc_rep_bwd_reduce_z(p(t[0]), p(coef), 1, p(t[2]), p(t[3]), p(t[4]), p(red), npix, Cc, S()))
-    print(f" | reduce_z {us:7.1f} us", end="")
+    print(f" | reduce_z {us:7.1f} us ({4*mb/us:5.2f} TB/s)", end="")
     us = timeit(lambda: lib.hc_rep_bwd_apply_z(p(t[0]), p(coef), 1, p(t[2]), p(t[3]), p(t[4]), p(bc), p(t[5]), p(t[6]), p(t[7]), npix, Cc, S()))
-    print(f" | apply_z {us:7.1f} us", end="")
+    print(f" | apply_z {us:7.1f} us ({7*mb/us:5.2f} TB/s)", end="")
     us = timeit(lambda: lib.hc_rep_apply(p(t[0]), p(t[1]), p(t[2]), p(coef), p(t[5]), p(st), npix, Cc, 1, S()))
-    print(f" | apply+stats {us:7.1f} us ({4*mb/us/1e3:5.2f} TB/s)", end="")
+    print(f" | apply+stats {us:7.1f} us ({4*mb/us:5.2f} TB/s)", end="")
     us = timeit(lambda: lib.hc_rep_apply(p(t[0]), p(t[1]), p(t[2]), p(coef), p(t[5]), None, npix, Cc, 1, S()))
-    print(f" | apply {us:7.1f} us ({4*mb/us/1e3:5.2f} TB/s)")
+    print(f" | apply {us:7.1f} us ({4*mb/us:5.2f} TB/s)")

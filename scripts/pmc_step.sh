@@ -12,7 +12,8 @@ python - <<'PY'
 import csv, glob, collections, json
 fam = lambda k: ("conv_gather" if "conv_gather_kernel" in k else "conv_rows" if "conv_rows_kernel" in k else
                  "conv_small" if ("conv_small" in k or "conv_resident" in k) else
-                 "conv_wgrad" if (("wgrad" in k or "wrep_kernel" in k) and "reduce" not in k and "dw3x3" not in k) else None)
+                 "conv_wgrad" if (("wgrad" in k or "wrep_kernel" in k) and "reduce" not in k and "dw3x3" not in k) else
+                 "bn_elementwise" if ("rep_apply_kernel" in k or "rep_bwd_apply" in k or "rep_bwd_reduce" in k or "channel_stats" in k) else None)
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in sorted(glob.glob("gpurun_out/pmc_step/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
@@ -23,7 +24,7 @@ for f in sorted(glob.glob("gpurun_out/pmc_step/**/*counter_collection.csv", recu
         a[0] += float(r["Counter_Value"]); a[1] += 1
 out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline",
        "note": "bytes per launch, averaged over every launch of the family (warm-up + timed steps); read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB"}
-for k in ("conv_gather", "conv_rows", "conv_small", "conv_wgrad"):
+for k in ("conv_gather", "conv_rows", "conv_small", "conv_wgrad", "bn_elementwise"):
     fr, fn = agg.get((k, "FETCH_SIZE"), [0, 0]); wr, wn = agg.get((k, "WRITE_SIZE"), [0, 0])
     if fn and wn:
         out[k] = {"launches_counted": fn, "read_bytes_per_launch": 2 * 1024 * fr / fn, "write_bytes_per_launch": 1024 * wr / wn,

@@ -1,0 +1,461 @@
+"""Full-size parity of everything on the path that is NOT a convolution (VERDICT r2 "next" item 1):
+
+(a) the RepBlock BatchNorm passes IN ISOLATION at batch 256 for the five tensor shapes of repvgg_a0 (BASELINE.json
+    configs[1]): hc_rep_bn_finalize / hc_rep_apply / hc_rep_bwd_reduce_z / hc_rep_bn_bwd_finalize / hc_rep_bwd_apply_z on
+    bf16-representable operands against torch-CPU fp32 ``F.batch_norm`` + autograd of the reference expression
+    ``relu(BN3(y3) + BN1(y1) [+ BN0(x)])`` (repvgg.py:71-73) - NOT against the bf16-emulating oracle;
+(b) the single-branch conv -> BN -> activation passes (hc_bn_act_apply / _bwd_reduce / _bwd_apply) with Mish / SiLU / ReLU6 /
+    LeakyReLU at the YOLOv4 608 x 608 batch-16 and ReXNet batch-256 shapes (models/utils.py:61-84), the squeeze-excite scale
+    passes (rexnet.py:63-66) and SPP / nearest upsampling at 608 x 608 (downsample.py:154-167, yolov4.py:64);
+(c) the fp8 gather-conv at batch 1024 on the repvgg_a2 layer shapes (configs[4]) against fp32 math on the same fp8 values;
+
+Bounds: fp32 outputs (sums, coefficients, parameter gradients) 2e-4; bf16-stored tensors 2e-3 (ONE round-to-nearest-even of an
+fp32 result is 1.65e-3 rel-L2, tests/test_gpu_fullsize_layers.py).  Where the activation has a kink (ReLU at 0, ReLU6 at 0 and 6)
+the elements whose fp32 pre-activation lies within 1e-5 of it are left out of the element-wise comparison: two correct fp32
+evaluations of z = a*y + b disagree about their sign there (counted and bounded: < 1e-4 of the tensor).
+"""
+import ctypes as C
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+N_C2 = int(os.environ.get("HC_FULLSIZE_N", "256"))
+N_C4 = int(os.environ.get("HC_FULLSIZE_N_YOLO", "16"))
+N_C5 = int(os.environ.get("HC_FULLSIZE_N_FP8", "1024"))
+TOL_BF16 = 2e-3
+TOL_F32 = 2e-4
+EPS = 1e-5
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def to_dev(t):
+    """fp32 NCHW host tensor (bf16-representable) -> NHWC bf16 on the GPU."""
+    from holocron_amd.ops import conv as cv
+    return cv.to_cl_bf16(t.cuda())
+
+
+def nchw(t):
+    return t.float().cpu().contiguous()
+
+
+def rel_masked(a, b, keep):
+    a, b = a[keep].double(), b[keep].double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _chan_stats(t, dev):
+    from holocron_amd import _lib
+    from holocron_amd._lib import check, ptr, stream
+    N, Cc, H, W = t.shape
+    st = torch.zeros((_lib.stat_replicas(), 2, Cc), dtype=torch.float32, device=dev)
+    check(_lib.load().hc_channel_stats(ptr(t), ptr(st), N * H * W, Cc, stream()), "hc_channel_stats")
+    return st
+
+
+C2_BN = [(48, 112, True), (48, 56, False), (96, 28, True), (192, 14, True), (1280, 7, True), (1280, 7, False)]
+
+
+@pytest.mark.parametrize("cfg", C2_BN, ids=["%d@%d_id%d" % (c[0], c[1], int(c[2])) for c in C2_BN])
+def test_c2_repblock_bn_passes_vs_fp32_batch_norm(cfg):
+    from holocron_amd import _lib
+    from holocron_amd._lib import RepBnBwdDesc, RepBnDesc, check, ptr, stream
+    from holocron_amd.ops import conv as cv
+    ch, H, ident = cfg
+    N = N_C2
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    g = gen(7000 + ch + H + int(ident))
+    shape = (N, ch, H, H)
+    y3 = bf16r(torch.randn(shape, generator=g) * 1.3 + 0.2)
+    y1 = bf16r(torch.randn(shape, generator=g) * 0.7 - 0.1)
+    x = bf16r(torch.rand(shape, generator=g)) if ident else None
+    up = bf16r(torch.rand(shape, generator=g) + 0.5)        # upstream gradient with a mean: channel sums are well conditioned
+    nb = 3 if ident else 2
+    gam = [torch.rand(ch, generator=g) + 0.5 for _ in range(nb)]
+    bet = [torch.randn(ch, generator=g) * 0.2 for _ in range(nb)]
+    rm0 = [torch.randn(ch, generator=g) * 0.1 for _ in range(nb)]
+    rv0 = [torch.rand(ch, generator=g) + 0.5 for _ in range(nb)]
+
+    # ---------------- HIP: the five launches of a block's BatchNorm work, in isolation
+    srcs = [to_dev(y3), to_dev(y1)] + ([to_dev(x)] if ident else [])
+    stats = [_chan_stats(t, dev) for t in srcs]
+    gam_d, bet_d = [t.to(dev) for t in gam], [t.to(dev) for t in bet]
+    rm_d, rv_d = [t.clone().to(dev) for t in rm0], [t.clone().to(dev) for t in rv0]
+    nbt_d = [torch.zeros((), dtype=torch.int64, device=dev) for _ in range(nb)]
+    coef = torch.empty((4, ch), dtype=torch.float32, device=dev)
+    save = torch.empty((6, ch), dtype=torch.float32, device=dev)
+    npix = N * H * H
+    d = RepBnDesc()
+    for b in range(3):
+        live = b < nb
+        d.gamma[b], d.beta[b] = (ptr(gam_d[b]), ptr(bet_d[b])) if live else (None, None)
+        d.running_mean[b], d.running_var[b] = (ptr(rm_d[b]), ptr(rv_d[b])) if live else (None, None)
+        d.num_batches_tracked[b] = ptr(nbt_d[b]) if live else None
+        d.stats[b] = ptr(stats[b]) if live else None
+    d.coef, d.save, d.C, d.count = ptr(coef), ptr(save), ch, npix
+    d.eps, d.momentum, d.training = EPS, 0.1, 1
+    check(lib.hc_rep_bn_finalize(C.byref(d), stream()), "hc_rep_bn_finalize")
+    out = cv.empty_cl(N, ch, H, H, dev)
+    out_stats = torch.zeros((_lib.stat_replicas(), 2, ch), dtype=torch.float32, device=dev)
+    check(lib.hc_rep_apply(ptr(srcs[0]), ptr(srcs[1]), ptr(srcs[2]) if ident else None, ptr(coef), ptr(out), ptr(out_stats),
+                           npix, ch, 1, stream()), "hc_rep_apply")
+    gd = to_dev(up)
+    red = torch.zeros((_lib.stat_replicas(), 4, ch), dtype=torch.float32, device=dev)
+    xid = srcs[2] if ident else None
+    check(lib.hc_rep_bwd_reduce_z(ptr(gd), ptr(coef), 1, ptr(srcs[0]), ptr(srcs[1]), ptr(xid), ptr(red), npix, ch, stream()),
+          "hc_rep_bwd_reduce_z")
+    dgam = torch.empty((3, ch), dtype=torch.float32, device=dev)
+    dbet = torch.empty((3, ch), dtype=torch.float32, device=dev)
+    bcoef = torch.empty((9, ch), dtype=torch.float32, device=dev)
+    bd = RepBnBwdDesc()
+    bd.red, bd.save, bd.bcoef = ptr(red), ptr(save), ptr(bcoef)
+    for b in range(3):
+        live = b < nb
+        bd.gamma[b] = ptr(gam_d[b]) if live else None
+        bd.dgamma[b] = ptr(dgam[b]) if live else None
+        bd.dbeta[b] = ptr(dbet[b]) if live else None
+    bd.C, bd.count, bd.has_identity, bd.accumulate, bd.frozen = ch, npix, 1 if ident else 0, 0, 0
+    check(lib.hc_rep_bn_bwd_finalize(C.byref(bd), stream()), "hc_rep_bn_bwd_finalize")
+    dy3, dy1 = torch.empty_like(srcs[0]), torch.empty_like(srcs[1])
+    dxid = torch.empty_like(srcs[2]) if ident else None
+    check(lib.hc_rep_bwd_apply_z(ptr(gd), ptr(coef), 1, ptr(srcs[0]), ptr(srcs[1]), ptr(xid), ptr(bcoef), ptr(dy3), ptr(dy1),
+                                 ptr(dxid), npix, ch, stream()), "hc_rep_bwd_apply_z")
+    torch.cuda.synchronize()
+    got_out, got_dy = nchw(out), [nchw(dy3), nchw(dy1)] + ([nchw(dxid)] if ident else [])
+    got_os = out_stats.double().sum(0).cpu()
+    del out, dy3, dy1, dxid, gd, srcs
+
+    # ---------------- reference: torch-CPU fp32, the reference block's expression and autograd
+    ins = [t.clone().requires_grad_(True) for t in ([y3, y1] + ([x] if ident else []))]
+    gp = [t.clone().requires_grad_(True) for t in gam]
+    bp = [t.clone().requires_grad_(True) for t in bet]
+    rm, rv = [t.clone() for t in rm0], [t.clone() for t in rv0]
+    z = sum(F.batch_norm(ins[b], rm[b], rv[b], gp[b], bp[b], True, 0.1, EPS) for b in range(nb))
+    ref_out = torch.relu(z)
+    grads = torch.autograd.grad((ref_out * up).sum(), ins + gp + bp)
+    zd = z.detach()
+    keep = zd.abs() > 1e-5                  # the ReLU's kink: sign of a |z| < 1e-5 pre-activation is not defined to fp32 accuracy
+    frac_out = 1.0 - float(keep.float().mean())
+    assert frac_out < 1e-4, frac_out
+    e_out = rel_masked(got_out, ref_out.detach(), keep)
+    errs = {"out": e_out}
+    for name, got, ref in zip(("dy3", "dy1", "dx_id"), got_dy, grads[:nb]):
+        errs[name] = rel_masked(got, ref, keep)
+    for b in range(nb):
+        errs[f"dgamma{b}"] = rel_l2(dgam[b].cpu(), grads[nb + b])
+        errs[f"dbeta{b}"] = rel_l2(dbet[b].cpu(), grads[2 * nb + b])
+        errs[f"rmean{b}"] = rel_l2(rm_d[b].cpu(), rm[b])
+        errs[f"rvar{b}"] = rel_l2(rv_d[b].cpu(), rv[b])
+        assert int(nbt_d[b].item()) == 1
+    # statistics of `out` for the next block's identity BatchNorm (sum, sum of squares of the STORED bf16 values)
+    ob = got_out.double()
+    errs["out_sum"] = float(((got_os[0] - ob.sum((0, 2, 3))).abs() / torch.sqrt((ob * ob).sum((0, 2, 3)) * npix)).max())
+    errs["out_sumsq"] = rel_l2(got_os[1], (ob * ob).sum((0, 2, 3)))
+    print(cfg, f"(kink-excluded {frac_out:.1e})", ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    for k, v in errs.items():
+        tol = TOL_BF16 if k in ("out", "dy3", "dy1", "dx_id") else TOL_F32
+        assert v < tol, (cfg, k, v, errs)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# act codes of hc_conv_desc: 1 relu, 3 leaky, 4 mish, 5 silu, 6 relu6
+def _act_ref(z, act, slope):
+    if act == 1:
+        return torch.relu(z)
+    if act == 3:
+        return F.leaky_relu(z, slope)
+    if act == 4:
+        return F.mish(z)
+    if act == 5:
+        return F.silu(z)
+    if act == 6:
+        return F.relu6(z)
+    return z
+
+
+# (channels, H, batch, act, residual channels): YOLOv4 @ 608 (Mish) and ReXNet-1.0x (SiLU after the expand conv,
+# ReLU6 after the depthwise conv, linear + partial-width shortcut after the project conv; rexnet.py:97-143)
+BN_ACT = [
+    (32, 608, N_C4, 4, 0), (64, 304, N_C4, 4, 0), (128, 152, N_C4, 4, 128), (256, 76, N_C4, 4, 0), (512, 38, N_C4, 4, 0),
+    (1024, 19, N_C4, 4, 0), (256, 19, N_C4, 3, 0),
+    (96, 112, N_C2, 5, 0), (162, 56, N_C2, 5, 0), (228, 28, N_C2, 6, 0), (432, 14, N_C2, 6, 0), (1044, 7, N_C2, 5, 0),
+    (38, 56, N_C2, 0, 27), (185, 7, N_C2, 0, 174),
+]
+
+
+@pytest.mark.parametrize("cfg", BN_ACT, ids=["%d@%d_n%d_act%d_res%d" % c for c in BN_ACT])
+def test_bn_act_passes_fullsize_vs_fp32(cfg):
+    """hc_rep_bn_finalize (one branch) -> hc_bn_act_apply [+ residual] -> hc_bn_act_bwd_reduce -> hc_rep_bn_bwd_finalize ->
+    hc_bn_act_bwd_apply, channel counts padded to multiples of 16 as nn/mbconv_op.py does (c_valid)."""
+    from holocron_amd import _lib
+    from holocron_amd._lib import RepBnBwdDesc, RepBnDesc, check, ptr, stream
+    from holocron_amd.nn.mbconv_op import ceil16
+    from holocron_amd.ops import conv as cv
+    ch, H, N, act, res_c = cfg
+    slope = 0.1
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    g = gen(8000 + ch + H + act)
+    Cp, Rp = ceil16(ch), ceil16(res_c) if res_c else 0
+    y = bf16r(torch.randn((N, ch, H, H), generator=g) * 1.5 + 0.3)
+    up = bf16r(torch.rand((N, ch, H, H), generator=g) + 0.5)
+    res = bf16r(torch.randn((N, res_c, H, H), generator=g)) if res_c else None
+    gamma, beta = torch.rand(ch, generator=g) + 0.5, torch.randn(ch, generator=g) * 0.3
+
+    def pad(t, cp):
+        if t.shape[1] == cp:
+            return t
+        o = torch.zeros((t.shape[0], cp) + tuple(t.shape[2:]))
+        o[:, :t.shape[1]] = t
+        return o
+    yd, gd = to_dev(pad(y, Cp)), to_dev(pad(up, Cp))
+    rd = to_dev(pad(res, Rp)) if res is not None else None
+    gam_d, bet_d = torch.ones(Cp, device=dev), torch.zeros(Cp, device=dev)
+    gam_d[:ch], bet_d[:ch] = gamma.to(dev), beta.to(dev)
+    rm_d, rv_d = torch.zeros(Cp, device=dev), torch.ones(Cp, device=dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    stats = _chan_stats(yd, dev)
+    coef = torch.empty((4, Cp), dtype=torch.float32, device=dev)
+    save = torch.empty((6, Cp), dtype=torch.float32, device=dev)
+    npix = N * H * H
+    d = RepBnDesc()
+    for b in range(3):
+        d.stats[b] = d.gamma[b] = d.beta[b] = d.running_mean[b] = d.running_var[b] = d.num_batches_tracked[b] = None
+    d.stats[0], d.gamma[0], d.beta[0] = ptr(stats), ptr(gam_d), ptr(bet_d)
+    d.running_mean[0], d.running_var[0], d.num_batches_tracked[0] = ptr(rm_d), ptr(rv_d), ptr(nbt)
+    d.coef, d.save, d.C, d.count, d.eps, d.momentum, d.training = ptr(coef), ptr(save), Cp, npix, EPS, 0.1, 1
+    if Cp != ch:
+        d.c_valid = ch
+    check(lib.hc_rep_bn_finalize(C.byref(d), stream()), "hc_rep_bn_finalize")
+    out = cv.empty_cl(N, Cp, H, H, dev)
+    check(lib.hc_bn_act_apply(ptr(yd), ptr(coef), ptr(rd), Rp, None, None, ptr(out), Cp, npix, Cp, act, slope, stream()),
+          "hc_bn_act_apply")
+    red = torch.zeros((_lib.stat_replicas(), 4, Cp), dtype=torch.float32, device=dev)
+    check(lib.hc_bn_act_bwd_reduce(ptr(gd), Cp, ptr(yd), ptr(coef), None, None, ptr(red), npix, Cp, act, slope, stream()),
+          "hc_bn_act_bwd_reduce")
+    dgam, dbet = torch.empty(Cp, device=dev), torch.empty(Cp, device=dev)
+    bcoef = torch.empty((9, Cp), dtype=torch.float32, device=dev)
+    bd = RepBnBwdDesc()
+    bd.red, bd.save, bd.bcoef = ptr(red), ptr(save), ptr(bcoef)
+    for b in range(3):
+        bd.gamma[b] = bd.dgamma[b] = bd.dbeta[b] = None
+    bd.gamma[0], bd.dgamma[0], bd.dbeta[0] = ptr(gam_d), ptr(dgam), ptr(dbet)
+    bd.C, bd.count, bd.has_identity, bd.accumulate, bd.frozen = Cp, npix, 0, 0, 0
+    if Cp != ch:
+        bd.c_valid = ch
+    check(lib.hc_rep_bn_bwd_finalize(C.byref(bd), stream()), "hc_rep_bn_bwd_finalize")
+    dy = torch.empty_like(yd)
+    check(lib.hc_bn_act_bwd_apply(ptr(gd), Cp, ptr(yd), ptr(coef), ptr(bcoef), None, None, ptr(dy), npix, Cp, act, slope, stream()),
+          "hc_bn_act_bwd_apply")
+    torch.cuda.synchronize()
+    got_out, got_dy = nchw(out), nchw(dy)
+    if Cp != ch:
+        assert float(got_out[:, ch:].abs().max()) == 0.0 and float(got_dy[:, ch:].abs().max()) == 0.0     # layout padding stays zero
+    got_out, got_dy = got_out[:, :ch], got_dy[:, :ch]
+    del out, dy, yd, gd
+
+    yr = y.clone().requires_grad_(True)
+    gp, bp = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.batch_norm(yr, None, None, gp, bp, True, 0.1, EPS)
+    o = _act_ref(z, act, slope)
+    if res is not None:
+        o = torch.cat([o[:, :res_c] + res, o[:, res_c:]], 1)            # out[:, :Cin] += x (rexnet.py:140-141)
+    gy, ggam, gbet = torch.autograd.grad((o * up).sum(), [yr, gp, bp])
+    zd = z.detach()
+    keep = torch.ones_like(zd, dtype=torch.bool)
+    if act in (1, 3, 6):
+        keep &= zd.abs() > 1e-5
+    if act == 6:
+        keep &= (zd - 6.0).abs() > 1e-5
+    assert 1.0 - float(keep.float().mean()) < 1e-4
+    errs = {"out": rel_masked(got_out, o.detach(), keep), "dy": rel_masked(got_dy, gy, keep),
+            "dgamma": rel_l2(dgam[:ch].cpu(), ggam), "dbeta": rel_l2(dbet[:ch].cpu(), gbet)}
+    print(cfg, ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    # the residual form rounds twice (bf16 act(z), then + res in the same fp32 expression: one store) - still one stored rounding
+    assert errs["out"] < TOL_BF16 and errs["dy"] < TOL_BF16, (cfg, errs)
+    assert errs["dgamma"] < TOL_F32 and errs["dbeta"] < TOL_F32, (cfg, errs)
+
+
+SE_SHAPES = [(300, 28), (432, 14), (768, 14), (1044, 7)]
+
+
+@pytest.mark.parametrize("cfg", SE_SHAPES, ids=["se%d@%d" % c for c in SE_SHAPES])
+def test_se_scale_passes_fullsize_vs_fp32(cfg):
+    """out = relu6(z * sigmoid(l)) and its two backward passes (rexnet.py:63-66, 126-129) at batch 256."""
+    from holocron_amd import _lib
+    from holocron_amd._lib import check, ptr, stream
+    from holocron_amd.nn.mbconv_op import ceil16
+    ch, H = cfg
+    N = N_C2
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    g = gen(9000 + ch + H)
+    Cp = ceil16(ch)
+    z = bf16r(torch.randn((N, Cp, H, H), generator=g) * 2 + 1)
+    lg = bf16r(torch.randn((N, Cp), generator=g))
+    up = bf16r(torch.rand((N, Cp, H, H), generator=g) + 0.5)
+    dpool = torch.randn((N, Cp), generator=g)
+    zd_, gd = to_dev(z), to_dev(up)
+    lgd = lg.to(dev).to(torch.bfloat16).contiguous()
+    out = torch.empty_like(zd_)
+    check(lib.hc_se_scale_fwd(ptr(zd_), ptr(lgd), ptr(out), N, H * H, Cp, 6, stream()), "hc_se_scale_fwd")
+    dgate = torch.empty((N, Cp), dtype=torch.float32, device=dev)
+    dl = torch.empty((N, Cp), dtype=torch.bfloat16, device=dev)
+    check(lib.hc_se_scale_bwd_gate(ptr(gd), ptr(zd_), ptr(lgd), ptr(dgate), ptr(dl), N, H * H, Cp, 6, stream()), "hc_se_scale_bwd_gate")
+    dpd = dpool.to(dev).contiguous()
+    dz = torch.empty_like(zd_)
+    check(lib.hc_se_scale_bwd_apply(ptr(gd), ptr(zd_), ptr(lgd), ptr(dpd), ptr(dz), N, H * H, Cp, 6, stream()), "hc_se_scale_bwd_apply")
+    torch.cuda.synchronize()
+    zr = z.clone().requires_grad_(True)
+    lr = lg.clone().requires_grad_(True)
+    s = torch.sigmoid(lr)
+    s.retain_grad()
+    u = zr * s[:, :, None, None]
+    o = F.relu6(u)
+    (o * up).sum().backward()
+    ud = u.detach()
+    keep = (ud.abs() > 1e-5) & ((ud - 6.0).abs() > 1e-5)
+    assert 1.0 - float(keep.float().mean()) < 1e-4
+    dz_ref = zr.grad + (dpool / (H * H))[:, :, None, None]
+    errs = {"out": rel_masked(nchw(out), o.detach(), keep), "dz": rel_masked(nchw(dz), dz_ref, keep),
+            "dgate": rel_l2(dgate.cpu(), s.grad), "dlogits": rel_l2(dl.float().cpu(), lr.grad)}
+    print(cfg, ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert errs["out"] < TOL_BF16 and errs["dz"] < TOL_BF16 and errs["dlogits"] < TOL_BF16, (cfg, errs)
+    assert errs["dgate"] < TOL_F32, (cfg, errs)
+
+
+def test_spp_and_upsample_at_608_vs_torch():
+    """SPP(5, 9, 13) on the 512 x 19 x 19 feature and the two nearest x2 upsamplings of the PAN at 608 x 608, batch 16: bit-equal
+    to torch's max_pool2d / interpolate on the same bf16 values (ties included), gradients exact in fp32."""
+    from holocron_amd.ops import nhwc
+    N = N_C4
+    g = gen(9500)
+    x = bf16r(torch.round(torch.randn((N, 512, 19, 19), generator=g) * 4) / 4)       # coarse values: many ties inside the windows
+    xg = to_dev(x).requires_grad_(True)
+    y = nhwc.spp_cl(xg)
+    up = bf16r(torch.rand((N, 2048, 19, 19), generator=g))
+    y.backward(to_dev(up))
+    torch.cuda.synchronize()
+    xr = x.clone().requires_grad_(True)
+    ref = torch.cat([xr] + [F.max_pool2d(xr, k, 1, k // 2) for k in (5, 9, 13)], 1)
+    ref.backward(up)
+    assert torch.equal(nchw(y.detach()), ref.detach())
+    assert rel_l2(nchw(xg.grad), bf16r(xr.grad)) < 1e-6                              # sums of <= 1 + 25 + 81 + 169 bf16 values, stored once
+    for (ch, H) in ((256, 19), (128, 38)):
+        a = bf16r(torch.randn((N, ch, H, H), generator=g))
+        ag = to_dev(a).requires_grad_(True)
+        o = nhwc.upsample2x_cl(ag)
+        w = bf16r(torch.rand((N, ch, 2 * H, 2 * H), generator=g))
+        o.backward(to_dev(w))
+        torch.cuda.synchronize()
+        ar = a.clone().requires_grad_(True)
+        r = F.interpolate(ar, scale_factor=2, mode="nearest")
+        r.backward(w)
+        assert torch.equal(nchw(o.detach()), r.detach())
+        assert rel_l2(nchw(ag.grad), ar.grad) < TOL_BF16
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (Cin, Cout, H, stride) of the re-parametrised repvgg_a2 at batch 1024
+C5_LAYERS = [(64, 64, 112, 1), (64, 96, 112, 2), (96, 96, 56, 1), (96, 192, 56, 2), (192, 192, 28, 1), (192, 384, 28, 2),
+             (384, 384, 14, 1), (384, 1408, 14, 2), (1408, 1408, 7, 1)]
+
+
+def _fp8r(t):
+    return t.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+
+
+@pytest.mark.parametrize("cfg", C5_LAYERS, ids=["%d-%d@%d_s%d" % c for c in C5_LAYERS])
+def test_c5_fp8_conv_layers_at_batch_1024(cfg):
+    """hc_conv_gather in ch_mult (fp8 e4m3) mode at the launch geometry of BASELINE configs[4] against fp32 math on the SAME fp8
+    operands with the same requantising epilogue; differences allowed: requantisation flips where the fp32 accumulation order
+    moves a value across an fp8 rounding boundary (< 1 % of the elements, one fp8 step each)."""
+    from holocron_amd import _lib
+    from holocron_amd.models.classification.repvgg_fp8 import quantize_weight_fp8
+    from holocron_amd.ops import conv as cv
+    cin, cout, H, stride = cfg
+    N = N_C5
+    g = gen(9700 + cin + cout + H)
+    cin_p, cout_p = (cin + 63) // 64 * 64, (cout + 63) // 64 * 64
+    x = _fp8r(torch.rand((N, cin, H, H), generator=g) * 3)                 # post-ReLU activations, quantised
+    w = torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5
+    bias = torch.randn((cout,), generator=g) * 0.2
+    sx_in, sx_out = 0.02, 0.03
+    sw = w.abs().amax(dim=(1, 2, 3)) / 448
+    wq = _fp8r(w / sw.view(-1, 1, 1, 1))
+    wpk, swp = quantize_weight_fp8(w.cuda(), cin_p, cout_p)
+    xq = torch.zeros((N, H, H, cin_p), dtype=torch.uint8)
+    xq[..., :cin] = x.permute(0, 2, 3, 1).contiguous().to(torch.float8_e4m3fn).view(torch.uint8)
+    xq = xq.cuda()
+    d = cv.fwd_desc(N, cin_p, H, H, cout_p, 3, 3, stride, 1)
+    out = torch.empty((N, d.OH, d.OW, cout_p), dtype=torch.uint8, device="cuda")
+    mult = (swp * (sx_in / sx_out)).contiguous()
+    badd = torch.zeros((cout_p,), device="cuda")
+    badd[:cout] = (bias / sx_out).cuda()
+    d.ch_mult = _lib.ptr(mult)
+    cv.launch_conv(d, xq, wpk, out, bias=badd, act=1)
+    torch.cuda.synchronize()
+    got = out.cpu().view(torch.float8_e4m3fn).float().permute(0, 3, 1, 2)
+    del out, xq
+    acc = F.conv2d(x, wq, None, stride, 1)
+    ref = _fp8r(torch.relu(acc * (sw * sx_in / sx_out).view(1, -1, 1, 1) + (bias / sx_out).view(1, -1, 1, 1)))
+    if cout_p > cout:
+        assert float(got[:, cout:].abs().max()) == 0.0
+    got = got[:, :cout]
+    same = float((got == ref).float().mean())
+    step_ok = float(((got - ref).abs() <= 0.126 * ref.abs().clamp(min=2 ** -6)).float().mean())
+    print(cfg, f"identical {same:.5f}, within one fp8 step {step_ok:.6f}, rel-L2 {rel_l2(got, ref):.2e}")
+    assert same > 0.99, (cfg, same)
+    assert step_ok == 1.0, (cfg, step_ok)
+
+
+def test_c5_fp8_stem_at_batch_1024():
+    """the stem of the fp8 executor (hc_im2col_small_fp8 + a 64-wide fp8 1x1 k-step) at batch 1024 against fp32 math on the same
+    quantised operands."""
+    from holocron_amd import _lib
+    from holocron_amd._lib import check, ptr, stream
+    from holocron_amd.models.classification.repvgg_fp8 import quantize_weight_fp8
+    from holocron_amd.ops import conv as cv
+    N, cout = N_C5, 64
+    g = gen(9800)
+    x = torch.rand((N, 3, 224, 224), generator=g)
+    w = torch.randn((cout, 3, 3, 3), generator=g) * 0.3
+    bias = torch.randn((cout,), generator=g) * 0.2
+    sx_in, sx_out = 1.0 / 448, 0.02
+    lib = _lib.load()
+    xg = x.cuda()
+    col = torch.empty((N, 112, 112, 64), dtype=torch.uint8, device="cuda")
+    check(lib.hc_im2col_small_fp8(ptr(xg), ptr(col), N, 3, 224, 224, 112, 112, 3, 3, 2, 1, 64, 1.0 / sx_in, stream()), "hc_im2col_small_fp8")
+    w2 = w.permute(0, 2, 3, 1).reshape(cout, 27, 1, 1)
+    wpk, swp = quantize_weight_fp8(w2.cuda(), 64, 64)
+    d = cv.fwd_desc(N, 64, 112, 112, 64, 1, 1, 1, 0)
+    out = torch.empty((N, 112, 112, 64), dtype=torch.uint8, device="cuda")
+    mult = (swp * (sx_in / sx_out)).contiguous()
+    badd = (bias / sx_out).cuda().contiguous()
+    d.ch_mult = _lib.ptr(mult)
+    cv.launch_conv(d, col, wpk, out, bias=badd, act=1)
+    torch.cuda.synchronize()
+    got = out.cpu().view(torch.float8_e4m3fn).float().permute(0, 3, 1, 2)
+    del out, col
+    xq = _fp8r(x / sx_in)
+    sw = w.abs().amax(dim=(1, 2, 3)) / 448
+    wq = _fp8r(w / sw.view(-1, 1, 1, 1))
+    acc = F.conv2d(xq, wq, None, 2, 1)
+    ref = _fp8r(torch.relu(acc * (sw * sx_in / sx_out).view(1, -1, 1, 1) + (bias / sx_out).view(1, -1, 1, 1)))
+    same = float((got == ref).float().mean())
+    print(f"fp8 stem: identical {same:.5f}")
+    assert same > 0.99
+    assert float(((got - ref).abs() <= 0.126 * ref.abs().clamp(min=2 ** -6)).float().mean()) == 1.0

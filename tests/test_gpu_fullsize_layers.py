@@ -82,6 +82,23 @@ def test_c2_conv_passes_vs_fp32_cpu(cfg):
     """forward 3x3 + 1x1 (with the statistics epilogue), fused data gradient and both weight gradients of one block shape,
     through the same launch helpers RepBlockFn uses (nn/repblock_op.py: block_convs_forward / block_dgrad / block_wgrad).
     Reference ops: aten::convolution / convolution_backward behind nn.Conv2d (models/utils.py:73, repvgg.py:57-60)."""
+    _c2_conv_passes(cfg)
+
+
+@pytest.mark.parametrize("cfg", C2_BLOCKS, ids=C2_IDS)
+def test_c2_conv_passes_deterministic_mode_vs_fp32_cpu(cfg):
+    """The same passes under ``set_deterministic(True)``: single-writer statistics slots (32768 replicas, per-wave LDS planes in
+    a fixed order instead of `ds_add_f32`) and single-writer split reductions are DIFFERENT code paths in every conv kernel;
+    round 2 only compared them with themselves (bit-identical reruns).  Here: against torch-CPU fp32, same bounds."""
+    import holocron_amd as h
+    h.set_deterministic(True)
+    try:
+        _c2_conv_passes(cfg)
+    finally:
+        h.set_deterministic(False)
+
+
+def _c2_conv_passes(cfg):
     from holocron_amd import _lib
     from holocron_amd.nn import repblock_op as rb
     from holocron_amd.ops import conv as cv
