@@ -25,6 +25,7 @@ SOURCES = {
     "conv_wgrad_rep.hip": [],
     "conv_rows.hip": [],
     "conv_rows48.hip": [],
+    "conv_s2.hip": [],
     "rep_bn.hip": [],
     "optim.hip": [],
     "nhwc_ops.hip": [],

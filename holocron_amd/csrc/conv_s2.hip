@@ -1,0 +1,393 @@
+// Stride-2 RepBlock forward for the HBM-bound front of RepVGG (reference: RepBlock.forward, holocron/models/classification/
+// repvgg.py:57-60,71-73 - a 3x3 / pad 1 and a 1x1 / pad 0 conv of the same input with stride 2, each followed by a training-mode
+// BatchNorm whose batch statistics need per-channel sum / sum of squares of the fp32 conv results):
+//
+//   stem            3 @ 224 x 224 (NCHW fp32, the image batch) -> 48 @ 112 x 112      693 MB of HBM traffic per launch at batch 256
+//   48 @ 112 x 112  -> 48 @ 56 x 56                                                   462 MB
+//   48 @ 56 x 56    -> 96 @ 28 x 28                                                   154 MB
+//
+// All three have 13 - 120 FLOP per byte: the roof is HBM, and what the gather-conv spent on them (an explicit
+// im2col column tensor for the stem - 411 MB written and read back -, 16-channel k-steps with 32-byte gathers, four separate
+// launches) was 2.3 - 3.8 x the algorithmic bytes on the read side.  Here a workgroup owns R output rows of
+// one image:
+//   * the 2R + 1 input rows it needs go into LDS ONCE (LDS DMA for the NHWC bf16 layers; fp32 planes -> bf16 [pixel][4] for the
+//     stem), zero halo through out-of-range DMA offsets;
+//   * the 3x3 and the 1x1 kernel are ONE K stream of 16-byte pieces (9 taps x Cin/8 pieces, then the Cin/8 pieces of the 1x1 at
+//     the centre tap): k32 step s = pieces 4s .. 4s+3, lane group g of v_mfma_f32_16x16x32_bf16 takes piece 4s + g of its pixel.
+//     3x3 rows multiply steps [0, S3), 1x1 rows steps [S1B, S); the step that straddles the boundary is used by both with zero
+//     weights on the other's pieces - 94 % of the issued MACs are real at 48 channels;
+//   * a wave owns 16 (or 32) output channels of BOTH convs and keeps their weights in registers for its whole life (the image of
+//     hc_pack_conv_weight modes 5 / 6 is one coalesced 1 KB load per fragment), pixel fragments are 16-byte LDS reads that are
+//     bank-conflict free at stride 2 because a window slot is an ODD number of 16-byte units (Cin/8 + 1 pad);
+//   * D[co][pixel]: a lane holds 4 consecutive channels of one pixel -> 8-byte stores, the waves of a workgroup fill whole pixels;
+//     BatchNorm sums are running register sums, folded over the 16 pixel lanes by DPP row rotations and flushed once per wave.
+// Several small workgroups per CU (window 16 - 63 KB) overlap one's window wait with the others' stores: no persistent loop.
+#include <cstdlib>
+#include "common.h"
+#include "../../include/holocron_hip.h"
+
+namespace cs2 {
+
+__device__ __forceinline__ float row16_sum(float v) {      // every lane of a DPP row ends up with the row total
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+// XCD-aware unit order: workgroups are dealt to the 8 XCDs round-robin in dispatch order; give XCD k the k-th contiguous run of
+// the (image, row block) list so that the row blocks that share halo rows meet in one L2
+__device__ __forceinline__ int xcd_tile(int L, int T) {
+    const int q = T >> 3, r = T & 7, xcd = L & 7, j = L >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + j;
+}
+
+struct Args {
+    hc_conv_s2_desc d;
+    int reps;
+};
+
+// ------------------------------------------------------------------------------------------------------------------ NHWC bf16 layers
+template <int CIN, int COUT, int WIN, int R, int CTW>
+struct Geo {
+    static constexpr int PT = CIN / 8;                   // 16-byte pieces per tap
+    static constexpr int NP3 = 9 * PT, NP = 10 * PT;     // pieces of the 3x3 part / of the whole K stream
+    static constexpr int S = (NP + 3) / 4;               // k32 steps
+    static constexpr int S3 = (NP3 + 3) / 4;             // steps [0, S3) carry 3x3 pieces
+    static constexpr int S1B = NP3 / 4;                  // steps [S1B, S) carry 1x1 pieces
+    static constexpr int S1 = S - S1B;
+    static constexpr int PSC = PT + 1, PS = PSC * 16;    // window slot: the pixel's channels + one pad chunk
+    static constexpr int WS = WIN + 1;                   // slots per window row: left halo + WIN pixels
+    static constexpr int ROWS = 2 * R + 1;
+    static constexpr int NSLOT = ROWS * WS;
+    static constexpr int NDMA = (NSLOT * PS + 1023) / 1024;
+    static constexpr int WINB = NDMA * 1024;
+    static constexpr int WOUT = WIN / 2, NPIX = R * WOUT, NFRAG = (NPIX + 15) / 16;
+    static constexpr int NW = COUT / (16 * CTW), NT = 64 * NW;
+    static constexpr int SMEM = WINB + 256;              // slack: the discarded columns of a ragged last fragment read past the window
+    static_assert(CIN % 8 == 0 && (PSC & 1) == 1, "a window slot must be an odd number of 16-byte units");
+    static_assert(COUT % (16 * CTW) == 0 && NT <= 1024, "waves");
+    static_assert(NP % 4 == 0, "the K stream must end on a k32 step");
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+};
+
+template <int CIN, int COUT, int WIN, int R, int CTW>
+__global__ __launch_bounds__(64 * (COUT / (16 * CTW))) void s2_fwd_kernel(const Args a) {
+    using G = Geo<CIN, COUT, WIN, R, CTW>;
+    constexpr int PT = G::PT, S = G::S, S3 = G::S3, S1B = G::S1B, S1 = G::S1, PS = G::PS, WS = G::WS, WOUT = G::WOUT;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const hc_conv_s2_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, g = lane >> 4;
+    const int H = d.H, HO = H / 2, RB = HO / R;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int n = tile / RB, r0 = (tile - n * RB) * R;
+    const unsigned lds0 = hc_lds_addr(smem);
+
+    // ---- window DMA: slot (r, x) holds input pixel (2 r0 - 1 + r, x - 1); the pad chunk, the halo and the tail are zero filled
+    {
+        const u32x4 rs = hc_raw_rsrc(d.x, (unsigned)d.N * H * WIN * CIN * 2u);
+        const unsigned img = (unsigned)n * (unsigned)(H * WIN * CIN * 2);
+        for (int j = wid; j < G::NDMA; j += G::NW) {
+            const int J = j * 64 + lane;
+            const int slot = J / G::PSC, c = J - slot * G::PSC;
+            const int r = slot / WS, x = slot - r * WS;
+            const int ih = 2 * r0 - 1 + r;
+            const bool ok = c < PT && slot < G::NSLOT && x >= 1 && ih >= 0;
+            const unsigned off = img + (unsigned)((ih * WIN + x - 1) * CIN * 2 + c * 16);
+            hc_dma16(rs, lds0 + (unsigned)(j * 1024), ok ? off : HC_OOB);
+        }
+    }
+
+    // ---- weights of this wave's channels: registers for the whole kernel.  Image (pack modes 5): [co tile][step][64 lanes][8]
+    const __amdgpu_buffer_rsrc_t rw3 = make_rsrc(d.w3img, (unsigned)(COUT / 16 * S3 * 1024));
+    const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(d.w1img, (unsigned)(COUT / 16 * S1 * 1024));
+    u32x4 a3[CTW][S3], a1[CTW][S1];
+#pragma unroll
+    for (int t = 0; t < CTW; ++t) {
+        const int ct = wid * CTW + t;
+#pragma unroll
+        for (int s = 0; s < S3; ++s) a3[t][s] = buf_load16(rw3, (unsigned)(lane * 16), (unsigned)((ct * S3 + s) * 1024));
+#pragma unroll
+        for (int s = 0; s < S1; ++s) a1[t][s] = buf_load16(rw1, (unsigned)(lane * 16), (unsigned)((ct * S1 + s) * 1024));
+    }
+    // byte offset of piece 4 s + g relative to the window slot of (2 orow, 2 ox): tap (tr, tc) -> ((tr WS) + tc) PS + 16 c
+    int boff[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int q = 4 * s + g;
+        const int tap = q < G::NP3 ? q / PT : 4;
+        const int c = q < G::NP3 ? q - tap * PT : q - G::NP3;
+        boff[s] = ((tap / 3) * WS + tap % 3) * PS + c * 16;
+    }
+
+    float st3[CTW][2][4], st1[CTW][2][4];
+#pragma unroll
+    for (int t = 0; t < CTW; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st3[t][k][e] = st1[t][k][e] = 0.f;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA pieces of this wave (and its weight loads) have landed
+    __syncthreads();                                      // ... everybody's have
+
+    bf16_t* y3 = reinterpret_cast<bf16_t*>(d.y3);
+    bf16_t* y1 = reinterpret_cast<bf16_t*>(d.y1);
+    const size_t obase = ((size_t)n * HO + r0) * WOUT * COUT;
+#pragma unroll 1
+    for (int f = 0; f < G::NFRAG; ++f) {
+        const int p = f * 16 + px;
+        const bool ok = p < G::NPIX;
+        const int pc = ok ? p : G::NPIX - 1;
+        const int orow = pc / WOUT, ox = pc - orow * WOUT;
+        const char* pb = smem + (2 * orow * WS + 2 * ox) * PS;
+        f32x4 acc3[CTW], acc1[CTW];
+#pragma unroll
+        for (int t = 0; t < CTW; ++t) acc3[t] = acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(pb + boff[s]);
+#pragma unroll
+            for (int t = 0; t < CTW; ++t) {
+                if (s < S3) acc3[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][s]), b, acc3[t], 0, 0, 0);
+                if (s >= S1B) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[t][s - S1B]), b, acc1[t], 0, 0, 0);
+            }
+        }
+        // lane (px, g) holds channels 16 ct + 4 g + e of pixel p
+#pragma unroll
+        for (int t = 0; t < CTW; ++t) {
+            const int co = 16 * (wid * CTW + t) + 4 * g;
+            if (d.stats3 != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v3 = ok ? acc3[t][e] : 0.f, v1 = ok ? acc1[t][e] : 0.f;
+                    st3[t][0][e] += v3; st3[t][1][e] += v3 * v3;
+                    st1[t][0][e] += v1; st1[t][1][e] += v1 * v1;
+                }
+            }
+            if (ok) {
+                const size_t o = obase + (size_t)p * COUT + co;
+                *reinterpret_cast<u32x2*>(y3 + o) = u32x2{pack_bf16x2(acc3[t][0], acc3[t][1]), pack_bf16x2(acc3[t][2], acc3[t][3])};
+                *reinterpret_cast<u32x2*>(y1 + o) = u32x2{pack_bf16x2(acc1[t][0], acc1[t][1]), pack_bf16x2(acc1[t][2], acc1[t][3])};
+            }
+        }
+    }
+    // ---- BatchNorm sums: fold the 16 pixel lanes of every group, lane px == e adds channel 4 g + e into this wave's replica slot
+    if (d.stats3 != nullptr) {
+        const size_t slot = (size_t)((blockIdx.x * G::NW + wid) % a.reps) * 2 * COUT;
+#pragma unroll
+        for (int t = 0; t < CTW; ++t) {
+            const int co = 16 * (wid * CTW + t) + 4 * g;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float m3 = 0.f, m1 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s3 = row16_sum(st3[t][k][e]), s1 = row16_sum(st1[t][k][e]);
+                    m3 = px == e ? s3 : m3;
+                    m1 = px == e ? s1 : m1;
+                }
+                if (px < 4) {
+                    atomicAdd(d.stats3 + slot + k * COUT + co + px, m3);
+                    atomicAdd(d.stats1 + slot + k * COUT + co + px, m1);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ stem (3 channels)
+// Window slot = one input pixel as {c0, c1, c2, 0} bf16 (8 bytes); a window row = [left halo | 224 pixels | one zero slot].  A kernel
+// row of the 3x3 is 16 k slots: the three pixels (2 ox - 1 .. 2 ox + 1) x 4 and four slots with zero weights, i.e. two 16-byte
+// reads at byte 16 ox and 16 ox + 16 of the row (aligned, conflict free).  k32 step 0 = kernel rows 0 and 1 (lane groups 0, 1 | 2, 3),
+// step 1 = kernel row 2 (the other half of its K reads row 2 again against zero weights); the 1x1 lives in step 0 (row 1, pixel 2 ox).
+template <int R>
+struct StemGeo {
+    static constexpr int WIN = 224, WOUT = 112, COUT = 48;
+    static constexpr int WSB = (WIN + 2) * 8;            // bytes per window row (226 slots)
+    static constexpr int ROWS = 2 * R + 1;
+    static constexpr int NFRAG = R * (WOUT / 16);
+    static constexpr int NT = 256;
+    static constexpr int SMEM = ROWS * WSB + 64;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void s2_stem_kernel(const Args a) {
+    using G = StemGeo<R>;
+    constexpr int WIN = G::WIN, WOUT = G::WOUT, COUT = G::COUT, WSB = G::WSB;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const hc_conv_s2_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, g = lane >> 4;
+    const int H = d.H, HO = H / 2, RB = HO / R;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int n = tile / RB, r0 = (tile - n * RB) * R;
+
+    // ---- weights: all three 16-channel tiles of both convs (pack mode 6): 3 x (2 + 1) fragments
+    const __amdgpu_buffer_rsrc_t rw3 = make_rsrc(d.w3img, 3u * 2u * 1024u);
+    const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(d.w1img, 3u * 1024u);
+    u32x4 a3[3][2], a1[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        a3[t][0] = buf_load16(rw3, (unsigned)(lane * 16), (unsigned)((t * 2 + 0) * 1024));
+        a3[t][1] = buf_load16(rw3, (unsigned)(lane * 16), (unsigned)((t * 2 + 1) * 1024));
+        a1[t] = buf_load16(rw1, (unsigned)(lane * 16), (unsigned)(t * 1024));
+    }
+
+    // ---- window: fp32 NCHW planes -> bf16 {c0, c1, c2, 0} slots.  One item = 4 consecutive pixels of a row (three float4 loads)
+    {
+        const float* xin = reinterpret_cast<const float*>(d.x) + (size_t)n * 3 * H * WIN;
+        constexpr int IPR = WIN / 4, NITEM = G::ROWS * IPR;
+        constexpr int NIT = (NITEM + G::NT - 1) / G::NT;
+        f32x4 v[NIT][3];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * G::NT + tid;
+            const int r = idx / IPR, c4 = idx - r * IPR;
+            const int ih = 2 * r0 - 1 + r;
+            const bool ok = idx < NITEM && ih >= 0;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+                v[it][ci] = ok ? *reinterpret_cast<const f32x4*>(xin + ((size_t)ci * H + ih) * WIN + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * G::NT + tid;
+            const int r = idx / IPR, c4 = idx - r * IPR;
+            if (idx < NITEM) {
+                char* wp = smem + r * WSB + (1 + 4 * c4) * 8;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<u32x2*>(wp + 8 * k) = u32x2{pack_bf16x2(v[it][0][k], v[it][1][k]), pack_bf16x2(v[it][2][k], 0.f)};
+            }
+        }
+        if (tid < G::ROWS * 2) {                       // left halo slot and the zero slot behind the last pixel
+            const int r = tid >> 1;
+            *reinterpret_cast<u32x2*>(smem + r * WSB + ((tid & 1) ? (WIN + 1) * 8 : 0)) = u32x2{0u, 0u};
+        }
+    }
+    float st3[3][2][4], st1[3][2][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st3[t][k][e] = st1[t][k][e] = 0.f;
+    __syncthreads();
+
+    bf16_t* y3 = reinterpret_cast<bf16_t*>(d.y3);
+    bf16_t* y1 = reinterpret_cast<bf16_t*>(d.y1);
+    const size_t obase = ((size_t)n * HO + r0) * WOUT * COUT;
+#pragma unroll 1
+    for (int f = wid; f < G::NFRAG; f += G::NT / 64) {
+        const int orow = f / (WOUT / 16), ox = (f - orow * (WOUT / 16)) * 16 + px;
+        const char* p0 = smem + (2 * orow + (g >> 1)) * WSB + 16 * ox + 16 * (g & 1);
+        const char* p1 = smem + (2 * orow + 2) * WSB + 16 * ox + 16 * (g & 1);
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(p0);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(p1);
+        const size_t o = obase + ((size_t)orow * WOUT + ox) * COUT + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            f32x4 c3 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][0]), b0, c3, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][1]), b1, c3, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[t]), b0, c1, 0, 0, 0);
+            if (d.stats3 != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st3[t][0][e] += c3[e]; st3[t][1][e] += c3[e] * c3[e];
+                    st1[t][0][e] += c1[e]; st1[t][1][e] += c1[e] * c1[e];
+                }
+            }
+            *reinterpret_cast<u32x2*>(y3 + o + 16 * t) = u32x2{pack_bf16x2(c3[0], c3[1]), pack_bf16x2(c3[2], c3[3])};
+            *reinterpret_cast<u32x2*>(y1 + o + 16 * t) = u32x2{pack_bf16x2(c1[0], c1[1]), pack_bf16x2(c1[2], c1[3])};
+        }
+    }
+    if (d.stats3 != nullptr) {
+        const size_t slot = (size_t)((blockIdx.x * (G::NT / 64) + wid) % a.reps) * 2 * COUT;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float m3 = 0.f, m1 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s3 = row16_sum(st3[t][k][e]), s1 = row16_sum(st1[t][k][e]);
+                    m3 = px == e ? s3 : m3;
+                    m1 = px == e ? s1 : m1;
+                }
+                if (px < 4) {
+                    atomicAdd(d.stats3 + slot + k * COUT + 16 * t + 4 * g + px, m3);
+                    atomicAdd(d.stats1 + slot + k * COUT + 16 * t + 4 * g + px, m1);
+                }
+            }
+    }
+}
+
+template <typename K>
+void set_smem(K kern, int smem) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+}
+
+template <int CIN, int COUT, int WIN, int R, int CTW>
+int launch_layer(const Args& a, hipStream_t st) {
+    using G = Geo<CIN, COUT, WIN, R, CTW>;
+    auto kern = s2_fwd_kernel<CIN, COUT, WIN, R, CTW>;
+    static bool once = false;
+    if (!once) { set_smem(kern, G::SMEM); once = true; }
+    const int grid = a.d.N * (a.d.H / 2 / R);
+    if (a.d.stats3 != nullptr && hc_get_deterministic() && grid * G::NW > a.reps) return HC_ERR_ARG;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::SMEM, st, a);
+    return hc_launch_status();
+}
+
+template <int R>
+int launch_stem(const Args& a, hipStream_t st) {
+    using G = StemGeo<R>;
+    auto kern = s2_stem_kernel<R>;
+    static bool once = false;
+    if (!once) { set_smem(kern, G::SMEM); once = true; }
+    const int grid = a.d.N * (a.d.H / 2 / R);
+    if (a.d.stats3 != nullptr && hc_get_deterministic() && grid * (G::NT / 64) > a.reps) return HC_ERR_ARG;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::SMEM, st, a);
+    return hc_launch_status();
+}
+
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e != nullptr ? atoi(e) : dflt;
+}
+
+}  // namespace cs2
+
+extern "C" int hc_conv_s2_supported(const hc_conv_s2_desc* dp) {
+    static const bool on = cs2::env_int("HC_CONV_S2", 1) != 0;
+    if (!on || dp == nullptr) return 0;
+    const hc_conv_s2_desc& d = *dp;
+    if (d.N < 1 || d.H != d.W) return 0;
+    if ((double)d.N * d.H * d.W * (d.x_nchw_f32 ? 12.0 : d.Cin * 2.0) >= 4294967000.0) return 0;
+    if ((double)d.N * (d.H / 2) * (d.W / 2) * d.Cout * 2.0 >= 4294967000.0) return 0;
+    if (d.x_nchw_f32) return d.Cin == 3 && d.Cout == 48 && d.W == 224 && d.H % 16 == 0;
+    if (d.Cin == 48 && d.Cout == 48 && d.W == 112) return d.H % 8 == 0;
+    if (d.Cin == 48 && d.Cout == 96 && d.W == 56) return d.H % 8 == 0;
+    return 0;
+}
+
+extern "C" int hc_conv_s2_fwd(const hc_conv_s2_desc* dp, hc_stream_t stream) {
+    if (!hc_conv_s2_supported(dp)) return HC_ERR_ARG;
+    const hc_conv_s2_desc& d = *dp;
+    if (d.x == nullptr || d.w3img == nullptr || d.w1img == nullptr || d.y3 == nullptr || d.y1 == nullptr) return HC_ERR_ARG;
+    if ((d.stats3 == nullptr) != (d.stats1 == nullptr)) return HC_ERR_ARG;
+    cs2::Args a;
+    a.d = d;
+    a.reps = hc_get_stat_replicas();
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rsel = cs2::env_int("HC_CONV_S2_R", 0);       // 0 = default rows per workgroup, 1 = the smaller variant (read per call: tests flip it)
+    if (d.x_nchw_f32) return rsel ? cs2::launch_stem<4>(a, st) : cs2::launch_stem<8>(a, st);
+    if (d.Cout == 48) return rsel ? cs2::launch_layer<48, 48, 112, 1, 1>(a, st) : cs2::launch_layer<48, 48, 112, 2, 1>(a, st);
+    return rsel ? cs2::launch_layer<48, 96, 56, 2, 2>(a, st) : cs2::launch_layer<48, 96, 56, 4, 2>(a, st);
+}

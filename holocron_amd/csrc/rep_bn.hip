@@ -637,8 +637,26 @@ __device__ __forceinline__ long rows_image_index(int rc, int kc, int tap, int Cc
     const int j = 8 * g + 4 * hi + e;
     return ((long)(tap * ((Cc + 31) >> 5) + t) * Cc + r) * 32 + j;       // a tap's channels are padded to whole k32 steps (C = 48: two)
 }
+// modes 5 / 6: the fragment images of conv_s2.hip (stride-2 forward), [co / 16][step][64 lanes][8] bf16 - one coalesced 1 KB load per
+// MFMA A fragment, lane = 16 g + (co % 16).
+//   mode 5 (NHWC layers, Cin % 8 == 0): the K stream is 16-byte pieces, piece q = tap0 + tap * (Cin / 8) + ci / 8 (tap0 = 0 for the
+//     3x3 kernel, 9 Cin / 8 for the 1x1); k32 step q / 4 - ld (ld = first step of THIS image), lane group q % 4, element ci % 8.
+//   mode 6 (stem, Cin = 3): a kernel row kh is 16 k slots (slot 4 kw + ci), step kh / 2, lane group 2 (kh % 2) + slot / 8; the 1x1
+//     passes tap0 = 4 (it sits at the centre tap) and has a one-step image.
+// Entries that no source element maps to (the other conv's pieces in a shared step, padding slots) must be zero: allocate zeroed.
+__device__ __forceinline__ long s2_image_index(int mode, int co, int ci, int t, int Cin, int tap0, int T, int ld) {
+    int s, g, e;
+    if (mode == 5) {
+        const int q = tap0 + t * (Cin >> 3) + (ci >> 3);
+        s = (q >> 2) - ld; g = q & 3; e = ci & 7;
+    } else {
+        const int ta = tap0 + t, kh = ta / 3, kw = ta - 3 * kh, slot = 4 * kw + ci;
+        s = (kh >> 1) - ld; g = 2 * (kh & 1) + (slot >> 3); e = slot & 7;
+    }
+    return ((((long)(co >> 4) * T + s) * 64) + g * 16 + (co & 15)) * 8 + e;
+}
 __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ wpk, int Cout, int Cin, int KH, int KW,
-                                   int mode, int tap0, int T) {
+                                   int mode, int tap0, int T, int ld) {
     const long total = (long)Cout * Cin * KH * KW;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int kw = (int)(i % KW);
@@ -657,6 +675,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
             wpk[rows_image_index(co, ci, tap0 + kh * KW + kw, Cout)] = v;
         } else if (mode == 4) {
             wpk[rows_image_index(ci, co, tap0 + (KH - 1 - kh) * KW + (KW - 1 - kw), Cout)] = v;
+        } else if (mode >= 5) {
+            wpk[s2_image_index(mode, co, ci, kh * KW + kw, Cin, tap0, T, ld)] = v;
         } else {
             wpk[(long)co * T + tap0 + (kh * KW + kw) * Cin + ci] = v;
         }
@@ -749,7 +769,8 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const hc_pack_it
                 const int ci = (int)(r % it.Cin), co = (int)(r / it.Cin);
                 const bf16_t v = f32_to_bf16(it.w[o]);
                 if (it.mode == 3) wpk[rows_image_index(co, ci, it.tap0 + t, it.Cout)] = v;
-                else wpk[rows_image_index(ci, co, it.tap0 + KK - 1 - t, it.Cout)] = v;
+                else if (it.mode == 4) wpk[rows_image_index(ci, co, it.tap0 + KK - 1 - t, it.Cout)] = v;
+                else wpk[s2_image_index(it.mode, co, ci, t, it.Cin, it.tap0, it.T, it.ld)] = v;
             }
         } else if (it.mode == 2 || KK > PK_MAXKK) {  // im2col order / large kernels: element-wise walk
             for (long o = o0 + threadIdx.x; o < o1; o += 256) {
@@ -1096,11 +1117,11 @@ int hc_nhwc_bf16_to_nchw(const void* x, float* y, int32_t N, int32_t C, int32_t 
 }
 int hc_pack_conv_weight(const float* w, void* wpk, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t mode, int32_t tap0,
                         int32_t T, hc_stream_t stream) {
-    if (w == nullptr || wpk == nullptr || mode < 0 || mode > 4) return HC_ERR_ARG;
+    if (w == nullptr || wpk == nullptr || mode < 0 || mode > 4) return HC_ERR_ARG;     // modes 5 / 6 need `ld`: hc_pack_conv_weights_multi
     if (mode >= 3 && (Cout != Cin || Cout % 48 != 0)) return HC_ERR_ARG;
     const long total = (long)Cout * Cin * KH * KW;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wpk, Cout, Cin, KH,
-                       KW, mode, tap0, T);
+                       KW, mode, tap0, T, 0);
     return hc_launch_status();
 }
 int hc_pack_conv_weights_multi(const hc_pack_item* items, int32_t nitems, int64_t max_elems, hc_stream_t stream) {

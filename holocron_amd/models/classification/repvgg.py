@@ -148,11 +148,9 @@ class RepVGG(nn.Sequential):
         sig = tuple((w.data_ptr(), dst.data_ptr()) for (w, dst, *_r) in items)
         cache = getattr(self, "_hc_pack_table", None)
         if cache is None or cache[0] != sig:
+            from ...nn.repblock_op import fill_pack_items
             arr = (_lib.PackItem * len(items))()
-            mx = 0
-            for a, (w, dst, Cout, Cin, KH, KW, mode, tap0, T) in zip(arr, items):
-                a.w, a.dst, a.Cout, a.Cin, a.KH, a.KW, a.mode, a.tap0, a.T = w.data_ptr(), dst.data_ptr(), Cout, Cin, KH, KW, mode, tap0, T
-                mx = max(mx, w.numel())
+            mx = fill_pack_items(arr, items)
             host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
             cache = (sig, host.to(items[0][0].device), len(items), mx)
             self._hc_pack_table = cache

@@ -19,7 +19,7 @@ import os
 import torch
 
 from .. import _lib
-from .._lib import RepBnBwdDesc, RepBnDesc, check, ptr, stream
+from .._lib import ConvS2Desc, PackItem, RepBnBwdDesc, RepBnDesc, check, ptr, stream
 from ..ops import conv as cv
 
 STEM_KPAD = 32
@@ -114,6 +114,29 @@ POOL = ZeroPool()
 _lib.on_replicas_changed(POOL.reset)
 
 
+def fill_pack_items(arr, items):
+    """items: (w, dst, Cout, Cin, KH, KW, mode, tap0, T[, ld]) tuples -> hc_pack_item array; returns the largest source size."""
+    mx = 0
+    for a, it in zip(arr, items):
+        w, dst, Cout, Cin, KH, KW, mode, tap0, T = it[:9]
+        a.w, a.dst, a.Cout, a.Cin, a.KH, a.KW, a.mode, a.tap0, a.T = w.data_ptr(), dst.data_ptr(), Cout, Cin, KH, KW, mode, tap0, T
+        a.ld = it[9] if len(it) > 9 else 0
+        mx = max(mx, w.numel())
+    return mx
+
+
+def launch_pack_items(items):
+    """One hc_pack_conv_weights_multi launch for a (small) item list: the path of a block whose images went stale on their own
+    (first call, geometry change); the models pack all their blocks in one launch per step instead."""
+    if not items:
+        return
+    import numpy as np
+    arr = (PackItem * len(items))()
+    mx = fill_pack_items(arr, items)
+    table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(items[0][0].device)
+    check(_lib.load().hc_pack_conv_weights_multi(table.data_ptr(), len(items), mx, stream()), "hc_pack_conv_weights_multi")
+
+
 class RepState:
     """Per-module host state: packed-weight caches, geometry descriptors, BN buffers."""
 
@@ -133,6 +156,8 @@ class RepState:
         self.packed_key = None
         self.rows_image = (False, False)   # set by descs(): (forward, data gradient) run on a row-unit kernel, which reads its own weight image
         self.stack_fwd = False      # set by pack_items(): 3x3 + 1x1 forward as ONE gather-conv over stacked weight rows
+        self.s2 = False             # set by descs(): the forward runs on the stride-2 row kernel (csrc/conv_s2.hip), which reads its own
+        self.s2_images = None       # fragment images (hc_pack_conv_weights_multi modes 5 / 6): (3x3, 1x1)
 
     # ---- packed weights (persistent buffers; refreshed by one multi-tensor launch per model) ----
     @staticmethod
@@ -144,6 +169,8 @@ class RepState:
         Cout, Cin = w3.shape[0], w3.shape[1]
         dev = w3.device
         stem = (Cin % 16) != 0
+        if self.s2:
+            return self._pack_items_s2(w3, w1, Cout, Cin, dev, stem)
         # small-channel stride-2 blocks and the stem read their input twice (3x3, then 1x1) in HBM-bound launches: stack the two
         # kernels as 2 * Cout weight rows (the 1x1 at the centre tap resp. at its im2col columns) and gather the input once
         self.stack_fwd = (stem or (self.stride == 2 and Cin <= 48)) and Cout % 4 == 0 and os.environ.get("HC_STACK_FWD", "1") != "0"
@@ -182,13 +209,33 @@ class RepState:
         return [(w3, wp3, Cout, Cin, 3, 3, 0, 0, 9), (w1, wp1, Cout, Cin, 1, 1, 0, 0, 1),
                 (w3, wpd, Cout, Cin, 3, 3, 1, 0, 10), (w1, wpd, Cout, Cin, 1, 1, 1, 9, 10)]
 
+    def _pack_items_s2(self, w3, w1, Cout, Cin, dev, stem):
+        """Stride-2 row kernel: fragment images [Cout / 16][steps][64][8] of both kernels (zero where the K stream carries the other
+        kernel's pieces) + the usual data-gradient image (the data gradient still runs on the gather-conv)."""
+        if stem:
+            s3, s1, s1b, mode, tap1 = 2, 1, 0, 6, 4
+        else:
+            pt = Cin // 8
+            s3, s1b, mode, tap1 = (9 * pt + 3) // 4, (9 * pt) // 4, 5, 9 * pt
+            s1 = (10 * pt + 3) // 4 - s1b
+        if self.s2_images is None or self.s2_images[0].device != dev:
+            self.s2_images = (torch.zeros((Cout // 16, s3, 64, 8), dtype=torch.bfloat16, device=dev),
+                              torch.zeros((Cout // 16, s1, 64, 8), dtype=torch.bfloat16, device=dev))
+            self.packed_key = None
+        if self.packed is None or (self.packed[2] is not None and self.packed[2].device != dev):
+            self.packed = (None, None, None if stem else torch.empty((Cin, 10, Cout), dtype=torch.bfloat16, device=dev))
+            self.packed_key = None
+        i3, i1 = self.s2_images
+        items = [(w3, i3, Cout, Cin, 3, 3, mode, 0, s3, 0), (w1, i1, Cout, Cin, 1, 1, mode, tap1, s1, s1b)]
+        if not stem:
+            wpd = self.packed[2]
+            items += [(w3, wpd, Cout, Cin, 3, 3, 1, 0, 10), (w1, wpd, Cout, Cin, 1, 1, 1, 9, 10)]
+        return items
+
     def ensure_packed(self, w3, w1):
         key = self.weights_key(w3, w1)
         if self.packed_key != key or self.packed is None:
-            lib = _lib.load()
-            for (w, dst, Cout, Cin, KH, KW, mode, tap0, T) in self.pack_items(w3, w1):
-                check(lib.hc_pack_conv_weight(ptr(w.detach()), ptr(dst), Cout, Cin, KH, KW, mode, tap0, T, stream()),
-                      "hc_pack_conv_weight")
+            launch_pack_items(self.pack_items(w3, w1))
             self.packed_key = key
         return self.packed
 
@@ -227,11 +274,23 @@ class RepState:
                     sf = cv.conv_small_desc(N, H, W, Cin, Cout, 0)
                 if sd is None:
                     sd = cv.conv_small_desc(N, H, W, Cout, Cin, 1)
-            self.desc[key] = (f3, f1, dg, sf, sd, rows)
+            s2d = None
+            if s == 2:
+                c = ConvS2Desc()
+                c.N, c.H, c.W, c.Cin, c.Cout, c.x_nchw_f32 = N, H, W, Cin, Cout, 1 if Cin % 16 else 0
+                if _lib.load().hc_conv_s2_supported(C.byref(c)):
+                    s2d = c
+            self.desc[key] = (f3, f1, dg, sf, sd, rows, s2d)
         rows = self.desc[key][5]
-        if rows != self.rows_image:    # this geometry reads the other weight-image format: drop the images, ensure_packed() rebuilds
-            self.rows_image, self.packed, self.packed_key = rows, None, None
+        s2 = self.desc[key][6] is not None
+        if rows != self.rows_image or s2 != self.s2:    # this geometry reads other weight images: drop them, ensure_packed() rebuilds
+            self.rows_image, self.s2, self.packed, self.packed_key = rows, s2, None, None
         return self.desc[key][:5]
+
+    def s2_desc(self, N, Cin, H, W, Cout):
+        """hc_conv_s2_desc of this geometry when the stride-2 row kernel takes its forward, else None."""
+        self.descs(N, Cin, H, W, Cout)
+        return self.desc[(N, Cin, H, W, Cout)][6]
 
 
 def _stats_of(x):
@@ -257,6 +316,20 @@ def block_convs_forward(st, src, w3, w1, geom, stats=None, stem_cin=None):
     wp3, wp1, _ = st.ensure_packed(w3, w1)
     y3 = cv.empty_cl(N, Cout, OH, OW, dev)
     y1 = cv.empty_cl(N, Cout, OH, OW, dev)
+    s2d = st.s2_desc(N, Cin, H, W, Cout)
+    if s2d is not None:
+        # stride-2 row kernel: `src` is the block input itself (the fp32 image batch for the stem - no column tensor)
+        if s2d.x_nchw_f32 and (src.dtype != torch.float32 or not src.is_contiguous() or tuple(src.shape) != (N, Cin, H, W)):
+            raise _lib.HipError("stride-2 stem kernel expects the contiguous NCHW fp32 image batch")
+        i3, i1 = st.s2_images
+        s2d.x, s2d.w3img, s2d.w1img, s2d.y3, s2d.y1 = ptr(src), ptr(i3), ptr(i1), ptr(y3), ptr(y1)
+        s2d.stats3 = None if stats is None else ptr(stats[0])
+        s2d.stats1 = None if stats is None else ptr(stats[1])
+        flops = 2.0 * N * OH * OW * Cout * 10 * Cin
+        nbytes = src.numel() * src.element_size() + 2 * y3.numel() * 2.0
+        with cv.profiled("conv_s2", flops, nbytes):
+            check(_lib.load().hc_conv_s2_fwd(C.byref(s2d), stream()), "hc_conv_s2_fwd")
+        return y3, y1
     fl3 = fl1 = None
     if stem_cin is not None:  # algorithmic flops of the real 3x3 / 1x1 convs, not of the padded im2col GEMM
         fl3, fl1 = 2.0 * N * OH * OW * Cout * 9 * stem_cin, 2.0 * N * OH * OW * Cout * stem_cin
@@ -320,10 +393,17 @@ class RepBlockFn(torch.autograd.Function):
         f3, f1, _, sf, _ = st.descs(N, Cin, H, W, Cout)
         OH, OW = (f3.OH, f3.OW)
         x_stats = None
+        stem_direct = False
         if stem:
             if st.identity:
                 raise NotImplementedError("identity branch with Cin % 16 != 0")
-            src = cv.im2col_small(x, 3, 3, st.stride, 1, STEM_KPAD)
+            stem_direct = st.s2_desc(N, Cin, H, W, Cout) is not None
+            if stem_direct:       # the stride-2 row kernel reads the image batch itself; the column tensor is built in backward
+                src = x.detach()
+                if src.dtype != torch.float32 or not src.is_contiguous():
+                    src = src.float().contiguous()
+            else:
+                src = cv.im2col_small(x, 3, 3, st.stride, 1, STEM_KPAD)
         else:
             src = cv.to_cl_bf16(x)
             if st.identity and st.training:
@@ -363,7 +443,7 @@ class RepBlockFn(torch.autograd.Function):
         with cv.profiled("bn_elementwise", 0.0, tb * (4 if st.identity else 3)):      # reads y3, y1 [, x], writes out
             check(lib.hc_rep_apply(ptr(y3), ptr(y1), ptr(src) if st.identity else None, ptr(coef), ptr(out), ptr(out_stats),
                                    N * OH * OW, Cout, 1 if relu else 0, stream()), "hc_rep_apply")
-        ctx.st, ctx.relu, ctx.stem = st, relu, stem
+        ctx.st, ctx.relu, ctx.stem, ctx.stem_direct = st, relu, stem, stem_direct
         ctx.geom = (N, Cin, H, W, Cout, OH, OW)
         ctx.was_training = st.training
         # `out` is not kept for the backward: its ReLU mask is recomputed from (y3, y1, src, coef) by the *_z kernels
@@ -420,6 +500,8 @@ class RepBlockFn(torch.autograd.Function):
                 raise NotImplementedError("input gradient of the im2col stem path")
             dx = block_dgrad(st, dy3, dy1, dxid, w3, w1, geom)
 
+        if ctx.stem_direct:       # the weight gradient of the stem is still a GEMM over the im2col column tensor
+            src = cv.im2col_small(src, 3, 3, st.stride, 1, STEM_KPAD)
         with cv.side_stream_for_wgrad((w3, w1), (src, dy3, dy1)) as side:
             dw3, dw1 = block_wgrad(st, src, dy3, dy1, w3, w1, geom, Cin if ctx.stem else None, defer=True)
             side.produced(dw3, dw1)

@@ -113,6 +113,27 @@ typedef struct {
 int hc_conv_small(const hc_conv_small_desc* d, hc_stream_t stream);
 int hc_conv_small_supported(const hc_conv_small_desc* d);
 
+/* Stride-2 RepBlock forward of the HBM-bound front layers (csrc/conv_s2.hip): y3 = conv3x3(x, stride 2, pad 1),
+ * y1 = conv1x1(x, stride 2) and the per-channel sum / sum of squares of both fp32 results - the two nn.Conv2d of a stride-2
+ * RepBlock (holocron/models/classification/repvgg.py:57-60) and the batch statistics of the nn.BatchNorm2d behind each
+ * (models/utils.py:76) - in ONE launch that reads the input once.  Replaces aten::convolution x 2 (+ the explicit im2col of the
+ * 3-channel stem).  x: NHWC bf16 [N][H][W][Cin], or with x_nchw_f32 the image batch itself, NCHW fp32 [N][3][H][W];
+ * w3img / w1img: the fragment images of hc_pack_conv_weights_multi modes 5 (6 for the stem); y3 / y1: NHWC bf16
+ * [N][H/2][W/2][Cout]; stats3 / stats1: [replicas][2][Cout] accumulators (+=) or both NULL.
+ * hc_conv_s2_supported: 1 for the shapes the kernel is built for (3 -> 48 @ 224, 48 -> 48 @ 112, 48 -> 96 @ 56), else 0. */
+typedef struct {
+    const void* x;
+    const void* w3img;
+    const void* w1img;
+    void* y3;
+    void* y1;
+    float* stats3;
+    float* stats1;
+    int32_t N, H, W, Cin, Cout, x_nchw_f32;
+} hc_conv_s2_desc;
+int hc_conv_s2_supported(const hc_conv_s2_desc* d);
+int hc_conv_s2_fwd(const hc_conv_s2_desc* d, hc_stream_t stream);
+
 /* Weight gradient dW[co][ci][kh][kw] = sum_m dy[m][co] * x[m + tap][ci].
  * Replaces aten::convolution_backward(weight).  Split-K over output pixels: partial fp32
  * slabs go to `ws` (at least hc_conv_wgrad_ws_bytes bytes), then a reduce kernel writes
@@ -167,7 +188,10 @@ typedef struct {
     const float* w;
     void* dst;
     int32_t Cout, Cin, KH, KW, mode, tap0, T;
-    int32_t ld; /* elements per packed row when the destination is channel padded (mode 0: >= Cin, mode 1: >= Cout); 0 = dense */
+    int32_t ld; /* elements per packed row when the destination is channel padded (mode 0: >= Cin, mode 1: >= Cout); 0 = dense.
+                 * modes 5 / 6 (fragment images of hc_conv_s2_fwd, bf16 [Cout/16][T steps][64][8], zero-initialised by the caller):
+                 * ld = first k32 step of this image, tap0 = first 16-byte piece (mode 5) / first tap (mode 6) - csrc/rep_bn.hip
+                 * s2_image_index */
 } hc_pack_item;
 int hc_pack_conv_weights_multi(const hc_pack_item* items, int32_t nitems, int64_t max_elems, hc_stream_t stream);
 

@@ -2,7 +2,8 @@
 # MFMA utilisation per kernel over the headline training step (eager launches so that every dispatch is counted): one PMC pass,
 # --kernel-trace only (no other trace domain: MI355X_MICROARCH.md / gpurun rule).  SQ_VALU_MFMA_BUSY_CYCLES counts cycles the
 # matrix pipe of a SIMD is busy (summed over SIMDs), GRBM_GUI_ACTIVE the cycles the kernel was on the chip:
-#     mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)       (the gfx94x MfmaUtil formula, counter_defs.yaml)
+#     mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)   (the gfx94x MfmaUtil formula, counter_defs.yaml; rocprofv3
+#     reports GRBM_GUI_ACTIVE summed over the 8 XCDs on gfx950: GUI_ACTIVE / dispatch time came out at 19 GHz = 8 x 2.4 in the first run)
 # SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512 = executed bf16 MFMA flops (padding included) -> executed TFLOP/s over the dispatch time.
 # Writes gpurun_out/pmc_mfma/mfma_util.txt (copy to profiles/).
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -28,7 +29,7 @@ for (_, name), d in rows.items():
         a[c] += v
 with open(O + "/mfma_util.txt", "w") as fh:
     fh.write(f"# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY -- {cmd}\n")
-    fh.write("# mfma_util = MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs); exec_TF = MOPS_BF16 * 512 / time (padding included); profiled clocks run ~5 % low\n")
+    fh.write("# mfma_util = MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); exec_TF = MOPS_BF16 * 512 / time (padding included); eff_GHz = GUI_ACTIVE / 8 / time\n")
     fh.write(f"{'kernel':<92} {'calls':>6} {'total_ms':>9} {'avg_us':>8} {'mfma_util':>9} {'exec_TF/s':>9} {'eff_GHz':>7}\n")
     tot_ns = tot_busy = tot_act = tot_mops = 0.0
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ns"]):
@@ -36,8 +37,8 @@ with open(O + "/mfma_util.txt", "w") as fh:
         busy, mops = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), a.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)
         tot_ns += ns; tot_busy += busy; tot_act += act; tot_mops += mops
         if a["n"] and ns > 0 and (busy > 0 or ns > 2e5):
-            util = busy / (act * 1024) if act else 0.0
-            fh.write(f"{k:<92} {int(a['n']):>6} {ns / 1e6:>9.3f} {ns / a['n'] / 1e3:>8.1f} {100 * util:>8.1f}% {mops * 512 / ns / 1e3:>9.1f} {act / ns if ns else 0:>7.2f}\n")
-    fh.write(f"{'ALL KERNELS':<92} {'':>6} {tot_ns / 1e6:>9.3f} {'':>8} {100 * tot_busy / (tot_act * 1024) if tot_act else 0:>8.1f}% {tot_mops * 512 / tot_ns / 1e3 if tot_ns else 0:>9.1f}\n")
+            util = busy / (act / 8 * 1024) if act else 0.0
+            fh.write(f"{k:<92} {int(a['n']):>6} {ns / 1e6:>9.3f} {ns / a['n'] / 1e3:>8.1f} {100 * util:>8.1f}% {mops * 512 / ns / 1e3:>9.1f} {act / 8 / ns if ns else 0:>7.2f}\n")
+    fh.write(f"{'ALL KERNELS':<92} {'':>6} {tot_ns / 1e6:>9.3f} {'':>8} {100 * tot_busy / (tot_act / 8 * 1024) if tot_act else 0:>8.1f}% {tot_mops * 512 / tot_ns / 1e3 if tot_ns else 0:>9.1f}\n")
 print(open(O + "/mfma_util.txt").read()[:6000])
 PY

@@ -434,7 +434,7 @@ def test_c5_fp8_stem_at_batch_1024():
     x = torch.rand((N, 3, 224, 224), generator=g)
     w = torch.randn((cout, 3, 3, 3), generator=g) * 0.3
     bias = torch.randn((cout,), generator=g) * 0.2
-    sx_in, sx_out = 1.0 / 448, 0.02
+    sx_in, sx_out = 2.0 ** -9, 0.02          # a power of two: x / sx_in on the host and x * (1 / sx_in) in the kernel are the same fp32 value
     lib = _lib.load()
     xg = x.cuda()
     col = torch.empty((N, 112, 112, 64), dtype=torch.uint8, device="cuda")

@@ -116,7 +116,9 @@ def _c2_conv_passes(cfg):
     w3g, w1g = w3.to(dev), w1.to(dev)
     geom = (N, cin, H, H, cout)
     stats = torch.zeros((2, _lib.stat_replicas(), 2, cout), device=dev)
-    y3, y1 = rb.block_convs_forward(st, src, w3g, w1g, geom, stats, cin if stem else None)
+    # the stem's forward reads the image batch itself when the stride-2 row kernel takes it (no column tensor; csrc/conv_s2.hip)
+    fsrc = xg if (stem and st.s2_desc(*geom) is not None) else src
+    y3, y1 = rb.block_convs_forward(st, fsrc, w3g, w1g, geom, stats, cin if stem else None)
     torch.cuda.synchronize()
 
     c3 = F.conv2d(x, w3, None, stride, 1)
