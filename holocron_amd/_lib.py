@@ -67,6 +67,11 @@ class ConvS2Desc(C.Structure):
                 ("Cout", c_int32), ("x_nchw_f32", c_int32)]
 
 
+class ConvS2DgradDesc(C.Structure):
+    _fields_ = [("dy3", c_void_p), ("dy1", c_void_p), ("wimg", c_void_p), ("dx", c_void_p),
+                ("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32)]
+
+
 class RepBnDesc(C.Structure):
     _fields_ = [("stats", c_void_p * 3), ("gamma", c_void_p * 3), ("beta", c_void_p * 3),
                 ("running_mean", c_void_p * 3), ("running_var", c_void_p * 3), ("num_batches_tracked", c_void_p * 3),
@@ -164,6 +169,8 @@ SIGNATURES = {
     "hc_conv_small_supported": (c_int32, [C.POINTER(ConvSmallDesc)]),
     "hc_conv_s2_supported": (c_int32, [C.POINTER(ConvS2Desc)]),
     "hc_conv_s2_fwd": (c_int32, [C.POINTER(ConvS2Desc), c_void_p]),
+    "hc_conv_s2_dgrad_supported": (c_int32, [C.POINTER(ConvS2DgradDesc)]),
+    "hc_conv_s2_dgrad": (c_int32, [C.POINTER(ConvS2DgradDesc), c_void_p]),
     "hc_conv_wgrad_ws_bytes": (c_int64, [C.POINTER(WgradDesc)]),
     "hc_conv_wgrad": (c_int32, [C.POINTER(WgradDesc), c_void_p]),
     "hc_rep_wgrad_supported": (c_int32, [C.POINTER(RepWgradDesc)]),

@@ -46,6 +46,7 @@ __device__ __forceinline__ int xcd_tile(int L, int T) {
 struct Args {
     hc_conv_s2_desc d;
     int reps;
+    int dbg;           // timing knock-outs (HC_CONV_S2_DBG; results are wrong): 1 no output stores, 2 no MFMAs, 4 no window loads
 };
 
 // ------------------------------------------------------------------------------------------------------------------ NHWC bf16 layers
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(64 * (COUT / (16 * CTW))) void s2_fwd_kernel(const 
             const int ih = 2 * r0 - 1 + r;
             const bool ok = c < PT && slot < G::NSLOT && x >= 1 && ih >= 0;
             const unsigned off = img + (unsigned)((ih * WIN + x - 1) * CIN * 2 + c * 16);
-            hc_dma16(rs, lds0 + (unsigned)(j * 1024), ok ? off : HC_OOB);
+            if (!(a.dbg & 4)) hc_dma16(rs, lds0 + (unsigned)(j * 1024), ok ? off : HC_OOB);
         }
     }
 
@@ -152,6 +153,10 @@ __global__ __launch_bounds__(64 * (COUT / (16 * CTW))) void s2_fwd_kernel(const 
             const bf16x8 b = *reinterpret_cast<const bf16x8*>(pb + boff[s]);
 #pragma unroll
             for (int t = 0; t < CTW; ++t) {
+                if (a.dbg & 2) {
+                    acc3[t][0] += (float)b[0] * __builtin_bit_cast(float, a3[t][s < S3 ? s : 0][0]);
+                    continue;
+                }
                 if (s < S3) acc3[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][s]), b, acc3[t], 0, 0, 0);
                 if (s >= S1B) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[t][s - S1B]), b, acc1[t], 0, 0, 0);
             }
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(64 * (COUT / (16 * CTW))) void s2_fwd_kernel(const 
                     st1[t][0][e] += v1; st1[t][1][e] += v1 * v1;
                 }
             }
-            if (ok) {
+            if (ok && !(a.dbg & 1)) {
                 const size_t o = obase + (size_t)p * COUT + co;
                 *reinterpret_cast<u32x2*>(y3 + o) = u32x2{pack_bf16x2(acc3[t][0], acc3[t][1]), pack_bf16x2(acc3[t][2], acc3[t][3])};
                 *reinterpret_cast<u32x2*>(y1 + o) = u32x2{pack_bf16x2(acc1[t][0], acc1[t][1]), pack_bf16x2(acc1[t][2], acc1[t][3])};
@@ -176,6 +181,158 @@ __global__ __launch_bounds__(64 * (COUT / (16 * CTW))) void s2_fwd_kernel(const 
         }
     }
     // ---- BatchNorm sums: fold the 16 pixel lanes of every group, lane px == e adds channel 4 g + e into this wave's replica slot
+    if (d.stats3 != nullptr) {
+        const size_t slot = (size_t)((blockIdx.x * G::NW + wid) % a.reps) * 2 * COUT;
+#pragma unroll
+        for (int t = 0; t < CTW; ++t) {
+            const int co = 16 * (wid * CTW + t) + 4 * g;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float m3 = 0.f, m1 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s3 = row16_sum(st3[t][k][e]), s1 = row16_sum(st1[t][k][e]);
+                    m3 = px == e ? s3 : m3;
+                    m1 = px == e ? s1 : m1;
+                }
+                if (px < 4) {
+                    atomicAdd(d.stats3 + slot + k * COUT + co + px, m3);
+                    atomicAdd(d.stats1 + slot + k * COUT + co + px, m1);
+                }
+            }
+        }
+    }
+}
+
+// Persistent form of the same kernel (HC_CONV_S2_V=1): two workgroups per CU walk the (image, row block) list of their XCD; the
+// weights are loaded ONCE per workgroup instead of once per row block (48 KB of L2 reads against a 38 - 63 KB window), the window
+// of block i + 1 is DMA'd into the second LDS buffer while block i is multiplied (one barrier per block), two pixel fragments run
+// as independent accumulator chains, and the BatchNorm sums are flushed once per workgroup.
+template <int CIN, int COUT, int WIN, int R, int CTW>
+__global__ __launch_bounds__(64 * (COUT / (16 * CTW))) void s2_fwd_persist_kernel(const Args a, const int ntiles) {
+    using G = Geo<CIN, COUT, WIN, R, CTW>;
+    constexpr int PT = G::PT, S = G::S, S3 = G::S3, S1B = G::S1B, S1 = G::S1, PS = G::PS, WS = G::WS, WOUT = G::WOUT;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const hc_conv_s2_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, g = lane >> 4;
+    const int H = d.H, HO = H / 2, RB = HO / R;
+    const unsigned lds0 = hc_lds_addr(smem);
+    // XCD k owns the k-th contiguous eighth of the tile list; its workgroups (local index j of GX) take tiles j, j + GX, ...
+    const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3, GX = gridDim.x >> 3;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int t_begin = xcd * q8 + (xcd < r8 ? xcd : r8), t_count = q8 + (xcd < r8 ? 1 : 0);
+    const u32x4 rs = hc_raw_rsrc(d.x, (unsigned)d.N * H * WIN * CIN * 2u);
+
+    auto stage = [&](int tl, int buf) __attribute__((always_inline)) {
+        const int tile = t_begin + tl;
+        const int n = tile / RB, r0 = (tile - n * RB) * R;
+        const unsigned img = (unsigned)n * (unsigned)(H * WIN * CIN * 2);
+        for (int j = wid; j < G::NDMA; j += G::NW) {
+            const int J = j * 64 + lane;
+            const int slot = J / G::PSC, c = J - slot * G::PSC;
+            const int r = slot / WS, x = slot - r * WS;
+            const int ih = 2 * r0 - 1 + r;
+            const bool ok = c < PT && slot < G::NSLOT && x >= 1 && ih >= 0;
+            const unsigned off = img + (unsigned)((ih * WIN + x - 1) * CIN * 2 + c * 16);
+            hc_dma16(rs, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * G::WINB + j * 1024)), ok ? off : HC_OOB);
+        }
+    };
+    if (jloc < t_count) stage(jloc, 0);
+
+    const __amdgpu_buffer_rsrc_t rw3 = make_rsrc(d.w3img, (unsigned)(COUT / 16 * S3 * 1024));
+    const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(d.w1img, (unsigned)(COUT / 16 * S1 * 1024));
+    u32x4 a3[CTW][S3], a1[CTW][S1];
+#pragma unroll
+    for (int t = 0; t < CTW; ++t) {
+        const int ct = wid * CTW + t;
+#pragma unroll
+        for (int s = 0; s < S3; ++s) a3[t][s] = buf_load16(rw3, (unsigned)(lane * 16), (unsigned)((ct * S3 + s) * 1024));
+#pragma unroll
+        for (int s = 0; s < S1; ++s) a1[t][s] = buf_load16(rw1, (unsigned)(lane * 16), (unsigned)((ct * S1 + s) * 1024));
+    }
+    int boff[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int q = 4 * s + g;
+        const int tap = q < G::NP3 ? q / PT : 4;
+        const int c = q < G::NP3 ? q - tap * PT : q - G::NP3;
+        boff[s] = ((tap / 3) * WS + tap % 3) * PS + c * 16;
+    }
+    float st3[CTW][2][4], st1[CTW][2][4];
+#pragma unroll
+    for (int t = 0; t < CTW; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st3[t][k][e] = st1[t][k][e] = 0.f;
+
+    bf16_t* y3 = reinterpret_cast<bf16_t*>(d.y3);
+    bf16_t* y1 = reinterpret_cast<bf16_t*>(d.y1);
+    constexpr int NF2 = (G::NFRAG + 1) / 2;
+    int it = 0;
+#pragma unroll 1
+    for (int tl = jloc; tl < t_count; tl += GX, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of block `tl` have landed (and its earlier stores are out)
+        __syncthreads();                                       // ... everybody's; and everybody is done reading the other buffer
+        if (tl + GX < t_count) stage(tl + GX, (it + 1) & 1);
+        const int tile = t_begin + tl;
+        const int n = tile / RB, r0 = (tile - n * RB) * R;
+        const size_t obase = ((size_t)n * HO + r0) * WOUT * COUT;
+        const char* wbase = smem + (it & 1) * G::WINB;
+#pragma unroll 1
+        for (int f2 = 0; f2 < NF2; ++f2) {
+            int p[2];
+            bool ok[2];
+            const char* pb[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                p[u] = (2 * f2 + u) * 16 + px;
+                ok[u] = p[u] < G::NPIX;
+                const int pc = ok[u] ? p[u] : G::NPIX - 1;
+                const int orow = pc / WOUT, ox = pc - orow * WOUT;
+                pb[u] = wbase + (2 * orow * WS + 2 * ox) * PS;
+            }
+            f32x4 acc3[2][CTW], acc1[2][CTW];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < CTW; ++t) acc3[u][t] = acc1[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                bf16x8 b[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) b[u] = *reinterpret_cast<const bf16x8*>(pb[u] + boff[s]);
+#pragma unroll
+                for (int t = 0; t < CTW; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (s < S3) acc3[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][s]), b[u], acc3[u][t], 0, 0, 0);
+                        if (s >= S1B) acc1[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[t][s - S1B]), b[u], acc1[u][t], 0, 0, 0);
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < CTW; ++t) {
+                    const int co = 16 * (wid * CTW + t) + 4 * g;
+                    if (d.stats3 != nullptr) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v3 = ok[u] ? acc3[u][t][e] : 0.f, v1 = ok[u] ? acc1[u][t][e] : 0.f;
+                            st3[t][0][e] += v3; st3[t][1][e] += v3 * v3;
+                            st1[t][0][e] += v1; st1[t][1][e] += v1 * v1;
+                        }
+                    }
+                    if (ok[u] && !(a.dbg & 1)) {
+                        const size_t o = obase + (size_t)p[u] * COUT + co;
+                        *reinterpret_cast<u32x2*>(y3 + o) = u32x2{pack_bf16x2(acc3[u][t][0], acc3[u][t][1]), pack_bf16x2(acc3[u][t][2], acc3[u][t][3])};
+                        *reinterpret_cast<u32x2*>(y1 + o) = u32x2{pack_bf16x2(acc1[u][t][0], acc1[u][t][1]), pack_bf16x2(acc1[u][t][2], acc1[u][t][3])};
+                    }
+                }
+        }
+    }
     if (d.stats3 != nullptr) {
         const size_t slot = (size_t)((blockIdx.x * G::NW + wid) % a.reps) * 2 * COUT;
 #pragma unroll
@@ -249,7 +406,7 @@ __global__ __launch_bounds__(256) void s2_stem_kernel(const Args a) {
             const int idx = it * G::NT + tid;
             const int r = idx / IPR, c4 = idx - r * IPR;
             const int ih = 2 * r0 - 1 + r;
-            const bool ok = idx < NITEM && ih >= 0;
+            const bool ok = idx < NITEM && ih >= 0 && !(a.dbg & 4);
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci)
                 v[it][ci] = ok ? *reinterpret_cast<const f32x4*>(xin + ((size_t)ci * H + ih) * WIN + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -293,9 +450,14 @@ __global__ __launch_bounds__(256) void s2_stem_kernel(const Args a) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             f32x4 c3 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
-            c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][0]), b0, c3, 0, 0, 0);
-            c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][1]), b1, c3, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[t]), b0, c1, 0, 0, 0);
+            if (a.dbg & 2) {
+                c3[0] = (float)b0[0] * __builtin_bit_cast(float, a3[t][0][0]);
+                c1[0] = (float)b1[0] * __builtin_bit_cast(float, a1[t][0]);
+            } else {
+                c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][0]), b0, c3, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][1]), b1, c3, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[t]), b0, c1, 0, 0, 0);
+            }
             if (d.stats3 != nullptr) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -303,8 +465,10 @@ __global__ __launch_bounds__(256) void s2_stem_kernel(const Args a) {
                     st1[t][0][e] += c1[e]; st1[t][1][e] += c1[e] * c1[e];
                 }
             }
-            *reinterpret_cast<u32x2*>(y3 + o + 16 * t) = u32x2{pack_bf16x2(c3[0], c3[1]), pack_bf16x2(c3[2], c3[3])};
-            *reinterpret_cast<u32x2*>(y1 + o + 16 * t) = u32x2{pack_bf16x2(c1[0], c1[1]), pack_bf16x2(c1[2], c1[3])};
+            if (!(a.dbg & 1)) {
+                *reinterpret_cast<u32x2*>(y3 + o + 16 * t) = u32x2{pack_bf16x2(c3[0], c3[1]), pack_bf16x2(c3[2], c3[3])};
+                *reinterpret_cast<u32x2*>(y1 + o + 16 * t) = u32x2{pack_bf16x2(c1[0], c1[1]), pack_bf16x2(c1[2], c1[3])};
+            }
         }
     }
     if (d.stats3 != nullptr) {
@@ -328,6 +492,125 @@ __global__ __launch_bounds__(256) void s2_stem_kernel(const Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ data gradient
+// dx[iy][ix][ci] of the same block: sum over the taps whose stride-2 footprint hits (iy, ix).  By output parity (py, px) = (iy & 1,
+// ix & 1), with a = iy >> 1, b = ix >> 1:
+//   (0, 0): dy3[a][b] . W3[1][1]  +  dy1[a][b] . W1                                      2 taps
+//   (0, 1): dy3[a][b + 1] . W3[1][0]  +  dy3[a][b] . W3[1][2]                            2 taps
+//   (1, 0): dy3[a + 1][b] . W3[0][1]  +  dy3[a][b] . W3[2][1]                            2 taps
+//   (1, 1): dy3[a + 1][b + 1] . W3[0][0] + dy3[a + 1][b] . W3[0][2] + dy3[a][b + 1] . W3[2][0] + dy3[a][b] . W3[2][2]      4 taps
+// One K stream of 10 taps x Cout / 8 pieces in exactly this order (pack mode 7): every class is a whole number of k32 steps, its
+// pixels are CONSECUTIVE dy pixels (stride 1 in LDS, conflict free for odd slot sizes), and a workgroup that owns R rows of dy
+// (+ one halo row / column, zero outside) produces 2 R complete rows of dx.  A wave owns 16 input channels, weights in registers.
+template <int CO, int CI, int WDX, int R>
+struct DGeo {
+    static constexpr int PT = CO / 8;
+    static constexpr int S = 10 * PT / 4;                // k32 steps of the whole stream
+    static constexpr int PSC = PT + 1, PS = PSC * 16;
+    static constexpr int WO = WDX / 2, WS = WO + 1;      // dy slots per window row: WO pixels + right halo
+    static constexpr int N3 = (R + 1) * WS, N1 = R * WS; // slots of the dy3 / dy1 windows
+    static constexpr int D3 = (N3 * PS + 1023) / 1024, D1 = (N1 * PS + 1023) / 1024;
+    static constexpr int OFF1 = D3 * 1024;               // dy1 window behind the dy3 window
+    static constexpr int NPIX = R * WO, NFRAG = (NPIX + 15) / 16;
+    static constexpr int NW = CI / 16, NT = 64 * NW;
+    static constexpr int SMEM = (D3 + D1) * 1024 + 256;
+    static_assert((PSC & 1) == 1 && (10 * PT) % 4 == 0 && (2 * PT) % 4 == 0, "K stream");
+};
+
+template <int CO, int CI, int WDX, int R>
+__global__ __launch_bounds__(64 * (CI / 16)) void s2_dgrad_kernel(const hc_conv_s2_dgrad_desc d, const int dbg) {
+    using G = DGeo<CO, CI, WDX, R>;
+    constexpr int PT = G::PT, S = G::S, PS = G::PS, WS = G::WS, WO = G::WO;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, g = lane >> 4;
+    const int H = d.H, HO = H / 2, RB = HO / R;
+    const int tile = xcd_tile(blockIdx.x, gridDim.x);
+    const int n = tile / RB, r0 = (tile - n * RB) * R;
+    const unsigned lds0 = hc_lds_addr(smem);
+    {
+        const unsigned bytes = (unsigned)d.N * HO * WO * CO * 2u;
+        const u32x4 rs3 = hc_raw_rsrc(d.dy3, bytes), rs1 = hc_raw_rsrc(d.dy1, bytes);
+        const unsigned img = (unsigned)n * (unsigned)(HO * WO * CO * 2);
+        for (int j = wid; j < G::D3 + G::D1; j += G::NW) {
+            const bool first = j < G::D3;
+            const int J = (first ? j : j - G::D3) * 64 + lane;
+            const int slot = J / G::PSC, c = J - slot * G::PSC;
+            const int r = slot / WS, x = slot - r * WS;
+            const bool ok = c < PT && x < WO && r0 + r < HO && slot < (first ? G::N3 : G::N1);
+            const unsigned off = img + (unsigned)(((r0 + r) * WO + x) * CO * 2 + c * 16);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(j * 1024));
+            if (dbg & 4) continue;
+            if (first) hc_dma16(rs3, dst, ok ? off : HC_OOB);
+            else hc_dma16(rs1, dst, ok ? off : HC_OOB);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(d.wimg, (unsigned)(CI / 16 * S * 1024));
+    u32x4 aw[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) aw[s] = buf_load16(rw, (unsigned)(lane * 16), (unsigned)((wid * S + s) * 1024));
+    // byte offset of piece 4 s + g relative to the dy3 slot of (a, b): stream position pos -> (tensor, da, db)
+    int boff[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int q = 4 * s + g, pos = q / PT, c = q - pos * PT;
+        // pos:      0      1(dy1)  2      3      4      5      6      7      8      9
+        const int da = (pos == 4 || pos == 6 || pos == 7) ? 1 : 0;
+        const int db = (pos == 2 || pos == 6 || pos == 8) ? 1 : 0;
+        boff[s] = (da * WS + db) * PS + c * 16 + (pos == 1 ? G::OFF1 : 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    bf16_t* dx = reinterpret_cast<bf16_t*>(d.dx);
+    const size_t obase = ((size_t)n * H + 2 * r0) * WDX * CI + 16 * wid + 4 * g;
+    constexpr int CS0 = 0, CS1 = 2 * PT / 4, CS2 = 4 * PT / 4, CS3 = 6 * PT / 4;     // first step of each parity class
+#pragma unroll 1
+    for (int f = 0; f < G::NFRAG; ++f) {
+        const int p = f * 16 + px;
+        const bool ok = p < G::NPIX;
+        const int pc = ok ? p : G::NPIX - 1;
+        const int a_ = pc / WO, b_ = pc - a_ * WO;
+        const char* pb = smem + (a_ * WS + b_) * PS;
+        f32x4 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(pb + boff[s]);
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int k = s < CS1 ? 0 : s < CS2 ? 1 : s < CS3 ? 2 : 3;
+            if (dbg & 2) acc[k][0] += (float)bv[0] * __builtin_bit_cast(float, aw[s][0]);
+            else acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aw[s]), bv, acc[k], 0, 0, 0);
+        }
+        if (ok && !(dbg & 1)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t o = obase + ((size_t)(2 * a_ + (k >> 1)) * WDX + 2 * b_ + (k & 1)) * CI;
+                *reinterpret_cast<u32x2*>(dx + o) = u32x2{pack_bf16x2(acc[k][0], acc[k][1]), pack_bf16x2(acc[k][2], acc[k][3])};
+            }
+        }
+        if ((dbg & 1) && acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 123.456f) dx[obase] = 0;
+    }
+    (void)CS0;
+}
+
+template <int CO, int CI, int WDX, int R>
+int launch_dgrad(const hc_conv_s2_dgrad_desc& d, hipStream_t st) {
+    using G = DGeo<CO, CI, WDX, R>;
+    auto kern = s2_dgrad_kernel<CO, CI, WDX, R>;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        once = true;
+    }
+    static const int dbg = getenv("HC_CONV_S2_DBG") ? atoi(getenv("HC_CONV_S2_DBG")) : 0;
+    hipLaunchKernelGGL(kern, dim3(d.N * (d.H / 2 / R)), dim3(G::NT), G::SMEM, st, d, dbg);
+    return hc_launch_status();
+}
+
 template <typename K>
 void set_smem(K kern, int smem) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -342,6 +625,22 @@ int launch_layer(const Args& a, hipStream_t st) {
     const int grid = a.d.N * (a.d.H / 2 / R);
     if (a.d.stats3 != nullptr && hc_get_deterministic() && grid * G::NW > a.reps) return HC_ERR_ARG;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::SMEM, st, a);
+    return hc_launch_status();
+}
+
+template <int CIN, int COUT, int WIN, int R, int CTW>
+int launch_persist(const Args& a, hipStream_t st, int wg_per_cu) {
+    using G = Geo<CIN, COUT, WIN, R, CTW>;
+    auto kern = s2_fwd_persist_kernel<CIN, COUT, WIN, R, CTW>;
+    constexpr int smem = 2 * G::WINB + 256;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool once = false;
+    if (!once) { set_smem(kern, smem); once = true; }
+    const int ntiles = a.d.N * (a.d.H / 2 / R);
+    int grid = 256 * wg_per_cu;
+    if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
+    if (a.d.stats3 != nullptr && hc_get_deterministic() && grid * G::NW > a.reps) return HC_ERR_ARG;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), smem, st, a, ntiles);
     return hc_launch_status();
 }
 
@@ -377,6 +676,24 @@ extern "C" int hc_conv_s2_supported(const hc_conv_s2_desc* dp) {
     return 0;
 }
 
+extern "C" int hc_conv_s2_dgrad_supported(const hc_conv_s2_dgrad_desc* dp) {
+    static const bool on = cs2::env_int("HC_CONV_S2_DGRAD", 1) != 0 && cs2::env_int("HC_CONV_S2", 1) != 0;
+    if (!on || dp == nullptr) return 0;
+    const hc_conv_s2_dgrad_desc& d = *dp;
+    if (d.N < 1 || d.H != d.W || d.H % 8 != 0) return 0;
+    if ((double)d.N * d.H * d.W * d.Cin * 2.0 >= 4294967000.0 || (double)d.N * (d.H / 2) * (d.W / 2) * d.Cout * 2.0 >= 4294967000.0) return 0;
+    return (d.Cin == 48 && d.Cout == 48 && d.W == 112) || (d.Cin == 48 && d.Cout == 96 && d.W == 56);
+}
+
+extern "C" int hc_conv_s2_dgrad(const hc_conv_s2_dgrad_desc* dp, hc_stream_t stream) {
+    if (!hc_conv_s2_dgrad_supported(dp)) return HC_ERR_ARG;
+    const hc_conv_s2_dgrad_desc& d = *dp;
+    if (d.dy3 == nullptr || d.dy1 == nullptr || d.wimg == nullptr || d.dx == nullptr) return HC_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d.Cout == 48) return cs2::launch_dgrad<48, 48, 112, 2>(d, st);
+    return cs2::launch_dgrad<96, 48, 56, 2>(d, st);
+}
+
 extern "C" int hc_conv_s2_fwd(const hc_conv_s2_desc* dp, hc_stream_t stream) {
     if (!hc_conv_s2_supported(dp)) return HC_ERR_ARG;
     const hc_conv_s2_desc& d = *dp;
@@ -385,9 +702,15 @@ extern "C" int hc_conv_s2_fwd(const hc_conv_s2_desc* dp, hc_stream_t stream) {
     cs2::Args a;
     a.d = d;
     a.reps = hc_get_stat_replicas();
+    a.dbg = cs2::env_int("HC_CONV_S2_DBG", 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rsel = cs2::env_int("HC_CONV_S2_R", 0);       // 0 = default rows per workgroup, 1 = the smaller variant (read per call: tests flip it)
     if (d.x_nchw_f32) return rsel ? cs2::launch_stem<4>(a, st) : cs2::launch_stem<8>(a, st);
+    const int ver = cs2::env_int("HC_CONV_S2_V", 0);          // 1: persistent double-buffered form
+    if (ver == 1) {
+        if (d.Cout == 48) return rsel ? cs2::launch_persist<48, 48, 112, 2, 1>(a, st, 1) : cs2::launch_persist<48, 48, 112, 1, 1>(a, st, 2);
+        return rsel ? cs2::launch_persist<48, 96, 56, 4, 2>(a, st, 1) : cs2::launch_persist<48, 96, 56, 2, 2>(a, st, 2);
+    }
     if (d.Cout == 48) return rsel ? cs2::launch_layer<48, 48, 112, 1, 1>(a, st) : cs2::launch_layer<48, 48, 112, 2, 1>(a, st);
     return rsel ? cs2::launch_layer<48, 96, 56, 2, 2>(a, st) : cs2::launch_layer<48, 96, 56, 4, 2>(a, st);
 }

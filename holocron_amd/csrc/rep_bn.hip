@@ -644,8 +644,15 @@ __device__ __forceinline__ long rows_image_index(int rc, int kc, int tap, int Cc
 //   mode 6 (stem, Cin = 3): a kernel row kh is 16 k slots (slot 4 kw + ci), step kh / 2, lane group 2 (kh % 2) + slot / 8; the 1x1
 //     passes tap0 = 4 (it sits at the centre tap) and has a one-step image.
 // Entries that no source element maps to (the other conv's pieces in a shared step, padding slots) must be zero: allocate zeroed.
-__device__ __forceinline__ long s2_image_index(int mode, int co, int ci, int t, int Cin, int tap0, int T, int ld) {
+__device__ __forceinline__ long s2_image_index(int mode, int co, int ci, int t, int Cin, int tap0, int T, int ld, int Cout = 0, int KK = 9) {
     int s, g, e;
+    if (mode == 7) {
+        // data gradient (conv_s2.hip s2_dgrad_kernel): rows = ci, K = co pieces, taps in output-parity order:
+        // (1,1) W1 | (1,0) (1,2) | (0,1) (2,1) | (0,0) (0,2) (2,0) (2,2)
+        const int pos = KK == 1 ? 1 : (t == 4 ? 0 : t == 3 ? 2 : t == 5 ? 3 : t == 1 ? 4 : t == 7 ? 5 : t == 0 ? 6 : t == 2 ? 7 : t == 6 ? 8 : 9);
+        const int q = pos * (Cout >> 3) + (co >> 3);
+        return ((((long)(ci >> 4) * T + (q >> 2)) * 64) + (q & 3) * 16 + (ci & 15)) * 8 + (co & 7);
+    }
     if (mode == 5) {
         const int q = tap0 + t * (Cin >> 3) + (ci >> 3);
         s = (q >> 2) - ld; g = q & 3; e = ci & 7;
@@ -676,7 +683,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
         } else if (mode == 4) {
             wpk[rows_image_index(ci, co, tap0 + (KH - 1 - kh) * KW + (KW - 1 - kw), Cout)] = v;
         } else if (mode >= 5) {
-            wpk[s2_image_index(mode, co, ci, kh * KW + kw, Cin, tap0, T, ld)] = v;
+            wpk[s2_image_index(mode, co, ci, kh * KW + kw, Cin, tap0, T, ld, Cout, KH * KW)] = v;
         } else {
             wpk[(long)co * T + tap0 + (kh * KW + kw) * Cin + ci] = v;
         }
@@ -770,7 +777,7 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const hc_pack_it
                 const bf16_t v = f32_to_bf16(it.w[o]);
                 if (it.mode == 3) wpk[rows_image_index(co, ci, it.tap0 + t, it.Cout)] = v;
                 else if (it.mode == 4) wpk[rows_image_index(ci, co, it.tap0 + KK - 1 - t, it.Cout)] = v;
-                else wpk[s2_image_index(it.mode, co, ci, t, it.Cin, it.tap0, it.T, it.ld)] = v;
+                else wpk[s2_image_index(it.mode, co, ci, t, it.Cin, it.tap0, it.T, it.ld, it.Cout, KK)] = v;
             }
         } else if (it.mode == 2 || KK > PK_MAXKK) {  // im2col order / large kernels: element-wise walk
             for (long o = o0 + threadIdx.x; o < o1; o += 256) {

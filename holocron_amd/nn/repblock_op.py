@@ -19,7 +19,7 @@ import os
 import torch
 
 from .. import _lib
-from .._lib import ConvS2Desc, PackItem, RepBnBwdDesc, RepBnDesc, check, ptr, stream
+from .._lib import ConvS2Desc, ConvS2DgradDesc, PackItem, RepBnBwdDesc, RepBnDesc, check, ptr, stream
 from ..ops import conv as cv
 
 STEM_KPAD = 32
@@ -158,6 +158,8 @@ class RepState:
         self.stack_fwd = False      # set by pack_items(): 3x3 + 1x1 forward as ONE gather-conv over stacked weight rows
         self.s2 = False             # set by descs(): the forward runs on the stride-2 row kernel (csrc/conv_s2.hip), which reads its own
         self.s2_images = None       # fragment images (hc_pack_conv_weights_multi modes 5 / 6): (3x3, 1x1)
+        self.s2_dgrad = False       # set by descs(): the data gradient runs on hc_conv_s2_dgrad (image of pack mode 7)
+        self.s2_dimg = None
 
     # ---- packed weights (persistent buffers; refreshed by one multi-tensor launch per model) ----
     @staticmethod
@@ -222,14 +224,21 @@ class RepState:
             self.s2_images = (torch.zeros((Cout // 16, s3, 64, 8), dtype=torch.bfloat16, device=dev),
                               torch.zeros((Cout // 16, s1, 64, 8), dtype=torch.bfloat16, device=dev))
             self.packed_key = None
-        if self.packed is None or (self.packed[2] is not None and self.packed[2].device != dev):
-            self.packed = (None, None, None if stem else torch.empty((Cin, 10, Cout), dtype=torch.bfloat16, device=dev))
+        gather_dgrad = not stem and not self.s2_dgrad
+        if self.packed is None or (self.packed[2] is not None) != gather_dgrad or (gather_dgrad and self.packed[2].device != dev):
+            self.packed = (None, None, torch.empty((Cin, 10, Cout), dtype=torch.bfloat16, device=dev) if gather_dgrad else None)
             self.packed_key = None
         i3, i1 = self.s2_images
         items = [(w3, i3, Cout, Cin, 3, 3, mode, 0, s3, 0), (w1, i1, Cout, Cin, 1, 1, mode, tap1, s1, s1b)]
-        if not stem:
+        if gather_dgrad:
             wpd = self.packed[2]
             items += [(w3, wpd, Cout, Cin, 3, 3, 1, 0, 10), (w1, wpd, Cout, Cin, 1, 1, 1, 9, 10)]
+        elif self.s2_dgrad:
+            sd = 10 * (Cout // 8) // 4
+            if self.s2_dimg is None or self.s2_dimg.device != dev:
+                self.s2_dimg = torch.zeros((Cin // 16, sd, 64, 8), dtype=torch.bfloat16, device=dev)
+                self.packed_key = None
+            items += [(w3, self.s2_dimg, Cout, Cin, 3, 3, 7, 0, sd), (w1, self.s2_dimg, Cout, Cin, 1, 1, 7, 1, sd)]
         return items
 
     def ensure_packed(self, w3, w1):
@@ -280,11 +289,17 @@ class RepState:
                 c.N, c.H, c.W, c.Cin, c.Cout, c.x_nchw_f32 = N, H, W, Cin, Cout, 1 if Cin % 16 else 0
                 if _lib.load().hc_conv_s2_supported(C.byref(c)):
                     s2d = c
-            self.desc[key] = (f3, f1, dg, sf, sd, rows, s2d)
+            s2g = None
+            if s == 2 and s2d is not None and Cin % 16 == 0:
+                c = ConvS2DgradDesc()
+                c.N, c.H, c.W, c.Cin, c.Cout = N, H, W, Cin, Cout
+                if _lib.load().hc_conv_s2_dgrad_supported(C.byref(c)):
+                    s2g = c
+            self.desc[key] = (f3, f1, dg, sf, sd, rows, s2d, s2g)
         rows = self.desc[key][5]
-        s2 = self.desc[key][6] is not None
-        if rows != self.rows_image or s2 != self.s2:    # this geometry reads other weight images: drop them, ensure_packed() rebuilds
-            self.rows_image, self.s2, self.packed, self.packed_key = rows, s2, None, None
+        s2, s2g = self.desc[key][6] is not None, self.desc[key][7] is not None
+        if rows != self.rows_image or s2 != self.s2 or s2g != self.s2_dgrad:    # this geometry reads other weight images: drop them, ensure_packed() rebuilds
+            self.rows_image, self.s2, self.s2_dgrad, self.packed, self.packed_key = rows, s2, s2g, None, None
         return self.desc[key][:5]
 
     def s2_desc(self, N, Cin, H, W, Cout):
@@ -353,6 +368,14 @@ def block_dgrad(st, dy3, dy1, dxid, w3, w1, geom):
     _, _, dg, _, sdg = st.descs(N, Cin, H, W, Cout)
     wpd = st.ensure_packed(w3, w1)[2]
     dx = cv.empty_cl(N, Cin, H, W, dy3.device)
+    s2g = st.desc[(N, Cin, H, W, Cout)][7]
+    if s2g is not None:
+        if dxid is not None:
+            raise _lib.HipError("stride-2 data gradient: a stride-2 RepBlock has no identity branch")
+        s2g.dy3, s2g.dy1, s2g.wimg, s2g.dx = ptr(dy3), ptr(dy1), ptr(st.s2_dimg), ptr(dx)
+        with cv.profiled("conv_s2", 2.0 * N * dy3.shape[2] * dy3.shape[3] * Cout * 10 * Cin, dx.numel() * 2.0 + 2 * dy3.numel() * 2.0):
+            check(_lib.load().hc_conv_s2_dgrad(C.byref(s2g), stream()), "hc_conv_s2_dgrad")
+        return dx
     if sdg is not None:
         cv.launch_conv_small_dgrad(sdg, dy3, dy1, wpd, dx, resid=dxid)
     else:

@@ -133,6 +133,18 @@ typedef struct {
 } hc_conv_s2_desc;
 int hc_conv_s2_supported(const hc_conv_s2_desc* d);
 int hc_conv_s2_fwd(const hc_conv_s2_desc* d, hc_stream_t stream);
+/* ... and its data gradient dx = conv3x3^T(dy3) + conv1x1^T(dy1) (aten::convolution_backward(input) of both convs, summed by
+ * autograd in the reference): dy3 / dy1 NHWC bf16 [N][H/2][W/2][Cout], dx NHWC bf16 [N][H][W][Cin], wimg = the fragment image of
+ * hc_pack_conv_weights_multi mode 7 (both kernels, taps ordered by output parity).  Shapes: 48 <- 48 @ 112, 48 <- 96 @ 56. */
+typedef struct {
+    const void* dy3;
+    const void* dy1;
+    const void* wimg;
+    void* dx;
+    int32_t N, H, W, Cin, Cout;
+} hc_conv_s2_dgrad_desc;
+int hc_conv_s2_dgrad_supported(const hc_conv_s2_dgrad_desc* d);
+int hc_conv_s2_dgrad(const hc_conv_s2_dgrad_desc* d, hc_stream_t stream);
 
 /* Weight gradient dW[co][ci][kh][kw] = sum_m dy[m][co] * x[m + tap][ci].
  * Replaces aten::convolution_backward(weight).  Split-K over output pixels: partial fp32
@@ -191,7 +203,8 @@ typedef struct {
     int32_t ld; /* elements per packed row when the destination is channel padded (mode 0: >= Cin, mode 1: >= Cout); 0 = dense.
                  * modes 5 / 6 (fragment images of hc_conv_s2_fwd, bf16 [Cout/16][T steps][64][8], zero-initialised by the caller):
                  * ld = first k32 step of this image, tap0 = first 16-byte piece (mode 5) / first tap (mode 6) - csrc/rep_bn.hip
-                 * s2_image_index */
+                 * s2_image_index.  mode 7: the data-gradient image of hc_conv_s2_dgrad, bf16 [Cin/16][T = 10 Cout/32 steps][64][8];
+                 * the 3x3 kernel with tap0 = 0, the 1x1 with tap0 = 1 (its position in the parity-ordered tap list) */
 } hc_pack_item;
 int hc_pack_conv_weights_multi(const hc_pack_item* items, int32_t nitems, int64_t max_elems, hc_stream_t stream);
 

@@ -41,3 +41,15 @@ for (cin, cout, H) in [(3, 48, 224), (48, 48, 112), (48, 96, 56)]:
     us = timeit(run)
     nbytes = x.numel() * (4 if stem else 2) + 2 * N * (H // 2) ** 2 * cout * 2
     print(f"{cin}->{cout}@{H}: {'conv_s2' if direct else 'gather '} {us:8.1f} us  {nbytes / us / 1e6:6.2f} TB/s algorithmic ({nbytes / 1e6:.0f} MB)")
+
+for (cin, cout, H) in [(48, 48, 112), (48, 96, 56)]:
+    dy3 = cv.to_cl_bf16(torch.randn((N, cout, H // 2, H // 2), device=dev))
+    dy1 = cv.to_cl_bf16(torch.randn((N, cout, H // 2, H // 2), device=dev))
+    w3 = torch.randn((cout, cin, 3, 3), device=dev) * 0.1
+    w1 = torch.randn((cout, cin, 1, 1), device=dev) * 0.1
+    st = rb.RepState(2, False)
+    geom = (N, cin, H, H, cout)
+    st.descs(*geom)
+    us = timeit(lambda: rb.block_dgrad(st, dy3, dy1, None, w3, w1, geom))
+    nbytes = N * H * H * cin * 2 + 2 * dy3.numel() * 2
+    print(f"dgrad {cin}<-{cout}@{H}: {'conv_s2' if st.s2_dgrad else 'gather '} {us:8.1f} us  {nbytes / us / 1e6:6.2f} TB/s algorithmic ({nbytes / 1e6:.0f} MB)")

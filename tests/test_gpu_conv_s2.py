@@ -53,6 +53,30 @@ def test_conv_s2_forward_and_statistics(cfg, rsel):
         assert rel_l2(s[1], s2) < 2e-4
 
 
+@pytest.mark.parametrize("cfg", [(48, 48, 112), (48, 96, 56)], ids=["48-48@112", "48-96@56"])
+def test_conv_s2_data_gradient(cfg):
+    """hc_conv_s2_dgrad against torch.nn.grad.conv2d_input of both convs (the sum autograd forms in the reference block)."""
+    from holocron_amd.nn import repblock_op as rb
+    from holocron_amd.ops import conv as cv
+    cin, cout, H = cfg
+    N = 3
+    g = torch.Generator().manual_seed(200 + cin + cout)
+    w3 = bf16r(torch.randn((cout, cin, 3, 3), generator=g) * 0.2)
+    w1 = bf16r(torch.randn((cout, cin, 1, 1), generator=g) * 0.5)
+    dy3 = bf16r(torch.randn((N, cout, H // 2, H // 2), generator=g))
+    dy1 = bf16r(torch.randn((N, cout, H // 2, H // 2), generator=g))
+    dev = torch.device("cuda:0")
+    st = rb.RepState(2, False)
+    geom = (N, cin, H, H, cout)
+    st.descs(*geom)
+    assert st.s2_dgrad
+    dx = rb.block_dgrad(st, cv.to_cl_bf16(dy3.to(dev)), cv.to_cl_bf16(dy1.to(dev)), None, w3.to(dev), w1.to(dev), geom)
+    torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_input((N, cin, H, H), w3, dy3, 2, 1) + torch.nn.grad.conv2d_input((N, cin, H, H), w1, dy1, 2, 0)
+    e = rel_l2(dx.float().cpu(), ref)
+    assert e < 2e-3, (cfg, e)
+
+
 def test_conv_s2_is_what_the_model_runs():
     """repvgg_a0's three front stride-2 blocks go through hc_conv_s2_fwd in a training step (and the step still matches the
     reference-generated goldens: tests/test_gpu_repvgg.py runs the same blocks at fixture size on the gather-conv path)."""
@@ -64,6 +88,6 @@ def test_conv_s2_is_what_the_model_runs():
     out.float().sum().backward()
     torch.cuda.synchronize()
     front = [m.features[0][0], m.features[1][0], m.features[2][0]]
-    assert all(b._hc.s2 for b in front)
+    assert all(b._hc.s2 for b in front) and all(b._hc.s2_dgrad for b in front[1:])
     assert not m.features[3][0]._hc.s2                      # 96 -> 192 @ 28 stays on the gather-conv
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
