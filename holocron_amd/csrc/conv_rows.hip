@@ -139,10 +139,14 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
     // touch 16 different cache lines per quarter wave: the texture addresser then takes longer than the MFMAs.)
     const unsigned wl = (unsigned)((48 * cw + (lane & 15)) * 64 + g * 16);
     u32x4 af[3][3];                                          // [step % 3][fragment]
-    auto load_a = [&](int buf, int s) __attribute__((always_inline)) {   // weight fragments of unit-local step s
+    // Forward: the 1x1 goes FIRST (sequence steps [0, S1) = image steps [S3, S)), so that its output stores drain under the nine taps of
+    // the 3x3 instead of behind the kernel's last MFMA (one exposed store burst per unit instead of two); the data gradient keeps the
+    // image order (its 1x1 source is staged into the window after the last tap).
+    auto load_a = [&](int buf, int s) __attribute__((always_inline)) {   // weight fragments of unit-local sequence step s
         if (DBG & 4) return;
+        const int ps = MODE == 0 ? (s < S1 ? S3 + s : s - S1) : s;
 #pragma unroll
-        for (int f = 0; f < 3; ++f) af[buf][f] = buf_load16(rsw, wl, (unsigned)(s * (C * 64) + f * 1024));
+        for (int f = 0; f < 3; ++f) af[buf][f] = buf_load16(rsw, wl, (unsigned)(ps * (C * 64) + f * 1024));
     };
 
     // ---- window DMA by the four waves of a team: slot (r, x) = r WW + x of a unit holds input pixel (row0 - 1 + r, x - 1); chunk PSC - 1
@@ -286,32 +290,41 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
         load_a(0, 0);
         load_a(1, 1);
         zero_acc();
-        load_b(0, (-WW - 1) * PS);
-        // 3x3 taps: the weight slices of a unit are one linear sequence of S3 (+ S1) steps when w1 directly follows w3's taps
-        // (dgrad packing), two sequences otherwise; the ring runs two steps ahead over the phase boundary either way
         // taps in pairs so that the register-set / ring-stage parity of every step is a compile-time constant for odd CK too
         auto tap_ofs = [&](int tap) __attribute__((always_inline)) { return tap < 9 ? ((tap / 3 - 1) * WW + (tap % 3 - 1)) * PS : 0; };
-        const bool pf8 = MODE == 0;                         // dgrad: the 1x1 source is staged after the last tap, nothing to prefetch
-#pragma nounroll
-        for (int tap = 0; tap < 8; tap += 2) {
-            const int o0 = tap_ofs(tap), o1 = tap_ofs(tap + 1), o2 = tap_ofs(tap + 2);
-            tap_block(std::integral_constant<int, 0>{}, tap * CK, S, o0, o1, true);
-            tap_block(std::integral_constant<int, (CK & 1)>{}, (tap + 1) * CK, S, o1, o2, true);
-        }
-        tap_block(std::integral_constant<int, 0>{}, 8 * CK, S, tap_ofs(8), 0, pf8);
         if (MODE == 0) {
-            epilogue(d.out3, d.stats3, nullptr, row0);
+            // 1x1 (centre tap) first, its epilogue (statistics + stores) is issued in front of the 3x3's 9 CK steps
+            load_b(0, 0);
+            tap_block(std::integral_constant<int, 0>{}, 0, S, 0, tap_ofs(0), true);
+            epilogue(d.out1, d.stats1, nullptr, row0);
             zero_acc();
+#pragma nounroll
+            for (int tap = 0; tap < 8; tap += 2) {
+                const int o0 = tap_ofs(tap), o1 = tap_ofs(tap + 1), o2 = tap_ofs(tap + 2);
+                tap_block(std::integral_constant<int, (CK & 1)>{}, (tap + 1) * CK, S, o0, o1, true);
+                tap_block(std::integral_constant<int, 0>{}, (tap + 2) * CK, S, o1, o2, true);
+            }
+            tap_block(std::integral_constant<int, (CK & 1)>{}, 9 * CK, S, tap_ofs(8), 0, false);
+            epilogue(d.out3, d.stats3, nullptr, row0);
         } else {
+            load_b(0, (-WW - 1) * PS);
+            // the weight slices of a unit are one linear sequence of S3 + S1 steps (w1 directly follows w3's taps in the dgrad packing);
+            // the ring runs two steps ahead over the phase boundary
+#pragma nounroll
+            for (int tap = 0; tap < 8; tap += 2) {
+                const int o0 = tap_ofs(tap), o1 = tap_ofs(tap + 1), o2 = tap_ofs(tap + 2);
+                tap_block(std::integral_constant<int, 0>{}, tap * CK, S, o0, o1, true);
+                tap_block(std::integral_constant<int, (CK & 1)>{}, (tap + 1) * CK, S, o1, o2, true);
+            }
+            tap_block(std::integral_constant<int, 0>{}, 8 * CK, S, tap_ofs(8), 0, false);   // the 1x1 source is staged after the last tap: nothing to prefetch
             // second source through the same window: only the unit's own rows (slots WW .. 8 WW) are read by the centre tap
             team_sync();
             stage_window(rsB, row0, (WW * PS) / 1024, (8 * WW * PS + PS + 1023) / 1024);
             team_sync();
             load_b(S3 & 1, 0);
+            tap_block(std::integral_constant<int, (S3 & 1)>{}, S3, S, 0, 0, false);
+            epilogue(d.out3, nullptr, d.resid, row0);
         }
-        tap_block(std::integral_constant<int, (S3 & 1)>{}, S3, S, 0, 0, false);
-        if (MODE == 0) epilogue(d.out1, d.stats1, nullptr, row0);
-        else epilogue(d.out3, nullptr, d.resid, row0);
     }
 }
 

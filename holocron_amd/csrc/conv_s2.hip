@@ -46,7 +46,7 @@ __device__ __forceinline__ int xcd_tile(int L, int T) {
 struct Args {
     hc_conv_s2_desc d;
     int reps;
-    int dbg;           // timing knock-outs (HC_CONV_S2_DBG; results are wrong): 1 no output stores, 2 no MFMAs, 4 no window loads
+    int dbg;           // timing knock-outs (HC_CONV_S2_DBG; results are wrong): 1 no output stores, 4 no window loads
 };
 
 // ------------------------------------------------------------------------------------------------------------------ NHWC bf16 layers
@@ -153,10 +153,6 @@ __global__ __launch_bounds__(64 * (COUT / (16 * CTW))) void s2_fwd_kernel(const 
             const bf16x8 b = *reinterpret_cast<const bf16x8*>(pb + boff[s]);
 #pragma unroll
             for (int t = 0; t < CTW; ++t) {
-                if (a.dbg & 2) {
-                    acc3[t][0] += (float)b[0] * __builtin_bit_cast(float, a3[t][s < S3 ? s : 0][0]);
-                    continue;
-                }
                 if (s < S3) acc3[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][s]), b, acc3[t], 0, 0, 0);
                 if (s >= S1B) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[t][s - S1B]), b, acc1[t], 0, 0, 0);
             }
@@ -368,7 +364,10 @@ struct StemGeo {
     static constexpr int ROWS = 2 * R + 1;
     static constexpr int NFRAG = R * (WOUT / 16);
     static constexpr int NT = 256;
-    static constexpr int SMEM = ROWS * WSB + 64;
+    static constexpr int OPITCH = 104;                   // staged output pixel: 96 bytes + 8 (26 dwords: the 8-byte writes of 16 pixels hit 32 banks once)
+    static constexpr int OST = 2 * 16 * OPITCH;          // per wave: one fragment of both outputs
+    static constexpr int WINB = (ROWS * WSB + 63) / 64 * 64;
+    static constexpr int SMEM = WINB + (NT / 64) * OST + 64;
 };
 
 template <int R>
@@ -446,18 +445,15 @@ __global__ __launch_bounds__(256) void s2_stem_kernel(const Args a) {
         const char* p1 = smem + (2 * orow + 2) * WSB + 16 * ox + 16 * (g & 1);
         const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(p0);
         const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(p1);
-        const size_t o = obase + ((size_t)orow * WOUT + ox) * COUT + 4 * g;
+        // outputs: staged per wave as [tensor][16 pixels][96 B], then three fully coalesced 16-byte store instructions (a fragment's
+        // 16 pixels x 48 channels are 1536 consecutive bytes of each output) with the non-temporal hint: written once, re-read much later
+        char* ost = smem + G::WINB + wid * G::OST + px * G::OPITCH + g * 8;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             f32x4 c3 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (a.dbg & 2) {
-                c3[0] = (float)b0[0] * __builtin_bit_cast(float, a3[t][0][0]);
-                c1[0] = (float)b1[0] * __builtin_bit_cast(float, a1[t][0]);
-            } else {
-                c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][0]), b0, c3, 0, 0, 0);
-                c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][1]), b1, c3, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[t]), b0, c1, 0, 0, 0);
-            }
+            c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][0]), b0, c3, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][1]), b1, c3, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[t]), b0, c1, 0, 0, 0);
             if (d.stats3 != nullptr) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -465,9 +461,19 @@ __global__ __launch_bounds__(256) void s2_stem_kernel(const Args a) {
                     st1[t][0][e] += c1[e]; st1[t][1][e] += c1[e] * c1[e];
                 }
             }
-            if (!(a.dbg & 1)) {
-                *reinterpret_cast<u32x2*>(y3 + o + 16 * t) = u32x2{pack_bf16x2(c3[0], c3[1]), pack_bf16x2(c3[2], c3[3])};
-                *reinterpret_cast<u32x2*>(y1 + o + 16 * t) = u32x2{pack_bf16x2(c1[0], c1[1]), pack_bf16x2(c1[2], c1[3])};
+            *reinterpret_cast<u32x2*>(ost + 32 * t) = u32x2{pack_bf16x2(c3[0], c3[1]), pack_bf16x2(c3[2], c3[3])};
+            *reinterpret_cast<u32x2*>(ost + 16 * G::OPITCH + 32 * t) = u32x2{pack_bf16x2(c1[0], c1[1]), pack_bf16x2(c1[2], c1[3])};
+        }
+        if (!(a.dbg & 1)) {
+            const size_t fbase = obase + ((size_t)orow * WOUT + (f - orow * (WOUT / 16)) * 16) * COUT;     // first element of the fragment
+            const char* rd = smem + G::WINB + wid * G::OST;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int q = i * 64 + lane, tz = q / 96, r = q - tz * 96, pp = r / 6, c = r - pp * 6;
+                const char* src = rd + tz * 16 * G::OPITCH + pp * G::OPITCH + c * 16;
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(src), hi = *reinterpret_cast<const u32x2*>(src + 8);
+                bf16_t* dst = (tz ? y1 : y3) + fbase + pp * COUT + c * 8;
+                __builtin_nontemporal_store(u32x4{lo[0], lo[1], hi[0], hi[1]}, reinterpret_cast<u32x4*>(dst));
             }
         }
     }
@@ -518,20 +524,26 @@ struct DGeo {
 };
 
 template <int CO, int CI, int WDX, int R>
-__global__ __launch_bounds__(64 * (CI / 16)) void s2_dgrad_kernel(const hc_conv_s2_dgrad_desc d, const int dbg) {
+__global__ __launch_bounds__(64 * (CI / 16)) void s2_dgrad_kernel(const hc_conv_s2_dgrad_desc d, const int ntiles, const int dbg) {
+    // persistent like s2_fwd_persist_kernel: weights once per workgroup, the dy windows of block i + 1 in flight under block i
     using G = DGeo<CO, CI, WDX, R>;
     constexpr int PT = G::PT, S = G::S, PS = G::PS, WS = G::WS, WO = G::WO;
+    constexpr int BUF = (G::D3 + G::D1) * 1024;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = lane & 15, g = lane >> 4;
     const int H = d.H, HO = H / 2, RB = HO / R;
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int n = tile / RB, r0 = (tile - n * RB) * R;
     const unsigned lds0 = hc_lds_addr(smem);
-    {
-        const unsigned bytes = (unsigned)d.N * HO * WO * CO * 2u;
-        const u32x4 rs3 = hc_raw_rsrc(d.dy3, bytes), rs1 = hc_raw_rsrc(d.dy1, bytes);
+    const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3, GX = gridDim.x >> 3;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int t_begin = xcd * q8 + (xcd < r8 ? xcd : r8), t_count = q8 + (xcd < r8 ? 1 : 0);
+    const unsigned bytes = (unsigned)d.N * HO * WO * CO * 2u;
+    const u32x4 rs3 = hc_raw_rsrc(d.dy3, bytes), rs1 = hc_raw_rsrc(d.dy1, bytes);
+
+    auto stage = [&](int tl, int buf) __attribute__((always_inline)) {
+        const int tile = t_begin + tl;
+        const int n = tile / RB, r0 = (tile - n * RB) * R;
         const unsigned img = (unsigned)n * (unsigned)(HO * WO * CO * 2);
         for (int j = wid; j < G::D3 + G::D1; j += G::NW) {
             const bool first = j < G::D3;
@@ -540,12 +552,14 @@ __global__ __launch_bounds__(64 * (CI / 16)) void s2_dgrad_kernel(const hc_conv_
             const int r = slot / WS, x = slot - r * WS;
             const bool ok = c < PT && x < WO && r0 + r < HO && slot < (first ? G::N3 : G::N1);
             const unsigned off = img + (unsigned)(((r0 + r) * WO + x) * CO * 2 + c * 16);
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(j * 1024));
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * BUF + j * 1024));
             if (dbg & 4) continue;
             if (first) hc_dma16(rs3, dst, ok ? off : HC_OOB);
             else hc_dma16(rs1, dst, ok ? off : HC_OOB);
         }
-    }
+    };
+    if (jloc < t_count) stage(jloc, 0);
+
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(d.wimg, (unsigned)(CI / 16 * S * 1024));
     u32x4 aw[S];
 #pragma unroll
@@ -560,54 +574,78 @@ __global__ __launch_bounds__(64 * (CI / 16)) void s2_dgrad_kernel(const hc_conv_
         const int db = (pos == 2 || pos == 6 || pos == 8) ? 1 : 0;
         boff[s] = (da * WS + db) * PS + c * 16 + (pos == 1 ? G::OFF1 : 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     bf16_t* dx = reinterpret_cast<bf16_t*>(d.dx);
-    const size_t obase = ((size_t)n * H + 2 * r0) * WDX * CI + 16 * wid + 4 * g;
-    constexpr int CS0 = 0, CS1 = 2 * PT / 4, CS2 = 4 * PT / 4, CS3 = 6 * PT / 4;     // first step of each parity class
+    constexpr int CS1 = 2 * PT / 4, CS2 = 4 * PT / 4, CS3 = 6 * PT / 4;     // first step of the parity classes 1, 2, 3
+    constexpr int NF2 = (G::NFRAG + 1) / 2;
+    int it = 0;
 #pragma unroll 1
-    for (int f = 0; f < G::NFRAG; ++f) {
-        const int p = f * 16 + px;
-        const bool ok = p < G::NPIX;
-        const int pc = ok ? p : G::NPIX - 1;
-        const int a_ = pc / WO, b_ = pc - a_ * WO;
-        const char* pb = smem + (a_ * WS + b_) * PS;
-        f32x4 acc[4];
+    for (int tl = jloc; tl < t_count; tl += GX, ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tl + GX < t_count) stage(tl + GX, (it + 1) & 1);
+        const int tile = t_begin + tl;
+        const int n = tile / RB, r0 = (tile - n * RB) * R;
+        const size_t obase = ((size_t)n * H + 2 * r0) * WDX * CI + 16 * wid + 4 * g;
+        const char* wbase = smem + (it & 1) * BUF;
+#pragma unroll 1
+        for (int f2 = 0; f2 < NF2; ++f2) {
+            int a_[2], b_[2];
+            bool ok[2];
+            const char* pb[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < 2; ++u) {
+                const int p = (2 * f2 + u) * 16 + px;
+                ok[u] = p < G::NPIX;
+                const int pc = ok[u] ? p : G::NPIX - 1;
+                a_[u] = pc / WO;
+                b_[u] = pc - a_[u] * WO;
+                pb[u] = wbase + (a_[u] * WS + b_[u]) * PS;
+            }
+            f32x4 acc[2][4];
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(pb + boff[s]);
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int k = s < CS1 ? 0 : s < CS2 ? 1 : s < CS3 ? 2 : 3;
-            if (dbg & 2) acc[k][0] += (float)bv[0] * __builtin_bit_cast(float, aw[s][0]);
-            else acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aw[s]), bv, acc[k], 0, 0, 0);
-        }
-        if (ok && !(dbg & 1)) {
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const size_t o = obase + ((size_t)(2 * a_ + (k >> 1)) * WDX + 2 * b_ + (k & 1)) * CI;
-                *reinterpret_cast<u32x2*>(dx + o) = u32x2{pack_bf16x2(acc[k][0], acc[k][1]), pack_bf16x2(acc[k][2], acc[k][3])};
+                for (int k = 0; k < 4; ++k) acc[u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const int k = s < CS1 ? 0 : s < CS2 ? 1 : s < CS3 ? 2 : 3;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(pb[u] + boff[s]);
+                    acc[u][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aw[s]), bv, acc[u][k], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (ok[u] && !(dbg & 1)) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const size_t o = obase + ((size_t)(2 * a_[u] + (k >> 1)) * WDX + 2 * b_[u] + (k & 1)) * CI;
+                        *reinterpret_cast<u32x2*>(dx + o) = u32x2{pack_bf16x2(acc[u][k][0], acc[u][k][1]), pack_bf16x2(acc[u][k][2], acc[u][k][3])};
+                    }
+                }
+                if ((dbg & 1) && acc[u][0][0] + acc[u][1][0] + acc[u][2][0] + acc[u][3][0] == 123.456f) dx[obase] = 0;
             }
         }
-        if ((dbg & 1) && acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 123.456f) dx[obase] = 0;
     }
-    (void)CS0;
 }
 
 template <int CO, int CI, int WDX, int R>
 int launch_dgrad(const hc_conv_s2_dgrad_desc& d, hipStream_t st) {
     using G = DGeo<CO, CI, WDX, R>;
     auto kern = s2_dgrad_kernel<CO, CI, WDX, R>;
+    constexpr int smem = 2 * (G::D3 + G::D1) * 1024 + 256;
+    static_assert(smem <= 80 * 1024, "two workgroups per CU");
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         once = true;
     }
     static const int dbg = getenv("HC_CONV_S2_DBG") ? atoi(getenv("HC_CONV_S2_DBG")) : 0;
-    hipLaunchKernelGGL(kern, dim3(d.N * (d.H / 2 / R)), dim3(G::NT), G::SMEM, st, d, dbg);
+    const int ntiles = d.N * (d.H / 2 / R);
+    int grid = 512;
+    if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), smem, st, d, ntiles, dbg);
     return hc_launch_status();
 }
 
@@ -705,8 +743,8 @@ extern "C" int hc_conv_s2_fwd(const hc_conv_s2_desc* dp, hc_stream_t stream) {
     a.dbg = cs2::env_int("HC_CONV_S2_DBG", 0);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rsel = cs2::env_int("HC_CONV_S2_R", 0);       // 0 = default rows per workgroup, 1 = the smaller variant (read per call: tests flip it)
-    if (d.x_nchw_f32) return rsel ? cs2::launch_stem<4>(a, st) : cs2::launch_stem<8>(a, st);
-    const int ver = cs2::env_int("HC_CONV_S2_V", 0);          // 1: persistent double-buffered form
+    if (d.x_nchw_f32) return rsel ? cs2::launch_stem<8>(a, st) : cs2::launch_stem<4>(a, st);
+    const int ver = cs2::env_int("HC_CONV_S2_V", 1);          // 1: persistent double-buffered form (default: -0.14 ms per step same-box), 0: one row block per workgroup
     if (ver == 1) {
         if (d.Cout == 48) return rsel ? cs2::launch_persist<48, 48, 112, 2, 1>(a, st, 1) : cs2::launch_persist<48, 48, 112, 1, 1>(a, st, 2);
         return rsel ? cs2::launch_persist<48, 96, 56, 4, 2>(a, st, 1) : cs2::launch_persist<48, 96, 56, 2, 2>(a, st, 2);
