@@ -171,6 +171,8 @@ SIGNATURES = {
     "hc_conv_s2_fwd": (c_int32, [C.POINTER(ConvS2Desc), c_void_p]),
     "hc_conv_s2_dgrad_supported": (c_int32, [C.POINTER(ConvS2DgradDesc)]),
     "hc_conv_s2_dgrad": (c_int32, [C.POINTER(ConvS2DgradDesc), c_void_p]),
+    "hc_conv_s2_stem_wgrad_ws_bytes": (c_int64, []),
+    "hc_conv_s2_stem_wgrad": (c_int32, [c_void_p] * 6 + [c_int32] * 4 + [c_void_p]),
     "hc_conv_wgrad_ws_bytes": (c_int64, [C.POINTER(WgradDesc)]),
     "hc_conv_wgrad": (c_int32, [C.POINTER(WgradDesc), c_void_p]),
     "hc_rep_wgrad_supported": (c_int32, [C.POINTER(RepWgradDesc)]),

@@ -649,6 +649,175 @@ int launch_dgrad(const hc_conv_s2_dgrad_desc& d, hipStream_t st) {
     return hc_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------------ stem weight gradient
+// dW3[co][ci][kh][kw] = sum_p dy3[p][co] x[ci][2 oy + kh - 1][2 ox + kw - 1],  dW1[co][ci] = sum_p dy1[p][co] x[ci][2 oy][2 ox]
+// straight from the fp32 image batch and the two NHWC gradients - no column tensor (the im2col path wrote 411 MB and read it twice).
+// GEMM view: M = 48 output channels (x 2 tensors), N = 16 k-slots per kernel row (slot 4 kw + ci, the forward kernel's layout),
+// K = output pixels.  Both operands have the pixel as their SLOW index in memory, which is what ds_read_b64_tr_b16 is for (lane a of
+// a 16-lane group addresses k-row a >> 2, 8-byte column chunk a & 3; lane i receives column i - scripts/probes/tr16_probe.hip):
+//   A = dy^T : LDS image [pixel][48] exactly as in HBM (96-byte pitch: 8 consecutive pixels fall into 8 distinct 32-byte bank slots),
+//   B = window: a k-row is an output pixel, its four column chunks the input pixels 2 ox - 1 .. 2 ox + 2 of kernel row kh (the 4th
+//       is the unused k-slot quad 12 .. 15).
+// Persistent workgroups walk (image, row pair) tiles and keep 12 accumulator tiles (3 co x 3 kh for dW3, 3 co for dW1) per wave; every
+// wave writes one fp32 slab, a second kernel adds the slabs in a fixed order (bit-reproducible) into the OIHW gradients.
+struct SwArgs {
+    const float* x;
+    const void* dy3;
+    const void* dy1;
+    float* ws;
+    int N, H, ntiles;
+};
+constexpr int SW_R = 2, SW_WIN = 224, SW_WOUT = 112, SW_CO = 48;
+constexpr int SW_WSB = (SW_WIN + 2) * 8;                  // window row bytes (as in the forward kernel)
+constexpr int SW_ROWS = 2 * SW_R + 1;
+constexpr int SW_WINB = (SW_ROWS * SW_WSB + 1023) / 1024 * 1024;
+constexpr int SW_NPIX = SW_R * SW_WOUT;                   // 224 pixels = 7 k32 steps
+constexpr int SW_DYB = SW_NPIX * SW_CO * 2;               // bytes of one gradient tile (21504 = 21 KB: 21 DMA pieces)
+constexpr int SW_DYP = (SW_DYB + 1023) / 1024;
+constexpr int SW_SMEM = SW_WINB + 2 * SW_DYP * 1024 + 64;
+constexpr int SW_SLAB = 12 * 256;                         // floats per wave slab: 12 tiles of 16 x 16
+
+__device__ __forceinline__ bf16x8 sw_tr_pair(const char* p0, const char* p1) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0), hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+__global__ __launch_bounds__(256) void s2_stem_wgrad_kernel(const SwArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int la = lane & 15, kq = lane >> 4;
+    const int H = a.H, HO = H / 2, RB = HO / SW_R;
+    const unsigned lds0 = hc_lds_addr(smem);
+    const unsigned dybytes = (unsigned)a.N * HO * SW_WOUT * SW_CO * 2u;
+    const u32x4 rs3 = hc_raw_rsrc(a.dy3, dybytes), rs1 = hc_raw_rsrc(a.dy1, dybytes);
+    f32x4 acc3[3][3], acc1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        acc1[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc3[c][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    char* sdy3 = smem + SW_WINB;
+    char* sdy1 = sdy3 + SW_DYP * 1024;
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int n = tile / RB, r0 = (tile - n * RB) * SW_R;
+        __syncthreads();                                  // everybody is done with the previous tile's LDS image
+        // gradient tiles: R output rows are contiguous in memory -> linear DMA (the rounded tail reads out of range -> zeros)
+        {
+            const unsigned base = (unsigned)((n * HO + r0) * SW_WOUT) * (unsigned)(SW_CO * 2);
+            for (int j = wid; j < 2 * SW_DYP; j += 4) {
+                const bool first = j < SW_DYP;
+                const int jj = first ? j : j - SW_DYP;
+                const unsigned off = (unsigned)(jj * 1024 + lane * 16);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(SW_WINB + j * 1024));
+                if (first) hc_dma16(rs3, dst, off < (unsigned)SW_DYB ? base + off : HC_OOB);
+                else hc_dma16(rs1, dst, off < (unsigned)SW_DYB ? base + off : HC_OOB);
+            }
+        }
+        // input window: fp32 planes -> {c0, c1, c2, 0} bf16 slots (slot x = input column x - 1)
+        {
+            const float* xin = a.x + (size_t)n * 3 * H * SW_WIN;
+            constexpr int IPR = SW_WIN / 4, NITEM = SW_ROWS * IPR;
+            constexpr int NIT = (NITEM + 255) / 256;
+            f32x4 v[NIT][3];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = it * 256 + tid;
+                const int r = idx / IPR, c4 = idx - r * IPR;
+                const int ih = 2 * r0 - 1 + r;
+                const bool ok = idx < NITEM && ih >= 0;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci)
+                    v[it][ci] = ok ? *reinterpret_cast<const f32x4*>(xin + ((size_t)ci * H + ih) * SW_WIN + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = it * 256 + tid;
+                const int r = idx / IPR, c4 = idx - r * IPR;
+                if (idx < NITEM) {
+                    char* wp = smem + r * SW_WSB + (1 + 4 * c4) * 8;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        *reinterpret_cast<u32x2*>(wp + 8 * k) = u32x2{pack_bf16x2(v[it][0][k], v[it][1][k]), pack_bf16x2(v[it][2][k], 0.f)};
+                }
+            }
+            if (tid < SW_ROWS * 2) {
+                const int r = tid >> 1;
+                *reinterpret_cast<u32x2*>(smem + r * SW_WSB + ((tid & 1) ? (SW_WIN + 1) * 8 : 0)) = u32x2{0u, 0u};
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // k32 steps of the tile, dealt to the four waves
+        for (int gstep = wid; gstep < SW_NPIX / 32; gstep += 4) {
+            const char* pa[2];
+            const char* pbw[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int p = 32 * gstep + 16 * h + 4 * kq + (la >> 2);       // this lane's k-row (output pixel of the tile)
+                const int ar = p / SW_WOUT, ox = p - ar * SW_WOUT;
+                pa[h] = sdy3 + p * (SW_CO * 2) + 8 * (la & 3);
+                pbw[h] = smem + (2 * ar) * SW_WSB + (2 * ox + (la & 3)) * 8;
+            }
+            bf16x8 b[3];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) b[kh] = sw_tr_pair(pbw[0] + kh * SW_WSB, pbw[1] + kh * SW_WSB);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const bf16x8 a3 = sw_tr_pair(pa[0] + 32 * c, pa[1] + 32 * c);
+                const bf16x8 a1 = sw_tr_pair(pa[0] + (sdy1 - sdy3) + 32 * c, pa[1] + (sdy1 - sdy3) + 32 * c);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) acc3[c][kh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b[kh], acc3[c][kh], 0, 0, 0);
+                acc1[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b[1], acc1[c], 0, 0, 0);
+            }
+        }
+    }
+    // slab of this wave: [12 tiles][row = co % 16][col = k slot]; lane (la = column, kq) holds rows 4 kq .. 4 kq + 3
+    float* slab = a.ws + (size_t)(blockIdx.x * 4 + wid) * SW_SLAB;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[((c * 3 + kh) * 16 + 4 * kq + r) * 16 + la] = acc3[c][kh][r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[((9 + c) * 16 + 4 * kq + r) * 16 + la] = acc1[c][r];
+    }
+}
+
+// dw3[co][ci][kh][kw] / dw1[co][ci] = (accumulate ? old : 0) + sum over the wave slabs, in slab order
+__global__ __launch_bounds__(256) void s2_stem_wgrad_reduce_kernel(const float* __restrict__ ws, int nslab, float* __restrict__ dw3,
+                                                                   float* __restrict__ dw1, int accumulate) {
+    const int e = blockIdx.x * 256 + threadIdx.x;         // element of a slab
+    if (e >= SW_SLAB) return;
+    const int tile = e >> 8, row = (e >> 4) & 15, col = e & 15;
+    const int kw = col >> 2, ci = col & 3;
+    if (kw > 2 || ci > 2) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nslab; k += 4) {
+        s0 += ws[(size_t)k * SW_SLAB + e];
+        s1 += ws[(size_t)(k + 1) * SW_SLAB + e];
+        s2 += ws[(size_t)(k + 2) * SW_SLAB + e];
+        s3 += ws[(size_t)(k + 3) * SW_SLAB + e];
+    }
+    for (; k < nslab; ++k) s0 += ws[(size_t)k * SW_SLAB + e];
+    const float v = (s0 + s1) + (s2 + s3);
+    if (tile < 9) {
+        const int c = tile / 3, kh = tile - 3 * c, co = 16 * c + row;
+        float* o = dw3 + ((co * 3 + ci) * 3 + kh) * 3 + kw;
+        *o = accumulate ? *o + v : v;
+    } else if (kw == 1) {
+        const int co = 16 * (tile - 9) + row;
+        float* o = dw1 + co * 3 + ci;
+        *o = accumulate ? *o + v : v;
+    }
+}
+
 template <typename K>
 void set_smem(K kern, int smem) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -730,6 +899,29 @@ extern "C" int hc_conv_s2_dgrad(const hc_conv_s2_dgrad_desc* dp, hc_stream_t str
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d.Cout == 48) return cs2::launch_dgrad<48, 48, 112, 2>(d, st);
     return cs2::launch_dgrad<96, 48, 56, 2>(d, st);
+}
+
+constexpr int HC_S2_STEM_WGRAD_GRID = 768;        // three 52 KB workgroups per CU
+
+extern "C" int64_t hc_conv_s2_stem_wgrad_ws_bytes(void) { return (int64_t)HC_S2_STEM_WGRAD_GRID * 4 * cs2::SW_SLAB * 4; }
+
+extern "C" int hc_conv_s2_stem_wgrad(const float* x, const void* dy3, const void* dy1, float* dw3, float* dw1, void* ws, int32_t N,
+                                     int32_t H, int32_t W, int32_t accumulate, hc_stream_t stream) {
+    static const bool on = cs2::env_int("HC_CONV_S2", 1) != 0 && cs2::env_int("HC_CONV_S2_STEM_WGRAD", 1) != 0;
+    if (!on) return HC_ERR_ARG;
+    if (x == nullptr || dy3 == nullptr || dy1 == nullptr || dw3 == nullptr || dw1 == nullptr || ws == nullptr) return HC_ERR_ARG;
+    if (N < 1 || W != 224 || H != 224 || (double)N * H * W * 12.0 >= 4294967000.0) return HC_ERR_ARG;
+    cs2::SwArgs a;
+    a.x = x; a.dy3 = dy3; a.dy1 = dy1; a.ws = reinterpret_cast<float*>(ws);
+    a.N = N; a.H = H; a.ntiles = N * (H / 2 / cs2::SW_R);
+    int grid = HC_S2_STEM_WGRAD_GRID;
+    if (grid > a.ntiles) grid = a.ntiles;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static bool once = false;
+    if (!once) { cs2::set_smem(cs2::s2_stem_wgrad_kernel, cs2::SW_SMEM); once = true; }
+    hipLaunchKernelGGL(cs2::s2_stem_wgrad_kernel, dim3(grid), dim3(256), cs2::SW_SMEM, st, a);
+    hipLaunchKernelGGL(cs2::s2_stem_wgrad_reduce_kernel, dim3((cs2::SW_SLAB + 255) / 256), dim3(256), 0, st, a.ws, grid * 4, dw3, dw1, accumulate);
+    return hc_launch_status();
 }
 
 extern "C" int hc_conv_s2_fwd(const hc_conv_s2_desc* dp, hc_stream_t stream) {

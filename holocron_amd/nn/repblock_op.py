@@ -389,6 +389,16 @@ def block_wgrad(st, src, dy3, dy1, w3, w1, geom, stem_cin=None, defer=False):
     N, Cin, H, W, Cout = geom
     lib = _lib.load()
     npix = dy3.shape[0] * dy3.shape[2] * dy3.shape[3]
+    if stem_cin is not None and src.dtype == torch.float32:
+        # the stride-2 stem kernels read the image batch itself (csrc/conv_s2.hip): no column tensor
+        dw3 = torch.empty_like(w3, dtype=torch.float32)
+        dw1 = torch.empty_like(w1, dtype=torch.float32)
+        ws = torch.empty((int(lib.hc_conv_s2_stem_wgrad_ws_bytes()),), dtype=torch.uint8, device=src.device)
+        with cv.profiled("conv_wgrad", 2.0 * npix * Cout * 10 * stem_cin, src.numel() * 4.0 + 2 * dy3.numel() * 2.0):
+            rc = lib.hc_conv_s2_stem_wgrad(ptr(src), ptr(dy3), ptr(dy1), ptr(dw3), ptr(dw1), ptr(ws), N, H, W, 0, stream())
+        if rc == 0:
+            return dw3, dw1
+        src = cv.im2col_small(src, 3, 3, st.stride, 1, STEM_KPAD)      # HC_CONV_S2_STEM_WGRAD=0 / other geometry: GEMM over the column tensor
     if stem_cin is not None:
         K = STEM_KPAD
         dwc3 = cv.conv_wgrad(src, dy3, K, Cout, 1, 1, 1, 0, flops=2.0 * npix * Cout * 9 * stem_cin)
@@ -523,8 +533,6 @@ class RepBlockFn(torch.autograd.Function):
                 raise NotImplementedError("input gradient of the im2col stem path")
             dx = block_dgrad(st, dy3, dy1, dxid, w3, w1, geom)
 
-        if ctx.stem_direct:       # the weight gradient of the stem is still a GEMM over the im2col column tensor
-            src = cv.im2col_small(src, 3, 3, st.stride, 1, STEM_KPAD)
         with cv.side_stream_for_wgrad((w3, w1), (src, dy3, dy1)) as side:
             dw3, dw1 = block_wgrad(st, src, dy3, dy1, w3, w1, geom, Cin if ctx.stem else None, defer=True)
             side.produced(dw3, dw1)

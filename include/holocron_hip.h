@@ -145,6 +145,13 @@ typedef struct {
 } hc_conv_s2_dgrad_desc;
 int hc_conv_s2_dgrad_supported(const hc_conv_s2_dgrad_desc* d);
 int hc_conv_s2_dgrad(const hc_conv_s2_dgrad_desc* d, hc_stream_t stream);
+/* ... and the weight gradients of the stem block (aten::convolution_backward(weight) of its 3x3 and 1x1 conv, repvgg.py:57-60 with
+ * in_channels = 3) straight from the image batch: x NCHW fp32 [N][3][224][224], dy3 / dy1 NHWC bf16 [N][112][112][48],
+ * dw3 fp32 [48][3][3][3], dw1 fp32 [48][3][1][1] (= or += with `accumulate`), ws: hc_conv_s2_stem_wgrad_ws_bytes() of scratch
+ * (per-wave partial slabs, added in a fixed order: bit-reproducible).  Returns an argument error for any other geometry. */
+int64_t hc_conv_s2_stem_wgrad_ws_bytes(void);
+int hc_conv_s2_stem_wgrad(const float* x, const void* dy3, const void* dy1, float* dw3, float* dw1, void* ws, int32_t N, int32_t H,
+                          int32_t W, int32_t accumulate, hc_stream_t stream);
 
 /* Weight gradient dW[co][ci][kh][kw] = sum_m dy[m][co] * x[m + tap][ci].
  * Replaces aten::convolution_backward(weight).  Split-K over output pixels: partial fp32

@@ -53,3 +53,16 @@ for (cin, cout, H) in [(48, 48, 112), (48, 96, 56)]:
     us = timeit(lambda: rb.block_dgrad(st, dy3, dy1, None, w3, w1, geom))
     nbytes = N * H * H * cin * 2 + 2 * dy3.numel() * 2
     print(f"dgrad {cin}<-{cout}@{H}: {'conv_s2' if st.s2_dgrad else 'gather '} {us:8.1f} us  {nbytes / us / 1e6:6.2f} TB/s algorithmic ({nbytes / 1e6:.0f} MB)")
+
+x = torch.rand((N, 3, 224, 224), device=dev)
+dy3 = cv.to_cl_bf16(torch.randn((N, 48, 112, 112), device=dev))
+dy1 = cv.to_cl_bf16(torch.randn((N, 48, 112, 112), device=dev))
+w3 = torch.randn((48, 3, 3, 3), device=dev)
+w1 = torch.randn((48, 3, 1, 1), device=dev)
+st = rb.RepState(2, False)
+geom = (N, 3, 224, 224, 48)
+direct = st.s2_desc(*geom) is not None
+col = None if direct else cv.im2col_small(x, 3, 3, 2, 1, rb.STEM_KPAD)
+us = timeit(lambda: rb.block_wgrad(st, x if direct else col, dy3, dy1, w3, w1, geom, 3))
+nbytes = x.numel() * 4 + 2 * dy3.numel() * 2
+print(f"stem wgrad: {'direct' if direct else 'im2col GEMM (column tensor not counted)'} {us:8.1f} us  {nbytes / us / 1e6:6.2f} TB/s algorithmic ({nbytes / 1e6:.0f} MB)")

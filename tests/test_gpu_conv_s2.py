@@ -77,6 +77,31 @@ def test_conv_s2_data_gradient(cfg):
     assert e < 2e-3, (cfg, e)
 
 
+def test_conv_s2_stem_weight_gradient():
+    """hc_conv_s2_stem_wgrad (both weight gradients of the stem from the fp32 image batch) against torch.nn.grad.conv2d_weight."""
+    from holocron_amd.nn import repblock_op as rb
+    from holocron_amd.ops import conv as cv
+    N, H, cout = 5, 224, 48
+    g = torch.Generator().manual_seed(300)
+    x = bf16r(torch.rand((N, 3, H, H), generator=g) - 0.4)
+    w3 = torch.randn((cout, 3, 3, 3), generator=g)
+    w1 = torch.randn((cout, 3, 1, 1), generator=g)
+    dy3 = bf16r(torch.randn((N, cout, H // 2, H // 2), generator=g))
+    dy1 = bf16r(torch.randn((N, cout, H // 2, H // 2), generator=g))
+    dev = torch.device("cuda:0")
+    st = rb.RepState(2, False)
+    geom = (N, 3, H, H, cout)
+    dw3, dw1 = rb.block_wgrad(st, x.to(dev), cv.to_cl_bf16(dy3.to(dev)), cv.to_cl_bf16(dy1.to(dev)), w3.to(dev), w1.to(dev), geom, 3)
+    torch.cuda.synchronize()
+    r3 = torch.nn.grad.conv2d_weight(x, w3.shape, dy3, 2, 1)
+    r1 = torch.nn.grad.conv2d_weight(x, w1.shape, dy1, 2, 0)
+    e3, e1 = rel_l2(dw3.cpu(), r3), rel_l2(dw1.cpu(), r1)
+    assert e3 < 2e-4 and e1 < 2e-4, (e3, e1)
+    # bit-reproducible (fixed-order slab reduction)
+    dw3b, dw1b = rb.block_wgrad(st, x.to(dev), cv.to_cl_bf16(dy3.to(dev)), cv.to_cl_bf16(dy1.to(dev)), w3.to(dev), w1.to(dev), geom, 3)
+    assert torch.equal(dw3, dw3b) and torch.equal(dw1, dw1b)
+
+
 def test_conv_s2_is_what_the_model_runs():
     """repvgg_a0's three front stride-2 blocks go through hc_conv_s2_fwd in a training step (and the step still matches the
     reference-generated goldens: tests/test_gpu_repvgg.py runs the same blocks at fixture size on the gather-conv path)."""

@@ -145,7 +145,7 @@ def _c2_conv_passes(cfg):
         print(f"{cfg}: dgrad {ed:.2e}")
         assert ed < (TOL_BF16 if res is None else 1.3 * TOL_BF16), (cfg, ed)
         del ref, dx
-    dw3, dw1 = rb.block_wgrad(st, src, dy3g, dy1g, w3g, w1g, geom, cin if stem else None)
+    dw3, dw1 = rb.block_wgrad(st, fsrc if stem else src, dy3g, dy1g, w3g, w1g, geom, cin if stem else None)
     torch.cuda.synchronize()
     r3 = torch.nn.grad.conv2d_weight(x, w3.shape, dy3, stride, 1)
     r1 = torch.nn.grad.conv2d_weight(x, w1.shape, dy1, stride, 0)
