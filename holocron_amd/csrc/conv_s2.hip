@@ -352,6 +352,195 @@ __global__ __launch_bounds__(64 * (COUT / (16 * CTW))) void s2_fwd_persist_kerne
     }
 }
 
+// Loader / consumer form (HC_CONV_S2_V=2).  What held the persistent kernel at ~3.5 TB/s was latency, not bandwidth: a wave's
+// `s_waitcnt vmcnt(0)` in front of a block waits for its window DMA AND for the output stores of the block before (vmcnt counts
+// stores on CDNA4, and a store is only "done" once it has reached the L2) - 28 blocks x 3-4 us per workgroup.  Here the fourth wave of
+// a workgroup does nothing but DMA: it keeps NB window buffers filled (per-lane source offsets precomputed once: one add per piece),
+// publishes block i through an LDS counter after its own counted vmcnt wait, and refills a buffer as soon as the three consumer
+// waves have checked it out; the consumers never wait on vector memory at all (their stores drain behind them) and the loader never
+// issues a store.  No s_barrier after the prologue: two LDS counters (conv_rows.hip's team counter pattern).
+template <int CIN, int COUT, int WIN, int R, int CTW, int NB>
+__global__ __launch_bounds__(64 * (COUT / (16 * CTW) + 1)) void s2_fwd_lc_kernel(const Args a, const int ntiles) {
+    using G = Geo<CIN, COUT, WIN, R, CTW>;
+    constexpr int PT = G::PT, S = G::S, S3 = G::S3, S1B = G::S1B, S1 = G::S1, PS = G::PS, WS = G::WS, WOUT = G::WOUT;
+    constexpr int NC = G::NW;                             // consumer waves; wave NC is the loader
+    constexpr int ND = G::NDMA;                           // DMA pieces per block, all issued by the loader
+    static_assert(ND <= 63, "vmcnt immediate: at most one block is left in flight across a wait");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const hc_conv_s2_desc& d = a.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = d.H, HO = H / 2, RB = HO / R;
+    const unsigned lds0 = hc_lds_addr(smem);
+    int* cnt = reinterpret_cast<int*>(smem + NB * G::WINB);      // [0] blocks published by the loader, [1] consumer check-outs
+    if (tid < 2) cnt[tid] = 0;
+    __syncthreads();
+    const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3, GX = gridDim.x >> 3;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int t_begin = xcd * q8 + (xcd < r8 ? xcd : r8), t_count = q8 + (xcd < r8 ? 1 : 0);
+    const int nloc = jloc < t_count ? (t_count - jloc + GX - 1) / GX : 0;       // blocks of this workgroup: jloc, jloc + GX, ...
+
+    if (wid == NC) {
+        // ------------------------------------------------------------------------------------------ loader wave
+        const u32x4 rs = hc_raw_rsrc(d.x, (unsigned)d.N * H * WIN * CIN * 2u);
+        // source offset of lane's chunk of piece j relative to input row 2 r0 - 1 of the image; bit 31: window row 0 (the zero halo
+        // row of the image's first block); HC_OOB: pad chunk / left halo / tail
+        unsigned soff[ND];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int J = j * 64 + lane;
+            const int slot = J / G::PSC, c = J - slot * G::PSC;
+            const int r = slot / WS, x = slot - r * WS;
+            const bool ok = c < PT && slot < G::NSLOT && x >= 1;
+            soff[j] = ok ? ((unsigned)((r * WIN + x - 1) * CIN * 2 + c * 16) | (r == 0 ? 0x80000000u : 0u)) : HC_OOB;
+        }
+        auto issue = [&](int i) __attribute__((always_inline)) {
+            const int tile = t_begin + jloc + i * GX;
+            const int n = tile / RB, r0 = (tile - n * RB) * R;
+            // may wrap below zero for r0 = 0: only row-0 lanes (forced out of range) would use the wrapped part
+            const unsigned base = (unsigned)n * (unsigned)(H * WIN * CIN * 2) + (unsigned)((2 * r0 - 1) * WIN * CIN * 2);
+            const unsigned dst = lds0 + (unsigned)((i % NB) * G::WINB);
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const unsigned so = soff[j];
+                const bool dead = so == HC_OOB || (r0 == 0 && (so & 0x80000000u));
+                hc_dma16(rs, __builtin_amdgcn_readfirstlane(dst + (unsigned)(j * 1024)), dead ? HC_OOB : base + (so & 0x7fffffffu));
+            }
+        };
+        for (int i = 0; i < NB && i < nloc; ++i) issue(i);
+        for (int i = 0; i < nloc; ++i) {
+            // blocks still in flight behind block i: min(nloc, i + NB) - i - 1
+            const int behind = (i + NB < nloc ? i + NB : nloc) - i - 1;
+            if (behind >= 1) hc_wait_vmcnt<ND>();           // the newest block may stay in flight (the counter's immediate ends at 63)
+            else hc_wait_vmcnt<0>();
+            if (lane == 0) __hip_atomic_store(cnt, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (i + NB < nloc) {
+                while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NC * (i + 1)) __builtin_amdgcn_s_sleep(2);
+                asm volatile("" ::: "memory");
+                issue(i + NB);
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------------------------------- consumer waves
+    const int px = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rw3 = make_rsrc(d.w3img, (unsigned)(COUT / 16 * S3 * 1024));
+    const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(d.w1img, (unsigned)(COUT / 16 * S1 * 1024));
+    u32x4 a3[CTW][S3], a1[CTW][S1];
+#pragma unroll
+    for (int t = 0; t < CTW; ++t) {
+        const int ct = wid * CTW + t;
+#pragma unroll
+        for (int s = 0; s < S3; ++s) a3[t][s] = buf_load16(rw3, (unsigned)(lane * 16), (unsigned)((ct * S3 + s) * 1024));
+#pragma unroll
+        for (int s = 0; s < S1; ++s) a1[t][s] = buf_load16(rw1, (unsigned)(lane * 16), (unsigned)((ct * S1 + s) * 1024));
+    }
+    int boff[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int q = 4 * s + g;
+        const int tap = q < G::NP3 ? q / PT : 4;
+        const int c = q < G::NP3 ? q - tap * PT : q - G::NP3;
+        boff[s] = ((tap / 3) * WS + tap % 3) * PS + c * 16;
+    }
+    float st3[CTW][2][4], st1[CTW][2][4];
+#pragma unroll
+    for (int t = 0; t < CTW; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st3[t][k][e] = st1[t][k][e] = 0.f;
+    bf16_t* y3 = reinterpret_cast<bf16_t*>(d.y3);
+    bf16_t* y1 = reinterpret_cast<bf16_t*>(d.y1);
+    constexpr int NF2 = (G::NFRAG + 1) / 2;
+#pragma unroll 1
+    for (int i = 0; i < nloc; ++i) {
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= i) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const int tile = t_begin + jloc + i * GX;
+        const int n = tile / RB, r0 = (tile - n * RB) * R;
+        const size_t obase = ((size_t)n * HO + r0) * WOUT * COUT;
+        const char* wbase = smem + (i % NB) * G::WINB;
+#pragma unroll 1
+        for (int f2 = 0; f2 < NF2; ++f2) {
+            int p[2];
+            bool ok[2];
+            const char* pb[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                p[u] = (2 * f2 + u) * 16 + px;
+                ok[u] = p[u] < G::NPIX;
+                const int pc = ok[u] ? p[u] : G::NPIX - 1;
+                const int orow = pc / WOUT, ox = pc - orow * WOUT;
+                pb[u] = wbase + (2 * orow * WS + 2 * ox) * PS;
+            }
+            f32x4 acc3[2][CTW], acc1[2][CTW];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < CTW; ++t) acc3[u][t] = acc1[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                bf16x8 b[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) b[u] = *reinterpret_cast<const bf16x8*>(pb[u] + boff[s]);
+#pragma unroll
+                for (int t = 0; t < CTW; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (s < S3) acc3[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][s]), b[u], acc3[u][t], 0, 0, 0);
+                        if (s >= S1B) acc1[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[t][s - S1B]), b[u], acc1[u][t], 0, 0, 0);
+                    }
+            }
+            if (f2 == NF2 - 1) {
+                // the last LDS reads of this block have returned (their MFMAs are issued): check the buffer out
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < CTW; ++t) {
+                    const int co = 16 * (wid * CTW + t) + 4 * g;
+                    if (d.stats3 != nullptr) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v3 = ok[u] ? acc3[u][t][e] : 0.f, v1 = ok[u] ? acc1[u][t][e] : 0.f;
+                            st3[t][0][e] += v3; st3[t][1][e] += v3 * v3;
+                            st1[t][0][e] += v1; st1[t][1][e] += v1 * v1;
+                        }
+                    }
+                    if (ok[u] && !(a.dbg & 1)) {
+                        const size_t o = obase + (size_t)p[u] * COUT + co;
+                        *reinterpret_cast<u32x2*>(y3 + o) = u32x2{pack_bf16x2(acc3[u][t][0], acc3[u][t][1]), pack_bf16x2(acc3[u][t][2], acc3[u][t][3])};
+                        *reinterpret_cast<u32x2*>(y1 + o) = u32x2{pack_bf16x2(acc1[u][t][0], acc1[u][t][1]), pack_bf16x2(acc1[u][t][2], acc1[u][t][3])};
+                    }
+                }
+        }
+    }
+    if (d.stats3 != nullptr) {
+        const size_t slot = (size_t)((blockIdx.x * NC + wid) % a.reps) * 2 * COUT;
+#pragma unroll
+        for (int t = 0; t < CTW; ++t) {
+            const int co = 16 * (wid * CTW + t) + 4 * g;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float m3 = 0.f, m1 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s3 = row16_sum(st3[t][k][e]), s1 = row16_sum(st1[t][k][e]);
+                    m3 = px == e ? s3 : m3;
+                    m1 = px == e ? s1 : m1;
+                }
+                if (px < 4) {
+                    atomicAdd(d.stats3 + slot + k * COUT + co + px, m3);
+                    atomicAdd(d.stats1 + slot + k * COUT + co + px, m1);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ stem (3 channels)
 // Window slot = one input pixel as {c0, c1, c2, 0} bf16 (8 bytes); a window row = [left halo | 224 pixels | one zero slot].  A kernel
 // row of the 3x3 is 16 k slots: the three pixels (2 ox - 1 .. 2 ox + 1) x 4 and four slots with zero weights, i.e. two 16-byte
@@ -674,7 +863,7 @@ constexpr int SW_WINB = (SW_ROWS * SW_WSB + 1023) / 1024 * 1024;
 constexpr int SW_NPIX = SW_R * SW_WOUT;                   // 224 pixels = 7 k32 steps
 constexpr int SW_DYB = SW_NPIX * SW_CO * 2;               // bytes of one gradient tile (21504 = 21 KB: 21 DMA pieces)
 constexpr int SW_DYP = (SW_DYB + 1023) / 1024;
-constexpr int SW_SMEM = SW_WINB + 2 * SW_DYP * 1024 + 64;
+constexpr int SW_SMEM = SW_WINB + 2 * SW_DYP * 1024 + 64;     // >= 4 * SW_SLAB * 4 = 49152: the end-of-kernel wave reduction reuses it
 constexpr int SW_SLAB = 12 * 256;                         // floats per wave slab: 12 tiles of 16 x 16
 
 __device__ __forceinline__ bf16x8 sw_tr_pair(const char* p0, const char* p1) {
@@ -776,37 +965,50 @@ __global__ __launch_bounds__(256) void s2_stem_wgrad_kernel(const SwArgs a) {
             }
         }
     }
-    // slab of this wave: [12 tiles][row = co % 16][col = k slot]; lane (la = column, kq) holds rows 4 kq .. 4 kq + 3
-    float* slab = a.ws + (size_t)(blockIdx.x * 4 + wid) * SW_SLAB;
+    // slab of this workgroup: [12 tiles][row = co % 16][col = k slot]; lane (la = column, kq) holds rows 4 kq .. 4 kq + 3.  The four
+    // waves are added through LDS in wave order (the tiles' LDS image is dead by now)
+    __syncthreads();
+    float* part = reinterpret_cast<float*>(smem) + wid * SW_SLAB;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) slab[((c * 3 + kh) * 16 + 4 * kq + r) * 16 + la] = acc3[c][kh][r];
+            for (int r = 0; r < 4; ++r) part[((c * 3 + kh) * 16 + 4 * kq + r) * 16 + la] = acc3[c][kh][r];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) slab[((9 + c) * 16 + 4 * kq + r) * 16 + la] = acc1[c][r];
+        for (int r = 0; r < 4; ++r) part[((9 + c) * 16 + 4 * kq + r) * 16 + la] = acc1[c][r];
     }
+    __syncthreads();
+    float* slab = a.ws + (size_t)blockIdx.x * SW_SLAB;
+    const float* all = reinterpret_cast<const float*>(smem);
+    for (int e = tid; e < SW_SLAB; e += 256) slab[e] = ((all[e] + all[SW_SLAB + e]) + all[2 * SW_SLAB + e]) + all[3 * SW_SLAB + e];
 }
 
-// dw3[co][ci][kh][kw] / dw1[co][ci] = (accumulate ? old : 0) + sum over the wave slabs, in slab order
+// dw3[co][ci][kh][kw] / dw1[co][ci] = (accumulate ? old : 0) + sum over the workgroup slabs.  One workgroup per 16 slab elements:
+// thread (e, part) adds the slabs part, part + 16, ... (four loads in flight), the 16 partial sums are combined in a fixed order
 __global__ __launch_bounds__(256) void s2_stem_wgrad_reduce_kernel(const float* __restrict__ ws, int nslab, float* __restrict__ dw3,
                                                                    float* __restrict__ dw1, int accumulate) {
-    const int e = blockIdx.x * 256 + threadIdx.x;         // element of a slab
-    if (e >= SW_SLAB) return;
+    __shared__ float sm[16][17];
+    const int el = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;                   // element of a slab
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = part;
+    for (; k + 48 < nslab; k += 64) {
+        s0 += ws[(size_t)k * SW_SLAB + e];
+        s1 += ws[(size_t)(k + 16) * SW_SLAB + e];
+        s2 += ws[(size_t)(k + 32) * SW_SLAB + e];
+        s3 += ws[(size_t)(k + 48) * SW_SLAB + e];
+    }
+    for (; k < nslab; k += 16) s0 += ws[(size_t)k * SW_SLAB + e];
+    sm[part][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (part != 0) return;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += sm[q][el];
     const int tile = e >> 8, row = (e >> 4) & 15, col = e & 15;
     const int kw = col >> 2, ci = col & 3;
     if (kw > 2 || ci > 2) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 3 < nslab; k += 4) {
-        s0 += ws[(size_t)k * SW_SLAB + e];
-        s1 += ws[(size_t)(k + 1) * SW_SLAB + e];
-        s2 += ws[(size_t)(k + 2) * SW_SLAB + e];
-        s3 += ws[(size_t)(k + 3) * SW_SLAB + e];
-    }
-    for (; k < nslab; ++k) s0 += ws[(size_t)k * SW_SLAB + e];
-    const float v = (s0 + s1) + (s2 + s3);
     if (tile < 9) {
         const int c = tile / 3, kh = tile - 3 * c, co = 16 * c + row;
         float* o = dw3 + ((co * 3 + ci) * 3 + kh) * 3 + kw;
@@ -848,6 +1050,22 @@ int launch_persist(const Args& a, hipStream_t st, int wg_per_cu) {
     if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
     if (a.d.stats3 != nullptr && hc_get_deterministic() && grid * G::NW > a.reps) return HC_ERR_ARG;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), smem, st, a, ntiles);
+    return hc_launch_status();
+}
+
+template <int CIN, int COUT, int WIN, int R, int CTW, int NB>
+int launch_lc(const Args& a, hipStream_t st, int wg_per_cu) {
+    using G = Geo<CIN, COUT, WIN, R, CTW>;
+    auto kern = s2_fwd_lc_kernel<CIN, COUT, WIN, R, CTW, NB>;
+    constexpr int smem = NB * G::WINB + 64;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool once = false;
+    if (!once) { set_smem(kern, smem); once = true; }
+    const int ntiles = a.d.N * (a.d.H / 2 / R);
+    int grid = 256 * wg_per_cu;
+    if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
+    if (a.d.stats3 != nullptr && hc_get_deterministic() && grid * G::NW > a.reps) return HC_ERR_ARG;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT + 64), smem, st, a, ntiles);
     return hc_launch_status();
 }
 
@@ -903,7 +1121,7 @@ extern "C" int hc_conv_s2_dgrad(const hc_conv_s2_dgrad_desc* dp, hc_stream_t str
 
 constexpr int HC_S2_STEM_WGRAD_GRID = 768;        // three 52 KB workgroups per CU
 
-extern "C" int64_t hc_conv_s2_stem_wgrad_ws_bytes(void) { return (int64_t)HC_S2_STEM_WGRAD_GRID * 4 * cs2::SW_SLAB * 4; }
+extern "C" int64_t hc_conv_s2_stem_wgrad_ws_bytes(void) { return (int64_t)HC_S2_STEM_WGRAD_GRID * cs2::SW_SLAB * 4; }
 
 extern "C" int hc_conv_s2_stem_wgrad(const float* x, const void* dy3, const void* dy1, float* dw3, float* dw1, void* ws, int32_t N,
                                      int32_t H, int32_t W, int32_t accumulate, hc_stream_t stream) {
@@ -920,7 +1138,7 @@ extern "C" int hc_conv_s2_stem_wgrad(const float* x, const void* dy3, const void
     static bool once = false;
     if (!once) { cs2::set_smem(cs2::s2_stem_wgrad_kernel, cs2::SW_SMEM); once = true; }
     hipLaunchKernelGGL(cs2::s2_stem_wgrad_kernel, dim3(grid), dim3(256), cs2::SW_SMEM, st, a);
-    hipLaunchKernelGGL(cs2::s2_stem_wgrad_reduce_kernel, dim3((cs2::SW_SLAB + 255) / 256), dim3(256), 0, st, a.ws, grid * 4, dw3, dw1, accumulate);
+    hipLaunchKernelGGL(cs2::s2_stem_wgrad_reduce_kernel, dim3(cs2::SW_SLAB / 16), dim3(256), 0, st, a.ws, grid, dw3, dw1, accumulate);
     return hc_launch_status();
 }
 
@@ -937,6 +1155,10 @@ extern "C" int hc_conv_s2_fwd(const hc_conv_s2_desc* dp, hc_stream_t stream) {
     const int rsel = cs2::env_int("HC_CONV_S2_R", 0);       // 0 = default rows per workgroup, 1 = the smaller variant (read per call: tests flip it)
     if (d.x_nchw_f32) return rsel ? cs2::launch_stem<8>(a, st) : cs2::launch_stem<4>(a, st);
     const int ver = cs2::env_int("HC_CONV_S2_V", 1);          // 1: persistent double-buffered form (default: -0.14 ms per step same-box), 0: one row block per workgroup
+    if (ver == 2) {                                           // loader / consumer waves
+        if (d.Cout == 48) return rsel ? cs2::launch_lc<48, 48, 112, 1, 1, 3>(a, st, 1) : cs2::launch_lc<48, 48, 112, 1, 1, 2>(a, st, 2);
+        return rsel ? cs2::launch_lc<48, 96, 56, 2, 2, 4>(a, st, 1) : cs2::launch_lc<48, 96, 56, 2, 2, 2>(a, st, 2);
+    }
     if (ver == 1) {
         if (d.Cout == 48) return rsel ? cs2::launch_persist<48, 48, 112, 2, 1>(a, st, 1) : cs2::launch_persist<48, 48, 112, 1, 1>(a, st, 2);
         return rsel ? cs2::launch_persist<48, 96, 56, 4, 2>(a, st, 1) : cs2::launch_persist<48, 96, 56, 2, 2>(a, st, 2);
