@@ -200,10 +200,14 @@ __global__ __launch_bounds__(64 * (COUT / (16 * CTW))) void s2_fwd_kernel(const 
     }
 }
 
-// Persistent form of the same kernel (HC_CONV_S2_V=1): two workgroups per CU walk the (image, row block) list of their XCD; the
+// Persistent form of the same kernel (the default; HC_CONV_S2_V=0 selects the one-block-per-workgroup form above): two workgroups per CU walk the (image, row block) list of their XCD; the
 // weights are loaded ONCE per workgroup instead of once per row block (48 KB of L2 reads against a 38 - 63 KB window), the window
 // of block i + 1 is DMA'd into the second LDS buffer while block i is multiplied (one barrier per block), two pixel fragments run
 // as independent accumulator chains, and the BatchNorm sums are flushed once per workgroup.
+// Measured and dropped: a loader / consumer split (a fourth wave that only issues DMA, LDS counters instead of barriers, so that no
+// consumer ever waits on vmcnt - which on CDNA4 also counts its output stores): 136 us against 147 us on the 48 @ 112 layer, nothing
+// on the step; one loader wave per CU with three buffers: 192 us.  With the stores knocked out the kernel still takes 111 - 117 us
+// for 308 MB: the window DMA (halo rows re-read per block, one zero-filled pad chunk in seven lanes) is what bounds it.
 template <int CIN, int COUT, int WIN, int R, int CTW>
 __global__ __launch_bounds__(64 * (COUT / (16 * CTW))) void s2_fwd_persist_kernel(const Args a, const int ntiles) {
     using G = Geo<CIN, COUT, WIN, R, CTW>;
@@ -331,195 +335,6 @@ __global__ __launch_bounds__(64 * (COUT / (16 * CTW))) void s2_fwd_persist_kerne
     }
     if (d.stats3 != nullptr) {
         const size_t slot = (size_t)((blockIdx.x * G::NW + wid) % a.reps) * 2 * COUT;
-#pragma unroll
-        for (int t = 0; t < CTW; ++t) {
-            const int co = 16 * (wid * CTW + t) + 4 * g;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                float m3 = 0.f, m1 = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float s3 = row16_sum(st3[t][k][e]), s1 = row16_sum(st1[t][k][e]);
-                    m3 = px == e ? s3 : m3;
-                    m1 = px == e ? s1 : m1;
-                }
-                if (px < 4) {
-                    atomicAdd(d.stats3 + slot + k * COUT + co + px, m3);
-                    atomicAdd(d.stats1 + slot + k * COUT + co + px, m1);
-                }
-            }
-        }
-    }
-}
-
-// Loader / consumer form (HC_CONV_S2_V=2).  What held the persistent kernel at ~3.5 TB/s was latency, not bandwidth: a wave's
-// `s_waitcnt vmcnt(0)` in front of a block waits for its window DMA AND for the output stores of the block before (vmcnt counts
-// stores on CDNA4, and a store is only "done" once it has reached the L2) - 28 blocks x 3-4 us per workgroup.  Here the fourth wave of
-// a workgroup does nothing but DMA: it keeps NB window buffers filled (per-lane source offsets precomputed once: one add per piece),
-// publishes block i through an LDS counter after its own counted vmcnt wait, and refills a buffer as soon as the three consumer
-// waves have checked it out; the consumers never wait on vector memory at all (their stores drain behind them) and the loader never
-// issues a store.  No s_barrier after the prologue: two LDS counters (conv_rows.hip's team counter pattern).
-template <int CIN, int COUT, int WIN, int R, int CTW, int NB>
-__global__ __launch_bounds__(64 * (COUT / (16 * CTW) + 1)) void s2_fwd_lc_kernel(const Args a, const int ntiles) {
-    using G = Geo<CIN, COUT, WIN, R, CTW>;
-    constexpr int PT = G::PT, S = G::S, S3 = G::S3, S1B = G::S1B, S1 = G::S1, PS = G::PS, WS = G::WS, WOUT = G::WOUT;
-    constexpr int NC = G::NW;                             // consumer waves; wave NC is the loader
-    constexpr int ND = G::NDMA;                           // DMA pieces per block, all issued by the loader
-    static_assert(ND <= 63, "vmcnt immediate: at most one block is left in flight across a wait");
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const hc_conv_s2_desc& d = a.d;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H = d.H, HO = H / 2, RB = HO / R;
-    const unsigned lds0 = hc_lds_addr(smem);
-    int* cnt = reinterpret_cast<int*>(smem + NB * G::WINB);      // [0] blocks published by the loader, [1] consumer check-outs
-    if (tid < 2) cnt[tid] = 0;
-    __syncthreads();
-    const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3, GX = gridDim.x >> 3;
-    const int q8 = ntiles >> 3, r8 = ntiles & 7;
-    const int t_begin = xcd * q8 + (xcd < r8 ? xcd : r8), t_count = q8 + (xcd < r8 ? 1 : 0);
-    const int nloc = jloc < t_count ? (t_count - jloc + GX - 1) / GX : 0;       // blocks of this workgroup: jloc, jloc + GX, ...
-
-    if (wid == NC) {
-        // ------------------------------------------------------------------------------------------ loader wave
-        const u32x4 rs = hc_raw_rsrc(d.x, (unsigned)d.N * H * WIN * CIN * 2u);
-        // source offset of lane's chunk of piece j relative to input row 2 r0 - 1 of the image; bit 31: window row 0 (the zero halo
-        // row of the image's first block); HC_OOB: pad chunk / left halo / tail
-        unsigned soff[ND];
-#pragma unroll
-        for (int j = 0; j < ND; ++j) {
-            const int J = j * 64 + lane;
-            const int slot = J / G::PSC, c = J - slot * G::PSC;
-            const int r = slot / WS, x = slot - r * WS;
-            const bool ok = c < PT && slot < G::NSLOT && x >= 1;
-            soff[j] = ok ? ((unsigned)((r * WIN + x - 1) * CIN * 2 + c * 16) | (r == 0 ? 0x80000000u : 0u)) : HC_OOB;
-        }
-        auto issue = [&](int i) __attribute__((always_inline)) {
-            const int tile = t_begin + jloc + i * GX;
-            const int n = tile / RB, r0 = (tile - n * RB) * R;
-            // may wrap below zero for r0 = 0: only row-0 lanes (forced out of range) would use the wrapped part
-            const unsigned base = (unsigned)n * (unsigned)(H * WIN * CIN * 2) + (unsigned)((2 * r0 - 1) * WIN * CIN * 2);
-            const unsigned dst = lds0 + (unsigned)((i % NB) * G::WINB);
-#pragma unroll
-            for (int j = 0; j < ND; ++j) {
-                const unsigned so = soff[j];
-                const bool dead = so == HC_OOB || (r0 == 0 && (so & 0x80000000u));
-                hc_dma16(rs, __builtin_amdgcn_readfirstlane(dst + (unsigned)(j * 1024)), dead ? HC_OOB : base + (so & 0x7fffffffu));
-            }
-        };
-        for (int i = 0; i < NB && i < nloc; ++i) issue(i);
-        for (int i = 0; i < nloc; ++i) {
-            // blocks still in flight behind block i: min(nloc, i + NB) - i - 1
-            const int behind = (i + NB < nloc ? i + NB : nloc) - i - 1;
-            if (behind >= 1) hc_wait_vmcnt<ND>();           // the newest block may stay in flight (the counter's immediate ends at 63)
-            else hc_wait_vmcnt<0>();
-            if (lane == 0) __hip_atomic_store(cnt, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (i + NB < nloc) {
-                while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NC * (i + 1)) __builtin_amdgcn_s_sleep(2);
-                asm volatile("" ::: "memory");
-                issue(i + NB);
-            }
-        }
-        return;
-    }
-    // ---------------------------------------------------------------------------------------------- consumer waves
-    const int px = lane & 15, g = lane >> 4;
-    const __amdgpu_buffer_rsrc_t rw3 = make_rsrc(d.w3img, (unsigned)(COUT / 16 * S3 * 1024));
-    const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(d.w1img, (unsigned)(COUT / 16 * S1 * 1024));
-    u32x4 a3[CTW][S3], a1[CTW][S1];
-#pragma unroll
-    for (int t = 0; t < CTW; ++t) {
-        const int ct = wid * CTW + t;
-#pragma unroll
-        for (int s = 0; s < S3; ++s) a3[t][s] = buf_load16(rw3, (unsigned)(lane * 16), (unsigned)((ct * S3 + s) * 1024));
-#pragma unroll
-        for (int s = 0; s < S1; ++s) a1[t][s] = buf_load16(rw1, (unsigned)(lane * 16), (unsigned)((ct * S1 + s) * 1024));
-    }
-    int boff[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int q = 4 * s + g;
-        const int tap = q < G::NP3 ? q / PT : 4;
-        const int c = q < G::NP3 ? q - tap * PT : q - G::NP3;
-        boff[s] = ((tap / 3) * WS + tap % 3) * PS + c * 16;
-    }
-    float st3[CTW][2][4], st1[CTW][2][4];
-#pragma unroll
-    for (int t = 0; t < CTW; ++t)
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) st3[t][k][e] = st1[t][k][e] = 0.f;
-    bf16_t* y3 = reinterpret_cast<bf16_t*>(d.y3);
-    bf16_t* y1 = reinterpret_cast<bf16_t*>(d.y1);
-    constexpr int NF2 = (G::NFRAG + 1) / 2;
-#pragma unroll 1
-    for (int i = 0; i < nloc; ++i) {
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= i) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-        const int tile = t_begin + jloc + i * GX;
-        const int n = tile / RB, r0 = (tile - n * RB) * R;
-        const size_t obase = ((size_t)n * HO + r0) * WOUT * COUT;
-        const char* wbase = smem + (i % NB) * G::WINB;
-#pragma unroll 1
-        for (int f2 = 0; f2 < NF2; ++f2) {
-            int p[2];
-            bool ok[2];
-            const char* pb[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                p[u] = (2 * f2 + u) * 16 + px;
-                ok[u] = p[u] < G::NPIX;
-                const int pc = ok[u] ? p[u] : G::NPIX - 1;
-                const int orow = pc / WOUT, ox = pc - orow * WOUT;
-                pb[u] = wbase + (2 * orow * WS + 2 * ox) * PS;
-            }
-            f32x4 acc3[2][CTW], acc1[2][CTW];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int t = 0; t < CTW; ++t) acc3[u][t] = acc1[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                bf16x8 b[2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) b[u] = *reinterpret_cast<const bf16x8*>(pb[u] + boff[s]);
-#pragma unroll
-                for (int t = 0; t < CTW; ++t)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        if (s < S3) acc3[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][s]), b[u], acc3[u][t], 0, 0, 0);
-                        if (s >= S1B) acc1[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[t][s - S1B]), b[u], acc1[u][t], 0, 0, 0);
-                    }
-            }
-            if (f2 == NF2 - 1) {
-                // the last LDS reads of this block have returned (their MFMAs are issued): check the buffer out
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int t = 0; t < CTW; ++t) {
-                    const int co = 16 * (wid * CTW + t) + 4 * g;
-                    if (d.stats3 != nullptr) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float v3 = ok[u] ? acc3[u][t][e] : 0.f, v1 = ok[u] ? acc1[u][t][e] : 0.f;
-                            st3[t][0][e] += v3; st3[t][1][e] += v3 * v3;
-                            st1[t][0][e] += v1; st1[t][1][e] += v1 * v1;
-                        }
-                    }
-                    if (ok[u] && !(a.dbg & 1)) {
-                        const size_t o = obase + (size_t)p[u] * COUT + co;
-                        *reinterpret_cast<u32x2*>(y3 + o) = u32x2{pack_bf16x2(acc3[u][t][0], acc3[u][t][1]), pack_bf16x2(acc3[u][t][2], acc3[u][t][3])};
-                        *reinterpret_cast<u32x2*>(y1 + o) = u32x2{pack_bf16x2(acc1[u][t][0], acc1[u][t][1]), pack_bf16x2(acc1[u][t][2], acc1[u][t][3])};
-                    }
-                }
-        }
-    }
-    if (d.stats3 != nullptr) {
-        const size_t slot = (size_t)((blockIdx.x * NC + wid) % a.reps) * 2 * COUT;
 #pragma unroll
         for (int t = 0; t < CTW; ++t) {
             const int co = 16 * (wid * CTW + t) + 4 * g;
@@ -1053,22 +868,6 @@ int launch_persist(const Args& a, hipStream_t st, int wg_per_cu) {
     return hc_launch_status();
 }
 
-template <int CIN, int COUT, int WIN, int R, int CTW, int NB>
-int launch_lc(const Args& a, hipStream_t st, int wg_per_cu) {
-    using G = Geo<CIN, COUT, WIN, R, CTW>;
-    auto kern = s2_fwd_lc_kernel<CIN, COUT, WIN, R, CTW, NB>;
-    constexpr int smem = NB * G::WINB + 64;
-    static_assert(smem <= 160 * 1024, "LDS budget");
-    static bool once = false;
-    if (!once) { set_smem(kern, smem); once = true; }
-    const int ntiles = a.d.N * (a.d.H / 2 / R);
-    int grid = 256 * wg_per_cu;
-    if (grid > ntiles) grid = (ntiles + 7) / 8 * 8;
-    if (a.d.stats3 != nullptr && hc_get_deterministic() && grid * G::NW > a.reps) return HC_ERR_ARG;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT + 64), smem, st, a, ntiles);
-    return hc_launch_status();
-}
-
 template <int R>
 int launch_stem(const Args& a, hipStream_t st) {
     using G = StemGeo<R>;
@@ -1155,10 +954,6 @@ extern "C" int hc_conv_s2_fwd(const hc_conv_s2_desc* dp, hc_stream_t stream) {
     const int rsel = cs2::env_int("HC_CONV_S2_R", 0);       // 0 = default rows per workgroup, 1 = the smaller variant (read per call: tests flip it)
     if (d.x_nchw_f32) return rsel ? cs2::launch_stem<8>(a, st) : cs2::launch_stem<4>(a, st);
     const int ver = cs2::env_int("HC_CONV_S2_V", 1);          // 1: persistent double-buffered form (default: -0.14 ms per step same-box), 0: one row block per workgroup
-    if (ver == 2) {                                           // loader / consumer waves
-        if (d.Cout == 48) return rsel ? cs2::launch_lc<48, 48, 112, 1, 1, 3>(a, st, 1) : cs2::launch_lc<48, 48, 112, 1, 1, 2>(a, st, 2);
-        return rsel ? cs2::launch_lc<48, 96, 56, 2, 2, 4>(a, st, 1) : cs2::launch_lc<48, 96, 56, 2, 2, 2>(a, st, 2);
-    }
     if (ver == 1) {
         if (d.Cout == 48) return rsel ? cs2::launch_persist<48, 48, 112, 2, 1>(a, st, 1) : cs2::launch_persist<48, 48, 112, 1, 1>(a, st, 2);
         return rsel ? cs2::launch_persist<48, 96, 56, 4, 2>(a, st, 1) : cs2::launch_persist<48, 96, 56, 2, 2>(a, st, 2);

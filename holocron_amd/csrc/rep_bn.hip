@@ -97,23 +97,27 @@ __device__ __forceinline__ void block_reduce_flush(const float (&v)[S][8], int c
 }
 
 // ---------------------------------------------------------------- forward BN finalize
-// one WAVE per channel: the 64 lanes sum the statistic replicas in parallel, lane 0 finishes.  Every load of the three branches - the
-// replicas, the affine parameters, the running statistics - is requested before the first one is used: the kernel is one memory
-// round trip long instead of three per branch (it is pure latency: 9.5 -> ~4 us, 27 launches per step).
+// A workgroup finishes 16 channels: thread (rg, ch) = (tid >> 4, tid & 15) adds the replicas rg, rg + 16, ... of channel ch - 16
+// consecutive channels per replica row are one 64-byte run, where the former one-wave-per-channel sweep touched 64 cache lines per
+// load instruction (10 us per launch in the round-2 trace for 590 KB of statistics) - the 16 partial sums meet in LDS in a fixed
+// order and the first 16 threads write the coefficients.  All loads of a thread are independent (one memory round trip); the order
+// of the additions is fixed, so the deterministic mode's single-writer slots still give bit-identical steps.
+constexpr int FIN_CH = 16, FIN_RG = 16;
 __global__ __launch_bounds__(256) void rep_bn_finalize_kernel(const hc_rep_bn_desc d, const int reps) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (c >= d.C) return;
+    __shared__ float sm[FIN_RG][6][FIN_CH + 1];
+    const int ch = threadIdx.x & (FIN_CH - 1), rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * FIN_CH + ch;
+    const bool cin = c < d.C;
     const float cnt = (float)d.count;
     // channels >= c_valid are layout padding: zero affine, no parameters / running statistics behind them
-    const bool chan_ok = d.c_valid <= 0 || c < d.c_valid;
+    const bool chan_ok = cin && (d.c_valid <= 0 || c < d.c_valid);
     bool on[3];
     float gam[3], bet[3], rm[3], rv[3], s1[3], s2[3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         on[b] = d.gamma[b] != nullptr && chan_ok;
         gam[b] = bet[b] = rm[b] = rv[b] = s1[b] = s2[b] = 0.f;
-        if (on[b]) {
+        if (on[b] && rg == 0) {
             gam[b] = d.gamma[b][c];
             bet[b] = d.beta[b][c];
             if (d.running_mean[b] != nullptr) {
@@ -123,32 +127,45 @@ __global__ __launch_bounds__(256) void rep_bn_finalize_kernel(const hc_rep_bn_de
         }
     }
     if (d.training) {
-        for (int r = lane; r < reps; r += 64) {
+#pragma unroll 8
+        for (int r = rg; r < reps; r += FIN_RG) {
 #pragma unroll
             for (int b = 0; b < 3; ++b)
                 if (on[b]) {
-                    s1[b] += d.stats[b][(2 * r) * d.C + c];
-                    s2[b] += d.stats[b][(2 * r + 1) * d.C + c];
+                    s1[b] += d.stats[b][(size_t)(2 * r) * d.C + c];
+                    s2[b] += d.stats[b][(size_t)(2 * r + 1) * d.C + c];
                 }
         }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            sm[rg][2 * b][ch] = s1[b];
+            sm[rg][2 * b + 1][ch] = s2[b];
+        }
     }
+    __syncthreads();
+    if (rg != 0 || !cin) return;
     float shift = 0.f;
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         float a = 0.f, mean = 0.f, invstd = 0.f;
         if (on[b]) {
             if (d.training) {
-                const float t1 = wave_sum(s1[b]), t2 = wave_sum(s2[b]);
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < FIN_RG; ++q) {
+                    t1 += sm[q][2 * b][ch];
+                    t2 += sm[q][2 * b + 1][ch];
+                }
                 mean = t1 / cnt;
                 float var = t2 / cnt - mean * mean;
                 var = var > 0.f ? var : 0.f;
                 invstd = rsqrtf(var + d.eps);
-                if (lane == 0 && d.running_mean[b] != nullptr) {
+                if (d.running_mean[b] != nullptr) {
                     const float unb = d.count > 1 ? var * (cnt / (cnt - 1.f)) : var;
                     d.running_mean[b][c] = (1.f - d.momentum) * rm[b] + d.momentum * mean;
                     d.running_var[b][c] = (1.f - d.momentum) * rv[b] + d.momentum * unb;
                 }
-                if (lane == 0 && c == 0 && d.num_batches_tracked[b] != nullptr) d.num_batches_tracked[b][0] += 1;
+                if (c == 0 && d.num_batches_tracked[b] != nullptr) d.num_batches_tracked[b][0] += 1;
             } else {
                 mean = rm[b];
                 invstd = rsqrtf(rv[b] + d.eps);
@@ -156,15 +173,13 @@ __global__ __launch_bounds__(256) void rep_bn_finalize_kernel(const hc_rep_bn_de
             a = gam[b] * invstd;
             shift += bet[b] - a * mean;
         }
-        if (lane == 0) {
-            d.coef[b * d.C + c] = a;
-            if (d.save != nullptr) {
-                d.save[(2 * b) * d.C + c] = mean;
-                d.save[(2 * b + 1) * d.C + c] = invstd;
-            }
+        d.coef[b * d.C + c] = a;
+        if (d.save != nullptr) {
+            d.save[(2 * b) * d.C + c] = mean;
+            d.save[(2 * b + 1) * d.C + c] = invstd;
         }
     }
-    if (lane == 0) d.coef[3 * d.C + c] = shift;
+    d.coef[3 * d.C + c] = shift;
 }
 
 // ---------------------------------------------------------------- forward apply
@@ -288,19 +303,20 @@ __global__ __launch_bounds__(EW_THREADS) void rep_bwd_reduce_kernel(const u32x4*
 }
 
 __global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_bn_bwd_desc d, const int reps) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (c >= d.C) return;
+    // same shape as the forward finalize: 16 channels per workgroup, 16 replica groups, coalesced replica rows, fixed-order LDS combine
+    __shared__ float sm[FIN_RG][4][FIN_CH + 1];
+    const int ch = threadIdx.x & (FIN_CH - 1), rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * FIN_CH + ch;
+    const bool cin = c < d.C;
     const float cnt = (float)d.count;
     const int nb = d.has_identity ? 3 : 2;
-    // like the forward finalize: everything is requested before anything is used (one round trip)
     bool on[3];
     float gam[3], mean_[3], inv_[3], dg0[3], db0[3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-        on[b] = b < nb && d.gamma[b] != nullptr && (d.c_valid <= 0 || c < d.c_valid);
+        on[b] = cin && b < nb && d.gamma[b] != nullptr && (d.c_valid <= 0 || c < d.c_valid);
         gam[b] = mean_[b] = inv_[b] = dg0[b] = db0[b] = 0.f;
-        if (on[b]) {
+        if (on[b] && rg == 0) {
             gam[b] = d.gamma[b][c];
             mean_[b] = d.save[(2 * b) * d.C + c];
             inv_[b] = d.save[(2 * b + 1) * d.C + c];
@@ -311,12 +327,23 @@ __global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_b
         }
     }
     float rsum[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = lane; r < reps; r += 64)
+    if (cin) {
+#pragma unroll 8
+        for (int r = rg; r < reps; r += FIN_RG)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rsum[k] += d.red[((size_t)r * 4 + k) * d.C + c];
+            for (int k = 0; k < 4; ++k) rsum[k] += d.red[((size_t)r * 4 + k) * d.C + c];
+    }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) rsum[k] = wave_sum(rsum[k]);
-    if (lane != 0) return;
+    for (int k = 0; k < 4; ++k) sm[rg][k][ch] = rsum[k];
+    __syncthreads();
+    if (rg != 0 || !cin) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < FIN_RG; ++q) t += sm[q][k][ch];
+        rsum[k] = t;
+    }
     const float sdz = rsum[0];
     for (int b = 0; b < 3; ++b) {
         float A = 0.f, B = 0.f, Cc = 0.f;
@@ -925,7 +952,7 @@ int hc_set_deterministic(int on) {
 
 int hc_rep_bn_finalize(const hc_rep_bn_desc* d, hc_stream_t stream) {
     if (d == nullptr || d->coef == nullptr || d->C <= 0) return HC_ERR_ARG;
-    hipLaunchKernelGGL(rep_bn_finalize_kernel, dim3((d->C + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d, hc_get_stat_replicas());
+    hipLaunchKernelGGL(rep_bn_finalize_kernel, dim3((d->C + FIN_CH - 1) / FIN_CH), dim3(256), 0, (hipStream_t)stream, *d, hc_get_stat_replicas());
     return hc_launch_status();
 }
 
@@ -1004,7 +1031,7 @@ int hc_rep_bwd_reduce_z(const void* g, const float* coef, int32_t act, const voi
 
 int hc_rep_bn_bwd_finalize(const hc_rep_bn_bwd_desc* d, hc_stream_t stream) {
     if (d == nullptr || d->red == nullptr || d->save == nullptr || d->bcoef == nullptr) return HC_ERR_ARG;
-    hipLaunchKernelGGL(rep_bn_bwd_finalize_kernel, dim3((d->C + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d, hc_get_stat_replicas());
+    hipLaunchKernelGGL(rep_bn_bwd_finalize_kernel, dim3((d->C + FIN_CH - 1) / FIN_CH), dim3(256), 0, (hipStream_t)stream, *d, hc_get_stat_replicas());
     return hc_launch_status();
 }
 

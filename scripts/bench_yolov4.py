@@ -37,10 +37,11 @@ def main():
     ap.add_argument("--eval", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     a = ap.parse_args()
-    # The YOLOv4 step is NOT replayed from a hipGraph: every forward packs the ragged ground truth and the DropBlock plan on the host
-    # and uploads them (pageable memcpy nodes would re-read freed host buffers on replay - a memory fault on the MI355X box).
-    a.no_graph = True
+    # The step is replayed from a hipGraph again (round 3): the ragged ground truth is packed ONCE into device tensors
+    # (models.detection.yolov4.PackedTargets) instead of on every forward - the per-forward packing became pageable memcpy nodes that
+    # re-read freed host buffers on replay (the memory fault of round 2); packing under capture now raises instead.
     import holocron_amd as h
+    from holocron_amd.models.detection.yolov4 import PackedTargets
 
     if a.eval:
         dev = torch.device("cuda:0")
@@ -66,7 +67,7 @@ def main():
 
     def make_batch(rank, dev):
         g = torch.Generator().manual_seed(1 + rank)
-        return torch.rand((a.batch, 3, a.size, a.size), generator=g).to(dev), targets(a.batch, g, dev)
+        return torch.rand((a.batch, 3, a.size, a.size), generator=g).to(dev), PackedTargets(targets(a.batch, g, dev), dev)
 
     def loss_of(model, x, t):
         return sum(v.sum() for v in model(x, t).values())

@@ -385,3 +385,59 @@ def test_cspdarknet53_mish_forward_backward_smoke():
     assert not torch.equal(outs[0], outs[1])     # fresh noise every step
     m(torch.rand((2, 3, 96, 96), device="cuda")).sum().backward()     # another resolution: the plan is re-recorded
     assert len(m._hc_drop_plan.entries) == ndrop
+
+
+def test_yolov4_step_replays_from_a_graph_with_packed_targets(golden, monkeypatch):
+    """the YOLOv4 training step faulted under hipGraph replay (its per-forward target packing became pageable
+    memcpy nodes).  With the ground truth packed once (PackedTargets) the whole step - forward, four losses, backward - is captured
+    and every replay reproduces the eager step; packing inside a capture is refused instead of recorded."""
+    import holocron_amd as h
+    from holocron_amd.models.detection.yolov4 import PackedTargets
+    gm = golden("yolo.pt")["model"]
+    m = _golden_yolov4(gm).cuda().train()
+    for mod in m.modules():                       # no DropBlock noise: eager and replayed steps must see the same function
+        if hasattr(mod, "p") and mod.__class__.__name__ == "DropBlock2d":
+            mod.p = 0.0
+    x = gm["x"].cuda()
+    tgt = _targets_to(gm["target"], "cuda")
+    packed = PackedTargets(tgt, x.device)
+    assert len(packed) == len(tgt)
+    out = {}
+
+    def step(t):
+        for p in m.parameters():
+            p.grad = None
+        losses = m(x, t)
+        sum(v.sum() for v in losses.values()).backward()
+        out["loss"] = torch.stack([v.sum().detach() for v in losses.values()])
+
+    step(tgt)
+    step(packed)                                  # same numbers through the packed form
+    torch.cuda.synchronize()
+    ref_loss = out["loss"].clone()
+    ref_grad = {n: p.grad.float().clone() for n, p in m.named_parameters() if p.grad is not None}
+    step(tgt)
+    assert torch.allclose(out["loss"], ref_loss, rtol=2e-2, atol=1e-3)
+    g = torch.cuda.CUDAGraph()
+    with monkeypatch.context() as mp:             # what a capture would see, without poisoning a real one
+        mp.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+        with pytest.raises(RuntimeError, match="before stream capture"):
+            h.models.detection.yolov4.YoloLayer._pack_targets(tgt, x.device)
+        with pytest.raises(RuntimeError, match="outside stream capture"):
+            PackedTargets(tgt, x.device)
+    step(packed)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        step(packed)
+    torch.cuda.synchronize()
+    for it in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.allclose(out["loss"], ref_loss, rtol=2e-2, atol=1e-3), (it, out["loss"], ref_loss)
+        for n, p in m.named_parameters():
+            if n in ref_grad and ("head1.3" in n or "head3" in n):       # close to the loss: well conditioned
+                e = float((p.grad.float() - ref_grad[n]).norm() / (ref_grad[n].norm() + 1e-12))
+                assert e < 5e-2, (it, n, e)
+    packed.update(tgt)                            # same counts: refill in place
+    with pytest.raises(ValueError):
+        packed.update(tgt[:1] + tgt[:1] if len(tgt) > 1 and tgt[0]["boxes"].shape[0] != tgt[1]["boxes"].shape[0] else [{"boxes": tgt[0]["boxes"][:0], "labels": tgt[0]["labels"][:0]}] * len(tgt))
