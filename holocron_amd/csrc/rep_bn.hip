@@ -116,30 +116,53 @@ __global__ __launch_bounds__(256) void rep_bn_finalize_kernel(const hc_rep_bn_de
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         on[b] = d.gamma[b] != nullptr && chan_ok;
-        gam[b] = bet[b] = rm[b] = rv[b] = s1[b] = s2[b] = 0.f;
-        if (on[b] && rg == 0) {
-            gam[b] = d.gamma[b][c];
-            bet[b] = d.beta[b][c];
-            if (d.running_mean[b] != nullptr) {
-                rm[b] = d.running_mean[b][c];
-                rv[b] = d.running_var[b][c];
-            }
-        }
+        s1[b] = s2[b] = 0.f;
+        // unconditional loads (a dead branch / channel reads branch 0's live address and is ignored): requested here, used after the
+        // replica sweep - no branch, no wait in front of the sweep
+        const int cs = cin ? c : d.C - 1;
+        const float* dummy = d.gamma[0] + cs;
+        gam[b] = *(on[b] ? d.gamma[b] + c : dummy);
+        bet[b] = *(on[b] ? d.beta[b] + c : dummy);
+        rm[b] = *((on[b] && d.running_mean[b] != nullptr) ? d.running_mean[b] + c : dummy);
+        rv[b] = *((on[b] && d.running_mean[b] != nullptr) ? d.running_var[b] + c : dummy);
     }
     if (d.training) {
-#pragma unroll 8
-        for (int r = rg; r < reps; r += FIN_RG) {
+        // branch-free loads: a condition per load makes the compiler branch around it and drain vmcnt behind every pair - 24 serial
+        // round trips (14 us measured).  A dead branch / channel reads a live one's address instead and is zeroed afterwards.
+        const float* sp[3];
+        const int cc = cin ? c : d.C - 1;
 #pragma unroll
-            for (int b = 0; b < 3; ++b)
-                if (on[b]) {
-                    s1[b] += d.stats[b][(size_t)(2 * r) * d.C + c];
-                    s2[b] += d.stats[b][(size_t)(2 * r + 1) * d.C + c];
+        for (int b = 0; b < 3; ++b) sp[b] = (d.stats[b] != nullptr ? d.stats[b] : d.stats[0]) + cc;
+        const size_t row = (size_t)d.C;
+        // eight replicas per round: 48 loads requested, THEN added (left alone the compiler pairs every load with its add behind a
+        // vmcnt(0..3) - a handful of loads in flight); rounds past the end re-read replica rg and add zero
+        for (int r0 = rg; r0 < reps; r0 += FIN_RG * 8) {
+            float v[8][6];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + u * FIN_RG;
+                const size_t rr = (size_t)(r < reps ? r : rg);
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    v[u][2 * b] = sp[b][(2 * rr) * row];
+                    v[u][2 * b + 1] = sp[b][(2 * rr + 1) * row];
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float keep = (r0 + u * FIN_RG) < reps ? 1.f : 0.f;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    s1[b] += keep * v[u][2 * b];
+                    s2[b] += keep * v[u][2 * b + 1];
+                }
+            }
         }
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-            sm[rg][2 * b][ch] = s1[b];
-            sm[rg][2 * b + 1][ch] = s2[b];
+            sm[rg][2 * b][ch] = on[b] ? s1[b] : 0.f;
+            sm[rg][2 * b + 1][ch] = on[b] ? s2[b] : 0.f;
         }
     }
     __syncthreads();
@@ -327,11 +350,26 @@ __global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_b
         }
     }
     float rsum[4] = {0.f, 0.f, 0.f, 0.f};
-    if (cin) {
-#pragma unroll 8
-        for (int r = rg; r < reps; r += FIN_RG)
+    {
+        const float* rp = d.red + (cin ? c : d.C - 1);
+        const size_t row = (size_t)d.C;
+        for (int r0 = rg; r0 < reps; r0 += FIN_RG * 8) {     // 32 loads requested, then added (see the forward finalize)
+            float v[8][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rsum[k] += d.red[((size_t)r * 4 + k) * d.C + c];
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + u * FIN_RG;
+                const size_t rr = (size_t)(r < reps ? r : rg);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[u][k] = rp[(rr * 4 + k) * row];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float keep = ((r0 + u * FIN_RG) < reps && cin) ? 1.f : 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rsum[k] += keep * v[u][k];
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) sm[rg][k][ch] = rsum[k];
