@@ -450,23 +450,15 @@ int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
     return hc_launch_status();
 }
 
-// 256 x 256 tile, eight waves (2 channel x 4 pixel), one workgroup per CU.  Per wave and k-step the 128 x 128 tile issues 8 DMA
-// instructions against 16 MFMAs (512 matrix-pipe cycles): at 100 - 185 cycles per LDS-DMA instruction inside a busy phase
-// (MI355X_MICROARCH.md) the DMA ISSUE, not the L2, is what holds the wide layers at ~900 TFLOP/s; the big tile issues the same 8
-// per 32 MFMAs.  Worth it only when the launch still fills the chip: >= 200 tiles, channels a multiple of 256.
-inline int tile256_mode() {
-    static const int m = [] { const char* e = getenv("HC_CONV_TILE256"); return e == nullptr ? 1 : atoi(e); }();
-    return m;
-}
-
+// Measured and dropped (round 3): a 256 x 256 tile with eight waves (launch_cfg<4, 2, 2, 4>, one workgroup per CU, 128 accumulator
+// registers per lane).  The idea: per wave and k-step the 128 x 128 tile issues 8 LDS-DMA instructions against 16 MFMAs, the big tile
+// the same 8 against 32.  Result on the 1280-channel layers of RepVGG-A0: 208 TFLOP/s against 855 - four times SLOWER (1779 us
+// against 433 us forward, 1976 against 473 us data gradient), YOLOv4 528 -> 485 img/s.  With 128 accumulators + 180 VGPRs the
+// kernel spills 576 bytes per lane and one 8-wave workgroup per CU leaves nothing to run while its barrier drains; the two
+// co-resident 4-wave workgroups of the 128 x 128 tile hide each other's barriers for free.
 template <int BK>
 int launch_bk(const hc_conv_desc& d, hipStream_t st) {
     const int C = d.Cout;
-    if (BK == 64 && tile256_mode() != 0 && C % 256 == 0 && d.co_split == 0) {
-        long tiles = 0;
-        for (int c = 0; c < d.nclass; ++c) tiles += ((long)d.N * d.cls[c].OHg * d.cls[c].OWg + 255) / 256 * (C / 256);
-        if (tiles >= (tile256_mode() == 2 ? 1 : 200)) return launch_cfg<4, 2, 2, 4, BK>(d, st);
-    }
     // channel tile: smallest padding waste, prefer the widest tile on ties
     if (C <= 64) return launch_cfg<1, 2, 2, 2, BK>(d, st);
     if (C <= 96) return launch_cfg<3, 1, 1, 4, BK>(d, st);

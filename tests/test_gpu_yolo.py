@@ -392,7 +392,7 @@ def test_yolov4_step_replays_from_a_graph_with_packed_targets(golden, monkeypatc
     memcpy nodes).  With the ground truth packed once (PackedTargets) the whole step - forward, four losses, backward - is captured
     and every replay reproduces the eager step; packing inside a capture is refused instead of recorded."""
     import holocron_amd as h
-    from holocron_amd.models.detection.yolov4 import PackedTargets
+    from holocron_amd.models.detection.yolov4 import PackedTargets, YoloLayer
     gm = golden("yolo.pt")["model"]
     m = _golden_yolov4(gm).cuda().train()
     for mod in m.modules():                       # no DropBlock noise: eager and replayed steps must see the same function
@@ -424,7 +424,7 @@ def test_yolov4_step_replays_from_a_graph_with_packed_targets(golden, monkeypatc
     with monkeypatch.context() as mp:             # what a capture would see, without poisoning a real one
         mp.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
         with pytest.raises(RuntimeError, match="before stream capture"):
-            h.models.detection.yolov4.YoloLayer._pack_targets(tgt, x.device)
+            YoloLayer._pack_targets(tgt, x.device)
         with pytest.raises(RuntimeError, match="outside stream capture"):
             PackedTargets(tgt, x.device)
     step(packed)
