@@ -135,8 +135,9 @@ class ConvBnActFn(torch.autograd.Function):
         out_ld = cl_ld(out)
         if out_ld is None or tuple(out.shape) != (N, Cout, OH, OW):
             raise _lib.HipError("conv_bn_act: `out` must be an NHWC bf16 view of shape %s" % ((N, Cout, OH, OW),))
-        check(lib.hc_bn_act_apply(ptr(y), ptr(coef), ptr(resc), Cout if resc is not None else 0, ptr(keep), ptr(count), ptr(out),
-                                  out_ld, npix, Cout, act, slope, stream()), "hc_bn_act_apply")
+        with cv.profiled("bn_elementwise", 0.0, npix * Cout * 2.0 * (3 if resc is not None else 2)):
+            check(lib.hc_bn_act_apply(ptr(y), ptr(coef), ptr(resc), Cout if resc is not None else 0, ptr(keep), ptr(count), ptr(out),
+                                      out_ld, npix, Cout, act, slope, stream()), "hc_bn_act_apply")
         ctx.drop = (keep, count)
         ctx.st, ctx.meta2 = st, (stride, pad, act, slope, im2col, training)
         ctx.geom = (N, Cin, H, W, Cout, KH, KW, OH, OW)
@@ -158,8 +159,9 @@ class ConvBnActFn(torch.autograd.Function):
         npix = N * OH * OW
         red = POOL.claim(ctx.red, ctx.red_gen, (_lib.stat_replicas(), 4, Cout), dev)   # stale after another forward's POOL.begin()
         ctx.red = None
-        check(lib.hc_bn_act_bwd_reduce(ptr(g), g_ld, ptr(y), ptr(coef), ptr(keep), ptr(count), ptr(red), npix, Cout, act, slope,
-                                       stream()), "hc_bn_act_bwd_reduce")
+        with cv.profiled("bn_elementwise", 0.0, npix * Cout * 2.0 * 2):
+            check(lib.hc_bn_act_bwd_reduce(ptr(g), g_ld, ptr(y), ptr(coef), ptr(keep), ptr(count), ptr(red), npix, Cout, act, slope,
+                                           stream()), "hc_bn_act_bwd_reduce")
         dgam = torch.empty((Cout,), dtype=torch.float32, device=dev)
         dbet = torch.empty((Cout,), dtype=torch.float32, device=dev)
         bcoef = torch.empty((9, Cout), dtype=torch.float32, device=dev)
@@ -172,8 +174,9 @@ class ConvBnActFn(torch.autograd.Function):
         d.frozen = 0 if training else 1               # eval mode / freeze_bn: running statistics, dy = a * dz
         check(lib.hc_rep_bn_bwd_finalize(C.byref(d), stream()), "hc_rep_bn_bwd_finalize")
         dy = torch.empty_like(y)
-        check(lib.hc_bn_act_bwd_apply(ptr(g), g_ld, ptr(y), ptr(coef), ptr(bcoef), ptr(keep), ptr(count), ptr(dy), npix, Cout, act,
-                                      slope, stream()), "hc_bn_act_bwd_apply")
+        with cv.profiled("bn_elementwise", 0.0, npix * Cout * 2.0 * 3):
+            check(lib.hc_bn_act_bwd_apply(ptr(g), g_ld, ptr(y), ptr(coef), ptr(bcoef), ptr(keep), ptr(count), ptr(dy), npix, Cout, act,
+                                          slope, stream()), "hc_bn_act_bwd_apply")
 
         dx = None
         if ctx.needs_input_grad[0]:

@@ -109,7 +109,8 @@ class PadConvBnActFn(torch.autograd.Function):
         y = cv.empty_cl(N, Cout_p, OH, OW, dev)
         stats = POOL.take((_lib.stat_replicas(), 2, Cout_p), dev) if training else None
         if depthwise:
-            check(lib.hc_dw3x3_fwd(ptr(x), ptr(wf), ptr(y), ptr(stats), N, H, W, Cout_p, stride, stream()), "hc_dw3x3_fwd")
+            with cv.profiled("dwconv", 18.0 * y.numel(), (x.numel() + y.numel()) * 2.0):
+                check(lib.hc_dw3x3_fwd(ptr(x), ptr(wf), ptr(y), ptr(stats), N, H, W, Cout_p, stride, stream()), "hc_dw3x3_fwd")
         else:
             key = ("f", N, Cin_p, H, W, Cout_p, KH, KW, stride, pad)
             if key not in st.desc:
@@ -138,8 +139,9 @@ class PadConvBnActFn(torch.autograd.Function):
             if cl_ld(res) != res_C or res_C > Cout_p or tuple(res.shape[2:]) != (OH, OW):
                 raise _lib.HipError("residual must be a dense NHWC bf16 tensor with at most the output's channels")
         out = cv.empty_cl(N, Cout_p, OH, OW, dev)
-        check(lib.hc_bn_act_apply(ptr(y), ptr(coef), ptr(res), res_C, None, None, ptr(out), Cout_p, npix, Cout_p, act, slope, stream()),
-              "hc_bn_act_apply")
+        with cv.profiled("bn_elementwise", 0.0, npix * Cout_p * 2.0 * (3 if res is not None else 2)):
+            check(lib.hc_bn_act_apply(ptr(y), ptr(coef), ptr(res), res_C, None, None, ptr(out), Cout_p, npix, Cout_p, act, slope, stream()),
+                  "hc_bn_act_apply")
         ctx.st, ctx.meta2 = st, (stride, pad, act, slope, training, depthwise, res_C)
         ctx.geom = (N, Cin, Cin_p, H, W, Cout, Cout_p, KH, KW, OH, OW)
         ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.stat_replicas(), 4, Cout_p), dev) if training else (None, -1)
@@ -159,8 +161,9 @@ class PadConvBnActFn(torch.autograd.Function):
         npix = N * OH * OW
         red = POOL.claim(ctx.red, ctx.red_gen, (_lib.stat_replicas(), 4, Cout_p), dev)   # stale after another forward's POOL.begin()
         ctx.red = None
-        check(lib.hc_bn_act_bwd_reduce(ptr(g), g_ld, ptr(y), ptr(coef), None, None, ptr(red), npix, Cout_p, act, slope, stream()),
-              "hc_bn_act_bwd_reduce")
+        with cv.profiled("bn_elementwise", 0.0, npix * Cout_p * 2.0 * 2):
+            check(lib.hc_bn_act_bwd_reduce(ptr(g), g_ld, ptr(y), ptr(coef), None, None, ptr(red), npix, Cout_p, act, slope, stream()),
+                  "hc_bn_act_bwd_reduce")
         dgam = torch.empty((Cout,), dtype=torch.float32, device=dev)
         dbet = torch.empty((Cout,), dtype=torch.float32, device=dev)
         bcoef = torch.empty((9, Cout_p), dtype=torch.float32, device=dev)
@@ -171,17 +174,20 @@ class PadConvBnActFn(torch.autograd.Function):
         d.frozen = 0 if training else 1               # eval mode / freeze_bn: running statistics, dy = a * dz
         check(lib.hc_rep_bn_bwd_finalize(C.byref(d), stream()), "hc_rep_bn_bwd_finalize")
         dy = torch.empty_like(y)
-        check(lib.hc_bn_act_bwd_apply(ptr(g), g_ld, ptr(y), ptr(coef), ptr(bcoef), None, None, ptr(dy), npix, Cout_p, act, slope,
-                                      stream()), "hc_bn_act_bwd_apply")
+        with cv.profiled("bn_elementwise", 0.0, npix * Cout_p * 2.0 * 3):
+            check(lib.hc_bn_act_bwd_apply(ptr(g), g_ld, ptr(y), ptr(coef), ptr(bcoef), None, None, ptr(dy), npix, Cout_p, act, slope,
+                                          stream()), "hc_bn_act_bwd_apply")
         wf, wb = st.pw
         dx = None
         if depthwise:
             if ctx.needs_input_grad[0]:
                 dx = cv.empty_cl(N, Cin_p, H, W, dev)
-                check(lib.hc_dw3x3_dgrad(ptr(dy), ptr(wf), ptr(wb), ptr(dx), N, H, W, Cout_p, stride, stream()), "hc_dw3x3_dgrad")
+                with cv.profiled("dwconv", 18.0 * dy.numel(), (dx.numel() + dy.numel()) * 2.0):
+                    check(lib.hc_dw3x3_dgrad(ptr(dy), ptr(wf), ptr(wb), ptr(dx), N, H, W, Cout_p, stride, stream()), "hc_dw3x3_dgrad")
             ws = torch.empty((lib.hc_dw3x3_wgrad_ws_bytes(Cout_p) // 4,), dtype=torch.float32, device=dev)
             dw = torch.empty_like(w, dtype=torch.float32)
-            check(lib.hc_dw3x3_wgrad(ptr(x), ptr(dy), ptr(ws), ptr(dw), N, H, W, Cout_p, Cout, stride, 0, stream()), "hc_dw3x3_wgrad")
+            with cv.profiled("dwconv", 18.0 * dy.numel(), (x.numel() + dy.numel()) * 2.0):
+                check(lib.hc_dw3x3_wgrad(ptr(x), ptr(dy), ptr(ws), ptr(dw), N, H, W, Cout_p, Cout, stride, 0, stream()), "hc_dw3x3_wgrad")
         else:
             if ctx.needs_input_grad[0]:
                 key = ("d", N, Cin_p, H, W, Cout_p, KH, KW, stride, pad)

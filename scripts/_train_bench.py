@@ -51,7 +51,7 @@ def best_threads_run(fn, counts=(8, 16, 32, 64)):
     return best, trial, host, default
 
 
-def run(a, build_model, make_batch, loss_of, metric, workload, train_gflop_per_img=None, cpu_baseline=None, extra=None):
+def run(a, build_model, make_batch, loss_of, metric, workload, train_gflop_per_img=None, cpu_baseline=None, extra=None, traffic_key=None):
     """build_model() -> nn.Module (CPU); make_batch(rank, device) -> (x, target); loss_of(model, x, target) -> scalar loss."""
     sys.stdout.flush()
     real_stdout = os.dup(1)
@@ -184,7 +184,18 @@ def run(a, build_model, make_batch, loss_of, metric, workload, train_gflop_per_i
             else:
                 roof = {"bound": "mfma", "kernel": dom, "achieved": fl / sec / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                         "frac": fl / sec / MFMA_BF16_PEAK}
-            roof.update({"traffic": None, "launches_per_step": n, "avg_launch_ms": sec / n * 1e3,
+            # HBM bytes per launch of the dominant family from the PMC passes over this same command (scripts/pmc_families.sh; the
+            # counters cannot be read from inside the process): this round's committed file when there is one, else null
+            traffic = traffic_src = None
+            if traffic_key is not None:
+                import json as _json
+                pf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"r03_pmc_{traffic_key}_traffic.json")
+                if os.path.exists(pf):
+                    with open(pf) as fh:
+                        traffic = _json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
+                    if traffic is not None:
+                        traffic_src = f"profiles/r03_pmc_{traffic_key}_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; committed, not live)"
+            roof.update({"traffic": traffic, "traffic_source": traffic_src, "launches_per_step": n, "avg_launch_ms": sec / n * 1e3,
                          "algorithmic_flops_per_launch": fl / n, "algorithmic_bytes_per_launch": nb / n,
                          "families": {k: {"tflops": v[0] / v[1] / 1e12, "gbps": v[3] / v[1] / 1e9, "ms_per_step": v[1] * 1e3,
                                           "launches": v[2]} for k, v in fam.items()}})

@@ -44,10 +44,32 @@ def main():
         t_bf16 = timeit(lambda: m(x), max(3, a.steps // 4), 2)
         t_fp8 = timeit(lambda: q(x), a.steps, a.warmup)
         agree = float((q(x[:256]).argmax(1) == m(x[:256]).float().argmax(1)).float().mean())
-    print(json.dumps({"metric": "images/sec inference, repvgg_a2 re-parametrised fp8 e4m3, 224^2", "value": a.batch / t_fp8, "unit": "img/s",
-                      "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": t_fp8 * 1e3, "dtype": "fp8 e4m3 (fp32 accumulate)",
-                      "data": "synthetic", "config": {"workload": f"repvgg_a2 reparam fp8 inference 224^2 bs{a.batch}"},
+        # roofline of the conv launches (HIP events on the launch stream, one instrumented forward)
+        from holocron_amd.ops import conv as cv
+        cv.PROFILE = []
+        q(x)
+        torch.cuda.synchronize()
+        fl = sum(f for (_, f, _, _, _) in cv.PROFILE)
+        sec = sum(e0.elapsed_time(e1) for (_, _, e0, e1, _) in cv.PROFILE) * 1e-3
+        nl = len(cv.PROFILE)
+        cv.PROFILE = None
+    peak = 5.0e15     # dense fp8 through v_mfma_scale_f32_32x32x64_f8f6f4 (MI355X_MICROARCH.md: 4.6-4.7 PF measured at K = 128)
+    traffic = src = None
+    pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "r03_pmc_repvgg_a2_fp8_traffic.json")
+    if os.path.exists(pf):
+        with open(pf) as fh:
+            traffic = json.load(fh).get("conv_gather", {}).get("hbm_bytes_per_launch")
+        src = "profiles/r03_pmc_repvgg_a2_fp8_traffic.json (committed PMC passes of this command)"
+    roof = {"bound": "mfma", "kernel": "conv_gather (fp8)", "achieved": fl / sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+            "frac": fl / sec / peak, "traffic": traffic, "traffic_source": src, "launches_per_step": nl, "avg_launch_ms": sec / nl * 1e3,
+            "note": "the block-scaled MFMA instruction is issued with UNIT block scales (E8M0 0x7f): quantisation is per-output-channel "
+                    "weight scales and static per-tensor activation scales folded into the epilogue, not OCP-MX per-32 block scaling"}
+    print(json.dumps({"metric": "images/sec inference, repvgg_a2 re-parametrised fp8 e4m3, 224^2", "value": a.batch / t_fp8, "unit": "images/sec",
+                      "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": t_fp8 * 1e3, "higher_is_better": True,
+                      "dtype": "fp8 e4m3 (fp32 accumulate)", "data": "synthetic",
+                      "config": {"workload": f"repvgg_a2 reparam fp8 inference 224^2 bs{a.batch} (BASELINE.json configs[4])"},
                       "tflops": INFER_GFLOP_PER_IMG * a.batch / t_fp8 / 1e3, "frac_of_5PF": INFER_GFLOP_PER_IMG * 1e9 * a.batch / t_fp8 / 5e15,
+                      "roofline": roof,
                       "bf16_img_s": a.batch / t_bf16, "bf16_ms": t_bf16 * 1e3, "top1_agreement_with_bf16": agree}))
 
 

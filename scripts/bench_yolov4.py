@@ -110,7 +110,7 @@ def main():
     tb.run(a, build, make_batch, loss_of, "images/sec fwd+loss+bwd+AdaBelief, YOLOv4 (CSP-darknet53) bs16/GPU 608^2 nc=80",
            f"yolov4 bf16 train step (fwd + 4 losses + bwd + AdaBelief), synthetic {a.size}^2, bs={a.batch} per MI355X "
            "(BASELINE.json configs[3]), random-init weights, 80 classes", train_gflop_per_img=TRAIN_GFLOP_PER_IMG if a.size == 608 else None,
-           cpu_baseline=cpu_baseline)
+           cpu_baseline=cpu_baseline, traffic_key="yolov4")
 
 
 if __name__ == "__main__":
