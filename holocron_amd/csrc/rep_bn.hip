@@ -16,10 +16,8 @@ constexpr int EW_THREADS = 256;
 struct EwGrid {
     int blocks;
 };
-// number of blocks such that (blocks*256) % (C/8) == 0 and every thread gets >= ~8 chunks.  `occ` = workgroups of this kernel that are
-// resident per CU (its VGPR allocation: 168 registers -> 3, 113 -> 4, 80 -> 6): a grid of 1024 workgroups of a 3-per-CU kernel is
-// 1.33 rounds - the last third runs on a quarter-full chip - so grids above one round are rounded to whole rounds of 256 * occ.
-inline int ew_blocks(long nchunks, int cg, int cpt_default = 8, int occ = 0) {
+// number of blocks such that (blocks*256) % (C/8) == 0 and every thread gets >= ~8 chunks
+inline int ew_blocks(long nchunks, int cg, int cpt_default = 8) {
     int a = cg, b = EW_THREADS;
     while (b) { int t = a % b; a = b; b = t; }
     const int unit = cg / a;  // blocks must be a multiple of this
@@ -34,15 +32,6 @@ inline int ew_blocks(long nchunks, int cg, int cpt_default = 8, int occ = 0) {
     if (want < floor_blocks) want = floor_blocks;
     if (want > 2048) want = 2048;
     if (want < 1) want = 1;
-    static const int rounds_on = getenv("HC_EW_ROUNDS") ? atoi(getenv("HC_EW_ROUNDS")) : 1;
-    if (occ > 0 && rounds_on) {
-        const long round_ = 256L * occ;
-        if (want > round_ / 2 + round_ / 4) {                 // at least ~3/4 of a round wanted: whole rounds
-            long r = (want + round_ / 2) / round_;
-            if (r < 1) r = 1;
-            want = r * round_;
-        }
-    }
     long k = (want + unit - 1) / unit;
     return (int)(k * unit);
 }
@@ -1009,7 +998,7 @@ int hc_rep_apply(const void* y3, const void* y1, const void* x, const float* coe
                  int32_t C, int32_t act, hc_stream_t stream) {
     if (y3 == nullptr || y1 == nullptr || coef == nullptr || out == nullptr || (C % 8) != 0) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
-    const int blocks = ew_blocks(nchunks, C / 8, out_stats ? 16 : 8, 6);
+    const int blocks = ew_blocks(nchunks, C / 8, out_stats ? 16 : 8);
     hipStream_t st = (hipStream_t)stream;
     const size_t sm = out_stats ? EW_THREADS * 17 * sizeof(float) : 0;
 #define HC_LAUNCH_APPLY1(ID, ST, NTM)                                                                                    \
@@ -1044,7 +1033,7 @@ static int rep_bwd_reduce_launch(const void* g, const void* out, const float* co
     if (g == nullptr || (out == nullptr && coef == nullptr) || y3 == nullptr || y1 == nullptr || red == nullptr || (C % 8) != 0)
         return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
-    const int blocks = ew_blocks(nchunks, C / 8, 16, 4);
+    const int blocks = ew_blocks(nchunks, C / 8, 16);
     hipStream_t st = (hipStream_t)stream;
     const size_t sm = EW_THREADS * 33 * sizeof(float);
 #define HC_RBR1(ID, ZM, NTM)                                                                                                             \
@@ -1092,7 +1081,7 @@ static int rep_bwd_apply_launch(const void* g, const void* out, const float* coe
         return HC_ERR_ARG;
     if ((x == nullptr) != (dxid == nullptr)) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
-    const int blocks = ew_blocks(nchunks, C / 8, 8, x != nullptr ? 3 : 4);
+    const int blocks = ew_blocks(nchunks, C / 8);
     hipStream_t st = (hipStream_t)stream;
 #define HC_RBA1(ID, ZM, NTM)                                                                                                         \
     hipLaunchKernelGGL((rep_bwd_apply_kernel<ID, ZM, NTM>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)g, (const u32x4*)out, \
