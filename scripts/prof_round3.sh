@@ -55,3 +55,5 @@ cp gpurun_out/pmc_repvgg_a2_fp8/traffic.json profiles/r03_pmc_repvgg_a2_fp8_traf
 timeout 300 python scripts/bench_repvgg_fp8.py > $O/r03_final_repvgg_a2_fp8_bench.json 2> $O/fp8.err
 ls -la $O | head -60
 cut -c1-300 $O/r03_final_bench.json
+timeout 200 python scripts/fixture_fracs.py 2>&1 | grep -v amdgpu > $O/fixture_fracs.txt; tail -1 $O/fixture_fracs.txt
+timeout 400 python -m pytest tests/test_gpu_yolo.py -q -x 2>&1 | tail -5 > $O/yolo_tests.log; cat $O/yolo_tests.log
