@@ -72,6 +72,15 @@ class ConvS2DgradDesc(C.Structure):
                 ("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32)]
 
 
+HC_MULTI_COPY_MAX = 64
+HC_MULTI_COPY_PIECE = 262144
+
+
+class MultiCopyDesc(C.Structure):
+    _fields_ = [("src", c_void_p * HC_MULTI_COPY_MAX), ("dst", c_void_p * HC_MULTI_COPY_MAX), ("n", c_int64 * HC_MULTI_COPY_MAX),
+                ("nitems", c_int32), ("src_bf16", c_int32), ("dst_bf16", c_int32), ("scale", C.c_float)]
+
+
 class RepBnDesc(C.Structure):
     _fields_ = [("stats", c_void_p * 3), ("gamma", c_void_p * 3), ("beta", c_void_p * 3),
                 ("running_mean", c_void_p * 3), ("running_var", c_void_p * 3), ("num_batches_tracked", c_void_p * 3),
@@ -158,6 +167,7 @@ SIGNATURES = {
     "hc_tadam_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "hc_adan_step": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "hc_lookahead_sync": (c_int32, [c_void_p, c_int32, c_float, c_void_p]),
+    "hc_multi_copy": (c_int32, [C.POINTER(MultiCopyDesc), c_void_p]),
     "hc_msbn_finalize": (c_int32, [C.POINTER(MsbnDesc), c_void_p]),
     "hc_msbn_bwd_finalize": (c_int32, [C.POINTER(MsbnDesc), c_void_p]),
     "hc_msbn_apply": (c_int32, [C.POINTER(MsbnIo), c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),

@@ -363,6 +363,57 @@ __global__ __launch_bounds__(256) void lookahead_sync_kernel(const hc_mt_chunk* 
     }
 }
 
+// ---------------------------------------------------------------- gradient-bucket pack / unpack (holocron_amd/parallel.py)
+// dst[i] = scale * src[i] over up to HC_MULTI_COPY_MAX tensor pieces in ONE launch, fp32 <-> fp32 / bf16.  The piece table travels
+// BY VALUE in the kernel arguments: nothing has to be uploaded (or kept alive) for a launch captured in a hipGraph, and the eager
+// step pays no host-to-device copy per bucket.  Pure streaming: 16 bytes per lane on the fp32 side when both pointers allow it.
+template <typename TS, typename TD>
+__device__ __forceinline__ void multi_copy_piece(const TS* __restrict__ src, TD* __restrict__ dst, const long n, const float scale) {
+    constexpr bool SB = sizeof(TS) == 2, DB = sizeof(TD) == 2;
+    auto ld = [&](long i) { if constexpr (SB) return bf16_to_f32(src[i]); else return src[i]; };
+    auto st = [&](long i, float v) { if constexpr (DB) dst[i] = f32_to_bf16(v); else dst[i] = v; };
+    const long t = (long)blockIdx.x * 256 + threadIdx.x, nt = (long)gridDim.x * 256;
+    const bool vec = (reinterpret_cast<uintptr_t>(src) % (4 * sizeof(TS)) == 0) && (reinterpret_cast<uintptr_t>(dst) % (4 * sizeof(TD)) == 0);
+    long done = 0;
+    if (vec) {
+        const long n4 = n >> 2;
+        for (long q = t; q < n4; q += nt) {
+            float v[4];
+            if constexpr (SB) {
+                const u32x2 w = reinterpret_cast<const u32x2*>(src)[q];
+                v[0] = bf16lo(w[0]); v[1] = bf16hi(w[0]); v[2] = bf16lo(w[1]); v[3] = bf16hi(w[1]);
+            } else {
+                const f32x4 w = reinterpret_cast<const f32x4*>(src)[q];
+                v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= scale;
+            if constexpr (DB) {
+                u32x2 w;
+                w[0] = pack_bf16x2(v[0], v[1]); w[1] = pack_bf16x2(v[2], v[3]);
+                reinterpret_cast<u32x2*>(dst)[q] = w;
+            } else {
+                const f32x4 w = {v[0], v[1], v[2], v[3]};
+                reinterpret_cast<f32x4*>(dst)[q] = w;
+            }
+        }
+        done = n4 << 2;
+    }
+    for (long i = done + t; i < n; i += nt) st(i, ld(i) * scale);
+}
+
+__global__ __launch_bounds__(256) void multi_copy_kernel(const hc_multi_copy_desc d) {
+    const int it = blockIdx.y;
+    const long n = d.n[it];
+    if (d.src_bf16) {
+        if (d.dst_bf16) multi_copy_piece(static_cast<const bf16_t*>(d.src[it]), static_cast<bf16_t*>(d.dst[it]), n, d.scale);
+        else multi_copy_piece(static_cast<const bf16_t*>(d.src[it]), static_cast<float*>(d.dst[it]), n, d.scale);
+    } else {
+        if (d.dst_bf16) multi_copy_piece(static_cast<const float*>(d.src[it]), static_cast<bf16_t*>(d.dst[it]), n, d.scale);
+        else multi_copy_piece(static_cast<const float*>(d.src[it]), static_cast<float*>(d.dst[it]), n, d.scale);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -375,6 +426,23 @@ int hc_adabelief_step(const hc_mt_chunk* chunks, int32_t nchunks, hc_adabelief_g
     // counting without any host write (a host-updated counter would race with queued replays)
     if (advance) hipLaunchKernelGGL(adabelief_advance_kernel, dim3((ngroups + 63) / 64), dim3(64), 0, st, groups, ngroups);
     if (nchunks > 0) hipLaunchKernelGGL(adabelief_kernel, dim3(nchunks), dim3(256), 0, st, chunks, groups);
+    return hc_launch_status();
+}
+
+int hc_multi_copy(const hc_multi_copy_desc* d, hc_stream_t stream) {
+    if (d == nullptr || d->nitems < 0 || d->nitems > HC_MULTI_COPY_MAX) return HC_ERR_ARG;
+    if (d->nitems == 0) return HC_OK;
+    long nmax = 0;
+    for (int i = 0; i < d->nitems; ++i) {
+        if (d->n[i] < 0 || (d->n[i] > 0 && (d->src[i] == nullptr || d->dst[i] == nullptr))) return HC_ERR_ARG;
+        nmax = d->n[i] > nmax ? d->n[i] : nmax;
+    }
+    if (nmax == 0) return HC_OK;
+    // pieces are at most a few hundred thousand elements (the host splits larger tensors): 16 workgroups sweep the largest one in
+    // a handful of rounds, and a launch of 64 such pieces is 1024 workgroups - four per CU
+    long gx = (nmax + 256 * 16 - 1) / (256 * 16);
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)gx, (unsigned)d->nitems), dim3(256), 0, (hipStream_t)stream, *d);
     return hc_launch_status();
 }
 

@@ -408,6 +408,24 @@ int hc_adan_step(const hc_mt_chunk* chunks, const hc_mt_chunk* extra, int32_t nc
  * slow += sync_rate * (fast - slow) when sync_rate > 0, then fast = slow. */
 int hc_lookahead_sync(const hc_mt_chunk* chunks, int32_t nchunks, float sync_rate, hc_stream_t stream);
 
+/* ---- gradient-bucket pack / unpack (no reference counterpart: the reference is single-device, holocron/trainer/core.py:90-104;
+ * this is the cast-copy on either side of the data-parallel all-reduce of SURVEY.md §8e, holocron_amd/parallel.py) ----
+ * dst[i][0..n[i]) = scale * src[i][0..n[i]) for nitems <= HC_MULTI_COPY_MAX pieces in ONE launch; element types fp32 or bf16
+ * (src_bf16 / dst_bf16).  The table is passed by value to the kernel, so the descriptor may live on the caller's stack and a launch
+ * captured in a hipGraph holds no reference to host memory.  The caller splits large tensors into pieces of a few hundred
+ * thousand elements (HC_MULTI_COPY_PIECE) so that every piece is swept by the same 16 workgroups. */
+#define HC_MULTI_COPY_MAX 64
+#define HC_MULTI_COPY_PIECE 262144
+typedef struct {
+    const void* src[HC_MULTI_COPY_MAX];
+    void* dst[HC_MULTI_COPY_MAX];
+    int64_t n[HC_MULTI_COPY_MAX];
+    int32_t nitems;
+    int32_t src_bf16, dst_bf16;   /* 0: fp32, 1: bf16 */
+    float scale;
+} hc_multi_copy_desc;
+int hc_multi_copy(const hc_multi_copy_desc* d, hc_stream_t stream);
+
 /* ---- pointwise / losses / boxes ---- */
 /* hard_mish: 0.5*x*clamp(x+2,0,2) (holocron/nn/functional.py:30-41), fp32, y may alias x. */
 int hc_hard_mish_fwd(const float* x, float* y, int64_t n, hc_stream_t stream);

@@ -73,7 +73,7 @@ def main():
            "rexnet1_0x bf16 train step (fwd+CE+bwd+AdaBelief), synthetic 224^2, bs=256 per MI355X (BASELINE.json configs[2]), "
            "random-init weights, 1000 classes", train_gflop_per_img=2.39, cpu_baseline=cpu_baseline,
            # >= 30 MB/img of algorithmic HBM bytes forward (bf16, BN / activation fused), ~3.5 x for a training step
-           extra=lambda sec, batch: {"hbm_floor_ms": 30e6 * 3.5 * batch / 6.29e12 * 1e3})
+           extra=lambda sec, batch: {"hbm_floor_ms": 30e6 * 3.5 * batch / 6.29e12 * 1e3}, traffic_key="rexnet")
 
 
 if __name__ == "__main__":

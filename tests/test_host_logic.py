@@ -112,9 +112,11 @@ def test_struct_sizes_match_header_layout(tmp_path):
              "hc_wgrad_desc": _lib.WgradDesc, "hc_pack_item": _lib.PackItem, "hc_rep_bn_desc": _lib.RepBnDesc,
              "hc_rep_bn_bwd_desc": _lib.RepBnBwdDesc, "hc_mt_chunk": _lib.MtChunk, "hc_adabelief_group": _lib.AdaBeliefGroup,
              "hc_lars_group": _lib.LarsGroup, "hc_drop_item": _lib.DropItem, "hc_adamx_group": _lib.AdamxGroup, "hc_lamb_group": _lib.LambGroup, "hc_msbn_branch": _lib.MsbnBranch,
-             "hc_msbn_desc": _lib.MsbnDesc, "hc_msbn_io": _lib.MsbnIo, "hc_rep_wgrad_desc": _lib.RepWgradDesc}
+             "hc_msbn_desc": _lib.MsbnDesc, "hc_msbn_io": _lib.MsbnIo, "hc_rep_wgrad_desc": _lib.RepWgradDesc,
+             "hc_conv_s2_desc": _lib.ConvS2Desc, "hc_conv_s2_dgrad_desc": _lib.ConvS2DgradDesc, "hc_multi_copy_desc": _lib.MultiCopyDesc}
     last = {"hc_conv_desc": "co_split", "hc_rep_wgrad_desc": "accumulate", "hc_pack_item": "ld", "hc_rep_bn_desc": "c_valid", "hc_rep_bn_bwd_desc": "frozen",
-            "hc_conv_small_desc": "mode", "hc_wgrad_desc": "beta", "hc_lamb_group": "mode", "hc_msbn_branch": "momentum", "hc_msbn_desc": "accumulate", "hc_msbn_io": "C"}
+            "hc_conv_small_desc": "mode", "hc_wgrad_desc": "beta", "hc_lamb_group": "mode", "hc_msbn_branch": "momentum", "hc_msbn_desc": "accumulate", "hc_msbn_io": "C",
+            "hc_conv_s2_desc": "x_nchw_f32", "hc_conv_s2_dgrad_desc": "Cout", "hc_multi_copy_desc": "scale"}
     src = tmp_path / "sz.c"
     lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{os.path.join(ROOT, "include", "holocron_hip.h")}"', "int main(void) {"]
     for name in pairs:
