@@ -34,9 +34,17 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // and one v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 0x7f) replaces two bf16 MFMAs at twice the rate;
 // the epilogue applies the per-channel dequant * requant factor and bias, ReLU, and stores fp8.
 typedef __attribute__((ext_vector_type(8))) int hc_i32x8;
-template <int MR, int NR, int WM, int WN, int BK, bool FP8>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_conv_desc d, const int reps, const int flags) {
+// NS: LDS stages of the k-loop.  2 = the classic double buffer (DMA of step s + 1 behind the MFMAs of step s, two co-resident
+// workgroups per CU hide each other's barriers).  4 = the BIG-TILE form for layers with thousands of channels (RepVGG's 1280-channel
+// blocks): one 4-wave workgroup per CU, 256 x 256 tile, every wave a 128 x 128 sub-tile in 256 accumulator registers - per k32 step
+// a CU then moves 96 KB through LDS (32 KB of DMA writes + 4 x 16 KB of fragment reads = 768 clocks at 128 B / clock) against 1031
+// clocks of MFMA, where the 128 x 128 tile moves 96 KB against 512: that kernel is LDS-bound at 2/3 of the matrix rate before
+// anything else goes wrong.  With nobody else on the CU the DMA runs THREE steps ahead (asm-issued buffer_load ... lds + counted
+// s_waitcnt vmcnt, the compiler's own wait insertion would drain the queue at every barrier).
+template <int MR, int NR, int WM, int WN, int BK, bool FP8, int NS = 2, int MINB = 2>
+__global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const hc_conv_desc d, const int reps, const int flags) {
     static_assert(!FP8 || BK == 32, "fp8: 64 one-byte channels per k-step");
+    static_assert(NS == 2 || !FP8, "the deep pipeline is bf16 only");
     constexpr int NT = 64 * WM * WN;
     constexpr int BC = 32 * MR * WM;  // output-channel tile (A rows)
     constexpr int BP = 32 * NR * WN;  // output-pixel tile (B cols)
@@ -197,6 +205,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
         }
     };
 
+    if constexpr (NS == 2) {
     // ---- main loop: the DMA of step s+1 is in flight during the MFMAs of step s; one barrier/step ----
     if (S > 0) issue(0, 0, 0);   // a parity class may have no taps (1x1 stride-2 dgrad): result is just resid
     int tap = 0, ck = 0;
@@ -213,6 +222,96 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
         compute(s & 1);
     }
     __syncthreads();
+    } else {
+    // ---- deep pipeline: stage s + NS - 1 is issued at step s (into the buffer step s - 1 just left), so NS - 2 whole steps of
+    // DMA stay in flight across every barrier.  A wave issues PER = XJ + WJ instructions per stage, all unconditional: the counted
+    // wait `vmcnt((NS - 2) PER)` is exactly "my share of stage s has landed".
+    static_assert(XQ % NW == 0 && WQ % NW == 0, "every wave issues the same number of DMA instructions per stage");
+    constexpr int PER = XJ + WJ;
+    static_assert((NS - 2) * PER <= 63, "vmcnt immediate");
+    const unsigned lds0 = hc_lds_addr(smem);
+    const int widu = __builtin_amdgcn_readfirstlane(wid);
+    auto uniform = [](const u32x4 r) __attribute__((always_inline)) {
+        u32x4 o;
+        o[0] = __builtin_amdgcn_readfirstlane(r[0]); o[1] = __builtin_amdgcn_readfirstlane(r[1]);
+        o[2] = __builtin_amdgcn_readfirstlane(r[2]); o[3] = __builtin_amdgcn_readfirstlane(r[3]);
+        return o;
+    };
+    const u32x4 qw = uniform(hc_raw_rsrc(d.wpk, (unsigned)Cout * T * srcC * 2u));
+    const u32x4 qx0 = uniform(hc_raw_rsrc(d.src0, src_bytes));
+    const u32x4 qx1 = uniform(hc_raw_rsrc(d.src1 != nullptr ? d.src1 : d.src0, src_bytes));
+    auto issue_deep = [&](int stage, int tap_, int ck_) __attribute__((always_inline)) {
+        const unsigned sw = lds0 + (unsigned)(stage * STAGE), sx = sw + WBYTES;
+        const int tp = cl.tap[tap_];
+        const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
+        const int sidx = (tp >> 16) & 0xff, wt = (tp >> 24) & 0xff;
+        const unsigned tofs = (unsigned)((dy * IW + dx) * srcC * 2 + ck_ * BK * 2);
+        if (sidx) {
+#pragma unroll
+            for (int j = 0; j < XJ; ++j)
+                hc_dma16(qx1, __builtin_amdgcn_readfirstlane(sx + (unsigned)((widu + j * NW) * 1024)),
+                         ((x_vmask[j] >> tap_) & 1u) ? x_base[j] + tofs : HC_OOB);
+        } else {
+#pragma unroll
+            for (int j = 0; j < XJ; ++j)
+                hc_dma16(qx0, __builtin_amdgcn_readfirstlane(sx + (unsigned)((widu + j * NW) * 1024)),
+                         ((x_vmask[j] >> tap_) & 1u) ? x_base[j] + tofs : HC_OOB);
+        }
+        const unsigned wk = (unsigned)(wt * srcC + ck_ * BK) * 2u;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j)
+            hc_dma16(qw, __builtin_amdgcn_readfirstlane(sw + (unsigned)((widu + j * NW) * 1024)), (w_off[j] == HC_OOB) ? HC_OOB : w_off[j] + wk);
+    };
+    static_assert(BK == 32, "two k16 halves per stage");
+    // Fragment schedule: with one wave per SIMD nobody else covers an LDS round trip, so the halves of a stage are skewed across the
+    // barrier - the reads of (s, first half) fly under the MFMAs of (s - 1, second half), those of (s, second half) under the
+    // MFMAs of (s, first half).  sched_barrier keeps the compiler from sinking every read next to its first use.
+    bf16x8 fa0[MR], fb0[NR], fa1[MR], fb1[NR];
+    auto read_half = [&](int stage, int kk, bf16x8 (&fa)[MR], bf16x8 (&fb)[NR]) __attribute__((always_inline)) {
+        const char* st = smem + stage * STAGE;
+        const char* pa = st + a_row0 + frag_off[kk];
+        const char* pb = st + b_row0 + frag_off[kk];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) fa[mr] = *reinterpret_cast<const bf16x8*>(pa + mr * 32 * BK * 2);
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) fb[nr] = *reinterpret_cast<const bf16x8*>(pb + nr * 32 * BK * 2);
+    };
+    auto mma_half = [&](const bf16x8 (&fa)[MR], const bf16x8 (&fb)[NR]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mr], fb[nr], acc[mr][nr], 0, 0, 0);
+    };
+    int tap = 0, ck = 0;
+    for (int p = 0; p < NS - 1 && p < S; ++p) {
+        issue_deep(p, tap, ck);
+        if (++tap == cl.ntaps) { tap = 0; ++ck; }
+    }
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+        const int ahead = S - 1 - s;                         // stages issued after s so far (capped at NS - 2 below)
+        if (ahead >= NS - 2) hc_wait_vmcnt<(NS - 2) * PER>();
+        else if (ahead == 1) hc_wait_vmcnt<PER>();
+        else hc_wait_vmcnt<0>();
+        __syncthreads();                                     // lgkmcnt(0) + s_barrier on gfx950: the DMA queue is left alone
+        if (s + NS - 1 < S) {
+            issue_deep((s + NS - 1) % NS, tap, ck);
+            if (++tap == cl.ntaps) { tap = 0; ++ck; }
+        }
+        read_half(s % NS, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s > 0) mma_half(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(s % NS, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (S > 0) mma_half(fa1, fb1);
+    hc_wait_vmcnt<0>();
+    __syncthreads();
+    }
 
     // ---- epilogue --------------------------------------------------------------------------
     const int lr = lane & 31, lh = lane >> 5;
@@ -270,7 +369,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
 #pragma unroll
                 for (int w = 1; w < WN; ++w) v += pl[w * 2 * BC];
                 const int cg_ = cbase + c;
-                if (d.co_split > 0) {      // stacked convolutions: each has its own statistics array
+                if (NS == 2 && d.co_split > 0) {      // stacked convolutions: each has its own statistics array
                     const int C1 = d.co_split, C2 = Cout - d.co_split;
                     if (cg_ < C1) atomicAdd(d.stats + (size_t)(blockIdx.x % reps) * 2 * C1 + which * C1 + cg_, v);
                     else atomicAdd(d.stats2 + (size_t)(blockIdx.x % reps) * 2 * C2 + which * C2 + (cg_ - C1), v);
@@ -342,11 +441,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[mr][nr][4 * q + e];
+                if constexpr (NS == 2) {        // (the big-tile form is only dispatched without these: hc_conv_gather)
                 if (d.pix_scale != nullptr) {   // NormConv2d: rstd_p * (sum_k W p_k - mean_p * sum_k W)  (functional.py:345-349)
                     const float ps = d.pix_scale[pix], pm = d.pix_shift[pix];
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (co + e < Cout) v[e] = ps * (v[e] - pm * d.ch_coef[co + e]);
+                }
                 }
                 if (d.bias != nullptr) {
 #pragma unroll
@@ -367,6 +468,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
                     o[0] = pack_bf16x2(v[0], v[1]);
                     o[1] = pack_bf16x2(v[2], v[3]);
                     *reinterpret_cast<u32x2*>(ost + ((wn * NR + nr) * 32 + lr) * OPITCH + (co - cbase) * 2) = o;
+                } else if constexpr (NS > 2) {       // big tile: staged stores only (hc_conv_gather checks)
                 } else if (d.co_split > 0) {         // stacked convolutions: two destinations with their own channel counts
                     const bool second = co >= d.co_split;
                     bf16_t* dp = second ? reinterpret_cast<bf16_t*>(d.dst2) + pix * (Cout - d.co_split) + (co - d.co_split)
@@ -416,7 +518,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
             const u32x2 lo = *reinterpret_cast<const u32x2*>(ost + pl * OPITCH + ch * 16);
             const u32x2 hi = *reinterpret_cast<const u32x2*>(ost + pl * OPITCH + ch * 16 + 8);
             const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-            if (d.co_split > 0) {
+            if (NS == 2 && d.co_split > 0) {
                 if (co >= d.co_split) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(d.dst2) + pix * (Cout - d.co_split) + (co - d.co_split)) = v;
                 else *reinterpret_cast<u32x4*>(dst + pix * d.co_split + co) = v;
             } else {
@@ -426,10 +528,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gather_kernel(const hc_c
     }
 }
 
-template <int MR, int NR, int WM, int WN, int BK, bool FP8 = false>
+template <int MR, int NR, int WM, int WN, int BK, bool FP8 = false, int NS = 2, int MINB = 2>
 int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
     constexpr int BC = 32 * MR * WM, BP = 32 * NR * WN;
-    constexpr int smem_k = 2 * (BC + BP) * BK * 2, smem_o = BP * (BC * 2 + 8);    // k-loop stages / output staging
+    constexpr int smem_k = NS * (BC + BP) * BK * 2, smem_o = BP * (BC * 2 + 8);    // k-loop stages / output staging
+    static_assert(smem_k <= 160 * 1024 && smem_o <= 160 * 1024, "LDS budget");
     constexpr int smem = smem_k > smem_o ? smem_k : smem_o;
     static const int flags = [] { const char* e = getenv("HC_CONV_STAGED_STORES"); return (e == nullptr || atoi(e) != 0) ? 1 : 0; }();
     int maxM = 0;
@@ -439,7 +542,7 @@ int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
     }
     if (maxM == 0) return HC_OK;
     dim3 grid((maxM + BP - 1) / BP, (d.Cout + BC - 1) / BC, d.nclass);
-    auto kern = conv_gather_kernel<MR, NR, WM, WN, BK, FP8>;
+    auto kern = conv_gather_kernel<MR, NR, WM, WN, BK, FP8, NS, MINB>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -450,12 +553,10 @@ int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
     return hc_launch_status();
 }
 
-// Measured and dropped (round 3): a 256 x 256 tile with eight waves (launch_cfg<4, 2, 2, 4>, one workgroup per CU, 128 accumulator
-// registers per lane).  The idea: per wave and k-step the 128 x 128 tile issues 8 LDS-DMA instructions against 16 MFMAs, the big tile
-// the same 8 against 32.  Result on the 1280-channel layers of RepVGG-A0: 208 TFLOP/s against 855 - four times SLOWER (1779 us
-// against 433 us forward, 1976 against 473 us data gradient), YOLOv4 528 -> 485 img/s.  With 128 accumulators + 180 VGPRs the
-// kernel spills 576 bytes per lane and one 8-wave workgroup per CU leaves nothing to run while its barrier drains; the two
-// co-resident 4-wave workgroups of the 128 x 128 tile hide each other's barriers for free.
+// Measured and dropped (round 3): a 256 x 256 tile with EIGHT waves (launch_cfg<4, 2, 2, 4>, 128 accumulator registers per lane) under
+// this kernel's old __launch_bounds__(512, 2): the bound capped the register file at 128 per lane, the kernel spilled 576 bytes per
+// lane and ran at 208 TFLOP/s against 855 (1779 us against 433 us forward on the 1280-channel layers).  The big tile that works is
+// the four-wave one above (NS = 4, MINB = 1: 512 registers per lane, 256 of them accumulators).
 template <int BK>
 int launch_bk(const hc_conv_desc& d, hipStream_t st) {
     const int C = d.Cout;
@@ -503,6 +604,17 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
         if ((d.srcC % 64) != 0 || (d.Cout % 4) != 0 || d.stats != nullptr || d.resid != nullptr || d.pix_scale != nullptr) return HC_ERR_ARG;
         if ((double)d.N * d.IH * d.IW * d.srcC >= 4294967280.0) return HC_ERR_ARG;
         return launch_fp8(d, st);
+    }
+    // Big-tile form (NS = 4, see the kernel): one 256 x 256 tile per CU, so it only pays when the tile count fills whole rounds of
+    // the 256 CUs (RepVGG-A0's 1280-channel layers at batch 256: 49 x 5 = 245 tiles) and K is long enough to amortise the 133 KB
+    // epilogue.  HC_CONV_BIG=0 sends these layers back to the 128 x 128 tile (same-box A/B).
+    static const int big = [] { const char* e = getenv("HC_CONV_BIG"); return e == nullptr ? 1 : atoi(e); }();
+    if (big && d.nclass == 1 && d.co_split == 0 && d.pix_scale == nullptr && d.srcC % 32 == 0 && d.Cout % 256 == 0) {
+        const long M = (long)d.N * d.cls[0].OHg * d.cls[0].OWg;
+        const long tiles = ((M + 255) / 256) * (d.Cout / 256), rem = tiles % 256;
+        const int S = d.cls[0].ntaps * (d.srcC / 32);
+        static const int staged = [] { const char* e = getenv("HC_CONV_STAGED_STORES"); return (e == nullptr || atoi(e) != 0) ? 1 : 0; }();
+        if (staged && tiles >= 224 && (rem == 0 || rem >= 224) && S >= 16) return launch_cfg<4, 4, 2, 2, 32, false, 4, 1>(d, st);
     }
     if (d.srcC % 64 == 0) return launch_bk<64>(d, st);
     if (d.srcC % 32 == 0) return launch_bk<32>(d, st);
