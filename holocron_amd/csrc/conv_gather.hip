@@ -44,7 +44,9 @@ typedef __attribute__((ext_vector_type(8))) int hc_i32x8;
 template <int MR, int NR, int WM, int WN, int BK, bool FP8, int NS = 2, int MINB = 2>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const hc_conv_desc d, const int reps, const int flags) {
     static_assert(!FP8 || BK == 32, "fp8: 64 one-byte channels per k-step");
-    static_assert(NS == 2 || !FP8, "the deep pipeline is bf16 only");
+    constexpr bool BIG = MINB == 1;       // one workgroup per CU: asm-issued DMA, skewed fragment schedule, pruned epilogue
+    static_assert(!BIG || !FP8, "the big-tile form is bf16 only");
+    static_assert(BIG || NS == 2, "the classic form is double-buffered");
     constexpr int NT = 64 * WM * WN;
     constexpr int BC = 32 * MR * WM;  // output-channel tile (A rows)
     constexpr int BP = 32 * NR * WN;  // output-pixel tile (B cols)
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
         }
     };
 
-    if constexpr (NS == 2) {
+    if constexpr (!BIG) {
     // ---- main loop: the DMA of step s+1 is in flight during the MFMAs of step s; one barrier/step ----
     if (S > 0) issue(0, 0, 0);   // a parity class may have no taps (1x1 stride-2 dgrad): result is just resid
     int tap = 0, ck = 0;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
         for (int j = 0; j < WJ; ++j)
             hc_dma16(qw, __builtin_amdgcn_readfirstlane(sw + (unsigned)((widu + j * NW) * 1024)), (w_off[j] == HC_OOB) ? HC_OOB : w_off[j] + wk);
     };
-    static_assert(BK == 32, "two k16 halves per stage");
+    constexpr int KK = BK / 16;
     // Fragment schedule: with one wave per SIMD nobody else covers an LDS round trip, so the halves of a stage are skewed across the
     // barrier - the reads of (s, first half) fly under the MFMAs of (s - 1, second half), those of (s, second half) under the
     // MFMAs of (s, first half).  sched_barrier keeps the compiler from sinking every read next to its first use.
@@ -276,6 +278,55 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) fb[nr] = *reinterpret_cast<const bf16x8*>(pb + nr * 32 * BK * 2);
     };
+    // The DMA of stage s + NS - 1 is not issued as a burst behind the barrier (where nothing covers it: an LDS-DMA instruction costs
+    // the issuing wave 100-185 cycles next to other memory instructions, 8 of them per stage = most of a stage's 1031 MFMA cycles)
+    // but ONE PIECE PER ROW OF FOUR MFMAS, inside the matrix stream, where it costs what fits between two MFMAs.
+    // Branch-free on purpose: a stage past the end is issued all the same with out-of-range offsets (zero fill into a buffer nobody
+    // reads - the vmcnt bookkeeping stays one constant), and the source descriptor of the tap is picked once per step; with scalar
+    // branches around every piece the compiler's wait-count pass gave up on the LDS queue and put lgkmcnt(0) in front of the first
+    // MFMA of every step, which serialises exactly the round trip the skew is there to hide.
+    struct Pend { u32x4 qx; unsigned sw, sx, tofs, wk, live; int tap; };
+    auto plan = [&](int stage, int tap_, int ck_, bool on) __attribute__((always_inline)) {
+        Pend c;
+        c.live = on ? 1u : 0u;
+        c.sw = lds0 + (unsigned)(stage * STAGE);
+        c.sx = c.sw + WBYTES;
+        const int tp = cl.tap[on ? tap_ : 0];
+        const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
+        const bool second = ((tp >> 16) & 0xff) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c.qx[i] = second ? qx1[i] : qx0[i];
+        c.tap = tap_;
+        c.tofs = (unsigned)((dy * IW + dx) * srcC * 2 + ck_ * BK * 2);
+        c.wk = (unsigned)(((tp >> 24) & 0xff) * srcC + ck_ * BK) * 2u;
+        return c;
+    };
+    auto piece = [&](const Pend& c, const int q) __attribute__((always_inline)) {      // q: compile-time piece index, x rows first
+        if (q < XJ) {
+            const unsigned voff = (((x_vmask[q] >> c.tap) & c.live) != 0u) ? x_base[q] + c.tofs : HC_OOB;
+            hc_dma16(c.qx, __builtin_amdgcn_readfirstlane(c.sx + (unsigned)((widu + q * NW) * 1024)), voff);
+        } else {
+            const int j = q - XJ;
+            const unsigned voff = (w_off[j] == HC_OOB || c.live == 0u) ? HC_OOB : w_off[j] + c.wk;
+            hc_dma16(qw, __builtin_amdgcn_readfirstlane(c.sw + (unsigned)((widu + j * NW) * 1024)), voff);
+        }
+    };
+    static_assert(PER % (KK * MR) == 0, "whole pieces per row of MFMAs");
+    constexpr int PPR = PER / (KK * MR);                 // pieces per row of NR MFMAs
+    // phase f of a step: MR rows of NR MFMAs on (fa, fb), row mr followed by the pieces [(f MR + mr) PPR, +PPR) of the pending stage
+    auto mma_phase = [&](const bf16x8 (&fa)[MR], const bf16x8 (&fb)[NR], const Pend& c, const int f, const bool mul) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            if (mul) {
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mr], fb[nr], acc[mr][nr], 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < PPR; ++e) piece(c, (f * MR + mr) * PPR + e);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     auto mma_half = [&](const bf16x8 (&fa)[MR], const bf16x8 (&fb)[NR]) __attribute__((always_inline)) {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
@@ -283,30 +334,40 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
             for (int nr = 0; nr < NR; ++nr)
                 acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mr], fb[nr], acc[mr][nr], 0, 0, 0);
     };
+#pragma unroll
+    for (int i = 0; i < MR; ++i) fa1[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NR; ++i) fb1[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     int tap = 0, ck = 0;
-    for (int p = 0; p < NS - 1 && p < S; ++p) {
+    for (int p = 0; p < NS - 1; ++p) {                       // S >= NS - 1 (hc_conv_gather dispatches this form for S >= 16 only)
         issue_deep(p, tap, ck);
         if (++tap == cl.ntaps) { tap = 0; ++ck; }
     }
 #pragma unroll 1
     for (int s = 0; s < S; ++s) {
-        const int ahead = S - 1 - s;                         // stages issued after s so far (capped at NS - 2 below)
-        if (ahead >= NS - 2) hc_wait_vmcnt<(NS - 2) * PER>();
-        else if (ahead == 1) hc_wait_vmcnt<PER>();
-        else hc_wait_vmcnt<0>();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the fragments read a phase ago are in (free by now) - said with
+                                                             // the builtin so that the compiler's own wait insertion knows it too
+        hc_wait_vmcnt<(NS - 2) * PER>();                     // NS - 2 stages stay in flight (real or, past the end, zero-fill dummies)
         __syncthreads();                                     // lgkmcnt(0) + s_barrier on gfx950: the DMA queue is left alone
-        if (s + NS - 1 < S) {
-            issue_deep((s + NS - 1) % NS, tap, ck);
-            if (++tap == cl.ntaps) { tap = 0; ++ck; }
+        const bool more = s + NS - 1 < S;
+        const Pend c = plan((s + NS - 1) % NS, tap, ck, more);
+        if (more && ++tap == cl.ntaps) { tap = 0; ++ck; }
+        const int stg = s % NS;
+        read_half(stg, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_phase(fa1, fb1, c, 0, true);                     // (s - 1, last k16): read before the barrier, multiplied behind it (zeros at s = 0)
+#pragma unroll
+        for (int kk = 1; kk < KK; ++kk) {
+            if (kk & 1) {
+                read_half(stg, kk, fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_phase(fa0, fb0, c, kk, true);
+            } else {
+                read_half(stg, kk, fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_phase(fa1, fb1, c, kk, true);
+            }
         }
-        read_half(s % NS, 0, fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s > 0) mma_half(fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        read_half(s % NS, 1, fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
     }
     if (S > 0) mma_half(fa1, fb1);
     hc_wait_vmcnt<0>();
@@ -369,7 +430,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
 #pragma unroll
                 for (int w = 1; w < WN; ++w) v += pl[w * 2 * BC];
                 const int cg_ = cbase + c;
-                if (NS == 2 && d.co_split > 0) {      // stacked convolutions: each has its own statistics array
+                if (!BIG && d.co_split > 0) {      // stacked convolutions: each has its own statistics array
                     const int C1 = d.co_split, C2 = Cout - d.co_split;
                     if (cg_ < C1) atomicAdd(d.stats + (size_t)(blockIdx.x % reps) * 2 * C1 + which * C1 + cg_, v);
                     else atomicAdd(d.stats2 + (size_t)(blockIdx.x % reps) * 2 * C2 + which * C2 + (cg_ - C1), v);
@@ -441,7 +502,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[mr][nr][4 * q + e];
-                if constexpr (NS == 2) {        // (the big-tile form is only dispatched without these: hc_conv_gather)
+                if constexpr (!BIG) {           // (the big-tile form is only dispatched without these: hc_conv_gather)
                 if (d.pix_scale != nullptr) {   // NormConv2d: rstd_p * (sum_k W p_k - mean_p * sum_k W)  (functional.py:345-349)
                     const float ps = d.pix_scale[pix], pm = d.pix_shift[pix];
 #pragma unroll
@@ -468,7 +529,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
                     o[0] = pack_bf16x2(v[0], v[1]);
                     o[1] = pack_bf16x2(v[2], v[3]);
                     *reinterpret_cast<u32x2*>(ost + ((wn * NR + nr) * 32 + lr) * OPITCH + (co - cbase) * 2) = o;
-                } else if constexpr (NS > 2) {       // big tile: staged stores only (hc_conv_gather checks)
+                } else if constexpr (BIG) {          // big tile: staged stores only (hc_conv_gather checks)
                 } else if (d.co_split > 0) {         // stacked convolutions: two destinations with their own channel counts
                     const bool second = co >= d.co_split;
                     bf16_t* dp = second ? reinterpret_cast<bf16_t*>(d.dst2) + pix * (Cout - d.co_split) + (co - d.co_split)
@@ -518,7 +579,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
             const u32x2 lo = *reinterpret_cast<const u32x2*>(ost + pl * OPITCH + ch * 16);
             const u32x2 hi = *reinterpret_cast<const u32x2*>(ost + pl * OPITCH + ch * 16 + 8);
             const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-            if (NS == 2 && d.co_split > 0) {
+            if (!BIG && d.co_split > 0) {
                 if (co >= d.co_split) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(d.dst2) + pix * (Cout - d.co_split) + (co - d.co_split)) = v;
                 else *reinterpret_cast<u32x4*>(dst + pix * d.co_split + co) = v;
             } else {
@@ -614,7 +675,10 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
         const long tiles = ((M + 255) / 256) * (d.Cout / 256), rem = tiles % 256;
         const int S = d.cls[0].ntaps * (d.srcC / 32);
         static const int staged = [] { const char* e = getenv("HC_CONV_STAGED_STORES"); return (e == nullptr || atoi(e) != 0) ? 1 : 0; }();
-        if (staged && tiles >= 224 && (rem == 0 || rem >= 224) && S >= 16) return launch_cfg<4, 4, 2, 2, 32, false, 4, 1>(d, st);
+        if (staged && tiles >= 224 && (rem == 0 || rem >= 224) && S >= 16) {
+            if (big == 2 && d.srcC % 64 == 0) return launch_cfg<4, 4, 2, 2, 64, false, 2, 1>(d, st);   // full 128-byte rows, one step ahead
+            return launch_cfg<4, 4, 2, 2, 32, false, 4, 1>(d, st);                                     // 64-byte rows, three steps ahead
+        }
     }
     if (d.srcC % 64 == 0) return launch_bk<64>(d, st);
     if (d.srcC % 32 == 0) return launch_bk<32>(d, st);
