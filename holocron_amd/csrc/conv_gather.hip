@@ -34,13 +34,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // and one v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 0x7f) replaces two bf16 MFMAs at twice the rate;
 // the epilogue applies the per-channel dequant * requant factor and bias, ReLU, and stores fp8.
 typedef __attribute__((ext_vector_type(8))) int hc_i32x8;
-// NS: LDS stages of the k-loop.  2 = the classic double buffer (DMA of step s + 1 behind the MFMAs of step s, two co-resident
-// workgroups per CU hide each other's barriers).  4 = the BIG-TILE form for layers with thousands of channels (RepVGG's 1280-channel
-// blocks): one 4-wave workgroup per CU, 256 x 256 tile, every wave a 128 x 128 sub-tile in 256 accumulator registers - per k32 step
-// a CU then moves 96 KB through LDS (32 KB of DMA writes + 4 x 16 KB of fragment reads = 768 clocks at 128 B / clock) against 1031
-// clocks of MFMA, where the 128 x 128 tile moves 96 KB against 512: that kernel is LDS-bound at 2/3 of the matrix rate before
-// anything else goes wrong.  With nobody else on the CU the DMA runs THREE steps ahead (asm-issued buffer_load ... lds + counted
-// s_waitcnt vmcnt, the compiler's own wait insertion would drain the queue at every barrier).
+// NS / MINB: (2, 2) = the classic form - double buffer, DMA of step s + 1 behind the MFMAs of step s, two co-resident 4-wave
+// workgroups per CU hide each other's barriers.  (4, 1) = the BIG-TILE form for layers with thousands of channels (RepVGG's
+// 1280-channel blocks): ONE workgroup per CU on a 256 x 256 tile, half the LDS-DMA and L1 bytes per flop of the 128 x 128 tile.
+// With nobody else on the CU the DMA runs THREE k32 steps ahead (asm-issued buffer_load ... lds + a counted s_waitcnt vmcnt: the
+// compiler's own wait insertion would drain the queue at every barrier), its pieces are issued one at a time inside the MFMA stream,
+// and the fragment reads of a step are skewed across the barrier.  Eight waves of 128 x 64 (two per SIMD, 128 accumulators each)
+// beat four waves of 128 x 128 (one per SIMD, 256 accumulators): see the table at the dispatch in hc_conv_gather.
 template <int MR, int NR, int WM, int WN, int BK, bool FP8, int NS = 2, int MINB = 2>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const hc_conv_desc d, const int reps, const int flags) {
     static_assert(!FP8 || BK == 32, "fp8: 64 one-byte channels per k-step");
@@ -286,12 +286,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
     // branches around every piece the compiler's wait-count pass gave up on the LDS queue and put lgkmcnt(0) in front of the first
     // MFMA of every step, which serialises exactly the round trip the skew is there to hide.
     struct Pend { u32x4 qx; unsigned sw, sx, tofs, wk, live; int tap; };
-    auto plan = [&](int stage, int tap_, int ck_, bool on) __attribute__((always_inline)) {
+    auto plan = [&](int stage, int tap_, int ck_, bool on, int tp) __attribute__((always_inline)) {   // tp = cl.tap[tap_], loaded a step ago
         Pend c;
         c.live = on ? 1u : 0u;
         c.sw = lds0 + (unsigned)(stage * STAGE);
         c.sx = c.sw + WBYTES;
-        const int tp = cl.tap[on ? tap_ : 0];
         const int dy = (int)(signed char)(tp & 0xff), dx = (int)(signed char)((tp >> 8) & 0xff);
         const bool second = ((tp >> 16) & 0xff) != 0;
 #pragma unroll
@@ -311,9 +310,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
             hc_dma16(qw, __builtin_amdgcn_readfirstlane(c.sw + (unsigned)((widu + j * NW) * 1024)), voff);
         }
     };
-    static_assert(PER % (KK * MR) == 0, "whole pieces per row of MFMAs");
-    constexpr int PPR = PER / (KK * MR);                 // pieces per row of NR MFMAs
-    // phase f of a step: MR rows of NR MFMAs on (fa, fb), row mr followed by the pieces [(f MR + mr) PPR, +PPR) of the pending stage
+    static_assert(PER % KK == 0, "whole pieces per phase");
+    constexpr int PPH = PER / KK;                        // pieces per phase, spread over its MR rows of NR MFMAs
+    // phase f of a step: MR rows of NR MFMAs on (fa, fb); piece k of the phase goes behind row k MR / PPH
     auto mma_phase = [&](const bf16x8 (&fa)[MR], const bf16x8 (&fb)[NR], const Pend& c, const int f, const bool mul) __attribute__((always_inline)) {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
@@ -323,7 +322,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
                     acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mr], fb[nr], acc[mr][nr], 0, 0, 0);
             }
 #pragma unroll
-            for (int e = 0; e < PPR; ++e) piece(c, (f * MR + mr) * PPR + e);
+            for (int k = 0; k < PPH; ++k)
+                if ((k * MR) / PPH == mr) piece(c, f * PPH + k);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -339,10 +339,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
 #pragma unroll
     for (int i = 0; i < NR; ++i) fb1[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     int tap = 0, ck = 0;
-    for (int p = 0; p < NS - 1; ++p) {                       // S >= NS - 1 (hc_conv_gather dispatches this form for S >= 16 only)
+    for (int p = 0; p < NS - 1; ++p) {                       // S >= NS - 1 (hc_conv_gather dispatches this form for S >= 128 only)
         issue_deep(p, tap, ck);
         if (++tap == cl.ntaps) { tap = 0; ++ck; }
     }
+    // tap words live in the lanes of one VGPR: a scalar load inside the loop would put an SMEM op on the lgkm counter, and with one
+    // outstanding (they return out of order) every LDS wait of the step degrades to lgkmcnt(0)
+    const int tapv = cl.tap[lane < HC_MAX_TAPS ? lane : 0];
+    int tpw = __builtin_amdgcn_readlane(tapv, tap);
 #pragma unroll 1
     for (int s = 0; s < S; ++s) {
         __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): the fragments read a phase ago are in (free by now) - said with
@@ -350,8 +354,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
         hc_wait_vmcnt<(NS - 2) * PER>();                     // NS - 2 stages stay in flight (real or, past the end, zero-fill dummies)
         __syncthreads();                                     // lgkmcnt(0) + s_barrier on gfx950: the DMA queue is left alone
         const bool more = s + NS - 1 < S;
-        const Pend c = plan((s + NS - 1) % NS, tap, ck, more);
+        const Pend c = plan((s + NS - 1) % NS, tap, ck, more, tpw);
         if (more && ++tap == cl.ntaps) { tap = 0; ++ck; }
+        tpw = __builtin_amdgcn_readlane(tapv, tap);
         const int stg = s % NS;
         read_half(stg, 0, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
@@ -666,9 +671,20 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
         if ((double)d.N * d.IH * d.IW * d.srcC >= 4294967280.0) return HC_ERR_ARG;
         return launch_fp8(d, st);
     }
-    // Big-tile form (NS = 4, see the kernel): one 256 x 256 tile per CU, so it only pays when the tile count fills whole rounds of
-    // the 256 CUs (RepVGG-A0's 1280-channel layers at batch 256: 49 x 5 = 245 tiles) and K is long enough to amortise the 133 KB
-    // epilogue.  HC_CONV_BIG=0 sends these layers back to the 128 x 128 tile (same-box A/B).
+    // Big-tile form (256 x 256, see the kernel): one workgroup per CU, so it only pays when the tile count fills whole rounds of the
+    // 256 CUs (RepVGG-A0's 1280-channel layers at batch 256: 49 x 5 = 245 tiles).  HC_CONV_BIG=0 sends these layers back to the
+    // 128 x 128 tile (same-box A/B), =2 picks the four-wave form.  Measured on those layers (scripts/bench_block1280.py, us per
+    // launch: 3x3 192 -> 1280 / 3x3 1280 -> 1280 / 1x1 1280 -> 1280 / data gradient 1280 -> 1280):
+    //     128 x 128, 2 workgroups per CU (round 2)            95 / 382 / 68 / 437     MFMA busy 0.46
+    //     256 x 256, 4 waves of 128 x 128, DMA as a burst    108 / 405 / 82 / 456     0.42   (64-byte rows, 3 steps ahead)
+    //     ... DMA pieces inside the MFMA stream              112 / 360 / 86 / 403     0.48
+    //     ... 128-byte rows (BK = 64), 1 step ahead          101 / 377 / 78 / 432     0.44
+    //     256 x 256, 8 waves of 128 x 64 (default)            78 / 337 / 61 / 384     0.53
+    //     ... 128-byte rows (BK = 64), 1 step ahead           80 / 349 / 63 / 398
+    // Knock-outs of the four-wave form: MFMAs + barriers alone 235 us (0.68 busy at 2.32 GHz), + fragment reads 295, + DMA 326, all
+    // three 373 at 2.05 GHz - with one wave per SIMD every LDS / DMA instruction is issue time the matrix pipe waits out, and the
+    // chip clocks down 12 % under the full mix.  Two waves per SIMD issue under each other's MFMAs; halving the bytes per flop is
+    // what the big tile adds on top of that.
     static const int big = [] { const char* e = getenv("HC_CONV_BIG"); return e == nullptr ? 1 : atoi(e); }();
     if (big && d.nclass == 1 && d.co_split == 0 && d.pix_scale == nullptr && d.srcC % 32 == 0 && d.Cout % 256 == 0) {
         const long M = (long)d.N * d.cls[0].OHg * d.cls[0].OWg;
@@ -676,8 +692,8 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
         const int S = d.cls[0].ntaps * (d.srcC / 32);
         static const int staged = [] { const char* e = getenv("HC_CONV_STAGED_STORES"); return (e == nullptr || atoi(e) != 0) ? 1 : 0; }();
         if (staged && tiles >= 224 && (rem == 0 || rem >= 224) && S >= 16) {
-            if (big == 2 && d.srcC % 64 == 0) return launch_cfg<4, 4, 2, 2, 64, false, 2, 1>(d, st);   // full 128-byte rows, one step ahead
-            return launch_cfg<4, 4, 2, 2, 32, false, 4, 1>(d, st);                                     // 64-byte rows, three steps ahead
+            if (big == 2) return launch_cfg<4, 4, 2, 2, 32, false, 4, 1>(d, st);
+            return launch_cfg<4, 2, 2, 4, 32, false, 4, 1>(d, st);
         }
     }
     if (d.srcC % 64 == 0) return launch_bk<64>(d, st);
