@@ -309,7 +309,28 @@ int launch(Plan& pl, hipStream_t st, bool do_launch) {
     }
     Args& a = pl.a;
     const int tiles = a.n_co_tiles * a.n_ci_tiles * a.n_tg;
-    int nsplit = (256 * occ) / tiles;     // one resident round of workgroups
+    // Split-K count.  Default: one resident round of workgroups (n = 256 occ / tiles).  For RepVGG-A0's 1280 x 1280 x 3 x 3 layer that
+    // is n = 1: 150 tiles of 392 steps on 256 CUs, 41 % of the chip idle for 531 us.  HC_WDMA_NSPLIT=0 picks n by a cost model instead
+    // (rounds(tiles n) x steps per split + n slabs of Cout T Cin 8 bytes at ~4 TB/s against ~55 ns per MFMA of a step): n = 3 there,
+    // 450 workgroups in two rounds of 131 steps.  Measured (same box, round 3): the weight-gradient family 2.56 -> 2.48 ms per step when
+    // the step runs on ONE stream - and the headline step, whose weight gradients run on a second stream, 10.687 -> 10.72 ms: the CUs
+    // the one-round launch leaves free are where the main stream's BatchNorm passes and data gradients run meanwhile.  So the rule
+    // stays; the model is what a single-stream caller wants (HC_WDMA_NSPLIT=n > 0 forces n).
+    const int slots = 256 * occ;
+    static const int forced = getenv("HC_WDMA_NSPLIT") ? atoi(getenv("HC_WDMA_NSPLIT")) : -1;
+    int nsplit = slots / tiles;
+    if (forced == 0) {
+        const double step_us = 0.055 * (2 * TG * 4);
+        const double slab_steps = ((double)a.d.Cout * a.d.KH * a.d.KW * a.d.Cin * 8.0 / 4.0e6) / step_us;
+        double best = 1e30;
+        for (int n = 1; n <= 64 && n <= a.total_steps; ++n) {
+            const int rounds = (tiles * n + slots - 1) / slots, per = (a.total_steps + n - 1) / n;
+            const double cost = (double)rounds * per + slab_steps * n;
+            if (cost < best) { best = cost; nsplit = n; }
+        }
+    } else if (forced > 0) {
+        nsplit = forced;
+    }
     if (nsplit < 1) nsplit = 1;
     if (nsplit > a.total_steps) nsplit = a.total_steps;
     a.steps_per_split = (a.total_steps + nsplit - 1) / nsplit;
