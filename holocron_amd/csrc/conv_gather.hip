@@ -681,6 +681,8 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
     //     ... 128-byte rows (BK = 64), 1 step ahead          101 / 377 / 78 / 432     0.44
     //     256 x 256, 8 waves of 128 x 64 (default)            78 / 337 / 61 / 384     0.53
     //     ... 128-byte rows (BK = 64), 1 step ahead           80 / 349 / 63 / 398
+    // The same pipelined loop on the 128 x 128 tile with two workgroups per CU: YOLOv4 530.5 -> 523 img/s, RepVGG-A0 neutral - there the
+    // co-resident workgroup already covers the burst, and the compiler's schedule of 4 reads + 4 MFMAs needs no skew.  Not kept.
     // Knock-outs of the four-wave form: MFMAs + barriers alone 235 us (0.68 busy at 2.32 GHz), + fragment reads 295, + DMA 326, all
     // three 373 at 2.05 GHz - with one wave per SIMD every LDS / DMA instruction is issue time the matrix pipe waits out, and the
     // chip clocks down 12 % under the full mix.  Two waves per SIMD issue under each other's MFMAs; halving the bytes per flop is
