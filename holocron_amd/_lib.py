@@ -201,7 +201,6 @@ SIGNATURES = {
     "hc_rep_bwd_reduce": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_void_p]),
     "hc_rep_bwd_reduce_z": (c_int32, [c_void_p, c_void_p, c_int32] + [c_void_p] * 4 + [c_int64, c_int32, c_void_p]),
     "hc_rep_bwd_apply_z": (c_int32, [c_void_p, c_void_p, c_int32] + [c_void_p] * 7 + [c_int64, c_int32, c_void_p]),
-    "hc_rep_bwd_fused_z": (c_int32, [c_void_p, c_void_p, c_int32] + [c_void_p] * 3 + [C.POINTER(RepBnBwdDesc)] + [c_void_p] * 4 + [c_int64, c_int32, c_void_p]),
     "hc_rep_bn_bwd_finalize": (c_int32, [C.POINTER(RepBnBwdDesc), c_void_p]),
     "hc_rep_bwd_apply": (c_int32, [c_void_p] * 9 + [c_int64, c_int32, c_void_p]),
     "hc_bn_act_apply": (c_int32, [c_void_p] * 3 + [c_int32] + [c_void_p] * 3 + [c_int32, c_int64, c_int32, c_int32, c_float, c_void_p]),
@@ -318,7 +317,6 @@ def set_deterministic(on: bool) -> None:
             fn()
 
 
-HC_ERR_ARG = 1
 _ERR = {1: "bad argument", 2: "kernel launch failure"}
 
 

@@ -282,11 +282,12 @@ __global__ __launch_bounds__(EW_THREADS) void channel_stats_kernel(const u32x4* 
 // ZMASK: the ReLU mask is recomputed from the pre-activation (coef = the forward's [4][C] affine; act 0 = no activation) instead of
 // read from `out` - one tensor less per pass (2 of the 13 tensor passes of a block's BatchNorm backward)
 template <bool HAS_ID, bool ZMASK, bool NT>
-__device__ __forceinline__ void rep_bwd_reduce_body(const u32x4* __restrict__ g, const u32x4* __restrict__ out,
-                                                    const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
-                                                    const u32x4* __restrict__ x, const float* __restrict__ coef,
-                                                    const int act, float* __restrict__ red,
-                                                    long nchunks, int C, const int reps, float* __restrict__ sred) {
+__global__ __launch_bounds__(EW_THREADS) void rep_bwd_reduce_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ out,
+                                                                    const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
+                                                                    const u32x4* __restrict__ x, const float* __restrict__ coef,
+                                                                    const int act, float* __restrict__ red,
+                                                                    long nchunks, int C, const int reps) {
+    extern __shared__ float sred[];  // [4][C]
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
     const long stride = (long)gridDim.x * EW_THREADS;
@@ -323,31 +324,12 @@ __device__ __forceinline__ void rep_bwd_reduce_body(const u32x4* __restrict__ g,
     (void)c0;
     block_reduce_flush<4>(sv, cg, C, red + (size_t)(blockIdx.x % reps) * 4 * C, sred, HAS_ID ? 4 : 3);
 }
-template <bool HAS_ID, bool ZMASK, bool NT>
-__global__ __launch_bounds__(EW_THREADS) void rep_bwd_reduce_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ out,
-                                                                    const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
-                                                                    const u32x4* __restrict__ x, const float* __restrict__ coef,
-                                                                    const int act, float* __restrict__ red,
-                                                                    long nchunks, int C, const int reps) {
-    extern __shared__ float sred[];  // [256][33]
-    rep_bwd_reduce_body<HAS_ID, ZMASK, NT>(g, out, y3, y1, x, coef, act, red, nchunks, C, reps, sred);
-}
 
-// COH: the caller is the fused backward kernel (below) - the replica sums were written by OTHER workgroups of the same launch and the
-// coefficients are read by them: device-scope loads / stores instead of plain ones (the L2s of the eight XCDs are not coherent
-// with each other inside a kernel)
-__device__ __forceinline__ float coh_load(const float* p) {
-    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void coh_store(float* p, float v) {
-    __hip_atomic_store(reinterpret_cast<int*>(p), __builtin_bit_cast(int, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool COH>
-__device__ __forceinline__ void rep_bn_bwd_finalize_body(const hc_rep_bn_bwd_desc& d, const int reps, const int blk,
-                                                         float (*sm)[4][FIN_CH + 1]) {
+__global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_bn_bwd_desc d, const int reps) {
     // same shape as the forward finalize: 16 channels per workgroup, 16 replica groups, coalesced replica rows, fixed-order LDS combine
+    __shared__ float sm[FIN_RG][4][FIN_CH + 1];
     const int ch = threadIdx.x & (FIN_CH - 1), rg = threadIdx.x >> 4;
-    const int c = blk * FIN_CH + ch;
+    const int c = blockIdx.x * FIN_CH + ch;
     const bool cin = c < d.C;
     const float cnt = (float)d.count;
     const int nb = d.has_identity ? 3 : 2;
@@ -378,7 +360,7 @@ __device__ __forceinline__ void rep_bn_bwd_finalize_body(const hc_rep_bn_bwd_des
                 const int r = r0 + u * FIN_RG;
                 const size_t rr = (size_t)(r < reps ? r : rg);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[u][k] = COH ? coh_load(rp + (rr * 4 + k) * row) : rp[(rr * 4 + k) * row];
+                for (int k = 0; k < 4; ++k) v[u][k] = rp[(rr * 4 + k) * row];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -416,38 +398,19 @@ __device__ __forceinline__ void rep_bn_bwd_finalize_body(const hc_rep_bn_bwd_des
             if (d.dgamma[b] != nullptr) d.dgamma[b][c] = d.accumulate ? dg0[b] + dgamma : dgamma;
             if (d.dbeta[b] != nullptr) d.dbeta[b][c] = d.accumulate ? db0[b] + sdz : sdz;
         }
-        if (COH) {
-            coh_store(d.bcoef + (3 * b) * d.C + c, A);
-            coh_store(d.bcoef + (3 * b + 1) * d.C + c, B);
-            coh_store(d.bcoef + (3 * b + 2) * d.C + c, Cc);
-        } else {
-            d.bcoef[(3 * b) * d.C + c] = A;
-            d.bcoef[(3 * b + 1) * d.C + c] = B;
-            d.bcoef[(3 * b + 2) * d.C + c] = Cc;
-        }
+        d.bcoef[(3 * b) * d.C + c] = A;
+        d.bcoef[(3 * b + 1) * d.C + c] = B;
+        d.bcoef[(3 * b + 2) * d.C + c] = Cc;
     }
-}
-__global__ __launch_bounds__(256) void rep_bn_bwd_finalize_kernel(const hc_rep_bn_bwd_desc d, const int reps) {
-    __shared__ float sm[FIN_RG][4][FIN_CH + 1];
-    rep_bn_bwd_finalize_body<false>(d, reps, blockIdx.x, sm);
 }
 
-template <bool COH>
-__device__ __forceinline__ void load8c(const float* p, float (&f)[8]) {
-    if (COH) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = coh_load(p + i);
-    } else {
-        load8f(p, f);
-    }
-}
-template <bool HAS_ID, bool ZMASK, bool NT, bool COH>
-__device__ __forceinline__ void rep_bwd_apply_body(const u32x4* __restrict__ g, const u32x4* __restrict__ out,
-                                                   const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
-                                                   const u32x4* __restrict__ x, const float* __restrict__ coef,
-                                                   const int act, const float* __restrict__ bc,
-                                                   u32x4* __restrict__ dy3, u32x4* __restrict__ dy1,
-                                                   u32x4* __restrict__ dxid, long nchunks, int C) {
+template <bool HAS_ID, bool ZMASK, bool NT>
+__global__ __launch_bounds__(EW_THREADS) void rep_bwd_apply_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ out,
+                                                                   const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
+                                                                   const u32x4* __restrict__ x, const float* __restrict__ coef,
+                                                                   const int act, const float* __restrict__ bc,
+                                                                   u32x4* __restrict__ dy3, u32x4* __restrict__ dy1,
+                                                                   u32x4* __restrict__ dxid, long nchunks, int C) {
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
     const long stride = (long)gridDim.x * EW_THREADS;
@@ -460,9 +423,9 @@ __device__ __forceinline__ void rep_bwd_apply_body(const u32x4* __restrict__ g, 
         load8f(coef + 3 * C + c0, sh);
     }
     float A3[8], B3[8], C3[8], A1[8], B1[8], C1[8], A0[8], B0[8], C0[8];
-    load8c<COH>(bc + 0 * C + c0, A3); load8c<COH>(bc + 1 * C + c0, B3); load8c<COH>(bc + 2 * C + c0, C3);
-    load8c<COH>(bc + 3 * C + c0, A1); load8c<COH>(bc + 4 * C + c0, B1); load8c<COH>(bc + 5 * C + c0, C1);
-    if (HAS_ID) { load8c<COH>(bc + 6 * C + c0, A0); load8c<COH>(bc + 7 * C + c0, B0); load8c<COH>(bc + 8 * C + c0, C0); }
+    load8f(bc + 0 * C + c0, A3); load8f(bc + 1 * C + c0, B3); load8f(bc + 2 * C + c0, C3);
+    load8f(bc + 3 * C + c0, A1); load8f(bc + 4 * C + c0, B1); load8f(bc + 5 * C + c0, C1);
+    if (HAS_ID) { load8f(bc + 6 * C + c0, A0); load8f(bc + 7 * C + c0, B0); load8f(bc + 8 * C + c0, C0); }
     for (long q = gtid; q < nchunks; q += stride) {
         float fg[8], fo[8], f3[8], f1[8], f0[8], o3[8], o1[8], o0[8];
         unpack8(ld16<NT>(g + q), fg);
@@ -482,61 +445,6 @@ __device__ __forceinline__ void rep_bwd_apply_body(const u32x4* __restrict__ g, 
         st16<NT>(dy1 + q, pack8(o1));
         if (HAS_ID) st16<NT>(dxid + q, pack8(o0));
     }
-}
-template <bool HAS_ID, bool ZMASK, bool NT>
-__global__ __launch_bounds__(EW_THREADS) void rep_bwd_apply_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ out,
-                                                                   const u32x4* __restrict__ y3, const u32x4* __restrict__ y1,
-                                                                   const u32x4* __restrict__ x, const float* __restrict__ coef,
-                                                                   const int act, const float* __restrict__ bc,
-                                                                   u32x4* __restrict__ dy3, u32x4* __restrict__ dy1,
-                                                                   u32x4* __restrict__ dxid, long nchunks, int C) {
-    rep_bwd_apply_body<HAS_ID, ZMASK, NT, false>(g, out, y3, y1, x, coef, act, bc, dy3, dy1, dxid, nchunks, C);
-}
-
-// ---------------------------------------------------------------- fused BatchNorm backward of a RepBlock: reduce -> finalize -> apply in ONE launch
-// The three kernels above are a dependent chain of two launch boundaries (and a 5 us finalize on 12 workgroups) per block, 27 blocks
-// per step; the tensors of the 192-channel blocks are 19 MB, so the boundaries are a third of the chain.  Here the grid is capped at
-// what is resident at once and the phases are separated by two grid-wide barriers on device-scope counters (`sync`: 2 zeroed
-// uint32): arrive = fence + atomic add by one lane, wait = that lane polls with s_sleep, bounded - a barrier that can never complete
-// (a grid larger than the resident capacity would be the only way) falls through after ~0.2 s with wrong numbers instead of hanging
-// the GPU.  Workgroups 0 .. C/16-1 run the finalize between the barriers; replica sums are read and coefficients written / read
-// with device-scope accesses (the XCDs' L2s are not coherent inside a kernel).
-struct RepBwdFused {
-    const u32x4 *g, *y3, *y1, *x;
-    const float* coef;
-    u32x4 *dy3, *dy1, *dxid;
-    unsigned int* sync;
-    float* red;                  // = fin.red (the descriptor holds it const: the finalize only reads it)
-    long nchunks;
-    int act, C, reps;
-    hc_rep_bn_bwd_desc fin;
-};
-__device__ __forceinline__ void grid_barrier(unsigned int* ctr, const unsigned int target) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();                                   // this workgroup's plain stores and atomics are out before it is counted
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        for (int spin = 0; spin < (1 << 21); ++spin) {
-            if (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-            __builtin_amdgcn_s_sleep(16);
-        }
-        __threadfence();
-    }
-    __syncthreads();
-}
-template <bool HAS_ID, bool NT>
-__global__ __launch_bounds__(EW_THREADS) void rep_bwd_fused_kernel(const RepBwdFused a) {
-    extern __shared__ float sred[];                        // [256][33]
-    __shared__ float smf[FIN_RG][4][FIN_CH + 1];
-    rep_bwd_reduce_body<HAS_ID, true, NT>(a.g, nullptr, a.y3, a.y1, a.x, a.coef, a.act, a.red, a.nchunks, a.C, a.reps, sred);
-    grid_barrier(a.sync, gridDim.x);
-    const int nfin = (a.C + FIN_CH - 1) / FIN_CH;
-    for (int blk = blockIdx.x; blk < nfin; blk += gridDim.x) {
-        rep_bn_bwd_finalize_body<true>(a.fin, a.reps, blk, smf);
-        __syncthreads();
-    }
-    grid_barrier(a.sync + 1, gridDim.x);
-    rep_bwd_apply_body<HAS_ID, true, NT, true>(a.g, nullptr, a.y3, a.y1, a.x, a.coef, a.act, a.fin.bcoef, a.dy3, a.dy1, a.dxid, a.nchunks, a.C);
 }
 
 // ---------------------------------------------------------------- generic conv -> BN -> activation (+ residual)
@@ -1199,50 +1107,6 @@ int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void*
                      void* dy1, void* dxid, int64_t npix, int32_t C, hc_stream_t stream) {
     if (out == nullptr) return HC_ERR_ARG;
     return rep_bwd_apply_launch(g, out, nullptr, 1, y3, y1, x, bcoef, dy3, dy1, dxid, npix, C, stream);
-}
-int hc_rep_bwd_fused_z(const void* g, const float* coef, int32_t act, const void* y3, const void* y1, const void* x,
-                       const hc_rep_bn_bwd_desc* fin, void* dy3, void* dy1, void* dxid, uint32_t* sync, int64_t npix, int32_t C,
-                       hc_stream_t stream) {
-    if (g == nullptr || coef == nullptr || (act != 0 && act != 1) || y3 == nullptr || y1 == nullptr || fin == nullptr || dy3 == nullptr ||
-        dy1 == nullptr || sync == nullptr || (C % 8) != 0 || fin->red == nullptr || fin->save == nullptr || fin->bcoef == nullptr || fin->C != C)
-        return HC_ERR_ARG;
-    if ((x == nullptr) != (dxid == nullptr)) return HC_ERR_ARG;
-    const long nchunks = (long)npix * (C / 8);
-    const bool nt = ew_streaming(nchunks);
-    const size_t sm = EW_THREADS * 33 * sizeof(float);
-    // resident capacity of the variant that will run (queried once each): every workgroup must be on the chip for the barriers
-    static int occ[2][2] = {{0, 0}, {0, 0}};
-    int& oc = occ[x != nullptr][nt];
-    if (oc == 0) {
-        int n = 0;
-        hipError_t e;
-        if (x != nullptr) e = nt ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rep_bwd_fused_kernel<true, true>, EW_THREADS, sm)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rep_bwd_fused_kernel<true, false>, EW_THREADS, sm);
-        else e = nt ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rep_bwd_fused_kernel<false, true>, EW_THREADS, sm)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rep_bwd_fused_kernel<false, false>, EW_THREADS, sm);
-        oc = (e == hipSuccess && n >= 1) ? n : 1;
-    }
-    int a = C / 8, b = EW_THREADS;
-    while (b) { const int t = a % b; a = b; b = t; }
-    const int unit = (C / 8) / a;                          // blocks must be a multiple of this (ew_blocks)
-    int blocks = ew_blocks(nchunks, C / 8, 16);
-    const int cap = 256 * oc;
-    if (blocks > cap) blocks = cap / unit * unit;
-    if (blocks < unit) return HC_ERR_ARG;                  // a channel count whose unit does not fit the chip: the caller takes the three-launch path
-    if (hc_get_deterministic() && blocks > hc_get_stat_replicas()) return HC_ERR_ARG;
-    RepBwdFused k;
-    k.g = (const u32x4*)g; k.y3 = (const u32x4*)y3; k.y1 = (const u32x4*)y1; k.x = (const u32x4*)x;
-    k.coef = coef; k.dy3 = (u32x4*)dy3; k.dy1 = (u32x4*)dy1; k.dxid = (u32x4*)dxid; k.sync = sync; k.red = const_cast<float*>(fin->red);
-    k.nchunks = nchunks; k.act = act; k.C = C; k.reps = hc_get_stat_replicas(); k.fin = *fin;
-    hipStream_t st = (hipStream_t)stream;
-    if (x != nullptr) {
-        if (nt) hipLaunchKernelGGL((rep_bwd_fused_kernel<true, true>), dim3(blocks), dim3(EW_THREADS), sm, st, k);
-        else hipLaunchKernelGGL((rep_bwd_fused_kernel<true, false>), dim3(blocks), dim3(EW_THREADS), sm, st, k);
-    } else {
-        if (nt) hipLaunchKernelGGL((rep_bwd_fused_kernel<false, true>), dim3(blocks), dim3(EW_THREADS), sm, st, k);
-        else hipLaunchKernelGGL((rep_bwd_fused_kernel<false, false>), dim3(blocks), dim3(EW_THREADS), sm, st, k);
-    }
-    return hc_launch_status();
 }
 int hc_rep_bwd_apply_z(const void* g, const float* coef, int32_t act, const void* y3, const void* y1, const void* x,
                        const float* bcoef, void* dy3, void* dy1, void* dxid, int64_t npix, int32_t C, hc_stream_t stream) {

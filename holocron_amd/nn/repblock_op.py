@@ -111,8 +111,6 @@ class ZeroPool:
 
 
 POOL = ZeroPool()
-# HC_BN_FUSED_BWD=0: the three-launch BatchNorm backward (reduce / finalize / apply) instead of the fused kernel
-FUSED_BN_BWD = os.environ.get("HC_BN_FUSED_BWD", "1") != "0"
 _lib.on_replicas_changed(POOL.reset)
 
 
@@ -474,7 +472,6 @@ class RepBlockFn(torch.autograd.Function):
         out_stats = POOL.take((_lib.stat_replicas(), 2, Cout), dev) if (st.emit_stats and st.training) else None
         # backward's reduction target, zeroed with the rest of the arena; re-validated in backward (ZeroPool.claim)
         ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.stat_replicas(), 4, Cout), dev) if st.training else (None, -1)
-        ctx.sync = POOL.take((4,), dev) if st.training else None     # the two grid-barrier counters of the fused backward (same generation as red)
         tb = N * OH * OW * Cout * 2.0            # bytes of one activation tensor of this block
         with cv.profiled("bn_elementwise", 0.0, tb * (4 if st.identity else 3)):      # reads y3, y1 [, x], writes out
             check(lib.hc_rep_apply(ptr(y3), ptr(y1), ptr(src) if st.identity else None, ptr(coef), ptr(out), ptr(out_stats),
@@ -500,9 +497,11 @@ class RepBlockFn(torch.autograd.Function):
         xid = src if st.identity else None
 
         red = POOL.claim(ctx.red, ctx.red_gen, (_lib.stat_replicas(), 4, Cout), dev)
-        sync = POOL.claim(ctx.sync, ctx.red_gen, (4,), dev)
-        ctx.red = ctx.sync = None      # a second backward through this node (retain_graph) gets fresh buffers
+        ctx.red = None      # a second backward through this node (retain_graph) gets a fresh buffer
         tb = npix * Cout * 2.0
+        with cv.profiled("bn_elementwise", 0.0, tb * (4 if st.identity else 3)):      # reads g, y3, y1 [, x]
+            check(lib.hc_rep_bwd_reduce_z(ptr(g), ptr(coef), act, ptr(y3), ptr(y1), ptr(xid), ptr(red), npix, Cout, stream()),
+                  "hc_rep_bwd_reduce_z")
         nb = 3 if st.identity else 2
         dgam = torch.empty((3, Cout), dtype=torch.float32, device=dev)
         dbet = torch.empty((3, Cout), dtype=torch.float32, device=dev)
@@ -517,28 +516,15 @@ class RepBlockFn(torch.autograd.Function):
             d.dbeta[b] = ptr(dbet[b]) if live else None
         d.C, d.count, d.has_identity, d.accumulate = Cout, npix, 1 if st.identity else 0, 0
         d.frozen = 0 if ctx.was_training else 1       # eval mode / freeze_bn: running statistics, dy = a * dz
+        with cv.profiled("bn_finalize", 0.0, 0.0):
+            check(lib.hc_rep_bn_bwd_finalize(C.byref(d), stream()), "hc_rep_bn_bwd_finalize")
+
         dy3 = torch.empty_like(y3)
         dy1 = torch.empty_like(y1)
         dxid = torch.empty_like(src) if st.identity else None
-        fused = False
-        if FUSED_BN_BWD:
-            # reduce -> finalize -> apply in one launch (two grid-wide barriers instead of two launch boundaries + a 12-workgroup launch)
-            with cv.profiled("bn_elementwise", 0.0, tb * (11 if st.identity else 8)):   # both passes: 4 + 7 resp. 3 + 5 tensor transfers
-                rc = lib.hc_rep_bwd_fused_z(ptr(g), ptr(coef), act, ptr(y3), ptr(y1), ptr(xid), C.byref(d), ptr(dy3), ptr(dy1),
-                                            ptr(dxid), ptr(sync), npix, Cout, stream())
-            if rc == 0:
-                fused = True
-            elif rc != _lib.HC_ERR_ARG:
-                check(rc, "hc_rep_bwd_fused_z")
-        if not fused:
-            with cv.profiled("bn_elementwise", 0.0, tb * (4 if st.identity else 3)):      # reads g, y3, y1 [, x]
-                check(lib.hc_rep_bwd_reduce_z(ptr(g), ptr(coef), act, ptr(y3), ptr(y1), ptr(xid), ptr(red), npix, Cout, stream()),
-                      "hc_rep_bwd_reduce_z")
-            with cv.profiled("bn_finalize", 0.0, 0.0):
-                check(lib.hc_rep_bn_bwd_finalize(C.byref(d), stream()), "hc_rep_bn_bwd_finalize")
-            with cv.profiled("bn_elementwise", 0.0, tb * (7 if st.identity else 5)):      # reads g, y3, y1 [, x], writes dy3, dy1 [, dx_id]
-                check(lib.hc_rep_bwd_apply_z(ptr(g), ptr(coef), act, ptr(y3), ptr(y1), ptr(xid), ptr(bcoef), ptr(dy3), ptr(dy1),
-                                             ptr(dxid), npix, Cout, stream()), "hc_rep_bwd_apply_z")
+        with cv.profiled("bn_elementwise", 0.0, tb * (7 if st.identity else 5)):      # reads g, y3, y1 [, x], writes dy3, dy1 [, dx_id]
+            check(lib.hc_rep_bwd_apply_z(ptr(g), ptr(coef), act, ptr(y3), ptr(y1), ptr(xid), ptr(bcoef), ptr(dy3), ptr(dy1),
+                                         ptr(dxid), npix, Cout, stream()), "hc_rep_bwd_apply_z")
 
         dx = None
         geom = (N, Cin, H, W, Cout)

@@ -278,14 +278,6 @@ typedef struct {
                                 * do not depend on the batch, so dy = a * dz (B = C = 0); dgamma / dbeta as in training mode */
 } hc_rep_bn_bwd_desc;
 int hc_rep_bn_bwd_finalize(const hc_rep_bn_bwd_desc* d, hc_stream_t stream);
-/* hc_rep_bwd_reduce_z -> hc_rep_bn_bwd_finalize -> hc_rep_bwd_apply_z as ONE launch (same arithmetic, same outputs: d->dgamma / dbeta,
- * d->bcoef, dy3, dy1, dx_id): the grid is capped at what is resident at once and the three phases are separated by grid-wide
- * barriers on `sync` (two ZEROED uint32 the call consumes; d->red zeroed as for hc_rep_bwd_reduce_z).  Replaces two launch
- * boundaries and the separate finalize launch per RepBlock of a backward pass (RepBlock.forward's autograd, repvgg.py:71-73).
- * HC_ERR_ARG when the shape cannot be served (the caller then issues the three calls). */
-int hc_rep_bwd_fused_z(const void* g, const float* coef, int32_t act, const void* y3, const void* y1, const void* x,
-                       const hc_rep_bn_bwd_desc* d, void* dy3, void* dy1, void* dxid, uint32_t* sync, int64_t npix, int32_t C,
-                       hc_stream_t stream);
 int hc_rep_bwd_apply(const void* g, const void* out, const void* y3, const void* y1, const void* x,
                      const float* bcoef, void* dy3, void* dy1, void* dxid, int64_t npix, int32_t C,
                      hc_stream_t stream);

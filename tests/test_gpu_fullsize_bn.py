@@ -133,36 +133,7 @@ def test_c2_repblock_bn_passes_vs_fp32_batch_norm(cfg):
     dxid = torch.empty_like(srcs[2]) if ident else None
     check(lib.hc_rep_bwd_apply_z(ptr(gd), ptr(coef), 1, ptr(srcs[0]), ptr(srcs[1]), ptr(xid), ptr(bcoef), ptr(dy3), ptr(dy1),
                                  ptr(dxid), npix, ch, stream()), "hc_rep_bwd_apply_z")
-    # the same three passes as ONE launch (hc_rep_bwd_fused_z: grid-wide barriers instead of launch boundaries) must reproduce them:
-    # identical arithmetic, only the order of the replica atomics differs
-    red2 = torch.zeros((_lib.stat_replicas(), 4, ch), dtype=torch.float32, device=dev)
-    sync = torch.zeros((4,), dtype=torch.int32, device=dev)
-    dgam2, dbet2, bcoef2 = torch.zeros_like(dgam), torch.zeros_like(dbet), torch.zeros_like(bcoef)
-    bd2 = RepBnBwdDesc()
-    bd2.red, bd2.save, bd2.bcoef = ptr(red2), ptr(save), ptr(bcoef2)
-    for b in range(3):
-        live = b < nb
-        bd2.gamma[b] = ptr(gam_d[b]) if live else None
-        bd2.dgamma[b] = ptr(dgam2[b]) if live else None
-        bd2.dbeta[b] = ptr(dbet2[b]) if live else None
-    bd2.C, bd2.count, bd2.has_identity, bd2.accumulate, bd2.frozen = ch, npix, 1 if ident else 0, 0, 0
-    dy3f, dy1f = torch.zeros_like(srcs[0]), torch.zeros_like(srcs[1])
-    dxidf = torch.zeros_like(srcs[2]) if ident else None
-    check(lib.hc_rep_bwd_fused_z(ptr(gd), ptr(coef), 1, ptr(srcs[0]), ptr(srcs[1]), ptr(xid), C.byref(bd2), ptr(dy3f), ptr(dy1f),
-                                 ptr(dxidf), ptr(sync), npix, ch, stream()), "hc_rep_bwd_fused_z")
     torch.cuda.synchronize()
-    assert int(sync[0]) == int(sync[1]) and int(sync[0]) > 0, sync        # both barriers were reached by every workgroup
-    fe = {"bcoef": rel_l2(bcoef2[:3 * nb].cpu(), bcoef[:3 * nb].cpu())}
-    for b in range(nb):
-        fe[f"dgamma{b}"] = rel_l2(dgam2[b].cpu(), dgam[b].cpu())
-        fe[f"dbeta{b}"] = rel_l2(dbet2[b].cpu(), dbet[b].cpu())
-    for name, a_, b_ in (("dy3", dy3f, dy3), ("dy1", dy1f, dy1)) + ((("dx_id", dxidf, dxid),) if ident else ()):
-        fe[name] = rel_l2(a_.float().cpu(), b_.float().cpu())
-        fe[name + "_same"] = 1.0 - float((a_ == b_).float().mean())
-    print(cfg, "fused vs three launches:", ", ".join(f"{k} {v:.1e}" for k, v in fe.items()))
-    for k, v in fe.items():
-        assert v < (5e-3 if k.endswith("_same") else (5e-4 if k in ("dy3", "dy1", "dx_id") else 1e-5)), (cfg, k, v, fe)
-    del dy3f, dy1f, dxidf, red2
     got_out, got_dy = nchw(out), [nchw(dy3), nchw(dy1)] + ([nchw(dxid)] if ident else [])
     got_os = out_stats.double().sum(0).cpu()
     del out, dy3, dy1, dxid, gd, srcs
