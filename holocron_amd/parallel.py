@@ -66,6 +66,22 @@ def _conv_ops():
 _HIP_COPY_DTYPES = (torch.float32, torch.bfloat16)
 
 
+def _copy_pieces(items, piece: int, per_launch: int):
+    """Launch plan of ``hc_multi_copy``: ``items`` = (src pointer, dst pointer, elements, src element size, dst element size) per
+    tensor -> list of launches, each a list of at most ``per_launch`` (src pointer, dst pointer, elements) pieces of at most
+    ``piece`` elements, tensors split in order (so that every piece is swept by the same 16 workgroups)."""
+    launches, cur = [], []
+    for sp, dp, n, se, de in items:
+        for o in range(0, n, piece):
+            cur.append((sp + o * se, dp + o * de, min(piece, n - o)))
+            if len(cur) == per_launch:
+                launches.append(cur)
+                cur = []
+    if cur:
+        launches.append(cur)
+    return launches
+
+
 def _hip_copy_all(dst: List[torch.Tensor], src: List[torch.Tensor], scale: float) -> bool:
     """The same on one MI355X through ``hc_multi_copy`` (csrc/optim.hip): up to 64 pieces of at most 256 K elements per launch, the
     piece table in the kernel arguments - so a bucket of RepVGG-A0 (24.7 M elements, ~300 pieces) is five launches that stream at
@@ -76,25 +92,19 @@ def _hip_copy_all(dst: List[torch.Tensor], src: List[torch.Tensor], scale: float
         return False
     for d, t in zip(dst, src):
         if (d.device != d0.device or t.device != d0.device or d.dtype != d0.dtype or t.dtype != s0.dtype
-                or d.numel() != t.numel() or not d.is_contiguous() or not t.is_contiguous()):
+                or d.shape != t.shape or not d.is_contiguous() or not t.is_contiguous()):
             return False
     from . import _lib
     from .ops import conv as _cv
     lib, st = _lib.load(), _cv.stream()
     desc = _lib.MultiCopyDesc()
     desc.src_bf16, desc.dst_bf16, desc.scale = int(s0.dtype == torch.bfloat16), int(d0.dtype == torch.bfloat16), float(scale)
-    se, de, piece, k = s0.element_size(), d0.element_size(), _lib.HC_MULTI_COPY_PIECE, 0
-    for d, t in zip(dst, src):
-        n, sp, dp = d.numel(), t.data_ptr(), d.data_ptr()
-        for o in range(0, n, piece):
-            desc.src[k], desc.dst[k], desc.n[k] = sp + o * se, dp + o * de, min(piece, n - o)
-            k += 1
-            if k == _lib.HC_MULTI_COPY_MAX:
-                desc.nitems = k
-                _cv.check(lib.hc_multi_copy(C.byref(desc), st), "hc_multi_copy")
-                k = 0
-    if k:
-        desc.nitems = k
+    se, de = s0.element_size(), d0.element_size()
+    items = [(t.data_ptr(), d.data_ptr(), d.numel(), se, de) for d, t in zip(dst, src)]
+    for pieces in _copy_pieces(items, _lib.HC_MULTI_COPY_PIECE, _lib.HC_MULTI_COPY_MAX):
+        for k, (sp, dp, n) in enumerate(pieces):
+            desc.src[k], desc.dst[k], desc.n[k] = sp, dp, n
+        desc.nitems = len(pieces)
         _cv.check(lib.hc_multi_copy(C.byref(desc), st), "hc_multi_copy")
     return True
 

@@ -491,3 +491,18 @@ def test_trainer_load_keeps_the_optimizer_state_through_reset_opt(tmp_path):
     for p, b in zip(opt3.param_groups[0]["params"], bufs):
         assert torch.equal(opt3.state[p]["momentum_buffer"], b)
     assert opt3.param_groups[0]["lr"] == 0.02
+
+
+def test_multi_copy_launch_plan_covers_every_element_once():
+    """parallel._copy_pieces (the piece table of hc_multi_copy): tensors are split in order into pieces of at most `piece` elements,
+    at most `per_launch` pieces per launch, byte offsets follow the element sizes of either side."""
+    from holocron_amd import parallel
+    items = [(1000, 50000, 10, 4, 2), (2000, 60000, 0, 4, 2), (3000, 70000, 25, 4, 2), (4000, 80000, 8, 4, 2)]
+    plan = parallel._copy_pieces(items, piece=8, per_launch=3)
+    assert all(1 <= len(l) <= 3 for l in plan) and all(len(l) == 3 for l in plan[:-1])
+    flat = [p for l in plan for p in l]
+    assert flat == [(1000, 50000, 8), (1032, 50016, 2),
+                    (3000, 70000, 8), (3032, 70016, 8), (3064, 70032, 8), (3096, 70048, 1),
+                    (4000, 80000, 8)]
+    assert parallel._copy_pieces([], 8, 3) == []
+
