@@ -27,14 +27,19 @@ def test_repblock_train_matches_reference(golden):
         # Gradients: an activation that sits within bf16 rounding of the ReLU kink flips its mask and
         # moves the gradients it feeds by O(1) (a handful of the 2*H*W*C elements per case).  So the
         # check is element-wise with a small allowed outlier fraction, not a norm.
+        # Measured on MI355X (profiles/r03_fixture_gradient_fractions.txt): worst fraction 0.946 (dx) / 0.9375 (one element of a
+        # 16-channel vector), worst rel-L2 0.056 / 0.061.  The norm bound caps what the outliers may be; the tight element-wise check
+        # (99.5 % within 1e-2) is the one against the bf16-emulating oracle below, where no mask can flip.
         if cin % 16 == 0:
             scale = float(c["dx"].abs().mean())
-            assert close_frac(x.grad.float().cpu(), c["dx"], 2e-2, 2e-2 * scale) > 0.90, c["cfg"]
+            assert close_frac(x.grad.float().cpu(), c["dx"], 2e-2, 2e-2 * scale) > 0.92, c["cfg"]
+            assert rel_l2(x.grad.float().cpu(), c["dx"]) < 0.1, c["cfg"]
         for n, p in blk.named_parameters():
             ref = c["dparams"][n]
             scale = float(ref.abs().mean())
             frac = close_frac(p.grad.cpu(), ref, 3e-2, 3e-2 * scale)
             assert frac > 0.9, (c["cfg"], n, frac)
+            assert rel_l2(p.grad.cpu(), ref) < 0.1, (c["cfg"], n)
         sd = blk.state_dict()
         for k, v in c["state_after"].items():
             if "running" in k:
