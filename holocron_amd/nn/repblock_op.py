@@ -44,6 +44,7 @@ class ZeroPool:
         self.depth = 0
         self.gen = 0
         self.retired = []
+        self.graph_users = 0        # live GraphedSteps whose graphs may reference a retired buffer
         self.buf_captured = False   # the current buffer was handed out while a stream capture was running
 
     def _retire(self):
@@ -52,8 +53,11 @@ class ZeroPool:
         self.buf, self.buf_captured = None, False
 
     def release_retired(self):
-        """Free the buffers kept alive for captured graphs (call when those graphs have been destroyed)."""
-        self.retired = []
+        """One holder of captured graphs (parallel.GraphedStep: ``graph_users`` counts them) has destroyed its graphs; the buffers
+        kept alive for captured graphs are freed when the last holder has."""
+        self.graph_users = max(0, self.graph_users - 1)
+        if self.graph_users == 0:
+            self.retired = []
 
     @property
     def active(self):
@@ -125,16 +129,30 @@ def fill_pack_items(arr, items):
     return mx
 
 
-def launch_pack_items(items):
+def launch_pack_items(items, cache=None):
     """One hc_pack_conv_weights_multi launch for a (small) item list: the path of a block whose images went stale on their own
-    (first call, geometry change); the models pack all their blocks in one launch per step instead."""
+    (first call, geometry change, a RepBlock used outside a model that packs all its blocks in one launch per step).
+
+    ``cache``: a dict owned by the caller.  The device-side item table is uploaded once per (source, destination) pointer signature and
+    kept there: a repack of the same buffers - every optimizer step for a free-standing block - is then a plain kernel launch, safe
+    under stream capture / GraphedStep.  A pageable host-to-device copy per repack would either fail inside a capture or be recorded
+    as a memcpy node whose host source is gone by the time the graph replays."""
     if not items:
         return
-    import numpy as np
-    arr = (PackItem * len(items))()
-    mx = fill_pack_items(arr, items)
-    table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(items[0][0].device)
-    check(_lib.load().hc_pack_conv_weights_multi(table.data_ptr(), len(items), mx, stream()), "hc_pack_conv_weights_multi")
+    sig = tuple((it[0].data_ptr(), it[1].data_ptr(), it[6], it[7]) for it in items)
+    ent = cache.get("table") if cache is not None else None
+    if ent is None or ent[0] != sig:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("RepBlock weight images must be packed once outside stream capture (run one eager step first): the item "
+                               "table upload is a host-to-device copy")
+        import numpy as np
+        arr = (PackItem * len(items))()
+        mx = fill_pack_items(arr, items)
+        table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(items[0][0].device)
+        ent = (sig, table, len(items), mx)
+        if cache is not None:
+            cache["table"] = ent
+    check(_lib.load().hc_pack_conv_weights_multi(ent[1].data_ptr(), ent[2], ent[3], stream()), "hc_pack_conv_weights_multi")
 
 
 class RepState:
@@ -154,6 +172,7 @@ class RepState:
         self.last_out_stats = None
         self.packed = None          # persistent packed-weight buffers (wp3, wp1, wpd)
         self.packed_key = None
+        self.pack_table = {}        # launch_pack_items' device-side item table (keyed by the buffer pointers)
         self.rows_image = (False, False)   # set by descs(): (forward, data gradient) run on a row-unit kernel, which reads its own weight image
         self.stack_fwd = False      # set by pack_items(): 3x3 + 1x1 forward as ONE gather-conv over stacked weight rows
         self.s2 = False             # set by descs(): the forward runs on the stride-2 row kernel (csrc/conv_s2.hip), which reads its own
@@ -244,7 +263,7 @@ class RepState:
     def ensure_packed(self, w3, w1):
         key = self.weights_key(w3, w1)
         if self.packed_key != key or self.packed is None:
-            launch_pack_items(self.pack_items(w3, w1))
+            launch_pack_items(self.pack_items(w3, w1), self.pack_table)
             self.packed_key = key
         return self.packed
 

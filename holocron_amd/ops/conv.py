@@ -451,10 +451,14 @@ class _RepWgradQueue:
         Cout, Cin = key[4], key[1]
         task = torch._C._current_graph_task_id()
         if self.armed and task != self.task:
-            # The pass that armed the queue never ran its final callback: the engine skips it when backward raises (an OOM the caller
-            # retries, KeyboardInterrupt, an error in a hook).  Its jobs belong to gradients nobody will read: drop them, or every
-            # later pass would find `armed` set, queue no callback and train on the zero-filled arena views.
-            self._abandon()
+            # Another graph task submits while the queue is armed.  Either the pass that armed it never ran its final callback (the
+            # engine skips it when backward raises: an OOM the caller retries, KeyboardInterrupt, an error in a hook), or this is a
+            # RE-ENTRANT backward nested inside a pass that is still running (torch.utils.checkpoint(use_reentrant=True), a
+            # backward() inside a custom Function: the task ids run [0, 1, 0]).  The two cannot be told apart here, and dropping the
+            # jobs would leave the zero-filled placeholders of the outer pass in .grad, so the stale jobs are LAUNCHED:
+            # their tuples keep every operand alive, and filling gradients nobody reads any more is harmless.  The queue is then
+            # disarmed, this pass arms it for its own task, and an outer pass that resumes afterwards re-arms it on its next submit.
+            self._flush_stale()
         dw3 = self._zeros((Cout, Cin, 3, 3), x.device, key)
         dw1 = self._zeros((Cout, Cin, 1, 1), x.device, key)
         # The queue must not hold the gradient TENSORS: AccumulateGrad only adopts a gradient it holds the sole reference to
@@ -471,10 +475,10 @@ class _RepWgradQueue:
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
         return dw3, dw1
 
-    def _abandon(self):
-        self.join()
-        self.jobs, self.armed, self.task = [], False, -1
-        self.arena, self.arena_used, self.arena_want, self.arena_first = None, 0, 0, None
+    def _flush_stale(self):
+        sizes = dict(self.arena_sizes)
+        self.flush()
+        self.arena_sizes = sizes                # a partial pass must not shrink the arena the next full pass gets
 
     def _launch_on_side(self):
         jobs, self.jobs = self.jobs, []

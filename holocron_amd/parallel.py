@@ -433,6 +433,9 @@ class GraphedStep:
         self.graphs: List[torch.cuda.CUDAGraph] = []
         self.spans: List[List[torch.Tensor]] = []      # per segment graph: the slices reduced after it
         self.final: Optional[torch.cuda.CUDAGraph] = None
+        self._works: list = []                         # collectives issued since the last _quiesce()
+        self._tracking = False
+        self._holds_pool = False                       # counted in POOL.graph_users (see release)
         if self.reducer is not None:
             self.reducer.set_overlap(False)
 
@@ -468,17 +471,41 @@ class GraphedStep:
         red.unpack()
         self.optimizer.step()
 
-    @staticmethod
-    def _quiesce() -> None:
+    def _quiesce(self) -> None:
+        """Nothing of ours is in flight when a capture begins: the device is idle and every collective this object issued says so
+        through its own Work handle (``is_completed`` = an event query from THIS thread, legal outside capture).  The process group's
+        watchdog thread also polls those events; that only matters to a "global"-mode capture (where hipEventQuery from any thread
+        is an error): the default with a live process group is "thread_local", which needs no settling time at all.  In global
+        mode the watchdog drops a finished collective within one of its 100 ms polling periods."""
         torch.cuda.synchronize()
-        if dist.is_initialized():
+        works, self._works = self._works, []
+        for w in works:
+            while not w.is_completed():          # cannot spin after the synchronize above unless the backend lags behind the device
+                import time
+                time.sleep(0.001)
+        if dist.is_initialized() and self.capture_error_mode == "global":
             import time
-            time.sleep(0.3)              # > the watchdog's 100 ms polling period
+            time.sleep(0.3)
 
     def _reduce_spans(self, spans):
-        return [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.reducer.group, async_op=True) for t in spans]
+        works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.reducer.group, async_op=True) for t in spans]
+        if self._tracking:                       # inside capture(): _quiesce() checks these handles; plain steps keep none
+            self._works += works
+        return works
 
     def capture(self) -> None:
+        self._tracking = True
+        try:
+            self._capture()
+        finally:
+            self._tracking = False
+            self._works = []
+
+    def _capture(self) -> None:
+        if not self._holds_pool:
+            from .nn.repblock_op import POOL
+            POOL.graph_users += 1
+            self._holds_pool = True
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -524,7 +551,9 @@ class GraphedStep:
     def release(self) -> None:
         self.graphs, self.spans, self.final = [], [], None
         from .nn.repblock_op import POOL
-        POOL.release_retired()           # statistics arenas that were only kept alive for these graphs
+        if self._holds_pool:             # statistics arenas that were only kept alive for captured graphs are freed when the LAST
+            self._holds_pool = False     # live GraphedStep lets go: another one may still replay against them
+            POOL.release_retired()
 
     def run(self) -> None:
         if not self.graphs:

@@ -47,15 +47,17 @@ class ClassificationTrainer(Trainer):
         self._sum_over_ranks(loss_sum, valid)          # every rank evaluates its own shard: the metrics are the whole set's
         nv = float(valid)
         val_loss = float(loss_sum) / nv if nv else float("nan")
+        # ONE fixed-shape collective whatever this rank saw: a rank whose validation shard is empty has no device counters, and if it
+        # all-reduced a different tensor (other dtype / path) than its peers the collectives would mismatch or deadlock.
+        # [top-1 hits, top-5 hits, samples, classes x saw-data, saw-data]
+        tot = torch.tensor([top1, top5, num_samples, float(ncls) if num_samples else 0.0, 1.0 if num_samples else 0.0],
+                           dtype=torch.float64, device=dev)
         if acc is not None and acc.counters is not None:
-            self._sum_over_ranks(acc.counters)
-            a1, a5, n = acc.compute()
-            if ncls < 5:                            # fewer than five classes: the reference never counts a top-5 hit (:64-65)
-                a5 = 0.0
-            return {"val_loss": val_loss, "acc1": a1, "acc5": a5}
-        host = torch.tensor([top1, top5, num_samples], dtype=torch.float64, device=dev)
-        self._sum_over_ranks(host)
-        top1, top5, num_samples = (float(v) for v in host.tolist())
+            tot[:3] += acc.counters.to(torch.float64)
+        self._sum_over_ranks(tot)
+        top1, top5, num_samples, cls_sum, seen = (float(v) for v in tot.tolist())
+        if seen and cls_sum / seen < 5:             # fewer than five classes: the reference never counts a top-5 hit (:64-65)
+            top5 = 0.0
         return {"val_loss": val_loss, "acc1": top1 / max(num_samples, 1), "acc5": top5 / max(num_samples, 1)}
 
     @staticmethod

@@ -258,6 +258,10 @@ class Trainer:
                     self.optimizer.add_param_group({"params": group, "weight_decay": wd})
         self.optimizer.zero_grad()
         self._restore_opt_state()
+        # data parallelism: build the reducer - and with it the rank-0 broadcast of parameters and buffers - HERE, before the first
+        # forward of fit_n_epochs / find_lr / check_setup.  Done lazily inside `_backprop_step` it ran between the first batch's
+        # forward and its backward: activations saved from the old weights met the new ones in that step's gradient.
+        self._grad_reducer()
 
     def _restore_opt_state(self) -> None:
         """Re-apply a state that ``load`` brought in to the groups ``_reset_opt`` just rebuilt (moments, step counts; the groups'
@@ -273,6 +277,17 @@ class Trainer:
         # state entries are keyed by the position of the parameter in the flattened groups: remap saved order -> current order
         saved_ids = [i for g in pending["param_groups"] for i in g["params"]]
         cur_ids = [i for g in groups for i in g["params"]]
+        # ... which is only right when both orders list the same parameters: a different `norm_weight_decay` / freeze setting between
+        # save and now keeps the count and permutes the order.  Every per-parameter tensor of a state entry must have the shape of the
+        # parameter it is about to be attached to (scalars - step counts - aside); otherwise moments would land on the wrong weights
+        # or fail later inside a fused optimizer kernel.
+        cur_params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        for s, p in zip(saved_ids, cur_params):
+            for v in pending["state"].get(s, {}).values():
+                if torch.is_tensor(v) and v.dim() > 0 and v.numel() > 1 and tuple(v.shape) != tuple(p.shape):
+                    warnings.warn("the loaded optimizer state lists the parameters in another order than the groups being optimised "
+                                  "now (different `norm_weight_decay` / freeze settings?): starting from a fresh state", stacklevel=3)
+                    return
         state = {c: pending["state"][s] for s, c in zip(saved_ids, cur_ids) if s in pending["state"]}
         self.optimizer.load_state_dict({"state": state, "param_groups": groups})
 

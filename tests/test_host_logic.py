@@ -380,8 +380,39 @@ def test_deferred_wgrad_queue_recovers_from_an_aborted_backward(monkeypatch):
     fq.launches.clear()
     _rep_like(w3, w1, x).backward()                  # the retry must not inherit `armed` (it would train on zero gradients)
     assert not cv._WREP.armed and not cv._WREP.jobs
-    assert len(fq.launches) == 1 and fq.launches[0][1] == 1      # the stale job was dropped, not launched
+    # the stale job is launched into buffers nobody reads (it cannot be told from the outer pass of a re-entrant backward, whose jobs
+    # must not be lost: ADVICE r3), then the retry's own
+    assert len(fq.launches) == 2 and all(n == 1 for _, n, _ in fq.launches)
     assert torch.equal(w3.grad, torch.ones_like(w3)) and torch.equal(w1.grad, torch.ones_like(w1))
+
+
+def test_deferred_wgrad_queue_survives_a_reentrant_backward(monkeypatch):
+    """torch.utils.checkpoint(use_reentrant=True) runs a nested backward (a new graph task) inside the outer pass: the jobs the outer
+    pass queued before it must still be launched (they were dropped and the zero placeholders stayed in .grad)."""
+    from torch.utils.checkpoint import checkpoint
+    fq = _FakeQueue(monkeypatch)
+    ws = [(torch.nn.Parameter(torch.zeros(16, 16, 3, 3)), torch.nn.Parameter(torch.zeros(16, 16, 1, 1))) for _ in range(3)]
+    x = torch.ones(2, 16, 4, 4, requires_grad=True)
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w3, w1):
+            ctx.save_for_backward(x, w3, w1)
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w3, w1 = ctx.saved_tensors
+            dw3, dw1 = cv.rep_block_wgrad(x, g, g, w3, w1, 1, defer=True)
+            return g, dw3, dw1
+
+    y = Fn.apply(x, *ws[0])                                         # backward order: block 2 (outer), block 1 (nested), block 0 (outer)
+    y = checkpoint(lambda t: Fn.apply(t, *ws[1]), y, use_reentrant=True)
+    y = Fn.apply(y, *ws[2])
+    y.sum().backward()
+    assert not cv._WREP.armed and not cv._WREP.jobs
+    for w3, w1 in ws:
+        assert torch.equal(w3.grad, torch.ones_like(w3)) and torch.equal(w1.grad, torch.ones_like(w1))
 
 
 def test_deferred_wgrad_not_used_when_something_reads_gradients_inside_the_pass(monkeypatch):
@@ -471,8 +502,14 @@ def test_trainer_load_keeps_the_optimizer_state_through_reset_opt(tmp_path):
     m2, opt2 = make()
     tr2 = ClassificationTrainer(m2, data, data[:1], torch.nn.CrossEntropyLoss(), opt2, gpu=None, output_file=str(tmp_path / "d.pth"))
     tr2.load(torch.load(str(tmp_path / "full.pth"), weights_only=False))
-    tr2._reset_opt(0.05, norm_weight_decay=0.0)      # a different grouping (norm parameters split off) than the saved one
+    import warnings
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        tr2._reset_opt(0.05, norm_weight_decay=0.0)  # a different grouping (norm parameters split off) than the saved one
     assert len(opt2.param_groups) == 2 and opt2.param_groups[0]["lr"] == 0.05
+    if not all(a is b for a, b in zip([p for grp in opt2.param_groups for p in grp["params"]], m2.parameters())):
+        # same count, another order: moments must not be attached by position to parameters of other shapes
+        assert any("another order" in str(w.message) for w in rec) and len(opt2.state) == 0
     # saved order = model.parameters() order; the regrouped optimizer holds the same tensors' state, matched by POSITION in the
     # saved flattening - which is only valid when the order is kept, so compare through the parameters themselves
     saved_order = list(m2.parameters())
@@ -491,6 +528,27 @@ def test_trainer_load_keeps_the_optimizer_state_through_reset_opt(tmp_path):
     for p, b in zip(opt3.param_groups[0]["params"], bufs):
         assert torch.equal(opt3.state[p]["momentum_buffer"], b)
     assert opt3.param_groups[0]["lr"] == 0.02
+
+
+def test_zero_pool_keeps_retired_arenas_until_the_last_graph_holder_releases():
+    """GraphedStep.release() freed every retired statistics arena of the process, also those another live GraphedStep's
+    graphs still replay against."""
+    from holocron_amd.nn.repblock_op import ZeroPool
+    from holocron_amd import parallel
+    pool = ZeroPool()
+    pool.retired = [torch.zeros(4)]
+    pool.graph_users = 2
+    pool.release_retired()
+    assert pool.graph_users == 1 and len(pool.retired) == 1       # one holder left: nothing is freed
+    pool.release_retired()
+    assert pool.graph_users == 0 and pool.retired == []
+    pool.release_retired()                                          # a release without a capture is harmless
+    assert pool.graph_users == 0
+    gs = parallel.GraphedStep(lambda: None, torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1))
+    from holocron_amd.nn.repblock_op import POOL
+    users = POOL.graph_users
+    gs.release()                                                    # never captured: does not touch the count
+    assert POOL.graph_users == users
 
 
 def test_multi_copy_launch_plan_covers_every_element_once():

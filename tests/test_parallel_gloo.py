@@ -380,13 +380,20 @@ def _worker_trainer(rank, world, port):
     train = _ListLoader([(torch.randn(4, 3, 2, 2, generator=g), torch.randint(0, 6, (4,), generator=g)) for _ in range(4)])
     val = _ListLoader(train[:2])
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
-    tr = ClassificationTrainer(model, train, val, torch.nn.CrossEntropyLoss(), opt, gpu=None, gradient_acc=2,
-                               output_file=os.path.join("/tmp", f"hc_trainer_{port}_{rank}.pth"))
-    out_file = tr.output_file
-    if os.path.exists(out_file):
-        os.remove(out_file)
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
+        # the reducer - and the rank-0 broadcast - exist from the first `_reset_opt` on, i.e. from the constructor: BEFORE the first
+        # forward, not between the first batch's forward and backward
+        tr = ClassificationTrainer(model, train, val, torch.nn.CrossEntropyLoss(), opt, gpu=None, gradient_acc=2,
+                                   output_file=os.path.join("/tmp", f"hc_trainer_{port}_{rank}.pth"))
+        assert tr._reducer is not None
+        flat0 = torch.cat([p.detach().flatten() for p in model.parameters()])
+        ref0 = flat0.clone()
+        dist.broadcast(ref0, src=0)
+        assert torch.equal(flat0, ref0)             # replicas are identical before any batch has been seen
+        out_file = tr.output_file
+        if os.path.exists(out_file):
+            os.remove(out_file)
         tr.fit_n_epochs(1, 0.1, sched_type="cosine")
     assert any("DistributedSampler" in str(w.message) for w in rec)      # a plain list is not rank-sharded: said so once
     assert tr._reducer is not None and tr._reducer.active and tr.step == 4 and tr.epoch == 1
@@ -422,6 +429,31 @@ def _worker_trainer(rank, world, port):
     other = flat.clone()
     dist.broadcast(other, src=0)
     assert torch.equal(flat, other) and bool(torch.isfinite(flat).all())
+    # a rank whose validation shard is EMPTY issues the same fixed-shape collectives as its peers (it all-reduced another
+    # tensor and the ranks deadlocked / mismatched); the metrics are those of the only shard with data
+    full = tr2.val_loader
+    alone = None
+    if rank == 0:
+        m0, n0, l0 = 0, 0, 0.0                         # reference value: rank 0's shard on its own, computed without collectives
+        model.eval()
+        with torch.no_grad():
+            for x, t in full:
+                o = model(x)
+                m0 += int((o.argmax(1) == t).sum())
+                n0 += x.shape[0]
+                l0 += float(torch.nn.functional.cross_entropy(o, t))
+        alone = (m0 / n0, l0 / len(full))
+    if rank == 1:
+        tr2.val_loader = _ListLoader([])
+    tr2.criterion = torch.nn.CrossEntropyLoss()
+    me = tr2.evaluate()
+    got = torch.tensor([me["acc1"], me["val_loss"]], dtype=torch.float64)
+    ref2 = got.clone()
+    dist.broadcast(ref2, src=0)
+    assert torch.equal(got, ref2)
+    if rank == 0:
+        assert abs(me["acc1"] - alone[0]) < 1e-9 and abs(me["val_loss"] - alone[1]) < 1e-5
+    tr2.val_loader = full
     dist.barrier()
     if rank == 0 and os.path.exists(out_file):
         os.remove(out_file)
