@@ -270,7 +270,7 @@ def main():
         # HBM bytes per launch from the PMC passes over this same command (scripts/pmc_step.sh; the counters cannot be read from
         # inside the process): taken from this round's committed file when there is one, else null
         traffic, traffic_src = None, None
-        for cand in ("r03_pmc_step_traffic.json", "r02_pmc_step_traffic.json"):
+        for cand in ("r04_pmc_step_traffic.json", "r03_pmc_step_traffic.json", "r02_pmc_step_traffic.json"):
             pmc_file = os.path.join(ROOT, "profiles", cand)
             if args.batch == 256 and os.path.exists(pmc_file) and traffic is None:
                 with open(pmc_file) as fh:
@@ -292,6 +292,17 @@ def main():
                                                 "hbm" if v[3] / HBM_PEAK > v[0] / MFMA_BF16_PEAK else "mfma"),
                                       "frac": max(v[3] / HBM_PEAK, v[0] / MFMA_BF16_PEAK) / v[1]}
                                   for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}})
+
+    # north_star's own metric: conv FLOPs / conv-family time against the dense bf16 MFMA peak, over every family that executes
+    # convolution MACs (forward, data gradient, weight gradient; BN / packing / optimizer launches are not in it)
+    conv_frac = None
+    if rank == 0 and roof is not None:
+        cf = {k: v for k, v in fam.items() if v[0] > 0.0}
+        c_fl, c_sec = sum(v[0] for v in cf.values()), sum(v[1] for v in cf.values())
+        if c_sec > 0:
+            conv_frac = {"frac": c_fl / c_sec / MFMA_BF16_PEAK, "tflops": c_fl / c_sec / 1e12, "peak_tflops": MFMA_BF16_PEAK / 1e12,
+                         "conv_ms_per_step": c_sec * 1e3, "conv_gflop_per_step": c_fl / 1e9, "families": sorted(cf),
+                         "source": "HIP events around every conv launch of the instrumented eager steps (same as roofline.families)"}
 
     if rank != 0:
         if distributed:
@@ -319,6 +330,7 @@ def main():
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "mode": graph_note,
                    "final_loss": final_loss},
         "mfma_fraction_whole_step": TRAIN_GFLOP_PER_IMG * 1e9 * imgs / dt / MFMA_BF16_PEAK / world,
+        "conv_mfma_fraction": conv_frac,
         "roofline": roof,
     }
     if world == 1 and not args.no_cpu_baseline:

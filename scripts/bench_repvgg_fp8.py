@@ -29,11 +29,40 @@ def timeit(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+def cpu_baseline(model, batch, iters=3):
+    """the reference's path for this config is the re-parametrised network in fp32 on the host cores
+    (repvgg.py:75-107 then a plain conv + ReLU chain); timed on the oracle's restatement, bounded sample."""
+    from oracle import repvgg as orv
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    import _train_bench as tb
+    nb, a_, b_ = orv.ARCH["repvgg_a2"]
+    ch = orv.widths(orv.PLANES, a_, b_)
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    x = torch.rand((batch, 3, 224, 224), generator=torch.Generator().manual_seed(0))
+    torch.set_flush_denormal(True)
+
+    def one():
+        with torch.no_grad():
+            orv.forward(sd, x, nb, ch, training=False)       # re-parametrised state dict: one conv + bias + ReLU per block
+        return batch
+    best, trial, host, default = tb.best_threads_run(one, counts=(8, 16, 32, 64))
+    t0 = time.perf_counter()
+    n = sum(one() for _ in range(iters))
+    dt = time.perf_counter() - t0
+    torch.set_num_threads(default)
+    return {"value": n / dt, "unit": "images/sec", "cores": best, "host_threads": host, "kind": "port",
+            "threads_tried": {str(k): round(v, 2) for k, v in trial.items()},
+            "sample": f"re-parametrised repvgg_a2 forward in torch-CPU fp32 (the reference's inference path), batch {batch}, "
+                      f"1 warm-up + {iters} timed iterations on the best of the tried thread counts"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     torch.manual_seed(0)
     m = h.models.repvgg_a2(num_classes=1000).cuda().eval()
@@ -64,12 +93,13 @@ def main():
             "frac": fl / sec / peak, "traffic": traffic, "traffic_source": src, "launches_per_step": nl, "avg_launch_ms": sec / nl * 1e3,
             "note": "the block-scaled MFMA instruction is issued with UNIT block scales (E8M0 0x7f): quantisation is per-output-channel "
                     "weight scales and static per-tensor activation scales folded into the epilogue, not OCP-MX per-32 block scaling"}
+    cpu = None if a.no_cpu_baseline else cpu_baseline(m, a.cpu_batch)
     print(json.dumps({"metric": "images/sec inference, repvgg_a2 re-parametrised fp8 e4m3, 224^2", "value": a.batch / t_fp8, "unit": "images/sec",
                       "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": t_fp8 * 1e3, "higher_is_better": True,
                       "dtype": "fp8 e4m3 (fp32 accumulate)", "data": "synthetic",
                       "config": {"workload": f"repvgg_a2 reparam fp8 inference 224^2 bs{a.batch} (BASELINE.json configs[4])"},
                       "tflops": INFER_GFLOP_PER_IMG * a.batch / t_fp8 / 1e3, "frac_of_5PF": INFER_GFLOP_PER_IMG * 1e9 * a.batch / t_fp8 / 5e15,
-                      "roofline": roof,
+                      "roofline": roof, "cpu_baseline": cpu,
                       "bf16_img_s": a.batch / t_bf16, "bf16_ms": t_bf16 * 1e3, "top1_agreement_with_bf16": agree}))
 
 

@@ -57,9 +57,36 @@ def main():
                 out = m(x)
             torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.steps
-        print(json.dumps({"metric": "images/sec eval fwd+decode+NMS, YOLOv4 608^2 nc=80", "value": a.batch / dt, "unit": "images/sec",
-                          "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3, "dtype": "bf16", "data": "synthetic",
-                          "config": {"workload": f"yolov4 {a.size}^2 bs{a.batch} eval"}, "detections_img0": int(out[0]["boxes"].shape[0])}))
+        # what the post-processing saw: 22 743 predictors per 608^2 image (3 x (19^2 + 38^2 + 76^2), yolov4.py:302-336); with random-init
+        # weights about half of them pass the objectness threshold, so the NMS works on thousands of candidates per image and scale
+        npred = 3 * sum((a.size // s) ** 2 for s in (32, 16, 8))
+        kept = [int(o["boxes"].shape[0]) for o in out]
+        line = {"metric": "images/sec eval fwd+decode+NMS, YOLOv4 608^2 nc=80", "value": a.batch / dt, "unit": "images/sec",
+                "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "bf16",
+                "data": "synthetic", "config": {"workload": f"yolov4 {a.size}^2 bs{a.batch} eval: forward + decode + score filter + NMS "
+                                                            "(BASELINE.md section 3 row C4), random-init weights, 80 classes"},
+                "predictors_per_image": npred, "detections_per_image_mean": sum(kept) / len(kept), "detections_img0": kept[0]}
+        if not a.no_cpu_baseline:
+            # the oracle's detect(): the reference's eval path restated on torch-CPU fp32 incl. the restated torchvision NMS
+            from oracle import yolov4 as ov
+            sd = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}
+            xc = x[: a.cpu_batch].float().cpu()
+            torch.set_flush_denormal(True)
+
+            def one():
+                with torch.no_grad():
+                    ov.detect(sd, xc, ov.CSP53, 80, ov.Cfg(act="mish", drop=(0.1, 7), training=False))
+                return a.cpu_batch
+            best, trial, host, default = tb.best_threads_run(one, counts=(16, 32, 64))
+            t0 = time.perf_counter()
+            n = sum(one() for _ in range(2))
+            cdt = time.perf_counter() - t0
+            torch.set_num_threads(default)
+            line["cpu_baseline"] = {"value": n / cdt, "unit": "images/sec", "cores": best, "host_threads": host, "kind": "port",
+                                    "threads_tried": {str(k): round(v, 3) for k, v in trial.items()},
+                                    "sample": f"oracle yolov4 608^2 eval forward + decode + NMS (torch-CPU fp32), batch {a.cpu_batch}, "
+                                              "2 timed iterations"}
+        print(json.dumps(line))
         return
 
     def build():

@@ -32,14 +32,15 @@ def test_repblock_train_matches_reference(golden):
         # (99.5 % within 1e-2) is the one against the bf16-emulating oracle below, where no mask can flip.
         if cin % 16 == 0:
             scale = float(c["dx"].abs().mean())
-            assert close_frac(x.grad.float().cpu(), c["dx"], 2e-2, 2e-2 * scale) > 0.92, c["cfg"]
-            assert rel_l2(x.grad.float().cpu(), c["dx"]) < 0.1, c["cfg"]
+            # bounds = the measured worst case + margin (mask flips depend on the order of the statistics atomics: not run-to-run stable)
+            assert close_frac(x.grad.float().cpu(), c["dx"], 2e-2, 2e-2 * scale) > 0.935, c["cfg"]
+            assert rel_l2(x.grad.float().cpu(), c["dx"]) < 0.075, c["cfg"]
         for n, p in blk.named_parameters():
             ref = c["dparams"][n]
             scale = float(ref.abs().mean())
             frac = close_frac(p.grad.cpu(), ref, 3e-2, 3e-2 * scale)
-            assert frac > 0.9, (c["cfg"], n, frac)
-            assert rel_l2(p.grad.cpu(), ref) < 0.1, (c["cfg"], n)
+            assert frac > 0.93, (c["cfg"], n, frac)          # 0.9375 = one element of a 16-channel vector
+            assert rel_l2(p.grad.cpu(), ref) < 0.075, (c["cfg"], n)
         sd = blk.state_dict()
         for k, v in c["state_after"].items():
             if "running" in k:
