@@ -3,6 +3,7 @@ and leaves every rank with identical parameters after an optimizer step."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -226,7 +227,7 @@ def test_graphed_step_segments_world2_eager_form():
     mp.spawn(_worker_segments, args=(2, _free_port()), nprocs=2, join=True)
 
 
-def _worker_three_segments(rank, world, port):
+def _worker_three_segments(rank, world, port, comm_dtype=torch.float32):
     """The N > 1 bench configuration (bench.py): backward cut in THREE by two BackwardCuts, three buckets aligned with the cuts -
     after segment k exactly buckets 0..k are complete, and the result is serial full-batch training."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -242,7 +243,7 @@ def _worker_three_segments(rank, world, port):
     rear_cut, mid_cut = BackwardCut(model[6]), BackwardCut(model[2])
     b1 = list(model[4].parameters())[-1]               # first parameter (backwards) in front of the rear cut
     b2 = list(model[0].parameters())[-1]               # ... in front of the middle cut
-    red = GradReducer(model.parameters(), bucket_mb=32.0, new_bucket_at=[b1, b2], overlap=False)
+    red = GradReducer(model.parameters(), bucket_mb=32.0, new_bucket_at=[b1, b2], overlap=False, comm_dtype=comm_dtype)
     assert [len(b.params) for b in red.buckets] == [2, 4, 2]
     torch.manual_seed(9)
     data, target = torch.randn(2 * world, 8), torch.randn(2 * world, 3)
@@ -271,13 +272,23 @@ def _worker_three_segments(rank, world, port):
         with torch.no_grad():
             for p in ref.parameters():
                 p -= 0.01 * p.grad
+    # fp32 wire: serial full-batch training to accumulation order; bf16 wire (bench.py --comm-dtype bf16): every averaged gradient
+    # element is one bf16 rounding (2^-9 relative) away, i.e. two SGD steps of lr 0.01 move a parameter by <= 2 * 0.01 * 2^-8 * |g|
+    tol = 1e-5 if comm_dtype == torch.float32 else 2e-3
     for a, b in zip(model.parameters(), ref.parameters()):
-        assert torch.allclose(a, b, atol=1e-5, rtol=1e-5), (a - b).abs().max()
+        assert torch.allclose(a, b, atol=tol, rtol=tol), (a - b).abs().max()
+    if comm_dtype != torch.float32:
+        assert any(not torch.equal(a, b) for a, b in zip(model.parameters(), ref.parameters()))     # the wire format really was bf16
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    other = flat.clone()
+    dist.broadcast(other, src=0)
+    assert torch.equal(flat, other)                   # whatever the wire format, the replicas stay bit-identical
     dist.destroy_process_group()
 
 
-def test_graphed_step_three_segments_world2():
-    mp.spawn(_worker_three_segments, args=(2, _free_port()), nprocs=2, join=True)
+@pytest.mark.parametrize("comm_dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_graphed_step_three_segments_world2(comm_dtype):
+    mp.spawn(_worker_three_segments, args=(2, _free_port(), comm_dtype), nprocs=2, join=True)
 
 
 # ---------------------------------------------------------------- gradient accumulation, guard, comm dtype, Trainer
