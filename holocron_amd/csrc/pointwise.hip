@@ -338,6 +338,71 @@ __global__ void ce_fwd_bwd_kernel(const float* __restrict__ logits, const long* 
 }
 
 
+// Mean label-smoothed cross entropy as the training loop calls it (nn.CrossEntropyLoss(label_smoothing=ls), mean reduction,
+// references/classification/train.py:194): forward = ONE single-workgroup launch that writes the scalar loss and the number of valid
+// rows (target != ignore_index); the partial sums are combined in a fixed order, so the loss is bit-reproducible.  torch's own
+// composition is ~25 launches (log_softmax, nll_loss, sum, neg, mul, div, masked_fill, ...).  aux = {valid rows}
+__global__ __launch_bounds__(1024) void ce_mean_fwd_kernel(const float* __restrict__ logits, const long* __restrict__ target,
+                                                           float* __restrict__ loss, float* __restrict__ aux, int N, int K, float ls,
+                                                           long ignore_index) {
+    __shared__ float s_nll[1024], s_sm[1024], s_cnt[1024];
+    float nll = 0.f, sm = 0.f, cnt = 0.f;
+    for (int n = threadIdx.x; n < N; n += 1024) {
+        const long tg = target[n];
+        if (tg == ignore_index) continue;
+        const float* px = logits + (long)n * K;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, px[k]);
+        float se = 0.f;
+        for (int k = 0; k < K; ++k) se += expf(px[k] - mx);
+        const float lse = logf(se) + mx;
+        float sum_logp = 0.f;
+        for (int k = 0; k < K; ++k) sum_logp += px[k] - lse;
+        nll += -(px[tg] - lse);
+        sm += -sum_logp;
+        cnt += 1.f;
+    }
+    s_nll[threadIdx.x] = nll; s_sm[threadIdx.x] = sm; s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s_nll[threadIdx.x] += s_nll[threadIdx.x + w];
+            s_sm[threadIdx.x] += s_sm[threadIdx.x + w];
+            s_cnt[threadIdx.x] += s_cnt[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float c = s_cnt[0];
+        // torch: (1 - ls) * mean(nll) + ls * mean(sum_k -logp_k) / K ; no valid row -> nan (0 / 0), like torch
+        loss[0] = (1.f - ls) * (s_nll[0] / c) + ls * ((s_sm[0] / c) / (float)K);
+        aux[0] = c;
+    }
+}
+// dlogits[n][k] = dloss * (softmax_k - (1 - ls) [k == target] - ls / K) / valid rows ; rows with the ignored target get zeros
+__global__ void ce_mean_bwd_kernel(const float* __restrict__ logits, const long* __restrict__ target, const float* __restrict__ dloss,
+                                   const float* __restrict__ aux, float* __restrict__ dlogits, int N, int K, float ls, long ignore_index) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float* px = logits + (long)n * K;
+    float* pd = dlogits + (long)n * K;
+    const long tg = target[n];
+    if (tg == ignore_index) {
+        for (int k = 0; k < K; ++k) pd[k] = 0.f;
+        return;
+    }
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, px[k]);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(px[k] - mx);
+    const float lse = logf(se) + mx;
+    const float gs = dloss[0] / aux[0];
+    for (int k = 0; k < K; ++k) {
+        const float p = expf(px[k] - lse);
+        pd[k] = (p - (1.f - ls) * (k == tg ? 1.f : 0.f) - ls / (float)K) * gs;
+    }
+}
+
 // ---------------------------------------------------------------- input side of the training step
 // Mixup (holocron/utils/data/collate.py:39-64): out[i] = lam x[i] + (1 - lam) x[perm[i]] over rows of D elements
 template <typename T>
@@ -462,6 +527,22 @@ int hc_focal_loss_bwd(const float* x, const int64_t* target, const float* weight
     if ((long)N * S == 0) return HC_OK;
     hipLaunchKernelGGL(focal_bwd_kernel, dim3(grid_for((long)N * S)), dim3(256), 0, (hipStream_t)stream, x, (const long*)target,
                        weight, dloss_el, dx, N, K, (long)S, gamma);
+    return hc_launch_status();
+}
+
+int hc_ce_mean_fwd(const float* logits, const int64_t* target, float* loss, float* aux, int32_t N, int32_t K, float label_smoothing,
+                   int64_t ignore_index, hc_stream_t stream) {
+    if (logits == nullptr || target == nullptr || loss == nullptr || aux == nullptr || N <= 0 || K <= 0) return HC_ERR_ARG;
+    hipLaunchKernelGGL(ce_mean_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, (const long*)target, loss, aux, N, K,
+                       label_smoothing, (long)ignore_index);
+    return hc_launch_status();
+}
+int hc_ce_mean_bwd(const float* logits, const int64_t* target, const float* dloss, const float* aux, float* dlogits, int32_t N,
+                   int32_t K, float label_smoothing, int64_t ignore_index, hc_stream_t stream) {
+    if (logits == nullptr || target == nullptr || dloss == nullptr || aux == nullptr || dlogits == nullptr || N <= 0 || K <= 0)
+        return HC_ERR_ARG;
+    hipLaunchKernelGGL(ce_mean_bwd_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, logits, (const long*)target, dloss,
+                       aux, dlogits, N, K, label_smoothing, (long)ignore_index);
     return hc_launch_status();
 }
 

@@ -12,7 +12,7 @@ from .. import _lib
 from .._lib import check, ptr, stream
 
 __all__ = ["hard_mish", "focal_loss", "dice_loss", "poly_loss", "dropblock2d", "global_avg_pool2d", "concat_downsample2d",
-           "norm_conv2d"]
+           "norm_conv2d", "cross_entropy"]
 
 
 class _HardMishFn(torch.autograd.Function):
@@ -152,6 +152,43 @@ class _PolySoftFn(torch.autograd.Function):
         check(_lib.load().hc_poly_loss_soft_bwd(ptr(xc), ptr(tc), ptr(wc), ptr(dl), ptr(dx), N, K, S, ign, eps, stream()),
               "hc_poly_loss_soft_bwd")
         return dx.to(dt), None, None, None, None
+
+
+class _CrossEntropyMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, target, label_smoothing, ignore_index):
+        _lib.require_gpu(x, target)
+        xc = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+        tc = target if (target.dtype == torch.int64 and target.is_contiguous()) else target.long().contiguous()
+        N, K = xc.shape
+        out = torch.empty((2,), dtype=torch.float32, device=x.device)          # {loss, valid rows}
+        check(_lib.load().hc_ce_mean_fwd(ptr(xc), ptr(tc), out.data_ptr(), out.data_ptr() + 4, N, K, float(label_smoothing),
+                                         int(ignore_index), stream()), "hc_ce_mean_fwd")
+        ctx.save_for_backward(xc, tc, out)
+        ctx.cfg = (float(label_smoothing), int(ignore_index), x.dtype)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        xc, tc, out = ctx.saved_tensors
+        ls, ign, dt = ctx.cfg
+        N, K = xc.shape
+        g = dloss if (dloss.dtype == torch.float32 and dloss.is_contiguous()) else dloss.float().contiguous()
+        dx = torch.empty_like(xc)
+        check(_lib.load().hc_ce_mean_bwd(ptr(xc), ptr(tc), ptr(g), out.data_ptr() + 4, ptr(dx), N, K, ls, ign, stream()),
+              "hc_ce_mean_bwd")
+        return (dx if dt == torch.float32 else dx.to(dt)), None, None, None
+
+
+def cross_entropy(x: Tensor, target: Tensor, label_smoothing: float = 0.0, ignore_index: int = -100) -> Tensor:
+    """Mean softmax cross entropy of ``[N, K]`` logits with label smoothing: the criterion of the reference's training loop
+    (``nn.CrossEntropyLoss(label_smoothing=...)``, references/classification/train.py:194) as two launches - forward, backward -
+    instead of torch's ~25.  Class-index targets, mean reduction over the rows whose target is not ``ignore_index``."""
+    if x.dim() != 2:
+        raise ValueError("cross_entropy expects [N, K] logits")
+    if target.shape != x.shape[:1]:
+        raise ValueError("cross_entropy expects class-index targets of shape [N]")
+    return _CrossEntropyMeanFn.apply(x, target, label_smoothing, ignore_index)
 
 
 def poly_loss(x: Tensor, target: Tensor, eps: float = 2.0, weight: Optional[Tensor] = None, ignore_index: int = -100,

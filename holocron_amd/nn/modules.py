@@ -6,7 +6,7 @@ from torch import Tensor, nn
 
 from . import functional as F
 
-__all__ = ["HardMish", "GlobalAvgPool2d", "FocalLoss", "DiceLoss", "PolyLoss", "DropBlock2d", "SPP", "FReLU", "SlimConv2d", "NormConv2d", "ConcatDownsample2d"]
+__all__ = ["HardMish", "GlobalAvgPool2d", "FocalLoss", "DiceLoss", "PolyLoss", "CrossEntropyLoss", "DropBlock2d", "SPP", "FReLU", "SlimConv2d", "NormConv2d", "ConcatDownsample2d"]
 
 
 class HardMish(nn.Module):
@@ -96,6 +96,18 @@ class PolyLoss(_Loss):
 
     def extra_repr(self) -> str:
         return f"eps={self.eps}, reduction='{self.reduction}'"
+
+
+class CrossEntropyLoss(nn.CrossEntropyLoss):
+    """``torch.nn.CrossEntropyLoss`` (the criterion of references/classification/train.py:194) whose common case - ``[N, K]`` logits on
+    the GPU, class-index targets, no class weights, mean reduction - runs as one HIP launch forward and one backward
+    (``F.cross_entropy``); every other configuration is torch's own."""
+
+    def forward(self, x: Tensor, target: Tensor) -> Tensor:
+        if (x.is_cuda and x.dim() == 2 and target.dim() == 1 and not target.is_floating_point() and self.weight is None
+                and self.reduction == "mean"):
+            return F.cross_entropy(x, target, self.label_smoothing, self.ignore_index)
+        return super().forward(x, target)
 
 
 class DropBlock2d(nn.Module):

@@ -26,7 +26,7 @@ class ClassificationTrainer(Trainer):
         loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
         valid = torch.zeros((), dtype=torch.float32, device=dev)
         acc = TopKAccuracy(5) if dev.type == "cuda" else None
-        top1 = top5 = num_samples = 0
+        top1 = top5 = num_samples = seen_batches = 0
         ncls = 0
         for x, target in self.val_loader:
             x, target = self.to_cuda(x, target)
@@ -43,14 +43,15 @@ class ClassificationTrainer(Trainer):
                 correct = pred.eq(target.view(-1, 1).expand_as(pred))
                 top1 += int(correct[:, 0].sum())
                 top5 += int(correct.any(dim=1).sum()) if out.shape[1] >= 5 else 0
-            num_samples += x.shape[0]
+                num_samples += x.shape[0]           # (the device counters of the branch above carry their own sample count)
+            seen_batches += 1
         self._sum_over_ranks(loss_sum, valid)          # every rank evaluates its own shard: the metrics are the whole set's
         nv = float(valid)
         val_loss = float(loss_sum) / nv if nv else float("nan")
         # ONE fixed-shape collective whatever this rank saw: a rank whose validation shard is empty has no device counters, and if it
         # all-reduced a different tensor (other dtype / path) than its peers the collectives would mismatch or deadlock.
         # [top-1 hits, top-5 hits, samples, classes x saw-data, saw-data]
-        tot = torch.tensor([top1, top5, num_samples, float(ncls) if num_samples else 0.0, 1.0 if num_samples else 0.0],
+        tot = torch.tensor([top1, top5, num_samples, float(ncls) if seen_batches else 0.0, 1.0 if seen_batches else 0.0],
                            dtype=torch.float64, device=dev)
         if acc is not None and acc.counters is not None:
             tot[:3] += acc.counters.to(torch.float64)

@@ -462,6 +462,15 @@ int hc_focal_loss_bwd(const float* x, const int64_t* target, const float* weight
 int hc_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss_el, float* dlogits, int32_t N, int32_t K,
                   float label_smoothing, hc_stream_t stream);
 
+/* The same criterion as the training loop calls it - nn.CrossEntropyLoss(label_smoothing=ls), mean over the rows whose target is
+ * not ignore_index (references/classification/train.py:194; torch composes it from ~25 aten launches): forward writes the scalar
+ * loss and aux[0] = number of valid rows in one single-workgroup launch (fixed-order sums); backward writes
+ * dlogits = dloss[0] * d(mean loss)/dlogits with dloss a DEVICE scalar (the upstream gradient autograd hands over). */
+int hc_ce_mean_fwd(const float* logits, const int64_t* target, float* loss, float* aux, int32_t N, int32_t K, float label_smoothing,
+                   int64_t ignore_index, hc_stream_t stream);
+int hc_ce_mean_bwd(const float* logits, const int64_t* target, const float* dloss, const float* aux, float* dlogits, int32_t N,
+                   int32_t K, float label_smoothing, int64_t ignore_index, hc_stream_t stream);
+
 /* Poly-1 loss (holocron/nn/functional.py:540-613).  Hard labels: target int64 [N][S], loss_el [N*S] =
  * w[t]*(-logp_t + eps*(1 - p_t)), valid as for focal.  Soft labels: target fp32 [N][K][S], loss_pos [N*S] =
  * sum over classes k != ignore_index (when 0 <= ignore_index < K) of w[k]*(-l_k + eps*(1 - exp l_k)),

@@ -167,6 +167,42 @@ def test_dropblock_batched_masks_equal_per_call_masks():
         off += n * h * w
 
 
+def test_cross_entropy_matches_torch_cpu_fp32():
+    """F.cross_entropy / nn.CrossEntropyLoss (the training loop's criterion, references/classification/train.py:194): value and
+    gradient against torch's own composition on the CPU in fp32, with label smoothing, ignored rows, a non-unit upstream gradient,
+    bf16 logits and more rows than one workgroup pass (1024)."""
+    import holocron_amd as h
+    g = torch.Generator().manual_seed(3)
+    for N, K, ls, ign, dt in [(256, 10, 0.1, -100, torch.float32), (37, 1000, 0.0, -100, torch.float32),
+                              (3000, 17, 0.2, 5, torch.float32), (64, 10, 0.1, -100, torch.bfloat16)]:
+        x = (torch.randn((N, K), generator=g) * 3).to(dt)
+        t = torch.randint(0, K, (N,), generator=g)
+        up = torch.rand((), generator=g) + 0.5
+        xr = x.float().clone().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(xr, t, label_smoothing=ls, ignore_index=ign)
+        (ref * up).backward()
+        xg = x.cuda().requires_grad_(True)
+        out = h.nn.functional.cross_entropy(xg, t.cuda(), label_smoothing=ls, ignore_index=ign)
+        (out * up.cuda()).backward()
+        assert out.dtype == torch.float32 and out.shape == ()
+        assert abs(float(out) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), (N, K, float(out), float(ref))
+        tol = 1e-6 if dt == torch.float32 else 4e-3          # bf16 logits: the returned gradient is rounded to bf16
+        assert xg.grad.dtype == dt
+        assert torch.allclose(xg.grad.float().cpu(), xr.grad, rtol=tol, atol=tol / N), (N, K, (xg.grad.float().cpu() - xr.grad).abs().max())
+        if ign >= 0:
+            assert bool((xg.grad[t.cuda() == ign] == 0).all())
+    # the module routes the common case to the HIP launches and anything else to torch
+    crit = h.nn.CrossEntropyLoss(label_smoothing=0.1)
+    x = torch.randn((32, 10), generator=g).cuda()
+    t = torch.randint(0, 10, (32,), generator=g).cuda()
+    assert abs(float(crit(x, t)) - float(torch.nn.functional.cross_entropy(x.cpu(), t.cpu(), label_smoothing=0.1))) < 2e-6
+    w = torch.rand(10).cuda()
+    assert torch.allclose(h.nn.CrossEntropyLoss(weight=w)(x, t), torch.nn.functional.cross_entropy(x, t, weight=w))
+    # two passes agree bit for bit (fixed-order sums)
+    a, b = h.nn.functional.cross_entropy(x, t, 0.1), h.nn.functional.cross_entropy(x, t, 0.1)
+    assert torch.equal(a, b)
+
+
 def test_global_avg_pool_matches_adaptive_avg_pool():
     """tests/test_nn_downsample.py:37-50 of the reference: GlobalAvgPool2d == AdaptiveAvgPool2d(1), plus gradients."""
     import holocron_amd as h
