@@ -1,6 +1,5 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/c2
-timeout 900 python -m pytest tests/test_gpu_boundary.py tests/test_gpu_pointwise.py -x -q -m gpu 2>&1 | tail -40 > gpurun_out/c2/tests.log
-HC_TORCH_LOSS=1 timeout 300 python bench.py --no-cpu-baseline --profile-steps 2 > gpurun_out/c2/bench_torchloss.json 2> gpurun_out/c2/bench.err
-timeout 300 python bench.py --no-cpu-baseline --profile-steps 2 > gpurun_out/c2/bench.json 2>> gpurun_out/c2/bench.err
-HC_LOSS=1 timeout 300 python scripts/prof_small_ops.py > gpurun_out/c2/small_ops.txt 2>&1
-cat gpurun_out/c2/tests.log; cut -c1-330 gpurun_out/c2/bench_torchloss.json;  cut -c1-330 gpurun_out/c2/bench.json; grep -v "^\[W\|Warn\|amdgpu" gpurun_out/c2/small_ops.txt | cut -c1-220 | head -70
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/c3
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_out/c3/tests.log
+timeout 400 python scripts/bench_yolov4.py --eval --batch 16 --steps 10 --warmup 3 > gpurun_out/c3/yolov4_eval.json 2> gpurun_out/c3/yolov4_eval.err
+timeout 400 python scripts/bench_repvgg_fp8.py > gpurun_out/c3/fp8.json 2> gpurun_out/c3/fp8.err
+cat gpurun_out/c3/tests.log; cat gpurun_out/c3/yolov4_eval.json; tail -3 gpurun_out/c3/yolov4_eval.err; cut -c1-1500 gpurun_out/c3/fp8.json; tail -3 gpurun_out/c3/fp8.err
