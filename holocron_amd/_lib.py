@@ -223,6 +223,7 @@ SIGNATURES = {
     "hc_box_pairwise_bwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int32, c_void_p]),
     "hc_nms_ws_bytes": (c_int64, [c_int32]),
     "hc_nms_sorted": (c_int32, [c_void_p, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hc_nms_sorted_batched": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hc_focal_loss_fwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int64, c_int32, c_float, c_void_p]),
     "hc_focal_loss_bwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int64, c_float, c_void_p]),
     "hc_ce_fwd_bwd": (c_int32, [c_void_p] * 4 + [c_int32, c_int32, c_float, c_void_p]),

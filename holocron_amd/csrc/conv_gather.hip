@@ -228,10 +228,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
     // ---- deep pipeline: stage s + NS - 1 is issued at step s (into the buffer step s - 1 just left), so NS - 2 whole steps of
     // DMA stay in flight across every barrier.  A wave issues PER = XJ + WJ instructions per stage, all unconditional: the counted
     // wait `vmcnt((NS - 2) PER)` is exactly "my share of stage s has landed".
-    static_assert(XQ % NW == 0 && WQ % NW == 0, "every wave issues the same number of DMA instructions per stage");
+    // every wave issues the same number of DMA instructions per stage (the counted wait needs that): the pixel rows must divide
+    // evenly over the waves; weight rows that do not (BC = 96, 192: 6 / 12 pieces over 8 waves) are padded with zero-fill pieces
+    // into a 1 KB scratch slot per wave behind the stages
+    static_assert(XQ % NW == 0, "the pixel tile must deal whole DMA pieces to every wave");
     constexpr int PER = XJ + WJ;
     static_assert((NS - 2) * PER <= 63, "vmcnt immediate");
     const unsigned lds0 = hc_lds_addr(smem);
+    constexpr bool WRAG = WQ % NW != 0;
+    const unsigned scratch = lds0 + (unsigned)(NS * STAGE);
     const int widu = __builtin_amdgcn_readfirstlane(wid);
     auto uniform = [](const u32x4 r) __attribute__((always_inline)) {
         u32x4 o;
@@ -261,8 +266,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
         }
         const unsigned wk = (unsigned)(wt * srcC + ck_ * BK) * 2u;
 #pragma unroll
-        for (int j = 0; j < WJ; ++j)
-            hc_dma16(qw, __builtin_amdgcn_readfirstlane(sw + (unsigned)((widu + j * NW) * 1024)), (w_off[j] == HC_OOB) ? HC_OOB : w_off[j] + wk);
+        for (int j = 0; j < WJ; ++j) {
+            const bool real = !WRAG || widu + j * NW < WQ;     // wave-uniform
+            hc_dma16(qw, __builtin_amdgcn_readfirstlane(real ? sw + (unsigned)((widu + j * NW) * 1024) : scratch + (unsigned)(widu * 1024)),
+                     (w_off[j] == HC_OOB) ? HC_OOB : w_off[j] + wk);
+        }
     };
     constexpr int KK = BK / 16;
     // Fragment schedule: with one wave per SIMD nobody else covers an LDS round trip, so the halves of a stage are skewed across the
@@ -307,13 +315,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
         } else {
             const int j = q - XJ;
             const unsigned voff = (w_off[j] == HC_OOB || c.live == 0u) ? HC_OOB : w_off[j] + c.wk;
-            hc_dma16(qw, __builtin_amdgcn_readfirstlane(c.sw + (unsigned)((widu + j * NW) * 1024)), voff);
+            const bool real = !WRAG || widu + j * NW < WQ;     // wave-uniform; the padding pieces zero-fill the wave's scratch slot
+            hc_dma16(qw, __builtin_amdgcn_readfirstlane(real ? c.sw + (unsigned)((widu + j * NW) * 1024) : scratch + (unsigned)(widu * 1024)), voff);
         }
     };
-    static_assert(PER % KK == 0, "whole pieces per phase");
-    constexpr int PPH = PER / KK;                        // pieces per phase, spread over its MR rows of NR MFMAs
-    // phase f of a step: MR rows of NR MFMAs on (fa, fb); piece k of the phase goes behind row k MR / PPH
+    // phase f of a step: MR rows of NR MFMAs on (fa, fb); the PER pieces of a stage are dealt over the KK phases (pieces
+    // [f PER / KK, (f + 1) PER / KK) go to phase f) and piece k of a phase's n goes behind row k MR / n
     auto mma_phase = [&](const bf16x8 (&fa)[MR], const bf16x8 (&fb)[NR], const Pend& c, const int f, const bool mul) __attribute__((always_inline)) {
+        const int p0 = (f * PER) / KK, p1 = ((f + 1) * PER) / KK, np = p1 - p0;
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
             if (mul) {
@@ -322,8 +331,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
                     acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mr], fb[nr], acc[mr][nr], 0, 0, 0);
             }
 #pragma unroll
-            for (int k = 0; k < PPH; ++k)
-                if ((k * MR) / PPH == mr) piece(c, f * PPH + k);
+            for (int k = 0; k < PER; ++k)
+                if (k < np && (k * MR) / (np > 0 ? np : 1) == mr) piece(c, p0 + k);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -597,7 +606,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
 template <int MR, int NR, int WM, int WN, int BK, bool FP8 = false, int NS = 2, int MINB = 2>
 int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
     constexpr int BC = 32 * MR * WM, BP = 32 * NR * WN;
-    constexpr int smem_k = NS * (BC + BP) * BK * 2, smem_o = BP * (BC * 2 + 8);    // k-loop stages / output staging
+    // k-loop stages (+ the big-tile form's scratch slots for padding weight pieces) / output staging
+    constexpr int smem_k = NS * (BC + BP) * BK * 2 + ((MINB == 1 && (BC * BK / 512) % (WM * WN) != 0) ? WM * WN * 1024 : 0), smem_o = BP * (BC * 2 + 8);
     static_assert(smem_k <= 160 * 1024 && smem_o <= 160 * 1024, "LDS budget");
     constexpr int smem = smem_k > smem_o ? smem_k : smem_o;
     static const int flags = [] { const char* e = getenv("HC_CONV_STAGED_STORES"); return (e == nullptr || atoi(e) != 0) ? 1 : 0; }();
@@ -687,13 +697,31 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
     // three 373 at 2.05 GHz - with one wave per SIMD every LDS / DMA instruction is issue time the matrix pipe waits out, and the
     // chip clocks down 12 % under the full mix.  Two waves per SIMD issue under each other's MFMAs; halving the bytes per flop is
     // what the big tile adds on top of that.
+    // The big-tile FAMILY (round 4): the same eight-wave pipelined kernel (a wave = 128 channels x 64 pixels) on 256 x 256 tiles for
+    // wide layers - a ragged last channel tile is allowed while at most 15 % of the tile rows are padding - and on 128 x 512 tiles for
+    // 97-128 output channels.  One workgroup per CU: it pays when the tiles fill the 256 CUs in whole rounds or in many rounds, so the
+    // predicate is the EFFICIENCY of the launch, (useful channels / tile channels) x (useful pixels / tile pixels) x (tiles / CU
+    // slots of the rounds they take), against HC_CONV_BIG_EFF (default 0.70).  Measured per shape against the 128 x 128 form
+    // (scripts/bench_bigtile.py, forward + statistics, us):
+    //     128 @ 76 x 76 batch 16 (eff 0.71)   54.0 -> 51.8      256 -> 512 @ 38 x 38 batch 16 (0.71)   83.4 -> 76.8
+    //     128 @ 28 x 28 batch 256 (0.77)     104.3 -> 98.6      256 @ 14 x 14 batch 256 (0.77)         88.6 -> 73.6
+    //     1280 @ 7 x 7 batch 256 (0.96)      383.9 -> 337.6     256 @ 38 x 38 batch 16 (0.35)          48.0 -> 73.8 (not dispatched)
+    // Tiles with 96-channel waves (96 x 512, 192 x 256, 384 x 128) were built and measured too: 0.82-0.97 of the 128 x 128 form
+    // at the same efficiencies (6 MFMAs per 5 fragment reads instead of 8 per 6) - not kept.
+    // HC_CONV_BIG=0 switches the family off (A/B), =2 is the four-wave 256 x 256 form of round 3.
     static const int big = [] { const char* e = getenv("HC_CONV_BIG"); return e == nullptr ? 1 : atoi(e); }();
-    if (big && d.nclass == 1 && d.co_split == 0 && d.pix_scale == nullptr && d.srcC % 32 == 0 && d.Cout % 256 == 0) {
+    static const double big_eff = [] { const char* e = getenv("HC_CONV_BIG_EFF"); return e == nullptr ? 0.70 : atof(e); }();
+    if (big && d.nclass == 1 && d.co_split == 0 && d.pix_scale == nullptr && d.srcC % 32 == 0 && d.Cout % 8 == 0) {
         const long M = (long)d.N * d.cls[0].OHg * d.cls[0].OWg;
-        const long tiles = ((M + 255) / 256) * (d.Cout / 256), rem = tiles % 256;
         const int S = d.cls[0].ntaps * (d.srcC / 32);
         static const int staged = [] { const char* e = getenv("HC_CONV_STAGED_STORES"); return (e == nullptr || atoi(e) != 0) ? 1 : 0; }();
-        if (staged && tiles >= 224 && (rem == 0 || rem >= 224) && S >= 16) {
+        const int C = d.Cout;
+        const int bc = (C > 96 && C <= 128) ? 128 : 256, bp = bc == 128 ? 512 : 256;
+        const long ct = (C + bc - 1) / bc, pt = (M + bp - 1) / bp, tiles = ct * pt, rounds = (tiles + 255) / 256;
+        const double ceff = (double)C / (double)(ct * bc);
+        const double eff = ceff * ((double)M / (double)(pt * bp)) * ((double)tiles / (double)(rounds * 256));
+        if (staged && S >= 16 && ceff >= 0.85 && eff >= big_eff) {
+            if (bc == 128) return launch_cfg<4, 2, 1, 8, 32, false, 4, 1>(d, st);
             if (big == 2) return launch_cfg<4, 4, 2, 2, 32, false, 4, 1>(d, st);
             return launch_cfg<4, 2, 2, 4, 32, false, 4, 1>(d, st);
         }

@@ -175,9 +175,8 @@ __global__ void box_pairwise_bwd_kernel(const float* __restrict__ b1, const floa
 
 // ---------------------------------------------------------------- NMS (torchvision.ops.nms semantics)
 // pass 1: mask[i][w] bit b set  <=>  j = 64*w + b > i  and  IoU(i, j) > thr
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr,
-                                                       unsigned long long* __restrict__ mask, int nw) {
-    const int rb = blockIdx.y, cb = blockIdx.x;
+__device__ __forceinline__ void nms_mask_body(const float* __restrict__ boxes, int n, float thr, unsigned long long* __restrict__ mask,
+                                              int nw, const int rb, const int cb) {
     if (cb < rb) return;  // only j > i matters
     const int lane = threadIdx.x;
     __shared__ float sb[64 * 4];
@@ -205,11 +204,24 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     }
     mask[(long)i * nw + cb] = bits;
 }
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr,
+                                                       unsigned long long* __restrict__ mask, int nw) {
+    nms_mask_body(boxes, n, thr, mask, nw, blockIdx.y, blockIdx.x);
+}
+// Batched form: blockIdx.z = problem; problem p owns boxes [off[p], off[p + 1]) and the mask words at ws + ws_off[p]
+__global__ __launch_bounds__(64) void nms_mask_batched_kernel(const float* __restrict__ boxes, const int* __restrict__ off, float thr,
+                                                               unsigned long long* __restrict__ ws, const long* __restrict__ ws_off) {
+    const int p = blockIdx.z;
+    const int o = off[p], n = off[p + 1] - o;
+    const int nw = (n + 63) / 64;
+    if ((int)blockIdx.x >= nw || (int)blockIdx.y >= nw) return;
+    nms_mask_body(boxes + (long)o * 4, n, thr, ws + ws_off[p], nw, blockIdx.y, blockIdx.x);
+}
 // pass 2: one workgroup walks the sorted boxes 64 at a time.  Wave 0 resolves the intra-block
 // dependency chain on the diagonal word with scalar code; then all threads OR the rows of the
 // kept boxes into the running "removed" bitmap held in LDS.
-__global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int nw,
-                                                         int* __restrict__ keep, int* __restrict__ nkeep) {
+__device__ __forceinline__ void nms_scan_body(const unsigned long long* __restrict__ mask, int n, int nw, int* __restrict__ keep,
+                                              int* __restrict__ nkeep) {
     extern __shared__ unsigned long long removed[];  // nw words
     __shared__ unsigned long long kept_sh;
     __shared__ int count_sh;
@@ -260,6 +272,23 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long
         __syncthreads();
     }
     if (tid == 0) nkeep[0] = count_sh;
+}
+__global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int nw,
+                                                         int* __restrict__ keep, int* __restrict__ nkeep) {
+    nms_scan_body(mask, n, nw, keep, nkeep);
+}
+// Batched form: one workgroup per problem (they run side by side on different CUs); kept indices are local to the problem and
+// land at keep + off[p]
+__global__ __launch_bounds__(1024) void nms_scan_batched_kernel(const unsigned long long* __restrict__ ws, const long* __restrict__ ws_off,
+                                                                 const int* __restrict__ off, int* __restrict__ keep,
+                                                                 int* __restrict__ nkeep) {
+    const int p = blockIdx.x;
+    const int o = off[p], n = off[p + 1] - o;
+    if (n <= 0) {
+        if (threadIdx.x == 0) nkeep[p] = 0;
+        return;
+    }
+    nms_scan_body(ws + ws_off[p], n, (n + 63) / 64, keep + o, nkeep + p);
 }
 
 // ---------------------------------------------------------------- focal loss (functional.py:59-113)
@@ -510,6 +539,23 @@ int hc_nms_sorted(const float* boxes, int32_t n, float iou_thr, void* ws, int32_
     if ((size_t)nw * 8 > 60000) return HC_ERR_ARG;  // bitmap must fit LDS (n <= 480000)
     hipLaunchKernelGGL(nms_mask_kernel, dim3(nw, nw), dim3(64), 0, st, boxes, n, iou_thr, (unsigned long long*)ws, nw);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), nw * 8, st, (const unsigned long long*)ws, n, nw, keep, nkeep);
+    return hc_launch_status();
+}
+
+int hc_nms_sorted_batched(const float* boxes, const int32_t* off, int32_t nprob, int32_t nmax, float iou_thr, void* ws,
+                          const int64_t* ws_off, int32_t* keep, int32_t* nkeep, hc_stream_t stream) {
+    if (nprob < 0 || nmax < 0 || nkeep == nullptr) return HC_ERR_ARG;
+    if (nprob == 0) return HC_OK;
+    if (off == nullptr) return HC_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (nmax == 0) return hc_zero_async(nkeep, sizeof(int32_t) * (size_t)nprob, st) == hipSuccess ? HC_OK : HC_ERR_LAUNCH;
+    if (boxes == nullptr || ws == nullptr || ws_off == nullptr || keep == nullptr || nprob > 65535) return HC_ERR_ARG;
+    const int nw = (nmax + 63) / 64;
+    if ((size_t)nw * 8 > 60000 || nw > 65535) return HC_ERR_ARG;
+    hipLaunchKernelGGL(nms_mask_batched_kernel, dim3(nw, nw, nprob), dim3(64), 0, st, boxes, off, iou_thr, (unsigned long long*)ws,
+                       (const long*)ws_off);
+    hipLaunchKernelGGL(nms_scan_batched_kernel, dim3(nprob), dim3(1024), nw * 8, st, (const unsigned long long*)ws, (const long*)ws_off,
+                       off, keep, nkeep);
     return hc_launch_status();
 }
 

@@ -337,6 +337,8 @@ class Yolov4Head(nn.Module):
         h3 = run_conv_sequence(self.pre_head3, h2, out=pa)
         o3 = run_conv_sequence(self.head3, cat_cl([h3, feats[2]], buf), padded_out=True)
 
+        if not self.training:          # the 3 x N NMS problems of the batch as one launch pair (same detections, same order)
+            return post_process_scales([self.yolo1, self.yolo2, self.yolo3], [o1, o2, o3])
         packed = YoloLayer._pack_targets(target, o1.device) if self.training else None
         y1 = self.yolo1(o1, target, packed)
         y2 = self.yolo2(o2, target, packed)
@@ -345,6 +347,58 @@ class Yolov4Head(nn.Module):
             return [{k: torch.cat((d1[k], d2[k], d3[k]), dim=0) for k in ("boxes", "scores", "labels")}
                     for d1, d2, d3 in zip(y1, y2, y3)]
         return {k: y1[k] + y2[k] + y3[k] for k in y1}
+
+
+def post_process_scales(layers, outs) -> List[Dict[str, Tensor]]:
+    """Eval path of the whole head in one go: what ``[layer.post_process_logits(o) for layer, o in zip(layers, outs)]`` followed by the
+    per-image concatenation of Yolov4Head.forward computes (yolov4.py:302-336, 603-609), detection for detection and in the same
+    order - but the ``N x len(layers)`` (image, scale) NMS problems run as ONE batched launch pair and the host waits for the
+    device twice per batch instead of twice per image and scale (the candidate counts, then the kept counts)."""
+    from ...ops.boxes import batched_nms_sorted
+    N, S, dev = outs[0].shape[0], len(layers), outs[0].device
+    thr = layers[0].rpn_nms_thresh
+    if any(l.rpn_nms_thresh != thr for l in layers):
+        raise ValueError("post_process_scales: the layers must share one NMS threshold")
+    bl, sl, ll, kl, sc_of = [], [], [], [], []
+    for si, (layer, x) in enumerate(zip(layers, outs)):
+        boxes, obj, score, label = layer._decode(x, True, True)
+        boxes, obj, score, label = boxes.view(N, -1, 4), obj.view(N, -1), score.view(N, -1), label.view(N, -1)
+        bl.append(boxes), sl.append(score), ll.append(label)
+        kl.append((obj >= 0.5) & (score >= layer.box_score_thresh))
+        sc_of.append(torch.full((boxes.shape[1],), si, dtype=torch.int64, device=dev))
+    boxes, score, label, keepm = torch.cat(bl, 1), torch.cat(sl, 1), torch.cat(ll, 1), torch.cat(kl, 1)
+    Pt = boxes.shape[1]
+    # problem of a candidate: image-major, so that an image's detections end up contiguous (scale 1, 2, 3: the reference's cat order)
+    pid = torch.arange(N, device=dev)[:, None] * S + torch.cat(sc_of)[None, :]
+    pid = torch.where(keepm, pid, torch.full_like(pid, N * S)).reshape(-1)
+    # stable sort by descending score, then stable sort by problem: every problem's candidates in descending score order with ties in
+    # (h, w, anchor) order - the order torchvision's nms visits them in
+    o1 = torch.sort(score.reshape(-1), descending=True, stable=True).indices
+    p1 = pid[o1]
+    o2 = torch.sort(p1, stable=True).indices
+    order, psort = o1[o2], p1[o2]
+    counts = torch.bincount(psort, minlength=N * S + 1)[: N * S]
+    counts_h = counts.cpu().tolist()                                    # host wait 1: the scratch and the grid need the sizes
+    total = sum(counts_h)
+    empty = {"boxes": boxes.new_zeros((0, 4)), "scores": score.new_zeros((0,)), "labels": label.new_zeros((0,))}
+    if total == 0:
+        return [dict(empty) for _ in range(N)]
+    order, psort = order[:total], psort[:total]
+    off = torch.zeros((N * S + 1,), dtype=torch.int32, device=dev)
+    off[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    flat_boxes = boxes.reshape(-1, 4)
+    keep, nkeep = batched_nms_sorted(flat_boxes[order].contiguous(), off, counts_h, thr)
+    pos = torch.arange(total, device=dev)
+    base = off[:-1].long()[psort]
+    sel = (pos - base) < nkeep.long()[psort]
+    final = order[(base + keep[:total].long())[sel]]                   # (boolean indexing: host wait 2)
+    fb, fs, fl = flat_boxes[final], score.reshape(-1)[final], label.reshape(-1)[final]
+    sizes = nkeep.view(N, S).sum(1).cpu().tolist()
+    out, at = [], 0
+    for n in range(N):
+        out.append({"boxes": fb[at:at + sizes[n]], "scores": fs[at:at + sizes[n]], "labels": fl[at:at + sizes[n]]})
+        at += sizes[n]
+    return out
 
 
 class YOLOv4(nn.Module):

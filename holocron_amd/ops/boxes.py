@@ -11,7 +11,7 @@ from torch import Tensor
 from .. import _lib
 from .._lib import check, ptr, stream
 
-__all__ = ["box_iou", "box_giou", "diou_loss", "ciou_loss", "iou_penalty", "aspect_ratio", "aspect_ratio_consistency",
+__all__ = ["batched_nms_sorted", "box_iou", "box_giou", "diou_loss", "ciou_loss", "iou_penalty", "aspect_ratio", "aspect_ratio_consistency",
            "nms"]
 
 _KINDS = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3, "penalty": 4, "arc": 5}
@@ -104,3 +104,33 @@ def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
     check(lib.hc_nms_sorted(ptr(b), n, float(iou_threshold), ptr(ws), ptr(keep), ptr(nkeep), stream()), "hc_nms_sorted")
     k = int(nkeep.item())
     return order[keep[:k].long()]
+
+
+def batched_nms_sorted(boxes: Tensor, off: Tensor, counts, iou_threshold: float):
+    """Greedy NMS of many independent problems in one launch pair (``hc_nms_sorted_batched``).
+
+    ``boxes`` [T, 4] fp32: the candidates of problem p are rows ``off[p] : off[p + 1]``, already in descending (stable) score
+    order; ``off`` int32 device tensor [P + 1]; ``counts``: the same sizes as a host list (they size the scratch).  Returns
+    ``(keep, nkeep)``: ``keep[off[p] : off[p] + nkeep[p]]`` are the kept rows of problem p, local to the problem, in score order -
+    box for box the decisions of ``nms`` (torchvision.ops.nms semantics, call site holocron/models/detection/yolov4.py:329)."""
+    _lib.require_gpu(boxes, off)
+    P = len(counts)
+    dev = boxes.device
+    nkeep = torch.empty((max(P, 1),), dtype=torch.int32, device=dev)
+    total = int(sum(counts))
+    keep = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
+    if P == 0:
+        return keep[:0], nkeep[:0]
+    words, ws_off = 0, []
+    for n in counts:
+        ws_off.append(words)
+        words += int(n) * ((int(n) + 63) // 64)
+    ws = torch.empty((max(words, 1),), dtype=torch.int64, device=dev)
+    wo = torch.tensor(ws_off, dtype=torch.int64).to(dev, non_blocking=True)
+    b = boxes.detach()
+    if b.dtype != torch.float32 or not b.is_contiguous():
+        b = b.float().contiguous()
+    check(_lib.load().hc_nms_sorted_batched(ptr(b), ptr(off), P, int(max(counts)), float(iou_threshold), ptr(ws), ptr(wo), ptr(keep),
+                                            ptr(nkeep), stream()), "hc_nms_sorted_batched")
+    return keep, nkeep
+

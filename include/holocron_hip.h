@@ -448,6 +448,14 @@ int hc_box_pairwise_bwd(const float* b1, const float* b2, const float* g, float*
 int64_t hc_nms_ws_bytes(int32_t n);
 int hc_nms_sorted(const float* boxes, int32_t n, float iou_thr, void* ws, int32_t* keep, int32_t* nkeep,
                   hc_stream_t stream);
+/* The same greedy NMS for `nprob` INDEPENDENT problems in one launch pair - the (image, scale) problems of a detector's eval batch
+ * (holocron/models/detection/yolov4.py:302-336 runs torchvision.ops.nms once per image inside each of the three YoloLayers).  Problem
+ * p owns the score-sorted boxes [off[p], off[p + 1]) of `boxes` (off: DEVICE int32 [nprob + 1]), its suppression bitmap lives at
+ * ws + ws_off[p] 64-bit words (DEVICE int64 [nprob]; n_p * ceil(n_p / 64) words each), its kept indices - local to the problem, in
+ * score order - are written to keep + off[p] and counted in nkeep[p].  nmax = the largest n_p (host value: grid and LDS size).
+ * Decisions are those of hc_nms_sorted box for box. */
+int hc_nms_sorted_batched(const float* boxes, const int32_t* off, int32_t nprob, int32_t nmax, float iou_thr, void* ws,
+                          const int64_t* ws_off, int32_t* keep, int32_t* nkeep, hc_stream_t stream);
 
 /* focal loss forward/backward (holocron/nn/functional.py:59-113); x [N][K][S] fp32 (S = product
  * of trailing dims), target int64 [N][S]; loss_el out [N*S] (unreduced), valid out uint8 [N*S]

@@ -491,3 +491,26 @@ def test_scout_nan_coherence_skips_outer_update():
         opt.step()
     torch.cuda.synchronize()
     assert torch.isfinite(w).all() and torch.isfinite(frozen).all()
+
+
+def test_batched_nms_equals_nms_problem_by_problem():
+    """hc_nms_sorted_batched: the kept rows of every problem are those of hc_nms_sorted on that problem alone (bit-exact index work),
+    for ragged sizes incl. empty and single-box problems and one larger than a 64-box block row."""
+    from holocron_amd.ops.boxes import batched_nms_sorted, nms
+    g = torch.Generator().manual_seed(11)
+    sizes = [0, 1, 63, 64, 65, 700, 0, 129, 2500]
+    boxes, offs = [], [0]
+    for n in sizes:
+        c = torch.rand((n, 2), generator=g)
+        wh = torch.rand((n, 2), generator=g) * 0.3 + 0.02
+        boxes.append(torch.cat([c, c + wh], 1))
+        offs.append(offs[-1] + n)
+    allb = torch.cat(boxes, 0).cuda()
+    off = torch.tensor(offs, dtype=torch.int32).cuda()
+    keep, nkeep = batched_nms_sorted(allb, off, sizes, 0.5)
+    nk = nkeep.cpu().tolist()
+    for p, n in enumerate(sizes):
+        # already "sorted": equal scores -> nms keeps the given order (stable sort)
+        want = nms(allb[offs[p]:offs[p + 1]], torch.ones((n,), device="cuda"), 0.5)
+        assert nk[p] == want.numel(), (p, n, nk[p], want.numel())
+        assert torch.equal(keep[offs[p]:offs[p] + nk[p]].long(), want)

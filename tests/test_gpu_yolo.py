@@ -445,3 +445,28 @@ def test_yolov4_step_replays_from_a_graph_with_packed_targets(golden, monkeypatc
     packed.update(tgt)                            # same counts: refill in place
     with pytest.raises(ValueError):
         packed.update(tgt[:1] + tgt[:1] if len(tgt) > 1 and tgt[0]["boxes"].shape[0] != tgt[1]["boxes"].shape[0] else [{"boxes": tgt[0]["boxes"][:0], "labels": tgt[0]["labels"][:0]}] * len(tgt))
+
+
+def test_batched_post_processing_equals_per_layer_post_processing():
+    """The eval path of the head (post_process_scales: every (image, scale) NMS problem of the batch in one launch pair) returns what
+    the three YoloLayers' own post_process_logits + the reference's per-image concatenation (yolov4.py:302-336, 603-609) return:
+    the same detections in the same order, bit for bit - also with empty problems and images without any candidate."""
+    from holocron_amd.models.detection.yolov4 import YoloLayer, post_process_scales
+    torch.manual_seed(5)
+    anchors = torch.tensor([[[12, 16], [19, 36], [40, 28]], [[36, 75], [76, 55], [72, 146]], [[142, 110], [192, 243], [459, 401]]],
+                           dtype=torch.float32) / 608
+    nc, N = 7, 5
+    layers = [YoloLayer(anchors[i], num_classes=nc, scale_xy=s).cuda().eval() for i, s in enumerate((1.2, 1.1, 1.05))]
+    outs = [torch.randn((N, 3 * (5 + nc), h, h), device="cuda") for h in (24, 12, 6)]
+    for o in outs:
+        o[3] -= 30.0                       # image 3: no candidate passes the objectness threshold at any scale
+    outs[1][0] -= 30.0                     # image 0: an empty problem between two populated ones
+    outs[2][1, :, :, :] = outs[2][1, :, :1, :1]     # image 1, coarsest scale: identical cells -> identical scores (ties) and heavy overlap
+    ref = [l.post_process_logits(o) for l, o in zip(layers, outs)]
+    ref = [{k: torch.cat([r[i][k] for r in ref], 0) for k in ("boxes", "scores", "labels")} for i in range(N)]
+    got = post_process_scales(layers, outs)
+    assert len(got) == N
+    assert sum(int(d["boxes"].shape[0]) for d in ref) > 200 and ref[3]["boxes"].shape[0] == 0
+    for a, b in zip(got, ref):
+        for k in ("boxes", "scores", "labels"):
+            assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
