@@ -43,7 +43,11 @@ class WgradDesc(C.Structure):
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("ws", c_void_p),
                 ("N", c_int32), ("IH", c_int32), ("IW", c_int32), ("Cin", c_int32), ("OH", c_int32), ("OW", c_int32),
                 ("Cout", c_int32), ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32),
-                ("beta", c_int32)]
+                ("beta", c_int32), ("co_valid", c_int32), ("ci_valid", c_int32)]
+
+
+class DwPackItem(C.Structure):
+    _fields_ = [("w", c_void_p), ("out", c_void_p), ("C", c_int32), ("Cpad", c_int32), ("flip", c_int32), ("pad_", c_int32)]
 
 
 HC_WREP_MAX_JOBS = 16
@@ -246,6 +250,7 @@ SIGNATURES = {
     "hc_yolo_loss_bwd": (c_int32, [c_void_p, c_int32, c_int64, c_int64, c_int64] + [c_int32] * 5 + [c_void_p, c_float]
                          + [c_void_p] * 8),
     "hc_dw3x3_pack": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    "hc_dw3x3_pack_multi": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
     "hc_dw3x3_fwd": (c_int32, [c_void_p] * 4 + [c_int32] * 5 + [c_void_p]),
     "hc_dw3x3_dgrad": (c_int32, [c_void_p] * 4 + [c_int32] * 5 + [c_void_p]),
     "hc_dw3x3_wgrad_ws_bytes": (c_int64, [c_int32]),

@@ -210,8 +210,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // through LDS and written as one contiguous run of 64*T floats of the OIHW gradient.  Few-channel layers have few
 // (co, ci tile) pairs and hundreds of splits: blockIdx.z spreads the splits over more workgroups, which then combine with
 // atomics (dw zeroed by the launcher when beta == 0).
+// civ: valid input channels of the destination (<= Cin): dw is [gridDim.x][civ][T], slab columns ci >= civ are padding and dropped
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int Cout, int T, int Cin,
-                                    int beta, int chunk) {
+                                    int beta, int chunk, int civ) {
     extern __shared__ float sm[];  // [T][64]
     const int co = blockIdx.x, ci0 = blockIdx.y * 64;
     const int t = threadIdx.x / 64, c = threadIdx.x % 64;
@@ -234,8 +235,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     __syncthreads();
     const int j = threadIdx.x;          // element j of the [64][T] output run
     const int cl = j / T, tt = j - cl * T;
-    if (ci0 + cl < Cin) {
-        float* o = dw + ((long)co * Cin + ci0 + cl) * T + tt;
+    if (ci0 + cl < civ) {
+        float* o = dw + ((long)co * civ + ci0 + cl) * T + tt;
         const float v = sm[tt * 64 + cl];
         if (gridDim.z > 1) atomicAdd(o, v);
         else *o = beta ? *o + v : v;
@@ -245,7 +246,9 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 // the split range goes over several workgroups when the (co, ci tile) grid alone cannot fill the chip
 static inline int launch_wgrad_reduce(const hc_wgrad_desc& d, int nsplit, hipStream_t st) {
     const int T = d.KH * d.KW;
-    const int base = d.Cout * ((d.Cin + 63) / 64);
+    const int cov = d.co_valid > 0 ? d.co_valid : d.Cout, civ = d.ci_valid > 0 ? d.ci_valid : d.Cin;
+    if (cov > d.Cout || civ > d.Cin) return HC_ERR_ARG;
+    const int base = cov * ((civ + 63) / 64);
     int nz = 1;
     if (base < 512 && nsplit >= 64 && !hc_get_deterministic()) {   // (the z-slices combine with atomics)
         nz = (512 + base - 1) / base;
@@ -255,10 +258,10 @@ static inline int launch_wgrad_reduce(const hc_wgrad_desc& d, int nsplit, hipStr
     const int chunk = (nsplit + nz - 1) / nz;
     nz = (nsplit + chunk - 1) / chunk;
     if (nz > 1 && !d.beta) {
-        if (hc_zero_async(d.dw, sizeof(float) * (size_t)d.Cout * d.Cin * T, st) != hipSuccess) return HC_ERR_LAUNCH;
+        if (hc_zero_async(d.dw, sizeof(float) * (size_t)cov * civ * T, st) != hipSuccess) return HC_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d.Cout, (d.Cin + 63) / 64, nz), dim3(64 * T), 64 * T * sizeof(float), st,
-                       reinterpret_cast<const float*>(d.ws), d.dw, nsplit, d.Cout, T, d.Cin, d.beta, chunk);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cov, (civ + 63) / 64, nz), dim3(64 * T), 64 * T * sizeof(float), st,
+                       reinterpret_cast<const float*>(d.ws), d.dw, nsplit, d.Cout, T, d.Cin, d.beta, chunk, civ);
     return hc_launch_status();
 }
 

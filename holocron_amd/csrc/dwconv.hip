@@ -274,6 +274,15 @@ __global__ void dw3x3_pack_kernel(const float* __restrict__ w, float* __restrict
     out[i] = c < C ? w[c * 9 + (flip ? 8 - t : t)] : 0.f;
 }
 
+// every depthwise kernel of a model in ONE launch (the per-step repack after the optimizer moved the weights): blockIdx.y = item
+__global__ void dw3x3_pack_multi_kernel(const hc_dwpack_item* __restrict__ items) {
+    const hc_dwpack_item it = items[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= it.Cpad * 9) return;
+    const int t = i / it.Cpad, c = i - t * it.Cpad;
+    it.out[i] = c < it.C ? it.w[c * 9 + (it.flip ? 8 - t : t)] : 0.f;
+}
+
 // elementwise max of two NHWC bf16 tensors (FReLU: max(x, bn(conv(x))), activation.py:79-82) and its gradient split
 __global__ void max_fwd_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b, u32x4* __restrict__ o, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -453,6 +462,14 @@ extern "C" {
 int hc_dw3x3_pack(const float* w, float* out, int32_t C, int32_t Cpad, int32_t flip, hc_stream_t stream) {
     if (w == nullptr || out == nullptr || C <= 0 || Cpad < C || (Cpad % 8) != 0) return HC_ERR_ARG;
     hipLaunchKernelGGL(dw3x3_pack_kernel, dim3((Cpad * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, out, C, Cpad, flip);
+    return hc_launch_status();
+}
+
+int hc_dw3x3_pack_multi(const hc_dwpack_item* items, int32_t nitems, int32_t max_cpad, hc_stream_t stream) {
+    if (nitems < 0 || max_cpad < 0) return HC_ERR_ARG;
+    if (nitems == 0 || max_cpad == 0) return HC_OK;
+    if (items == nullptr || nitems > 65535) return HC_ERR_ARG;
+    hipLaunchKernelGGL(dw3x3_pack_multi_kernel, dim3((max_cpad * 9 + 255) / 256, nitems), dim3(256), 0, (hipStream_t)stream, items);
     return hc_launch_status();
 }
 

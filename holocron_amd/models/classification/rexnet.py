@@ -21,7 +21,7 @@ from ... import _lib
 from ...nn import GlobalAvgPool2d
 from ...nn import init
 from ...nn.convbn_op import act_code, conv_bn_act
-from ...nn.mbconv_op import SeGateFn, _PadChannelsFn, ceil16, padded_conv_bias, padded_conv_bn_act
+from ...nn.mbconv_op import SeGateFn, _PadChannelsFn, ceil16, padded_conv_bias, padded_conv_bn_act, padded_model_scope
 from ...nn.repblock_op import POOL
 from ..utils import conv_sequence
 
@@ -163,6 +163,8 @@ class ReXNet(nn.Sequential):
     def forward(self, x: Tensor) -> Tensor:  # type: ignore[override]
         _lib.require_gpu(x)
         POOL.begin(x.device)
+        scope = padded_model_scope(self)
+        scope.__enter__()
         try:
             mods = list(self.features)
             blocks = [m for m in mods if isinstance(m, ReXBlock)]
@@ -179,6 +181,7 @@ class ReXNet(nn.Sequential):
                 pooled = pooled[:, :tail[0].out_channels]
             return self.head(pooled)
         finally:
+            scope.__exit__(None, None, None)
             POOL.end()
 
 

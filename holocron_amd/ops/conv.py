@@ -325,8 +325,9 @@ class side_stream_for_wgrad:
         return False
 
 
-def conv_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, out=None, accumulate=False, flops=None):
-    """dW (fp32 OIHW) of a conv from NHWC-bf16 ``x`` [N,Cin,H,W] and ``dy`` [N,Cout,OH,OW]."""
+def conv_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, out=None, accumulate=False, flops=None, valid=None):
+    """dW (fp32 OIHW) of a conv from NHWC-bf16 ``x`` [N,Cin,H,W] and ``dy`` [N,Cout,OH,OW].  ``valid`` = (Cout_v, Cin_v): the
+    operands are channel-padded and the result is the unpadded [Cout_v, Cin_v, KH, KW] gradient of the parameter itself."""
     N, _, H, W = x.shape
     _, _, OH, OW = dy.shape
     d = WgradDesc()
@@ -336,8 +337,11 @@ def conv_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, out=None, accumulate=False
     lib = _lib.load()
     nbytes = lib.hc_conv_wgrad_ws_bytes(C.byref(d))
     ws = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=x.device)
+    if valid is not None:
+        d.co_valid, d.ci_valid = int(valid[0]), int(valid[1])
     if out is None:
-        out = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=x.device)
+        out = torch.empty((Cout, Cin, KH, KW) if valid is None else (int(valid[0]), int(valid[1]), KH, KW), dtype=torch.float32,
+                          device=x.device)
     d.x, d.dy, d.dw, d.ws = ptr(x), ptr(dy), ptr(out), ptr(ws)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

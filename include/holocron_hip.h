@@ -165,6 +165,9 @@ typedef struct {
     int32_t N, IH, IW, Cin, OH, OW, Cout;
     int32_t KH, KW, stride, pad;
     int32_t beta;
+    int32_t co_valid, ci_valid; /* channel-padded operands (ReXNet's 27, 38, 50 ... carried as multiples of 16): when > 0, dw is the
+                                 * UNPADDED gradient [co_valid][ci_valid][KH][KW] of the parameter itself - the padding rows / columns
+                                 * of the slabs are dropped by the reduce kernel instead of by a slicing copy afterwards; 0 = Cout / Cin */
 } hc_wgrad_desc;
 int64_t hc_conv_wgrad_ws_bytes(const hc_wgrad_desc* d);
 int hc_conv_wgrad(const hc_wgrad_desc* d, hc_stream_t stream);
@@ -591,6 +594,14 @@ int hc_leaky_bwd(const void* g, int32_t g_ld, const void* out, void* dy, int64_t
  * statistics sum / sum of squares of the fp32 results into stats [HC_STAT_REPLICAS][2][C] (zeroed by the caller).
  * wgrad: dw fp32 OIHW [Creal][1][3][3] (= or +=); ws scratch of hc_dw3x3_wgrad_ws_bytes(C). ---- */
 int hc_dw3x3_pack(const float* w, float* out, int32_t C, int32_t Cpad, int32_t flip, hc_stream_t stream);
+/* ... and for every depthwise kernel of a model in one launch: `items` is a DEVICE array (uploaded once; the pointers do not change
+ * between steps), max_cpad the largest Cpad among them. */
+typedef struct {
+    const float* w;
+    float* out;
+    int32_t C, Cpad, flip, pad_;
+} hc_dwpack_item;
+int hc_dw3x3_pack_multi(const hc_dwpack_item* items, int32_t nitems, int32_t max_cpad, hc_stream_t stream);
 int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t N, int32_t H, int32_t W, int32_t C,
                  int32_t stride, hc_stream_t stream);
 int hc_dw3x3_dgrad(const void* dy, const float* wpk, const float* wpk_flipped, void* dx, int32_t N, int32_t H, int32_t W,

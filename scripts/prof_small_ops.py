@@ -12,24 +12,36 @@ import holocron_amd as h
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-m = h.models.repvgg_a0(num_classes=10).to(dev).train()
+MODEL = os.environ.get("MODEL", "repvgg_a0")
+USE_HC_LOSS = os.environ.get("HC_LOSS", "1") == "1"
+if MODEL == "yolov4":
+    from holocron_amd.models.detection.yolov4 import PackedTargets
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bench_yolov4 import targets
+    m = h.models.detection.yolov4(pretrained_backbone=False, num_classes=80).to(dev).train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand((16, 3, 608, 608), generator=g).to(dev)
+    t = PackedTargets(targets(16, g, dev), dev)
+else:
+    m = getattr(h.models, MODEL)(num_classes=10 if MODEL.startswith("repvgg") else 1000).to(dev).train()
+    x = torch.rand(256, 3, 224, 224, device=dev)
+    t = torch.randint(0, 10, (256,), device=dev)
 opt = h.optim.AdaBelief(m.parameters(), lr=1e-3, betas=(0.95, 0.99), eps=1e-6)
-x = torch.rand(256, 3, 224, 224, device=dev)
-t = torch.randint(0, 10, (256,), device=dev)
 loss_buf = torch.zeros((), device=dev)
-USE_HC_LOSS = os.environ.get("HC_LOSS", "0") == "1"
 
 
 def step():
     with record_function("PH_zero"):
         opt.zero_grad(set_to_none=True)
     with record_function("PH_fwd"):
-        logits = m(x)
+        logits = m(x, t) if MODEL == "yolov4" else m(x)
     with record_function("PH_loss"):
-        if USE_HC_LOSS:
+        if MODEL == "yolov4":
+            loss = sum(v.sum() for v in logits.values())
+        elif USE_HC_LOSS:
             loss = h.nn.functional.cross_entropy(logits, t, label_smoothing=0.1)
         else:
-            loss = torch.nn.functional.cross_entropy(logits, t, label_smoothing=0.1)
+            loss = torch.nn.functional.cross_entropy(logits.float(), t, label_smoothing=0.1)
     with record_function("PH_bwd"):
         loss.backward()
     with record_function("PH_copy"):
@@ -64,7 +76,7 @@ for ev in evs:
         continue
     nk += len(ev.kernels)
     kn = ",".join(sorted({k.name.replace("void ", "").replace("at::native::", "").split("(")[0][:42] for k in ev.kernels}))
-    key = (phase_of(ev), ev.name[:40], str(ev.input_shapes)[:60], kn[:90])
+    key = (phase_of(ev), ev.name[:40], str(ev.input_shapes)[:60] if os.environ.get("SHAPES", "1") == "1" else "", kn[:90])
     agg[key] += len(ev.kernels)
     tim[key] += sum(k.duration for k in ev.kernels)
 print(f"kernel launches per step: {nk / NSTEP:.1f}")
