@@ -708,7 +708,8 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
     //     1280 @ 7 x 7 batch 256 (0.96)      383.9 -> 337.6     256 @ 38 x 38 batch 16 (0.35)          48.0 -> 73.8 (not dispatched)
     // Tiles with 96-channel waves (96 x 512, 192 x 256, 384 x 128) were built and measured too: 0.82-0.97 of the 128 x 128 form
     // at the same efficiencies (6 MFMAs per 5 fragment reads instead of 8 per 6) - not kept.
-    // HC_CONV_BIG=0 switches the family off (A/B), =2 is the four-wave 256 x 256 form of round 3.
+    // HC_CONV_BIG=0 switches the family off (A/B).  (The four-wave 256 x 256 form of round 3 - 0.42-0.48 of the matrix pipe against
+    // 0.53 - is retired: git show 067617d:holocron_amd/csrc/conv_gather.hip.)
     static const int big = [] { const char* e = getenv("HC_CONV_BIG"); return e == nullptr ? 1 : atoi(e); }();
     static const double big_eff = [] { const char* e = getenv("HC_CONV_BIG_EFF"); return e == nullptr ? 0.70 : atof(e); }();
     if (big && d.nclass == 1 && d.co_split == 0 && d.pix_scale == nullptr && d.srcC % 32 == 0 && d.Cout % 8 == 0) {
@@ -722,7 +723,6 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
         const double eff = ceff * ((double)M / (double)(pt * bp)) * ((double)tiles / (double)(rounds * 256));
         if (staged && S >= 16 && ceff >= 0.85 && eff >= big_eff) {
             if (bc == 128) return launch_cfg<4, 2, 1, 8, 32, false, 4, 1>(d, st);
-            if (big == 2) return launch_cfg<4, 4, 2, 2, 32, false, 4, 1>(d, st);
             return launch_cfg<4, 2, 2, 4, 32, false, 4, 1>(d, st);
         }
     }

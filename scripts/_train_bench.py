@@ -189,12 +189,13 @@ def run(a, build_model, make_batch, loss_of, metric, workload, train_gflop_per_i
             traffic = traffic_src = None
             if traffic_key is not None:
                 import json as _json
-                pf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"r03_pmc_{traffic_key}_traffic.json")
-                if os.path.exists(pf):
-                    with open(pf) as fh:
-                        traffic = _json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
-                    if traffic is not None:
-                        traffic_src = f"profiles/r03_pmc_{traffic_key}_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; committed, not live)"
+                for rnd in ("r04", "r03"):
+                    pf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{rnd}_pmc_{traffic_key}_traffic.json")
+                    if traffic is None and os.path.exists(pf):
+                        with open(pf) as fh:
+                            traffic = _json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
+                        if traffic is not None:
+                            traffic_src = f"profiles/{rnd}_pmc_{traffic_key}_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; committed, not live)"
             roof.update({"traffic": traffic, "traffic_source": traffic_src, "launches_per_step": n, "avg_launch_ms": sec / n * 1e3,
                          "algorithmic_flops_per_launch": fl / n, "algorithmic_bytes_per_launch": nb / n,
                          "families": {k: {"tflops": v[0] / v[1] / 1e12, "gbps": v[3] / v[1] / 1e9, "ms_per_step": v[1] * 1e3,

@@ -2,7 +2,7 @@
 # HBM-side traffic per launch of every kernel family over one training-step command (eager launches so that every dispatch is
 # counted): two separate PMC passes (FETCH_SIZE, WRITE_SIZE) with --kernel-trace only, as MI355X_MICROARCH.md prescribes.
 # FETCH_SIZE is doubled (gfx950 counts 128-byte requests as 64 bytes for 16-byte-per-lane reads); both counters are in KiB.
-#   usage: pmc_families.sh <name> <command ...>      -> gpurun_out/pmc_<name>/traffic.json  (copy to profiles/r03_pmc_<name>_traffic.json)
+#   usage: pmc_families.sh <name> <command ...>      -> gpurun_out/pmc_<name>/traffic.json  (copy to profiles/rNN_pmc_<name>_traffic.json)
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 NAME=$1; shift
 O=gpurun_out/pmc_$NAME; mkdir -p $O; rm -rf $O/*

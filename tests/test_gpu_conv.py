@@ -56,6 +56,40 @@ def test_conv_forward_matches_cpu(N, Cin, Cout, H, W, k, stride):
     assert rel_l2(_to_nchw_f32(relu), F.relu(ref)) < 3e-3
 
 
+BIG_TILE_CASES = [
+    # N, Cin, Cout, H, W: shapes the efficiency predicate of the big-tile family (csrc/conv_gather.hip: hc_conv_gather) sends to the
+    # eight-wave pipelined kernel - ragged last pixel tile, ragged last channel tile, the 128 x 512 tile, and a launch of several rounds
+    (90, 64, 480, 19, 19),     # 256 x 256 tiles, 2 channel tiles (the second 224 of 256 rows), 127 pixel tiles with a ragged last one
+    (31, 64, 112, 64, 64),     # 128 x 512 tiles, 112 of 128 channel rows, 248 tiles
+    (16, 128, 128, 76, 76),    # YOLOv4's 128 @ 76 x 76 at batch 16: 181 tiles of 128 x 512, ragged last tile
+    (40, 96, 256, 40, 41),     # 256 x 256, 257 tiles: one full round + one tile (efficiency 0.5: stays on the 128 x 128 form)
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", BIG_TILE_CASES)
+def test_conv_forward_big_tile_family_matches_cpu(N, Cin, Cout, H, W):
+    """3x3 forward + statistics + bias + ReLU through cv.conv2d at sizes where the launch-efficiency predicate picks the big-tile family
+    (and one where it must not): against torch-CPU fp32 on bf16-representable operands, same bounds as the small cases."""
+    from holocron_amd import _lib
+    from holocron_amd.ops import conv as cv
+    torch.manual_seed(Cin + Cout + H)
+    x = bf16r(torch.randn(N, Cin, H, W))
+    w = bf16r(torch.randn(Cout, Cin, 3, 3) / (Cin * 9) ** 0.5)
+    b = torch.randn(Cout)
+    ref = F.conv2d(x, w, b, 1, 1)
+    stats = torch.zeros(_lib.stat_replicas(), 2, Cout, device="cuda")
+    out = cv.conv2d(x.cuda(), w.cuda(), b.cuda(), 1, 1, stats=stats)
+    assert rel_l2(_to_nchw_f32(out), ref) < 3e-3
+    # element-wise too: a mis-addressed ragged tile would hide in a norm over 10^7 elements
+    assert float((_to_nchw_f32(out) - ref).abs().max()) < 0.05 * float(ref.abs().max())
+    nob = (ref - b.view(1, -1, 1, 1)).double()
+    s = stats.cpu().double().sum(0)
+    assert (s[0] - nob.sum((0, 2, 3))).abs().max() < 2e-4 * float(nob.abs().sum((0, 2, 3)).max())
+    assert rel_l2(s[1], (nob * nob).sum((0, 2, 3))) < 2e-4
+    relu = cv.conv2d(x.cuda(), w.cuda(), b.cuda(), 1, 1, act=1)
+    assert rel_l2(_to_nchw_f32(relu), F.relu(ref)) < 3e-3
+
+
 def test_conv_forward_stem_im2col():
     from holocron_amd.ops import conv as cv
     torch.manual_seed(3)
