@@ -210,6 +210,9 @@ SIGNATURES = {
     "hc_bn_act_apply": (c_int32, [c_void_p] * 3 + [c_int32] + [c_void_p] * 3 + [c_int32, c_int64, c_int32, c_int32, c_float, c_void_p]),
     "hc_bn_act_bwd_reduce": (c_int32, [c_void_p, c_int32] + [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_float, c_void_p]),
     "hc_bn_act_bwd_apply": (c_int32, [c_void_p, c_int32] + [c_void_p] * 6 + [c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "hc_bn_act_apply_post": (c_int32, [c_void_p] * 3 + [c_int32] + [c_void_p] * 5 + [c_int32, c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "hc_bn_act_bwd_reduce_post": (c_int32, [c_void_p, c_int32] + [c_void_p] * 7 + [c_int64, c_int32, c_int32, c_float, c_void_p]),
+    "hc_bn_act_bwd_apply_post": (c_int32, [c_void_p, c_int32] + [c_void_p] * 9 + [c_int64, c_int32, c_int32, c_float, c_void_p]),
     "hc_nhwc_copy": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int64, c_int32, c_void_p]),
     "hc_upsample2x_fwd": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32] + [c_int32] * 4 + [c_void_p]),
     "hc_upsample2x_bwd": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32] + [c_int32] * 4 + [c_void_p]),

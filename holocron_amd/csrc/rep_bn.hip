@@ -495,7 +495,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_apply_kernel(const u32x4* _
                                                                   const u32x4* __restrict__ res, int res_cg,
                                                                   const float* __restrict__ keep, const float* __restrict__ count,
                                                                   u32x4* __restrict__ out, int out_ld8, long npix, int C, int act,
-                                                                  float slope) {
+                                                                  float slope, const float* __restrict__ keep2,
+                                                                  const float* __restrict__ count2) {
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
     const long stride = (long)gridDim.x * EW_THREADS;   // multiple of cg
@@ -506,6 +507,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_apply_kernel(const u32x4* _
     load8f(coef + c0, a);
     load8f(coef + 3 * C + c0, sh);
     const float dsc = keep != nullptr ? drop_scale(count, npix) : 1.f;
+    // a second DropBlock BEHIND the residual add (DarkNet's ResBlock: dropblock(x + conv(x)), darknetv3.py:59-61) rides along too
+    const float dsc2 = keep2 != nullptr ? drop_scale(count2, npix) : 1.f;
     for (long p = gtid / cg; p < npix; p += pstep) {
         const long q = p * cg + cgi;
         float fy[8], fr[8], o[8];
@@ -514,11 +517,13 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_apply_kernel(const u32x4* _
         const bool has_r = HAS_RES && cgi < res_cg;
         if (has_r) unpack8(res[p * res_cg + cgi], fr);
         const float kp = keep != nullptr ? keep[p] * dsc : 1.f;
+        const float kp2 = keep2 != nullptr ? keep2[p] * dsc2 : 1.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float z = act_fwd(a[i] * fy[i] + sh[i], act, slope);
             if (keep != nullptr) z *= kp;
             if (has_r) z += fr[i];
+            if (keep2 != nullptr) z *= kp2;
             o[i] = z;
         }
         out[p * out_ld8 + cgi] = pack8(o);
@@ -529,7 +534,8 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32
                                                                        const u32x4* __restrict__ y, const float* __restrict__ coef,
                                                                        const float* __restrict__ keep, const float* __restrict__ count,
                                                                        float* __restrict__ red, long npix, int C, int act,
-                                                                       float slope, const int reps) {
+                                                                       float slope, const int reps, const float* __restrict__ keep2,
+                                                                       const float* __restrict__ count2) {
     extern __shared__ float sred[];
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
@@ -541,6 +547,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32
     load8f(coef + c0, a);
     load8f(coef + 3 * C + c0, sh);
     const float dsc = keep != nullptr ? drop_scale(count, npix) : 1.f;
+    const float dsc2 = keep2 != nullptr ? drop_scale(count2, npix) : 1.f;
     float sv[2][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) sv[0][i] = sv[1][i] = 0.f;
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32
         float fg[8], fy[8];
         unpack8(g[p * g_ld8 + cgi], fg);
         unpack8(y[p * cg + cgi], fy);
-        const float kp = keep != nullptr ? keep[p] * dsc : 1.f;
+        const float kp = (keep != nullptr ? keep[p] * dsc : 1.f) * (keep2 != nullptr ? keep2[p] * dsc2 : 1.f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float dz = fg[i] * kp * act_bwd(a[i] * fy[i] + sh[i], act, slope);
@@ -564,7 +571,9 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_apply_kernel(const u32x
                                                                       const u32x4* __restrict__ y, const float* __restrict__ coef,
                                                                       const float* __restrict__ bc, const float* __restrict__ keep,
                                                                       const float* __restrict__ count, u32x4* __restrict__ dy,
-                                                                      long npix, int C, int act, float slope) {
+                                                                      long npix, int C, int act, float slope,
+                                                                      const float* __restrict__ keep2, const float* __restrict__ count2,
+                                                                      u32x4* __restrict__ gres) {
     const int cg = C / 8;
     const long gtid = (long)blockIdx.x * EW_THREADS + threadIdx.x;
     const long stride = (long)gridDim.x * EW_THREADS;
@@ -578,11 +587,18 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_apply_kernel(const u32x
     load8f(bc + C + c0, B);
     load8f(bc + 2 * C + c0, Cc);
     const float dsc = keep != nullptr ? drop_scale(count, npix) : 1.f;
+    const float dsc2 = keep2 != nullptr ? drop_scale(count2, npix) : 1.f;
     for (long p = gtid / cg; p < npix; p += pstep) {
         const long q = p * cg + cgi;
         float fg[8], fy[8], o[8];
         unpack8(g[p * g_ld8 + cgi], fg);
         unpack8(y[q], fy);
+        if (keep2 != nullptr) {      // gradient through the DropBlock behind the residual add: what the residual input receives
+            const float kp2 = keep2[p] * dsc2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fg[i] *= kp2;
+            if (gres != nullptr) gres[q] = pack8(fg);
+        }
         const float kp = keep != nullptr ? keep[p] * dsc : 1.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1116,40 +1132,57 @@ int hc_rep_bwd_apply_z(const void* g, const float* coef, int32_t act, const void
 
 int hc_bn_act_apply(const void* y, const float* coef, const void* res, int32_t res_C, const float* keep, const float* count,
                     void* out, int32_t out_ld, int64_t npix, int32_t C, int32_t act, float slope, hc_stream_t stream) {
+    return hc_bn_act_apply_post(y, coef, res, res_C, keep, count, nullptr, nullptr, out, out_ld, npix, C, act, slope, stream);
+}
+int hc_bn_act_apply_post(const void* y, const float* coef, const void* res, int32_t res_C, const float* keep, const float* count,
+                         const float* keep2, const float* count2, void* out, int32_t out_ld, int64_t npix, int32_t C, int32_t act,
+                         float slope, hc_stream_t stream) {
     if (y == nullptr || coef == nullptr || out == nullptr || (C % 8) != 0 || (out_ld % 8) != 0 || out_ld < C) return HC_ERR_ARG;
     if (res != nullptr && (res_C <= 0 || res_C > C || (res_C % 8) != 0)) return HC_ERR_ARG;
-    if ((keep == nullptr) != (count == nullptr)) return HC_ERR_ARG;
+    if ((keep == nullptr) != (count == nullptr) || (keep2 == nullptr) != (count2 == nullptr)) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8);
     hipStream_t st = (hipStream_t)stream;
     if (res != nullptr)
         hipLaunchKernelGGL((bn_act_apply_kernel<true>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)y, coef, (const u32x4*)res,
-                           res_C / 8, keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope);
+                           res_C / 8, keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope, keep2, count2);
     else
         hipLaunchKernelGGL((bn_act_apply_kernel<false>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)y, coef, (const u32x4*)res,
-                           0, keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope);
+                           0, keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope, keep2, count2);
     return hc_launch_status();
 }
 int hc_bn_act_bwd_reduce(const void* g, int32_t g_ld, const void* y, const float* coef, const float* keep, const float* count,
                          float* red, int64_t npix, int32_t C, int32_t act, float slope, hc_stream_t stream) {
+    return hc_bn_act_bwd_reduce_post(g, g_ld, y, coef, keep, count, nullptr, nullptr, red, npix, C, act, slope, stream);
+}
+int hc_bn_act_bwd_reduce_post(const void* g, int32_t g_ld, const void* y, const float* coef, const float* keep, const float* count,
+                              const float* keep2, const float* count2, float* red, int64_t npix, int32_t C, int32_t act, float slope,
+                              hc_stream_t stream) {
     if (g == nullptr || y == nullptr || coef == nullptr || red == nullptr || (C % 8) != 0 || (g_ld % 8) != 0 || g_ld < C) return HC_ERR_ARG;
-    if ((keep == nullptr) != (count == nullptr)) return HC_ERR_ARG;
+    if ((keep == nullptr) != (count == nullptr) || (keep2 == nullptr) != (count2 == nullptr)) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8, 16);
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(blocks), dim3(EW_THREADS), EW_THREADS * 17 * sizeof(float), (hipStream_t)stream,
-                       (const u32x4*)g, g_ld / 8, (const u32x4*)y, coef, keep, count, red, (long)npix, C, act, slope, hc_get_stat_replicas());
+                       (const u32x4*)g, g_ld / 8, (const u32x4*)y, coef, keep, count, red, (long)npix, C, act, slope, hc_get_stat_replicas(),
+                       keep2, count2);
     return hc_launch_status();
 }
 int hc_bn_act_bwd_apply(const void* g, int32_t g_ld, const void* y, const float* coef, const float* bcoef, const float* keep,
                         const float* count, void* dy, int64_t npix, int32_t C, int32_t act, float slope, hc_stream_t stream) {
+    return hc_bn_act_bwd_apply_post(g, g_ld, y, coef, bcoef, keep, count, nullptr, nullptr, nullptr, dy, npix, C, act, slope, stream);
+}
+int hc_bn_act_bwd_apply_post(const void* g, int32_t g_ld, const void* y, const float* coef, const float* bcoef, const float* keep,
+                             const float* count, const float* keep2, const float* count2, void* gres, void* dy, int64_t npix,
+                             int32_t C, int32_t act, float slope, hc_stream_t stream) {
     if (g == nullptr || y == nullptr || coef == nullptr || bcoef == nullptr || dy == nullptr || (C % 8) != 0 || (g_ld % 8) != 0 ||
         g_ld < C)
         return HC_ERR_ARG;
-    if ((keep == nullptr) != (count == nullptr)) return HC_ERR_ARG;
+    if ((keep == nullptr) != (count == nullptr) || (keep2 == nullptr) != (count2 == nullptr)) return HC_ERR_ARG;
+    if (gres != nullptr && keep2 == nullptr) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u32x4*)g, g_ld / 8,
-                       (const u32x4*)y, coef, bcoef, keep, count, (u32x4*)dy, (long)npix, C, act, slope);
+                       (const u32x4*)y, coef, bcoef, keep, count, (u32x4*)dy, (long)npix, C, act, slope, keep2, count2, (u32x4*)gres);
     return hc_launch_status();
 }
 int hc_gap_fwd(const void* x, float* y, int32_t N, int32_t HW, int32_t C, hc_stream_t stream) {

@@ -50,10 +50,9 @@ class ResBlock(nn.Module):
             self.conv[-1].inplace = False
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        out = run_conv_sequence(self.conv, x, residual=x)
-        if hasattr(self, "dropblock"):
-            out = self.dropblock(out)
-        return out
+        # dropblock(x + conv(x)) (darknetv3.py:59-61): the DropBlock behind the residual add rides in the last unit's BatchNorm passes
+        # (hc_bn_act_*_post) instead of being a read + write of the block output of its own, forward and backward
+        return run_conv_sequence(self.conv, x, residual=x, post_drop=getattr(self, "dropblock", None))
 
     forward_hip = forward
 

@@ -82,7 +82,8 @@ class ConvBnActFn(torch.autograd.Function):
     def forward(ctx, x, w, gamma, beta, res, st, meta, out_holder=None):
         lib = _lib.load()
         out = None if out_holder is None else out_holder[0]
-        stride, pad, act, slope, bnbuf, eps, momentum, training, drop = meta
+        stride, pad, act, slope, bnbuf, eps, momentum, training, drop = meta[:9]
+        drop2 = meta[9] if len(meta) > 9 else None       # DropBlock BEHIND the residual add (DarkNet ResBlock), same pass
         Cout, Cin, KH, KW = w.shape
         N, _, H, W = x.shape
         dev = x.device
@@ -130,15 +131,20 @@ class ConvBnActFn(torch.autograd.Function):
         keep = count = None
         if drop is not None and training and drop[0] > 0:
             keep, count = dropblock_keep(N, OH, OW, drop[0], drop[1], dev)
+        keep2 = count2 = None
+        if drop2 is not None and drop2[0] > 0:           # drawn AFTER the unit's own mask: the order the separate modules drew in
+            keep2, count2 = dropblock_keep(N, OH, OW, drop2[0], drop2[1], dev)
         if out is None:
             out = cv.empty_cl(N, Cout, OH, OW, dev)
         out_ld = cl_ld(out)
         if out_ld is None or tuple(out.shape) != (N, Cout, OH, OW):
             raise _lib.HipError("conv_bn_act: `out` must be an NHWC bf16 view of shape %s" % ((N, Cout, OH, OW),))
         with cv.profiled("bn_elementwise", 0.0, npix * Cout * 2.0 * (3 if resc is not None else 2)):
-            check(lib.hc_bn_act_apply(ptr(y), ptr(coef), ptr(resc), Cout if resc is not None else 0, ptr(keep), ptr(count), ptr(out),
-                                      out_ld, npix, Cout, act, slope, stream()), "hc_bn_act_apply")
+            check(lib.hc_bn_act_apply_post(ptr(y), ptr(coef), ptr(resc), Cout if resc is not None else 0, ptr(keep), ptr(count),
+                                           ptr(keep2), ptr(count2), ptr(out), out_ld, npix, Cout, act, slope, stream()),
+                  "hc_bn_act_apply_post")
         ctx.drop = (keep, count)
+        ctx.drop2 = (keep2, count2)
         ctx.st, ctx.meta2 = st, (stride, pad, act, slope, im2col, training)
         ctx.geom = (N, Cin, H, W, Cout, KH, KW, OH, OW)
         ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.stat_replicas(), 4, Cout), dev) if training else (None, -1)
@@ -156,12 +162,13 @@ class ConvBnActFn(torch.autograd.Function):
         dev = g.device
         g, g_ld = as_cl_view(g)
         keep, count = ctx.drop
+        keep2, count2 = ctx.drop2
         npix = N * OH * OW
         red = POOL.claim(ctx.red, ctx.red_gen, (_lib.stat_replicas(), 4, Cout), dev)   # stale after another forward's POOL.begin()
         ctx.red = None
         with cv.profiled("bn_elementwise", 0.0, npix * Cout * 2.0 * 2):
-            check(lib.hc_bn_act_bwd_reduce(ptr(g), g_ld, ptr(y), ptr(coef), ptr(keep), ptr(count), ptr(red), npix, Cout, act, slope,
-                                           stream()), "hc_bn_act_bwd_reduce")
+            check(lib.hc_bn_act_bwd_reduce_post(ptr(g), g_ld, ptr(y), ptr(coef), ptr(keep), ptr(count), ptr(keep2), ptr(count2), ptr(red),
+                                                npix, Cout, act, slope, stream()), "hc_bn_act_bwd_reduce_post")
         dgam = torch.empty((Cout,), dtype=torch.float32, device=dev)
         dbet = torch.empty((Cout,), dtype=torch.float32, device=dev)
         bcoef = torch.empty((9, Cout), dtype=torch.float32, device=dev)
@@ -174,9 +181,11 @@ class ConvBnActFn(torch.autograd.Function):
         d.frozen = 0 if training else 1               # eval mode / freeze_bn: running statistics, dy = a * dz
         check(lib.hc_rep_bn_bwd_finalize(C.byref(d), stream()), "hc_rep_bn_bwd_finalize")
         dy = torch.empty_like(y)
-        with cv.profiled("bn_elementwise", 0.0, npix * Cout * 2.0 * 3):
-            check(lib.hc_bn_act_bwd_apply(ptr(g), g_ld, ptr(y), ptr(coef), ptr(bcoef), ptr(keep), ptr(count), ptr(dy), npix, Cout, act,
-                                          slope, stream()), "hc_bn_act_bwd_apply")
+        # the residual input's gradient: the incoming one, or - behind a fused post-residual DropBlock - its masked form
+        gres = torch.empty_like(y) if (keep2 is not None and ctx.has_res) else None
+        with cv.profiled("bn_elementwise", 0.0, npix * Cout * 2.0 * (3 if gres is None else 4)):
+            check(lib.hc_bn_act_bwd_apply_post(ptr(g), g_ld, ptr(y), ptr(coef), ptr(bcoef), ptr(keep), ptr(count), ptr(keep2), ptr(count2),
+                                               ptr(gres), ptr(dy), npix, Cout, act, slope, stream()), "hc_bn_act_bwd_apply_post")
 
         dx = None
         if ctx.needs_input_grad[0]:
@@ -197,7 +206,7 @@ class ConvBnActFn(torch.autograd.Function):
             else:
                 dw = cv.conv_wgrad(src, dy, Cin, Cout, KH, KW, stride, pad)
             side.produced(dw)
-        return dx, dw, dgam, dbet, (g if ctx.has_res else None), None, None, None
+        return dx, dw, dgam, dbet, ((gres if gres is not None else g) if ctx.has_res else None), None, None, None
 
 
 class ConvBiasFn(torch.autograd.Function):
@@ -388,10 +397,11 @@ def fusable(conv, bn, act):
             and conv.out_channels % 16 == 0 and act_code(act) is not None)
 
 
-def conv_bn_act(x, conv, bn, act=None, residual=None, drop=None, out=None):
+def conv_bn_act(x, conv, bn, act=None, residual=None, drop=None, out=None, post_drop=None):
     """out = dropblock(act(bn(conv(x)))) [+ residual] on the fused HIP path.  ``drop``: a DropBlock2d-like module
     (attributes ``drop_prob``, ``block_size``) applied after the activation, or None.  ``out``: NHWC bf16 slice of a
-    concat buffer to write the result into."""
+    concat buffer to write the result into.  ``post_drop``: a second DropBlock2d applied to the SUM (DarkNet's ResBlock,
+    darknetv3.py:59-61: ``dropblock(x + conv(x))``) in the same passes."""
     st = getattr(conv, "_hc", None)
     if st is None:
         st = conv._hc = ConvState()
@@ -400,8 +410,11 @@ def conv_bn_act(x, conv, bn, act=None, residual=None, drop=None, out=None):
     dp = None
     if drop is not None and drop.training and drop.drop_prob > 0:
         dp = (float(drop.drop_prob), int(drop.block_size))
+    dp2 = None
+    if post_drop is not None and post_drop.training and post_drop.drop_prob > 0:
+        dp2 = (float(post_drop.drop_prob), int(post_drop.block_size))
     meta = (conv.stride[0], conv.padding[0], code, slope,
-            (bn.running_mean, bn.running_var, bn.num_batches_tracked), bn.eps, momentum, bn.training, dp)
+            (bn.running_mean, bn.running_var, bn.num_batches_tracked), bn.eps, momentum, bn.training, dp, dp2)
     return ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, residual, st, meta, None if out is None else [out])
 
 
@@ -460,7 +473,7 @@ def plan_conv_sequence(seq):
     return units
 
 
-def run_conv_sequence(seq, x, residual=None, out=None, padded_out=False):
+def run_conv_sequence(seq, x, residual=None, out=None, padded_out=False, post_drop=None):
     """Execute the modules of a ``conv_sequence`` list / nn.Sequential on the HIP path, fusing every
     [Conv2d, BatchNorm2d, activation?, DropBlock2d?] run into one conv_bn_act call.  ``residual`` is added to the
     output of the LAST unit (DarkNet ResBlock: ``out = conv(x); out += identity``) and ``out`` (a concat slice)
@@ -474,12 +487,13 @@ def run_conv_sequence(seq, x, residual=None, out=None, padded_out=False):
         except AttributeError:
             pass
     last = len(units) - 1
-    if (residual is not None or out is not None) and (last < 0 or units[last][0] != "fused"):
-        raise NotImplementedError("residual / out need the sequence to end with a fused conv unit")
+    if (residual is not None or out is not None or post_drop is not None) and (last < 0 or units[last][0] != "fused"):
+        raise NotImplementedError("residual / out / post_drop need the sequence to end with a fused conv unit")
     for k, u in enumerate(units):
         kind = u[0]
         if kind == "fused":
-            x = conv_bn_act(x, u[1], u[2], u[3], residual if k == last else None, u[4], out if k == last else None)
+            x = conv_bn_act(x, u[1], u[2], u[3], residual if k == last else None, u[4], out if k == last else None,
+                            post_drop if k == last else None)
         elif kind == "convbias":
             x = conv_bias(x, u[1])
             if x.shape[1] != u[1].out_channels and not (padded_out and k == last):

@@ -307,6 +307,20 @@ int hc_bn_act_bwd_reduce(const void* g, int32_t g_ld, const void* y, const float
 int hc_bn_act_bwd_apply(const void* g, int32_t g_ld, const void* y, const float* coef, const float* bcoef,
                         const float* keep, const float* count, void* dy, int64_t npix, int32_t C, int32_t act,
                         float slope, hc_stream_t stream);
+/* ... with a SECOND DropBlock behind the residual add riding in the same passes: DarkNet's ResBlock is
+ * dropblock(x + conv_sequence(x)) (holocron/models/classification/darknetv3.py:44-61), i.e. out = (act(z)*keep*scale + res)*keep2*scale2.
+ * Backward: the incoming gradient is multiplied by keep2*scale2 first; `gres` (dense [npix][C] bf16, optional) receives that product -
+ * the gradient of the residual input - so that no separate DropBlock pass (one read + one write of the block output, forward and
+ * backward) is left.  keep2 / count2 NULL: the plain forms above. */
+int hc_bn_act_apply_post(const void* y, const float* coef, const void* res, int32_t res_C, const float* keep, const float* count,
+                         const float* keep2, const float* count2, void* out, int32_t out_ld, int64_t npix, int32_t C, int32_t act,
+                         float slope, hc_stream_t stream);
+int hc_bn_act_bwd_reduce_post(const void* g, int32_t g_ld, const void* y, const float* coef, const float* keep, const float* count,
+                              const float* keep2, const float* count2, float* red, int64_t npix, int32_t C, int32_t act, float slope,
+                              hc_stream_t stream);
+int hc_bn_act_bwd_apply_post(const void* g, int32_t g_ld, const void* y, const float* coef, const float* bcoef, const float* keep,
+                             const float* count, const float* keep2, const float* count2, void* gres, void* dy, int64_t npix,
+                             int32_t C, int32_t act, float slope, hc_stream_t stream);
 
 /* ---- NHWC bf16 data movement of the CSP / PAN / SPP stacks (darknetv4.py:112-115, yolov4.py:134-139,
  * nn/modules/downsample.py:154-167).  `*_ld` = channels per pixel of the buffer, `*_c0` = first channel; all % 8. ----
