@@ -79,9 +79,14 @@ class ConvState:
 
 class ConvBnActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, res, st, meta, out_holder=None):
+    def forward(ctx, x, w, gamma, beta, res, st, meta, out_holder=None, link=None):
         lib = _lib.load()
         out = None if out_holder is None else out_holder[0]
+        # ``link`` couples the two units of a residual block whose shortcut is the block INPUT (DarkNet ResBlock): the unit that adds
+        # the residual ("sink") parks the residual's gradient in link["grad"] instead of returning it, and the unit that consumes the
+        # block input ("source", whose backward runs later) hands it to its data-gradient launch as `resid` - dx arrives complete and
+        # autograd has no second gradient of x to add (one elementwise launch per block and step)
+        ctx.link = link
         stride, pad, act, slope, bnbuf, eps, momentum, training, drop = meta[:9]
         drop2 = meta[9] if len(meta) > 9 else None       # DropBlock BEHIND the residual add (DarkNet ResBlock), same pass
         Cout, Cin, KH, KW = w.shape
@@ -196,7 +201,15 @@ class ConvBnActFn(torch.autograd.Function):
                 st.desc[key] = cv.dgrad_desc(N, Cin, H, W, Cout, [(KH, KW, pad, 0, 0)], stride)
             wpd = st.bwd_cache.get((w,), lambda: cv.pack_weight(w, 1))
             dx = cv.empty_cl(N, Cin, H, W, dev)
-            cv.launch_conv(st.desc[key], dy, wpd, dx)
+            extra = None
+            if ctx.link is not None and ctx.link.get("role") == "source":
+                extra = ctx.link.pop("grad", None)          # parked by the block's last unit (its backward ran first)
+                if extra is not None:
+                    if tuple(extra.shape) != (N, Cin, H, W):
+                        raise RuntimeError("linked residual gradient does not have the block input's shape")
+                    if cl_ld(extra) != Cin:
+                        extra = extra.contiguous(memory_format=torch.channels_last)
+            cv.launch_conv(st.desc[key], dy, wpd, dx, resid=extra)
         with cv.side_stream_for_wgrad((w,), (src, dy)) as side:
             if im2col:
                 Kpad = src.shape[1]
@@ -206,7 +219,12 @@ class ConvBnActFn(torch.autograd.Function):
             else:
                 dw = cv.conv_wgrad(src, dy, Cin, Cout, KH, KW, stride, pad)
             side.produced(dw)
-        return dx, dw, dgam, dbet, ((gres if gres is not None else g) if ctx.has_res else None), None, None, None
+        gr = (gres if gres is not None else g) if ctx.has_res else None
+        if gr is not None and ctx.link is not None and ctx.link.get("role") == "sink" and ctx.link.get("armed"):
+            peer = ctx.link["peer"]
+            peer["grad"] = gr if g_ld == Cout or gres is not None else gr.contiguous(memory_format=torch.channels_last)
+            gr = None                                       # delivered through the source unit's dx
+        return dx, dw, dgam, dbet, gr, None, None, None, None
 
 
 class ConvBiasFn(torch.autograd.Function):
@@ -397,7 +415,7 @@ def fusable(conv, bn, act):
             and conv.out_channels % 16 == 0 and act_code(act) is not None)
 
 
-def conv_bn_act(x, conv, bn, act=None, residual=None, drop=None, out=None, post_drop=None):
+def conv_bn_act(x, conv, bn, act=None, residual=None, drop=None, out=None, post_drop=None, link=None):
     """out = dropblock(act(bn(conv(x)))) [+ residual] on the fused HIP path.  ``drop``: a DropBlock2d-like module
     (attributes ``drop_prob``, ``block_size``) applied after the activation, or None.  ``out``: NHWC bf16 slice of a
     concat buffer to write the result into.  ``post_drop``: a second DropBlock2d applied to the SUM (DarkNet's ResBlock,
@@ -415,7 +433,7 @@ def conv_bn_act(x, conv, bn, act=None, residual=None, drop=None, out=None, post_
         dp2 = (float(post_drop.drop_prob), int(post_drop.block_size))
     meta = (conv.stride[0], conv.padding[0], code, slope,
             (bn.running_mean, bn.running_var, bn.num_batches_tracked), bn.eps, momentum, bn.training, dp, dp2)
-    return ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, residual, st, meta, None if out is None else [out])
+    return ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, residual, st, meta, None if out is None else [out], link)
 
 
 def _is_act(m):
@@ -489,11 +507,17 @@ def run_conv_sequence(seq, x, residual=None, out=None, padded_out=False, post_dr
     last = len(units) - 1
     if (residual is not None or out is not None or post_drop is not None) and (last < 0 or units[last][0] != "fused"):
         raise NotImplementedError("residual / out / post_drop need the sequence to end with a fused conv unit")
+    # residual == the sequence's own input and both ends are fused units of a stride-1 chain: couple them (ConvBnActFn `link`)
+    src_link = sink_link = None
+    if (residual is not None and residual is x and last >= 1 and units[0][0] == "fused" and x.requires_grad and torch.is_grad_enabled()
+            and units[0][1].in_channels % 16 == 0 and all(u[0] == "fused" for u in units)):
+        src_link = {"role": "source"}
+        sink_link = {"role": "sink", "peer": src_link, "armed": True}
     for k, u in enumerate(units):
         kind = u[0]
         if kind == "fused":
             x = conv_bn_act(x, u[1], u[2], u[3], residual if k == last else None, u[4], out if k == last else None,
-                            post_drop if k == last else None)
+                            post_drop if k == last else None, sink_link if k == last else (src_link if k == 0 else None))
         elif kind == "convbias":
             x = conv_bias(x, u[1])
             if x.shape[1] != u[1].out_channels and not (padded_out and k == last):
