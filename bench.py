@@ -122,6 +122,18 @@ def main():
         # gradients come first; their bucket ends exactly at the cut, so its all-reduce runs behind the rest of backward.
         rear_mod = model.features[-1][-1]
         rear = {id(p) for p in rear_mod.parameters()} | {id(p) for p in model.head.parameters()}
+        # The first cut sits in the MIDDLE of the 192-channel stage (features[3][8]), not right behind the last block: the weight
+        # gradient of the 1280 x 1280 block (0.63 ms) runs on the side stream and must be joined before its graph ends, so the first
+        # graph needs main-stream work for it to hide behind (one-rank cost of the N > 1 path, same box: 11.10 ms with the cut behind
+        # the last block, 11.01 behind the last stage, 10.90 here, 10.95 at features[3][11]; single graph 10.56).  The first bucket
+        # grows from 65.6 to 86 MB and still has the remaining ~6 ms of backward to be reduced behind.  HC_BENCH_CUT0="stage:block"
+        # moves it, "" puts it back behind the last block.
+        c0 = os.environ.get("HC_BENCH_CUT0", "3:8")
+        if c0:
+            si, bi = (int(v) for v in c0.split(":"))
+            flat = [(i, j) for i, st in enumerate(model.features) for j in range(len(st))]
+            rear_mod = model.features[si][bi]
+            rear = {id(p) for (i, j) in flat if (i, j) >= (si, bi) for p in model.features[i][j].parameters()} | {id(p) for p in model.head.parameters()}
         front_last = next(p for p in reversed(list(model.parameters())) if id(p) not in rear)
         comm = torch.bfloat16 if args.comm_dtype == "bf16" else torch.float32
         # ... and in three: a second cut in front of the 192-channel stage.  The middle bucket (that stage + the first 1280-channel
@@ -197,7 +209,7 @@ def main():
         if ok:
             mb = [sum(t.numel() * t.element_size() for t in sp) / 1e6 for sp in gstep.spans] if distributed else []
             graph_note = ("weight gradients on a second stream; " if wgrad_side else "") + ("hipGraph replay of the full step" if not distributed else
-                          f"hipGraphs with eager RCCL all-reduces of the {args.comm_dtype} gradient between them (fwd + bwd of last block/head | "
+                          f"hipGraphs with eager RCCL all-reduces of the {args.comm_dtype} gradient between them (fwd + bwd down to the first cut | "
                           + " | ".join(f"all-reduce {m:.1f} MB" + (" behind: next part of bwd" if i + 1 < len(mb) else " (exposed)")
                                        for i, m in enumerate(mb)) + " | unpack + AdaBelief)")
         else:
