@@ -45,16 +45,21 @@ struct Args {
     int delay;         // start-up delay of the second team (s_sleep rounds): de-phases the two teams of a workgroup
 };
 
+// W > 0: the map width is a compile-time constant (the two RepVGG-A0 stages at 224 x 224: their codegen is what rounds 2-3 tuned).
+// W == 0: the FAMILY form - any width up to 16 SEGW pixels (SEGW = 1 for 192 channels, 2 for 96) and any height (ragged last unit):
+// the window keeps the pitch of the widest map, the width is a kernel argument.  RepVGG-A0 at any input resolution stays on this
+// kernel (192 @ 12 x 12 / 16 x 16, 96 @ 24 x 24 / 32 x 32, ...).
 template <int C, int W>
 struct Geo {
     static constexpr int CK = C / 32;                      // k32 steps per tap
     static constexpr int PSC = C / 8 + 1;                  // 16-byte chunks per window slot (one pad chunk)
     static constexpr int PS = PSC * 16;                    // bytes per window slot
-    static constexpr int WW = W + 1;                       // slots per window row: left halo + W pixels (the right halo is the next row's left)
+    static constexpr int SEGW = W > 0 ? (W + 15) / 16 : (C >= 192 ? 1 : 2);   // 16-pixel segments per row = pixel waves of a team
+    static constexpr int WMAX = W > 0 ? W : 16 * SEGW;
+    static constexpr int WW = WMAX + 1;                    // slots per window row: left halo + W pixels (the right halo is the next row's left)
     static constexpr int NSLOT = (UR + 2) * WW + 1;
     static constexpr int NDMA = (NSLOT * PS + 1023) / 1024;   // 1 KB DMA instructions per window
     static constexpr int WIN = NDMA * 1024;
-    static constexpr int SEGW = (W + 15) / 16;             // 16-pixel segments per row = pixel waves of a team
     static constexpr int CWN = 4 / SEGW;                   // channel waves of a team
     static constexpr int SMEM = 2 * WIN + 64 + 1024;       // one window per team + the two team counters + slack: the fragment reads of
                                                            // discarded columns run up to a few hundred bytes past the second window
@@ -104,12 +109,13 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int team = wid >> 2, w4 = wid & 3;
     const int cw = w4 % G::CWN, pw = w4 / G::CWN;
-    const int H = d.H, UPI = H / UR;
+    const int H = d.H, UPI = W > 0 ? H / UR : (H + UR - 1) / UR;
+    const int Wr = W > 0 ? W : d.W;                        // map width: compile-time for the tuned instantiations
     const int n = blockIdx.x;
     const unsigned lds0 = hc_lds_addr(smem);
     const int px = lane & 15, g = lane >> 4;
     const int col = 16 * pw + px;
-    const bool col_ok = col < W;
+    const bool col_ok = col < Wr;
     const int region = team * G::WIN;
     // The two teams synchronise only among themselves (an LDS arrival counter per team instead of s_barrier) and the second one starts
     // late: one team's window wait / re-staging / store drain then runs under the other team's MFMAs instead of next to its own
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
     if (team == 1)
         for (int i = 0; i < a.delay; ++i) __builtin_amdgcn_s_sleep(64);
 
-    const unsigned act_bytes = (unsigned)d.N * H * W * C * 2u;
+    const unsigned act_bytes = (unsigned)d.N * H * Wr * C * 2u;
     const u32x4 rsA = uniform_rsrc(d.srcA, act_bytes);
     const u32x4 rsB = uniform_rsrc(MODE == 1 ? d.srcB : d.srcA, act_bytes);
     const __amdgpu_buffer_rsrc_t rsw = make_rsrc(d.w3, (unsigned)(S * C * 64));
@@ -153,14 +159,14 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
     // of a slot, the halo and the rounded tail are zero-filled through out-of-range offsets.  j0 .. j1: which 1 KB pieces.
     auto stage_window = [&](const u32x4 rs, int row0, int j0, int j1) __attribute__((always_inline)) {
         if (DBG & 8) return;
-        const unsigned img = (unsigned)n * (unsigned)(H * W * C * 2);
+        const unsigned img = (unsigned)n * (unsigned)(H * Wr * C * 2);
         for (int j = j0 + w4; j < j1; j += 4) {
             const int J = j * 64 + lane;
             const int slot = J / G::PSC, c = J - slot * G::PSC;
             const int r = slot / WW, x = slot - r * WW;
             const int ih = row0 - 1 + r;
-            const bool ok = c < G::PSC - 1 && slot < G::NSLOT && x >= 1 && ih >= 0 && ih < H;
-            const unsigned off = img + (unsigned)((ih * W + x - 1) * C * 2 + c * 16);
+            const bool ok = c < G::PSC - 1 && slot < G::NSLOT && x >= 1 && (W > 0 || x <= Wr) && ih >= 0 && ih < H;
+            const unsigned off = img + (unsigned)((ih * Wr + x - 1) * C * 2 + c * 16);
             hc_dma16(rs, lds0 + (unsigned)(region + j * 1024), ok ? off : HC_OOB);
         }
     };
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
             if (t == 123.456f) reinterpret_cast<float*>(outp)[tid] = t;
             return;
         }
-        const size_t img = (size_t)n * H * W * C;
+        const size_t img = (size_t)n * H * Wr * C;
         __builtin_amdgcn_sched_barrier(0);     // the residual loads below stay below: hoisted into the last k-steps they spill the accumulators
         float st[2][12];
 #pragma unroll
@@ -232,7 +238,9 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
             for (int e = 0; e < 12; ++e) st[k][e] = 0.f;
 #pragma unroll
         for (int i = 0; i < UR; ++i) {
-            const size_t e0 = img + (size_t)((row0 + i) * W + (col_ok ? col : 0)) * C + cbase;
+            const bool ok = col_ok && (W > 0 || row0 + i < H);          // family form: the last unit of an image may be ragged
+            const int rr = W > 0 ? row0 + i : (ok ? row0 + i : 0);          // (compile-time form: the tuned instantiations' own address)
+            const size_t e0 = img + (size_t)(rr * Wr + (col_ok ? col : 0)) * C + cbase;
             bf16_t* op = reinterpret_cast<bf16_t*>(outp) + e0;
             const bf16_t* rp = residp != nullptr ? reinterpret_cast<const bf16_t*>(residp) + e0 : nullptr;
             // channel pieces of this lane: 8 g + 4 f (f = 0, 1) and 32 + 4 g (f = 2).  Forward: one 16-byte + one 8-byte store; the data
@@ -246,19 +254,19 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
                 if (stats != nullptr) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float x = col_ok ? v[e] : 0.f;
+                        const float x = ok ? v[e] : 0.f;
                         st[0][f * 4 + e] += x;
                         st[1][f * 4 + e] += x * x;
                     }
                 }
-                if (MODE == 1 && rp != nullptr && col_ok) {
+                if (MODE == 1 && rp != nullptr && ok) {
                     const u32x2 rv = *reinterpret_cast<const u32x2*>(rp + cofs);
                     v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]); v[2] += bf16lo(rv[1]); v[3] += bf16hi(rv[1]);
                 }
                 pk[f] = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                if (MODE == 1 && col_ok) *reinterpret_cast<u32x2*>(op + cofs) = pk[f];
+                if (MODE == 1 && ok) *reinterpret_cast<u32x2*>(op + cofs) = pk[f];
             }
-            if (MODE == 0 && col_ok) {
+            if (MODE == 0 && ok) {
                 *reinterpret_cast<u32x4*>(op) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
                 *reinterpret_cast<u32x2*>(op + 32 - 4 * g) = pk[2];
             }
@@ -330,6 +338,9 @@ __global__ __launch_bounds__(NT, 1) void conv_rows_kernel(const Args a) {
 
 template <int C, int W>
 bool shape_ok(const hc_conv_small_desc& d) {
+    if (W == 0)        // the family form: any width one team's pixel waves cover, any height
+        return d.C == C && d.Cout == C && d.W >= 1 && d.W <= Geo<C, 0>::WMAX && d.H >= 1 && d.N >= 1 &&
+               (double)d.N * d.H * d.W * C * 2.0 < 2147483000.0;
     return d.C == C && d.Cout == C && d.W == W && d.H >= 2 * UR && d.H % (2 * UR) == 0 && d.H <= 56 && d.N >= 1 &&
            (double)d.N * d.H * d.W * C * 2.0 < 2147483000.0;
 }
@@ -365,7 +376,11 @@ void launch(const Args& a, hipStream_t st) {
 bool hc_conv_rows_supported(const hc_conv_small_desc& d) {
     static const bool on = [] { const char* e = getenv("HC_CONV_ROWS"); return e == nullptr || atoi(e) != 0; }();
     if (!on || (d.mode & HC_CONV_SMALL_ROWS_IMAGE) == 0 || (d.mode & ~(HC_CONV_SMALL_ROWS_IMAGE | 1)) != 0) return false;
-    return crw::shape_ok<192, 14>(d) || crw::shape_ok<96, 28>(d);
+    // a predicate, not a shape list: 192 channels up to 16 pixels wide, 96 channels up to 32, any height (HC_CONV_ROWS_ANY=0: only the
+    // two tuned 224 x 224 stages, as in rounds 2-3)
+    static const bool any = [] { const char* e = getenv("HC_CONV_ROWS_ANY"); return e == nullptr || atoi(e) != 0; }();
+    if (crw::shape_ok<192, 14>(d) || crw::shape_ok<96, 28>(d)) return true;
+    return any && (crw::shape_ok<192, 0>(d) || crw::shape_ok<96, 0>(d));
 }
 int hc_conv_rows_launch(const hc_conv_small_desc& d, hipStream_t st) {
     if (!hc_conv_rows_supported(d)) return HC_ERR_ARG;
@@ -379,7 +394,9 @@ int hc_conv_rows_launch(const hc_conv_small_desc& d, hipStream_t st) {
     a.reps = hc_get_stat_replicas();
     static const int delay = getenv("HC_CRW_DELAY") ? atoi(getenv("HC_CRW_DELAY")) : 0;
     a.delay = delay;
-    if (d.C == 192) crw::launch<192, 14>(a, st);
-    else crw::launch<96, 28>(a, st);
+    if (crw::shape_ok<192, 14>(d)) crw::launch<192, 14>(a, st);
+    else if (crw::shape_ok<96, 28>(d)) crw::launch<96, 28>(a, st);
+    else if (d.C == 192) { if (dg) crw::launch1<192, 0, 1, 0>(a, st); else crw::launch1<192, 0, 0, 0>(a, st); }
+    else { if (dg) crw::launch1<96, 0, 1, 0>(a, st); else crw::launch1<96, 0, 0, 0>(a, st); }
     return hc_launch_status();
 }

@@ -52,12 +52,18 @@ def test_rows_image_layout(C):
                 assert got[rows_index(ci, co, 9, C)] == w1b[co, ci, 0, 0]
 
 
-@pytest.mark.parametrize("N,C,H", [(2, 192, 14), (256, 192, 14), (3, 96, 28), (256, 96, 28), (5, 192, 28), (2, 96, 56), (3, 48, 112), (64, 48, 56)])
-def test_conv_rows_vs_fp32(N, C, H):
-    """forward (3x3 + 1x1 + statistics) and data gradient (+ residual); W is the template size, H any multiple of 14"""
+@pytest.mark.parametrize("N,C,H,W", [(2, 192, 14, None), (256, 192, 14, None), (3, 96, 28, None), (256, 96, 28, None), (5, 192, 28, None),
+                                     (2, 96, 56, None), (3, 48, 112, None), (64, 48, 56, None),
+                                     # the family form (round 4): any width up to 16 (192 channels) / 32 (96 channels) pixels, any height
+                                     # - odd unit counts, a ragged last unit, maps narrower than a fragment
+                                     (3, 192, 12, 12), (2, 192, 16, 16), (5, 192, 7, 7), (2, 192, 21, 14), (2, 192, 9, 13), (3, 192, 1, 3),
+                                     (3, 96, 24, 24), (2, 96, 32, 32), (2, 96, 14, 14), (2, 96, 30, 17), (4, 96, 7, 28), (64, 192, 16, 16)])
+def test_conv_rows_vs_fp32(N, C, H, W):
+    """forward (3x3 + 1x1 + statistics) and data gradient (+ residual); W None: the tuned template size (H any multiple of 14)"""
     from holocron_amd import _lib
     from holocron_amd.ops import conv as cv
-    W = {192: 14, 96: 28, 48: H}[C]
+    if W is None:
+        W = {192: 14, 96: 28, 48: H}[C]
     bf = lambda t: t.to(torch.bfloat16).float()
     g = torch.Generator(device="cuda").manual_seed(N + C)
     x = bf(torch.randn(N, C, H, W, device="cuda", generator=g))
@@ -116,5 +122,8 @@ def test_streaming_48_channel_kernel_with_its_data_gradient():
 
 def test_conv_rows_unsupported_shapes():
     from holocron_amd.ops import conv as cv
-    for (N, H, W, C) in [(4, 14, 14, 96), (4, 28, 28, 192), (4, 21, 14, 192), (4, 14, 14, 128), (4, 7, 14, 192)]:
+    for (N, H, W, C) in [(4, 28, 28, 192), (4, 14, 17, 192), (4, 14, 14, 128), (4, 14, 40, 96), (4, 14, 14, 64)]:
         assert cv.conv_small_desc(N, H, W, C, C, cv.ROWS_IMAGE) is None
+    # ... and what the dispatch predicate takes since round 4 (it was a list of two shapes)
+    for (N, H, W, C) in [(4, 14, 14, 96), (4, 21, 14, 192), (4, 7, 14, 192), (4, 16, 16, 192), (4, 32, 32, 96), (4, 5, 9, 96)]:
+        assert cv.conv_small_desc(N, H, W, C, C, cv.ROWS_IMAGE) is not None and cv.conv_small_desc(N, H, W, C, C, cv.ROWS_IMAGE | 1) is not None
