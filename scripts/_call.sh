@@ -1,6 +1,12 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/c16
-timeout 1200 python -m pytest tests/test_gpu_rexnet.py tests/test_gpu_mobileone.py tests/test_gpu_convs.py tests/test_gpu_fullsize_bn.py tests/test_gpu_boundary.py tests/test_gpu_yolo.py -x -q -m gpu 2>&1 | tail -8 > gpurun_out/c16/tests.log
-timeout 300 python scripts/bench_rexnet.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/c16/rexnet.json 2>/dev/null
-timeout 300 python scripts/bench_mobileone.py 2>/dev/null | cut -c1-250 > gpurun_out/c16/mobileone.txt
-HC_PAD_WIDE_FROM=0 timeout 300 python scripts/bench_mobileone.py 2>/dev/null | cut -c1-250 >> gpurun_out/c16/mobileone.txt
-cat gpurun_out/c16/tests.log; cut -c1-250 gpurun_out/c16/rexnet.json; cat gpurun_out/c16/mobileone.txt
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/c18
+runr() { tag=$1; shift; env "$@" timeout 300 python scripts/bench_rexnet.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],3))"; }
+runh() { tag=$1; shift; env "$@" timeout 300 python bench.py --no-cpu-baseline --profile-steps 1 --steps 150 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],3))"; }
+runf() { tag=$1; shift; env "$@" timeout 300 python scripts/bench_repvgg_fp8.py --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],3), round(d['bf16_ms'],3))"; }
+runr rex_fill0 HC_CONV_FILL=0
+runr rex_fill400 A=1
+runr rex_fill0b HC_CONV_FILL=0
+runr rex_fill400b A=1
+runh head_fill0 HC_CONV_FILL=0
+runh head_fill400 A=1
+runf fp8_fill0 HC_CONV_FILL=0
+runf fp8_fill400 A=1

@@ -65,7 +65,10 @@ def run(env):
 
 
 def main():
-    a, b = run({"HC_CONV_BIG": "0"}), run({"HC_CONV_BIG": "1", "HC_CONV_BIG_EFF": "0"})
+    if os.environ.get("BIGTILE_AB_FILL"):      # A/B of the small-launch rule instead: 64-channel tiles when the launch underfills the chip
+        a, b = run({"HC_CONV_FILL": "0"}), run({"HC_CONV_FILL": os.environ["BIGTILE_AB_FILL"]})
+    else:
+        a, b = run({"HC_CONV_BIG": "0"}), run({"HC_CONV_BIG": "1", "HC_CONV_BIG_EFF": "0"})
     print(f"{'shape':<26} {'GFLOP':>7} {'128x128 us':>10} {'TF/s':>6} {'family us':>10} {'TF/s':>6} {'ratio':>6} {'tile':>9} {'eff':>5}  same bits / stats")
     for name, N, Cin, H, Cout, k in SHAPES:
         fl = 2.0 * N * H * H * Cout * Cin * k * k
