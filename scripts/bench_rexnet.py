@@ -32,7 +32,7 @@ def main():
                 torch.randint(0, 1000, (a.batch,), device=dev, generator=g))
 
     def loss_of(model, x, t):
-        return F.cross_entropy(model(x).float(), t)
+        return h.nn.functional.cross_entropy(model(x).float(), t)      # the same criterion as two HIP launches (round 4)
 
     def cpu_baseline():
         """oracle.rexnet.forward (the reference's rexnet1_0x restated on torch-CPU fp32) + CE + autograd + the oracle's AdaBelief."""

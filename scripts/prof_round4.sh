@@ -55,6 +55,7 @@ trace yolov4 "rocprofv3 --kernel-trace --stats -- python scripts/bench_yolov4.py
 bash scripts/pmc_families.sh repvgg_a2_fp8 python scripts/bench_repvgg_fp8.py --steps 2 --warmup 1 > $O/pmc_fp8.log 2>&1
 cp gpurun_out/pmc_repvgg_a2_fp8/traffic.json profiles/r04_pmc_repvgg_a2_fp8_traffic.json; cp gpurun_out/pmc_repvgg_a2_fp8/traffic.json $O/r04_pmc_repvgg_a2_fp8_traffic.json
 timeout 300 python scripts/bench_repvgg_fp8.py > $O/r04_final_repvgg_a2_fp8_bench.json 2> $O/fp8.err
+timeout 300 python scripts/bench_mobileone.py > $O/r04_final_mobileone_bench.json 2> $O/mobileone.err
 ls -la $O | head -60
 cut -c1-300 $O/r04_final_bench.json
 timeout 200 python scripts/fixture_fracs.py 2>&1 | grep -v amdgpu > $O/fixture_fracs.txt; tail -1 $O/fixture_fracs.txt
