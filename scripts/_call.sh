@@ -1,14 +1,5 @@
-cd $GRAFT_REPO_ROOT
-runr() { tag=$1; shift; env "$@" timeout 300 python scripts/bench_rexnet.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],3))"; }
-runy() { tag=$1; shift; env "$@" timeout 300 python scripts/bench_yolov4.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$tag', round(d['ms_per_step'],3))"; }
-runr rex_base A=1
-runr rex_ew512 HC_EW_FLOOR=512
-runr rex_ew2048 HC_EW_FLOOR=2048
-runr rex_ew4096 HC_EW_FLOOR=4096
-runr rex_nt16 HC_EW_NT_MB=16
-runy yolo_base A=1
-runy yolo_ew512 HC_EW_FLOOR=512
-runy yolo_ew2048 HC_EW_FLOOR=2048
-runy yolo_ew4096 HC_EW_FLOOR=4096
-runy yolo_side HC_WGRAD_SIDE_STREAM=1
-runr rex_side HC_WGRAD_SIDE_STREAM=1
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/c20
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > gpurun_out/c20/tests.log
+timeout 300 python scripts/bench_mobileone.py --no-cpu-baseline > gpurun_out/c20/mobileone.json 2> gpurun_out/c20/mobileone.err
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/c20/smoke.log 2>&1
+cat gpurun_out/c20/tests.log; cut -c1-300 gpurun_out/c20/mobileone.json; tail -2 gpurun_out/c20/mobileone.err; tail -1 gpurun_out/c20/smoke.log
