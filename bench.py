@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--profile-steps", type=int, default=8, help="instrumented eager steps behind the roofline object (untimed)")
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
+    ap.add_argument("--arch", default="repvgg_a0", help="the headline is repvgg_a0 (BASELINE.json configs[1]); other RepVGG variants for "
+                                                        "side measurements (their line says so and carries no MFMA fraction)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
@@ -112,7 +114,8 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1)
 
     torch.manual_seed(0)
-    model = h.models.repvgg_a0(num_classes=10).to(dev).train()
+    model = getattr(h.models, args.arch)(num_classes=10).to(dev).train()
+    headline = args.arch == "repvgg_a0"
     if distributed:
         parallel.broadcast_parameters(model)
     opt = h.optim.AdaBelief(model.parameters(), lr=1e-3, betas=(0.95, 0.99), eps=1e-6, weight_decay=0.0)
@@ -128,7 +131,7 @@ def main():
         # the last block, 11.01 behind the last stage, 10.90 here, 10.95 at features[3][11]; single graph 10.56).  The first bucket
         # grows from 65.6 to 86 MB and still has the remaining ~6 ms of backward to be reduced behind.  HC_BENCH_CUT0="stage:block"
         # moves it, "" puts it back behind the last block.
-        c0 = os.environ.get("HC_BENCH_CUT0", "3:8")
+        c0 = os.environ.get("HC_BENCH_CUT0", "3:8" if len(model.features[3]) > 8 else "")
         if c0:
             si, bi = (int(v) for v in c0.split(":"))
             flat = [(i, j) for i, st in enumerate(model.features) for j in range(len(st))]
@@ -287,7 +290,7 @@ def main():
         traffic, traffic_src = None, None
         for cand in ("r04_pmc_step_traffic.json", "r03_pmc_step_traffic.json", "r02_pmc_step_traffic.json"):
             pmc_file = os.path.join(ROOT, "profiles", cand)
-            if args.batch == 256 and os.path.exists(pmc_file) and traffic is None:
+            if headline and args.batch == 256 and os.path.exists(pmc_file) and traffic is None:
                 with open(pmc_file) as fh:
                     traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
                 if traffic is not None:
@@ -328,7 +331,7 @@ def main():
     imgs = args.batch * world * args.steps
     ms = dt / args.steps * 1e3
     out = {
-        "metric": "images/sec fwd+bwd+AdaBelief, RepVGG-A0 bs256/GPU 224^2",
+        "metric": "images/sec fwd+bwd+AdaBelief, RepVGG-A0 bs256/GPU 224^2" if headline else f"images/sec fwd+bwd+AdaBelief, {args.arch} bs{args.batch}/GPU 224^2",
         "value": imgs / dt,
         "unit": "images/sec",
         "n_gpus": world,
@@ -340,11 +343,13 @@ def main():
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic",
-        "config": {"workload": "repvgg_a0 bf16 train step (fwd+bwd+AdaBelief), synthetic 224^2, bs=256 per MI355X "
-                               "(BASELINE.json configs[1]), random-init weights, 10 classes, CE label_smoothing 0.1",
+        "config": {"workload": ("repvgg_a0 bf16 train step (fwd+bwd+AdaBelief), synthetic 224^2, bs=256 per MI355X "
+                                "(BASELINE.json configs[1]), random-init weights, 10 classes, CE label_smoothing 0.1") if headline else
+                               f"{args.arch} bf16 train step (fwd+bwd+AdaBelief), synthetic 224^2, bs={args.batch} per MI355X (side measurement, "
+                               "not a BASELINE config), random-init weights, 10 classes, CE label_smoothing 0.1",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "mode": graph_note,
                    "final_loss": final_loss},
-        "mfma_fraction_whole_step": TRAIN_GFLOP_PER_IMG * 1e9 * imgs / dt / MFMA_BF16_PEAK / world,
+        "mfma_fraction_whole_step": (TRAIN_GFLOP_PER_IMG * 1e9 * imgs / dt / MFMA_BF16_PEAK / world) if headline else None,
         "conv_mfma_fraction": conv_frac,
         "roofline": roof,
     }

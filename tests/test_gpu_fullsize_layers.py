@@ -98,12 +98,28 @@ def test_c2_conv_passes_deterministic_mode_vs_fp32_cpu(cfg):
         h.set_deterministic(False)
 
 
-def _c2_conv_passes(cfg):
+# Block shapes of the OTHER RepVGG variants (repvgg.py:146-154, 224 x 224 input): repvgg_a1 / b0 (64, 128, 256 channels) and
+# repvgg_a2 (96, 192, 384) - none of them is a shape a specialised kernel was written for, so this is the generic dispatch
+# (gather-conv incl. its big-tile family, image-resident conv, fused / transposing weight gradients) at full map size, batch 64
+RV_OTHER_BLOCKS = [
+    (64, 64, 56, 1, True), (128, 128, 28, 1, True), (256, 256, 14, 1, True), (128, 256, 28, 2, False),
+    (96, 96, 56, 1, True), (192, 192, 28, 1, True), (384, 384, 14, 1, True), (192, 384, 28, 2, False),
+]
+
+
+@pytest.mark.parametrize("cfg", RV_OTHER_BLOCKS, ids=["%d@%d-%d_s%d" % (c[0], c[2], c[1], c[3]) for c in RV_OTHER_BLOCKS])
+def test_other_repvgg_block_shapes_vs_fp32_cpu(cfg):
+    """The same four passes (forward 3x3 + 1x1 + statistics, fused data gradient, both weight gradients) as test_c2_conv_passes_* for
+    the block shapes of repvgg_a1 / b0 / a2, against torch-CPU fp32 convolutions, same bounds."""
+    _c2_conv_passes(cfg, N=64)
+
+
+def _c2_conv_passes(cfg, N=None):
     from holocron_amd import _lib
     from holocron_amd.nn import repblock_op as rb
     from holocron_amd.ops import conv as cv
     cin, cout, H, stride, ident = cfg
-    N = N_C2
+    N = N_C2 if N is None else N
     g = gen(1000 + cin + cout + H)
     x = bf16r(torch.rand((N, cin, H, H), generator=g))
     w3 = bf16r(torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cout * 9)) ** 0.5)
