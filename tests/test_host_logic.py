@@ -214,18 +214,21 @@ def test_weight_gradient_workspace_planner():
 
 
 def test_row_unit_conv_planner_accepts_and_rejects():
-    """hc_conv_small_supported with HC_CONV_SMALL_ROWS_IMAGE (host code): the row-unit kernel takes exactly 192 channels on 14-wide and
-    96 channels on 28-wide maps whose height is a whole number of unit pairs (two 4-wave teams x 7 rows), forward and data gradient;
-    without the flag the same shapes still resolve to the older kernels (or to the gather-conv)."""
+    """hc_conv_small_supported with HC_CONV_SMALL_ROWS_IMAGE (host code): the row-unit kernel takes 192 channels on maps up to 16 pixels
+    wide and 96 channels up to 32, any height (round 4: a predicate - the two 224 x 224 stages keep their tuned instantiations, every
+    other width / height runs the family form), forward and data gradient; without the flag the same shapes still resolve to the older
+    kernels (or to the gather-conv)."""
     from holocron_amd.ops import conv as cv
     R = cv.ROWS_IMAGE
     for a in [(256, 14, 14, 192, 192, R), (256, 14, 14, 192, 192, R | 1), (256, 28, 28, 96, 96, R), (3, 28, 28, 96, 96, R | 1),
               (5, 28, 14, 192, 192, R), (2, 56, 28, 96, 96, R),
+              (4, 14, 14, 96, 96, R), (4, 21, 14, 192, 192, R), (4, 7, 14, 192, 192, R | 1), (4, 70, 14, 192, 192, R), (3, 16, 16, 192, 192, R),
+              (3, 32, 32, 96, 96, R | 1), (2, 5, 9, 96, 96, R),          # the family form: other widths, odd unit counts, ragged heights
               (256, 112, 112, 48, 48, R), (256, 56, 56, 48, 48, R), (2, 8, 112, 48, 48, R)]:   # streaming 48-channel kernel: forward
         d = cv.conv_small_desc(*a)
         assert d is not None and d.mode == a[5], a
-    for a in [(4, 14, 14, 96, 96, R), (4, 28, 28, 192, 192, R), (4, 21, 14, 192, 192, R), (4, 7, 14, 192, 192, R), (4, 14, 14, 128, 128, R),
-              (4, 70, 14, 192, 192, R), (4, 14, 14, 192, 96, R), (4, 14, 14, 192, 192, R | 2),
+    for a in [(4, 28, 28, 192, 192, R), (4, 14, 17, 192, 192, R), (4, 14, 40, 96, 96, R), (4, 14, 14, 128, 128, R), (4, 14, 14, 64, 64, R),
+              (4, 14, 14, 192, 96, R), (4, 14, 14, 192, 192, R | 2),
               (4, 112, 112, 48, 48, R | 1),     # its data gradient stays on the persistent kernel unless HC_CONV_ROWS48=2
               (4, 110, 112, 48, 48, R), (4, 28, 28, 48, 48, R), (4, 60, 56, 48, 48, R)]:
         assert cv.conv_small_desc(*a) is None, a
