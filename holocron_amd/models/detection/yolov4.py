@@ -263,17 +263,26 @@ class YoloLayer(nn.Module):
         gt_img = torch.tensor(img, dtype=torch.int32).to(device, non_blocking=True)
         return gt_boxes, gt_labels, gt_img, gt_off
 
-    def _compute_losses_logits(self, x: Tensor, target: List[Dict[str, Tensor]], packed=None) -> Dict[str, Tensor]:
+    def _weighted_losses(self, x: Tensor, target: List[Dict[str, Tensor]], packed=None) -> Tensor:
+        """The four losses of this layer as ONE fp32 vector [obj, noobj, bbox, clf], already weighted by the lambdas and divided by the
+        batch size (yolov4.py:411-420): one multiply by a cached device vector instead of a mul and a div per entry."""
         if packed is None:
             packed = self._pack_targets(target, x.device)
         sums = _YoloLossFn.apply(x, self, packed)
         n = x.shape[0]
-        return {
-            "obj_loss": self.lambda_obj * sums[0] / n,
-            "noobj_loss": self.lambda_noobj * sums[1] / n,
-            "bbox_loss": (self.lambda_coords * sums[2] / n).reshape(1),
-            "clf_loss": self.lambda_class * sums[3] / n,
-        }
+        key = (n, float(self.lambda_obj), float(self.lambda_noobj), float(self.lambda_coords), float(self.lambda_class), x.device)
+        if getattr(self, "_hc_coef_key", None) != key:
+            self._hc_coef = torch.tensor([self.lambda_obj / n, self.lambda_noobj / n, self.lambda_coords / n, self.lambda_class / n],
+                                         dtype=torch.float32).to(x.device)
+            self._hc_coef_key = key
+        return sums * self._hc_coef
+
+    @staticmethod
+    def _loss_dict(w: Tensor) -> Dict[str, Tensor]:
+        return {"obj_loss": w[0], "noobj_loss": w[1], "bbox_loss": w[2].reshape(1), "clf_loss": w[3]}
+
+    def _compute_losses_logits(self, x: Tensor, target: List[Dict[str, Tensor]], packed=None) -> Dict[str, Tensor]:
+        return self._loss_dict(self._weighted_losses(x, target, packed))
 
     def forward(self, x: Tensor, target: Optional[List[Dict[str, Tensor]]] = None, packed=None):
         if self.training and target is None:
@@ -339,14 +348,12 @@ class Yolov4Head(nn.Module):
 
         if not self.training:          # the 3 x N NMS problems of the batch as one launch pair (same detections, same order)
             return post_process_scales([self.yolo1, self.yolo2, self.yolo3], [o1, o2, o3])
-        packed = YoloLayer._pack_targets(target, o1.device) if self.training else None
-        y1 = self.yolo1(o1, target, packed)
-        y2 = self.yolo2(o2, target, packed)
-        y3 = self.yolo3(o3, target, packed)
-        if not self.training:
-            return [{k: torch.cat((d1[k], d2[k], d3[k]), dim=0) for k in ("boxes", "scores", "labels")}
-                    for d1, d2, d3 in zip(y1, y2, y3)]
-        return {k: y1[k] + y2[k] + y3[k] for k in y1}
+        # training: the three scales' weighted loss vectors are added as vectors (two launches) and THEN split into the reference's
+        # dict (yolov4.py:611-640 adds the twelve scalars one by one)
+        packed = YoloLayer._pack_targets(target, o1.device)
+        w = (self.yolo1._weighted_losses(o1, target, packed) + self.yolo2._weighted_losses(o2, target, packed)
+             + self.yolo3._weighted_losses(o3, target, packed))
+        return YoloLayer._loss_dict(w)
 
 
 def post_process_scales(layers, outs) -> List[Dict[str, Tensor]]:
