@@ -20,6 +20,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# A finished group of deferred RepBlock weight gradients (e.g. the 192-channel stage's) goes to a second stream as soon as backward
+# moves on to another block shape, instead of waiting for the end-of-pass flush: it then runs beside the HBM-bound passes of the
+# 96- / 48-channel stages.  Same box, three pairs: 10.80 / 10.80 / 10.80 ms without, 10.69 / 10.79 / 10.68 with (read at import).
+os.environ.setdefault("HC_WREP_SIDE", "1")
 
 MFMA_BF16_PEAK = 2.5e15   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12         # HBM3E spec, same guide (6.29 TB/s measured copy)
