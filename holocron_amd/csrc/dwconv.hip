@@ -5,6 +5,7 @@
 // the 3 x (TW*stride + 2) input window of a strip is loaded once and reused by the TW outputs.  The launch keeps a
 // thread's channel group fixed, so the 72 weights stay in registers and the BatchNorm statistics (sum, sum of
 // squares of the fp32 results, like the MFMA conv epilogue) are register running sums flushed once per workgroup.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/holocron_hip.h"
 
@@ -140,6 +141,123 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_fwd_kernel(const u32x4* __re
     if (stats != nullptr) block_reduce_flush<2>(sv, cg, C, stats + (size_t)(blockIdx.x % reps) * 2 * C, sred);
 }
 
+// ---------------------------------------------------------------- forward, stride 1, LDS-TILED (round 4)
+// The strip kernel above loads the 3 x (TW + 2) window of every TW outputs from global memory: 4.5 16-byte loads per output, two
+// thirds of them rows another wave (usually another CU) has just fetched - L2 hits, but each one a texture-path request, and that
+// request rate held the kernel at 1.85 TB/s.  Here a workgroup owns a 64-channel slice (blockIdx.y) and walks 8 x 32 output tiles:
+// the 10 x 34 input window of a tile goes HBM / L2 -> LDS by DMA once (1.33 fetched bytes per output byte instead of 4.5, zero halo =
+// out-of-range offsets), and the 3 x 10 window of a thread's 8-pixel strip is 30 ds_read_b128 of it.  Two workgroups per CU overlap one
+// tile's DMA wait with the other's arithmetic.  Same tap order per output as the strip kernel: bit-identical results.
+namespace dwt {
+constexpr int TH = 8, SW = 8, NSTRIP = 4, TW = SW * NSTRIP;        // tile: 8 rows x 32 columns
+constexpr int PITCH_PX = 40, PX_BYTES = 128, ROW_BYTES = PITCH_PX * PX_BYTES, ROWS = TH + 2, WIN_BYTES = ROWS * ROW_BYTES;   // 51 200 B
+constexpr int PIECES_ROW = PITCH_PX / 8, PIECES = ROWS * PIECES_ROW;
+}
+__global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_fwd_tile_kernel(const void* __restrict__ x, const float* __restrict__ w,
+                                                                       u32x4* __restrict__ y, float* __restrict__ stats, int N, int H,
+                                                                       int W, int C, const int reps, int tiles_x, int tiles_y) {
+    using namespace dwt;
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];
+    const int cg = C / 8, slice = blockIdx.y;
+    const int gs = min(8, cg - slice * 8);                 // channel groups of this slice
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gl = tid & 7, sidx = (tid >> 3) & (NSTRIP - 1), r = tid >> 5;
+    const bool live = gl < gs;
+    const int cgi = slice * 8 + (live ? gl : 0);
+    float wr[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(w + (size_t)t * C + cgi * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(w + (size_t)t * C + cgi * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wr[t][e] = a[e]; wr[t][4 + e] = b[e]; }
+    }
+    float sv[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sv[0][e] = sv[1][e] = 0.f;
+    u32x4 rs;
+    {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(x);
+        rs[0] = __builtin_amdgcn_readfirstlane((unsigned)v);
+        rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32) & 0xffffu);
+        rs[2] = __builtin_amdgcn_readfirstlane((unsigned)((long)N * H * W * C * 2));
+        rs[3] = 0x00020000u;
+    }
+    const unsigned lds0 = hc_lds_addr(dsm);
+    const int ntiles = N * tiles_y * tiles_x;
+    // DMA lane constants: lane -> (pixel of the 8-pixel piece, channel group)
+    const int dpx = lane >> 3, dgr = lane & 7;
+    const unsigned choff = (unsigned)((slice * 64 + dgr * 8) * 2);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / (tiles_y * tiles_x), rem = tile - n * (tiles_y * tiles_x);
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        __syncthreads();                                   // everybody is done reading the previous window
+        for (int q = wid; q < PIECES; q += 4) {
+            const int wr_ = q / PIECES_ROW, px = (q - wr_ * PIECES_ROW) * 8 + dpx;
+            const int iy = oy0 - 1 + wr_, ix = ox0 - 1 + px;
+            const bool ok = dgr < gs && px < TW + 2 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const unsigned off = (unsigned)(((n * H + iy) * W + ix) * C * 2) + choff;
+            hc_dma16(rs, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(q * 1024)), ok ? off : HC_OOB);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int oy = oy0 + r;
+        if (live && oy < H) {
+            float acc[SW][8];
+#pragma unroll
+            for (int j = 0; j < SW; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+            const char* base = dsm + r * ROW_BYTES + (sidx * SW) * PX_BYTES + gl * 16;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int c = 0; c < SW + 2; ++c) {
+                    float f[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(base + kh * ROW_BYTES + c * PX_BYTES), f);
+#pragma unroll
+                    for (int j = 0; j < SW; ++j) {
+                        const int kw = c - j;
+                        if (kw < 0 || kw > 2) continue;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[j][e] += wr[kh * 3 + kw][e] * f[e];
+                    }
+                }
+            }
+            u32x4* orow = y + ((long)(n * H + oy) * W) * cg + cgi;
+#pragma unroll
+            for (int j = 0; j < SW; ++j) {
+                const int ox = ox0 + sidx * SW + j;
+                if (ox >= W) break;
+                orow[(long)ox * cg] = pack8(acc[j]);
+                if (stats != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { sv[0][e] += acc[j][e]; sv[1][e] += acc[j][e] * acc[j][e]; }
+                }
+            }
+        }
+    }
+    if (stats != nullptr) {         // the 32 threads of a channel group are combined in LDS (fixed order), one atomic per (k, channel)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(dsm);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[tid * 17 + k * 8 + e] = live ? sv[k][e] : 0.f;
+        __syncthreads();
+        float* rep = stats + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) % reps) * 2 * C;
+        for (int o = tid; o < 2 * 64; o += DW_THREADS) {
+            const int k = o >> 6, c = o & 63, g = c >> 3, e = c & 7;
+            if (g >= gs) continue;
+            float sum = 0.f;
+            for (int t = g; t < DW_THREADS; t += 8) sum += red[t * 17 + k * 8 + e];
+            atomicAdd(rep + (size_t)k * C + slice * 64 + c, sum);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- stride-2 data gradient
 // dx[n][h][w][c] = sum over taps with (h + 1 - kh) and (w + 1 - kw) even of w[kh][kw][c] * dy[n][(h+1-kh)/2][(w+1-kw)/2][c]
 __global__ __launch_bounds__(DW_THREADS) void dw3x3_dgrad_s2_kernel(const u32x4* __restrict__ dy, const float* __restrict__ w,
@@ -248,6 +366,106 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_wgrad_kernel(const u32x4* __
         }
     }
     block_reduce_flush<9>(acc, cg, C, dw + (size_t)(blockIdx.x % reps) * 9 * C, sred);
+}
+
+// ---------------------------------------------------------------- weight gradient, stride 1, LDS-TILED (round 4)
+// Same tiling as dw3x3_fwd_tile_kernel: the 10 x 34 x 64-channel window of x goes to LDS by DMA once per 8 x 32 tile, a thread multiplies
+// the 8 gradient pixels of its strip (read straight from global memory, 16 bytes each, 128-byte runs over the channel groups) with
+// the 3 x 10 window around them and keeps its 72 running sums for the whole kernel; one LDS reduction over the 32 threads of a channel
+// group and one atomic per (tap, channel) at the end, into the replica slab the strip kernel writes too.
+__global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_wgrad_tile_kernel(const void* __restrict__ x, const u32x4* __restrict__ dy,
+                                                                         float* __restrict__ dw, int N, int H, int W, int C, const int reps,
+                                                                         int tiles_x, int tiles_y) {
+    using namespace dwt;
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];
+    const int cg = C / 8, slice = blockIdx.y;
+    const int gs = min(8, cg - slice * 8);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gl = tid & 7, sidx = (tid >> 3) & (NSTRIP - 1), r = tid >> 5;
+    const bool live = gl < gs;
+    const int cgi = slice * 8 + (live ? gl : 0);
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    u32x4 rs;
+    {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(x);
+        rs[0] = __builtin_amdgcn_readfirstlane((unsigned)v);
+        rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32) & 0xffffu);
+        rs[2] = __builtin_amdgcn_readfirstlane((unsigned)((long)N * H * W * C * 2));
+        rs[3] = 0x00020000u;
+    }
+    const unsigned lds0 = hc_lds_addr(dsm);
+    const int ntiles = N * tiles_y * tiles_x;
+    const int dpx = lane >> 3, dgr = lane & 7;
+    const unsigned choff = (unsigned)((slice * 64 + dgr * 8) * 2);
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / (tiles_y * tiles_x), rem = tile - n * (tiles_y * tiles_x);
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        __syncthreads();
+        for (int q = wid; q < PIECES; q += 4) {
+            const int wr_ = q / PIECES_ROW, px = (q - wr_ * PIECES_ROW) * 8 + dpx;
+            const int iy = oy0 - 1 + wr_, ix = ox0 - 1 + px;
+            const bool ok = dgr < gs && px < TW + 2 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const unsigned off = (unsigned)(((n * H + iy) * W + ix) * C * 2) + choff;
+            hc_dma16(rs, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(q * 1024)), ok ? off : HC_OOB);
+        }
+        // the gradient pixels of this thread's strip, straight from global memory (in flight beside the window DMA)
+        const int oy = oy0 + r;
+        u32x4 gp[SW];
+        const u32x4* grow = dy + ((long)(n * H + (oy < H ? oy : 0)) * W) * cg + cgi;
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+            const int ox = ox0 + sidx * SW + j;
+            gp[j] = (live && oy < H && ox < W) ? grow[(long)ox * cg] : zero4;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (live && oy < H) {
+            const char* base = dsm + r * ROW_BYTES + (sidx * SW) * PX_BYTES + gl * 16;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int c = 0; c < SW + 2; ++c) {
+                    float f[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(base + kh * ROW_BYTES + c * PX_BYTES), f);
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int j = c - kw;
+                        if (j < 0 || j >= SW) continue;
+                        float g[8];
+                        unpack8(gp[j], g);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[kh * 3 + kw][e] += g[e] * f[e];
+                    }
+                }
+            }
+        }
+    }
+    // 9 x 8 sums per thread -> per (tap, channel) over the 32 threads of a channel group, three taps at a time through LDS
+    float* red = reinterpret_cast<float*>(dsm);
+    float* rep = dw + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) % reps) * 9 * C;
+#pragma unroll
+    for (int k0 = 0; k0 < 9; k0 += 3) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[tid * 25 + k * 8 + e] = live ? acc[k0 + k][e] : 0.f;
+        __syncthreads();
+        for (int o = tid; o < 3 * 64; o += DW_THREADS) {
+            const int k = o >> 6, c = o & 63, g = c >> 3, e = c & 7;
+            if (g >= gs) continue;
+            float sum = 0.f;
+            for (int t = g; t < DW_THREADS; t += 8) sum += red[t * 25 + k * 8 + e];
+            atomicAdd(rep + (size_t)(k0 + k) * C + slice * 64 + c, sum);
+        }
+    }
 }
 
 // dw OIHW fp32 [C][1][3][3] = sum over replicas of slab [R][9][Cpad]; 8 lanes per element (c fastest: coalesced slab reads),
@@ -482,7 +700,26 @@ int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t
     hipStream_t st = (hipStream_t)stream;
     const int cg = C / 8;
     const size_t lds = stats != nullptr ? (size_t)DW_THREADS * 17 * sizeof(float) : 0;
-    if (stride == 1) {
+    // HC_DW_TILE=0: the strip kernel for every stride-1 launch (A/B); the LDS-tiled kernel takes maps of at least HC_DW_TILE_MINW
+    // (default 24) pixels and 32-bit byte offsets
+    static const int tile_on = [] { const char* e = getenv("HC_DW_TILE"); return e == nullptr ? 1 : atoi(e); }();
+    static const int tile_minw = [] { const char* e = getenv("HC_DW_TILE_MINW"); return e == nullptr ? 24 : atoi(e); }();
+    static const int tile_minc = [] { const char* e = getenv("HC_DW_TILE_MINC"); return e == nullptr ? 32 : atoi(e); }();
+    if (stride == 1 && tile_on && W >= tile_minw && H >= 8 && C >= tile_minc && (double)N * H * W * C * 2.0 < 4294967000.0) {
+        const int tiles_x = (W + dwt::TW - 1) / dwt::TW, tiles_y = (H + dwt::TH - 1) / dwt::TH;
+        const int nslices = (cg + 7) / 8;
+        const long ntiles = (long)N * tiles_x * tiles_y;
+        long gx = (2 * 256 + nslices - 1) / nslices;       // two resident workgroups per CU over all slices
+        if (gx > ntiles) gx = ntiles;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_fwd_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dwt::WIN_BYTES);
+            attr = true;
+        }
+        if (stats != nullptr && hc_get_deterministic() && gx * nslices > hc_get_stat_replicas()) return HC_ERR_ARG;
+        hipLaunchKernelGGL(dw3x3_fwd_tile_kernel, dim3((unsigned)gx, nslices), dim3(DW_THREADS), dwt::WIN_BYTES, st, x, wpk, (u32x4*)y, stats,
+                           N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
+    } else if (stride == 1) {
         constexpr int TW = 4;
         const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
         hipLaunchKernelGGL((dw3x3_fwd_kernel<1, TW>), dim3(dw_blocks(items, cg, 2)), dim3(DW_THREADS), lds, st, (const u32x4*)x, wpk,
@@ -526,7 +763,24 @@ int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N
     const int cg = C / 8;
     if ((long)N * OH * OW > 0) {
         const size_t lds = (size_t)DW_THREADS * 25 * sizeof(float);
-        if (stride == 1) {
+        static const int tile_on = [] { const char* e = getenv("HC_DW_TILE"); return e == nullptr ? 1 : atoi(e); }();
+        static const int tile_minw = [] { const char* e = getenv("HC_DW_TILE_MINW"); return e == nullptr ? 24 : atoi(e); }();
+        static const int tile_minc = [] { const char* e = getenv("HC_DW_TILE_MINC"); return e == nullptr ? 32 : atoi(e); }();
+        if (stride == 1 && tile_on && W >= tile_minw && H >= 8 && C >= tile_minc && (double)N * H * W * C * 2.0 < 4294967000.0 &&
+            !hc_get_deterministic()) {
+            const int tiles_x = (W + dwt::TW - 1) / dwt::TW, tiles_y = (H + dwt::TH - 1) / dwt::TH;
+            const int nslices = (cg + 7) / 8;
+            const long ntiles = (long)N * tiles_x * tiles_y;
+            long gx = (2 * 256 + nslices - 1) / nslices;
+            if (gx > ntiles) gx = ntiles;
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_wgrad_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dwt::WIN_BYTES);
+                attr = true;
+            }
+            hipLaunchKernelGGL(dw3x3_wgrad_tile_kernel, dim3((unsigned)gx, nslices), dim3(DW_THREADS), dwt::WIN_BYTES, st, x, (const u32x4*)dy,
+                               (float*)ws, N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
+        } else if (stride == 1) {
             constexpr int TW = 4;
             const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
             hipLaunchKernelGGL((dw3x3_wgrad_kernel<1, TW>), dim3(dw_blocks(items, cg, 4)), dim3(DW_THREADS), lds, st, (const u32x4*)x,

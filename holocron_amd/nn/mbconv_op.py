@@ -23,13 +23,15 @@ from .convbn_op import ConvState, act_code, as_cl_view, cl_ld
 from .repblock_op import POOL
 
 
-# Wide layers travel with their channel count padded to a multiple of 64 instead of 16 (HC_PAD_WIDE_FROM, default 200 channels;
+# Wide layers travel with their channel count padded to a multiple of 64 instead of 16 (HC_PAD_WIDE_FROM, default 160 channels;
 # 0 = always 16).  The gather-conv's k-step is the largest of 64 / 32 / 16 channels that divides the padded count: ReXNet's late
 # widths (228, 300, 366, 432, 840, 906, 972 -> 240, 304, 368, 432, 848, 912, 976) are all = 16 mod 32, so every 1 x 1 convolution
 # over them ran 15-61 sixteen-channel steps, each a DMA round trip for a quarter of the MFMA work of a 64-channel step.  Padding those
 # tensors costs 2-7 % more bytes on layers that are 7 x 7 / 14 x 14 / 28 x 28 maps; rexnet1_0x step 22.45 -> 21.92 ms (same box;
-# 32-channel padding 22.09, padding from 96 channels on 22.84: the 56 x 56 stages are HBM-bound and pay for their padding).
-_PAD_WIDE_FROM = int(__import__("os").environ.get("HC_PAD_WIDE_FROM", "200"))
+# 32-channel padding 22.09, padding from 96 channels on 22.84: the 56 x 56 stages are HBM-bound and pay for their padding).  With the
+# LDS-tiled depthwise kernels (64-channel slices: csrc/dwconv.hip) the threshold moved from 200 to 160: 162 -> 192 channels is three
+# whole slices (22.36 -> 22.22 ms same-box).
+_PAD_WIDE_FROM = int(__import__("os").environ.get("HC_PAD_WIDE_FROM", "160"))
 _PAD_WIDE_TO = int(__import__("os").environ.get("HC_PAD_WIDE_TO", "64"))
 
 

@@ -1,0 +1,58 @@
+"""Depthwise 3x3 forward (stride 1, with statistics) shape by shape: strip kernel (HC_DW_TILE=0) against the LDS-tiled kernel, at the
+rexnet1_0x batch-256 shapes.  Re-runs itself in two child processes (the switch is read once per process)."""
+import json
+import os
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SHAPES = [(256, 32, 112), (256, 176, 56), (256, 304, 28), (256, 432, 14), (256, 96, 56), (256, 64, 112), (256, 128, 56)]
+
+
+def child():
+    import torch
+    from holocron_amd import _lib
+    from holocron_amd._lib import check, ptr, stream
+    from holocron_amd.ops import conv as cv
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    out = {}
+    for N, C, H in SHAPES:
+        g = torch.Generator(device=dev).manual_seed(C)
+        x = cv.to_cl_bf16(torch.rand((N, C, H, H), device=dev, generator=g) - 0.5)
+        w = torch.randn((9, C), device=dev, generator=g)
+        y = cv.empty_cl(N, C, H, H, dev)
+        stats = torch.zeros((_lib.stat_replicas(), 2, C), device=dev)
+        for _ in range(3):
+            check(lib.hc_dw3x3_fwd(ptr(x), ptr(w), ptr(y), ptr(stats), N, H, H, C, 1, stream()), "dw")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            check(lib.hc_dw3x3_fwd(ptr(x), ptr(w), ptr(y), ptr(stats), N, H, H, C, 1, stream()), "dw")
+        e1.record()
+        torch.cuda.synchronize()
+        out["%d@%d" % (C, H)] = {"us": e0.elapsed_time(e1) * 100.0, "crc": int(y.view(torch.int16).to(torch.int64).sum().item()),
+                                 "mb": 2.0 * x.numel() * 2 / 1e6}
+    print("RESULT " + json.dumps(out))
+
+
+def run(env):
+    e = dict(os.environ)
+    e.update(env)
+    e["DW_CHILD"] = "1"
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=e, capture_output=True, text=True)
+    for line in r.stdout.splitlines():
+        if line.startswith("RESULT "):
+            return json.loads(line[7:])
+    raise RuntimeError(r.stdout[-2000:] + r.stderr[-3000:])
+
+
+if __name__ == "__main__":
+    if os.environ.get("DW_CHILD") == "1":
+        child()
+    else:
+        a, b = run({"HC_DW_TILE": "0"}), run({"HC_DW_TILE": "1", "HC_DW_TILE_MINW": "8", "HC_DW_TILE_MINC": "8"})
+        print(f"{'shape':<10} {'MB':>7} {'strip us':>9} {'TB/s':>6} {'tile us':>9} {'TB/s':>6}  same bits")
+        for k in a:
+            print(f"{k:<10} {a[k]['mb']:>7.0f} {a[k]['us']:>9.1f} {a[k]['mb'] / a[k]['us']:>6.2f} {b[k]['us']:>9.1f} {b[k]['mb'] / b[k]['us']:>6.2f}  {a[k]['crc'] == b[k]['crc']}")
