@@ -148,21 +148,29 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_fwd_kernel(const u32x4* __re
 // the 10 x 34 input window of a tile goes HBM / L2 -> LDS by DMA once (1.33 fetched bytes per output byte instead of 4.5, zero halo =
 // out-of-range offsets), and the 3 x 10 window of a thread's 8-pixel strip is 30 ds_read_b128 of it.  Two workgroups per CU overlap one
 // tile's DMA wait with the other's arithmetic.  Same tap order per output as the strip kernel: bit-identical results.
-namespace dwt {
-constexpr int TH = 8, SW = 8, NSTRIP = 4, TW = SW * NSTRIP;        // tile: 8 rows x 32 columns
-constexpr int PITCH_PX = 40, PX_BYTES = 128, ROW_BYTES = PITCH_PX * PX_BYTES, ROWS = TH + 2, WIN_BYTES = ROWS * ROW_BYTES;   // 51 200 B
-constexpr int PIECES_ROW = PITCH_PX / 8, PIECES = ROWS * PIECES_ROW;
-}
+// Tile shapes: 8 rows x 32 columns (NSTRIP = 4) for wide maps, 16 x 16 (NSTRIP = 2) for the 14 x 14 / 16 x 16 maps - 256 threads =
+// 8 channel groups x NSTRIP strips of 8 pixels x TH rows either way
+template <int NSTRIP_>
+struct DwTile {
+    static constexpr int NSTRIP = NSTRIP_, SW = 8, TW = SW * NSTRIP, TH = 32 / NSTRIP;
+    static constexpr int PITCH_PX = (TW + 2 + 7) / 8 * 8, PX_BYTES = 128, ROW_BYTES = PITCH_PX * PX_BYTES, ROWS = TH + 2;
+    static constexpr int WIN_BYTES = ROWS * ROW_BYTES;     // 51 200 B (8 x 32) / 55 296 B (16 x 16)
+    static constexpr int PIECES_ROW = PITCH_PX / 8, PIECES = ROWS * PIECES_ROW;
+};
+template <int NSTRIP_>
 __global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_fwd_tile_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                                        u32x4* __restrict__ y, float* __restrict__ stats, int N, int H,
                                                                        int W, int C, const int reps, int tiles_x, int tiles_y) {
-    using namespace dwt;
+    using G = DwTile<NSTRIP_>;
+    constexpr int TH = G::TH, SW = G::SW, NSTRIP = G::NSTRIP, TW = G::TW, ROW_BYTES = G::ROW_BYTES, PX_BYTES = G::PX_BYTES, PIECES = G::PIECES,
+                  PIECES_ROW = G::PIECES_ROW;
+    (void)TH;
     extern __shared__ __attribute__((aligned(1024))) char dsm[];
     const int cg = C / 8, slice = blockIdx.y;
     const int gs = min(8, cg - slice * 8);                 // channel groups of this slice
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gl = tid & 7, sidx = (tid >> 3) & (NSTRIP - 1), r = tid >> 5;
+    const int gl = tid & 7, sidx = (tid >> 3) & (NSTRIP - 1), r = tid / (8 * NSTRIP);
     const bool live = gl < gs;
     const int cgi = slice * 8 + (live ? gl : 0);
     float wr[9][8];
@@ -373,16 +381,20 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_wgrad_kernel(const u32x4* __
 // the 8 gradient pixels of its strip (read straight from global memory, 16 bytes each, 128-byte runs over the channel groups) with
 // the 3 x 10 window around them and keeps its 72 running sums for the whole kernel; one LDS reduction over the 32 threads of a channel
 // group and one atomic per (tap, channel) at the end, into the replica slab the strip kernel writes too.
+template <int NSTRIP_>
 __global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_wgrad_tile_kernel(const void* __restrict__ x, const u32x4* __restrict__ dy,
                                                                          float* __restrict__ dw, int N, int H, int W, int C, const int reps,
                                                                          int tiles_x, int tiles_y) {
-    using namespace dwt;
+    using G = DwTile<NSTRIP_>;
+    constexpr int TH = G::TH, SW = G::SW, NSTRIP = G::NSTRIP, TW = G::TW, ROW_BYTES = G::ROW_BYTES, PX_BYTES = G::PX_BYTES, PIECES = G::PIECES,
+                  PIECES_ROW = G::PIECES_ROW;
+    (void)TH;
     extern __shared__ __attribute__((aligned(1024))) char dsm[];
     const int cg = C / 8, slice = blockIdx.y;
     const int gs = min(8, cg - slice * 8);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gl = tid & 7, sidx = (tid >> 3) & (NSTRIP - 1), r = tid >> 5;
+    const int gl = tid & 7, sidx = (tid >> 3) & (NSTRIP - 1), r = tid / (8 * NSTRIP);
     const bool live = gl < gs;
     const int cgi = slice * 8 + (live ? gl : 0);
     float acc[9][8];
@@ -701,24 +713,31 @@ int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t
     const int cg = C / 8;
     const size_t lds = stats != nullptr ? (size_t)DW_THREADS * 17 * sizeof(float) : 0;
     // HC_DW_TILE=0: the strip kernel for every stride-1 launch (A/B); the LDS-tiled kernel takes maps of at least HC_DW_TILE_MINW
-    // (default 24) pixels and 32-bit byte offsets
+    // (default 12) pixels and 32-bit byte offsets
     static const int tile_on = [] { const char* e = getenv("HC_DW_TILE"); return e == nullptr ? 1 : atoi(e); }();
-    static const int tile_minw = [] { const char* e = getenv("HC_DW_TILE_MINW"); return e == nullptr ? 24 : atoi(e); }();
+    static const int tile_minw = [] { const char* e = getenv("HC_DW_TILE_MINW"); return e == nullptr ? 12 : atoi(e); }();
     static const int tile_minc = [] { const char* e = getenv("HC_DW_TILE_MINC"); return e == nullptr ? 32 : atoi(e); }();
     if (stride == 1 && tile_on && W >= tile_minw && H >= 8 && C >= tile_minc && (double)N * H * W * C * 2.0 < 4294967000.0) {
-        const int tiles_x = (W + dwt::TW - 1) / dwt::TW, tiles_y = (H + dwt::TH - 1) / dwt::TH;
+        const bool narrow = W <= 16;                       // 16 x 16 tiles for the 14 x 14 / 16 x 16 maps, 8 x 32 otherwise
+        const int tw = narrow ? DwTile<2>::TW : DwTile<4>::TW, th = narrow ? DwTile<2>::TH : DwTile<4>::TH;
+        const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
         const int nslices = (cg + 7) / 8;
         const long ntiles = (long)N * tiles_x * tiles_y;
         long gx = (2 * 256 + nslices - 1) / nslices;       // two resident workgroups per CU over all slices
         if (gx > ntiles) gx = ntiles;
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_fwd_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dwt::WIN_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_fwd_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, DwTile<4>::WIN_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_fwd_tile_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DwTile<2>::WIN_BYTES);
             attr = true;
         }
         if (stats != nullptr && hc_get_deterministic() && gx * nslices > hc_get_stat_replicas()) return HC_ERR_ARG;
-        hipLaunchKernelGGL(dw3x3_fwd_tile_kernel, dim3((unsigned)gx, nslices), dim3(DW_THREADS), dwt::WIN_BYTES, st, x, wpk, (u32x4*)y, stats,
-                           N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
+        if (narrow)
+            hipLaunchKernelGGL(dw3x3_fwd_tile_kernel<2>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwTile<2>::WIN_BYTES, st, x, wpk, (u32x4*)y,
+                               stats, N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
+        else
+            hipLaunchKernelGGL(dw3x3_fwd_tile_kernel<4>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwTile<4>::WIN_BYTES, st, x, wpk, (u32x4*)y,
+                               stats, N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
     } else if (stride == 1) {
         constexpr int TW = 4;
         const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
@@ -764,22 +783,29 @@ int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N
     if ((long)N * OH * OW > 0) {
         const size_t lds = (size_t)DW_THREADS * 25 * sizeof(float);
         static const int tile_on = [] { const char* e = getenv("HC_DW_TILE"); return e == nullptr ? 1 : atoi(e); }();
-        static const int tile_minw = [] { const char* e = getenv("HC_DW_TILE_MINW"); return e == nullptr ? 24 : atoi(e); }();
+        static const int tile_minw = [] { const char* e = getenv("HC_DW_TILE_MINW"); return e == nullptr ? 12 : atoi(e); }();
         static const int tile_minc = [] { const char* e = getenv("HC_DW_TILE_MINC"); return e == nullptr ? 32 : atoi(e); }();
         if (stride == 1 && tile_on && W >= tile_minw && H >= 8 && C >= tile_minc && (double)N * H * W * C * 2.0 < 4294967000.0 &&
             !hc_get_deterministic()) {
-            const int tiles_x = (W + dwt::TW - 1) / dwt::TW, tiles_y = (H + dwt::TH - 1) / dwt::TH;
+            const bool narrow = W <= 16;
+            const int tw = narrow ? DwTile<2>::TW : DwTile<4>::TW, th = narrow ? DwTile<2>::TH : DwTile<4>::TH;
+            const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
             const int nslices = (cg + 7) / 8;
             const long ntiles = (long)N * tiles_x * tiles_y;
             long gx = (2 * 256 + nslices - 1) / nslices;
             if (gx > ntiles) gx = ntiles;
             static bool attr = false;
             if (!attr) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_wgrad_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dwt::WIN_BYTES);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_wgrad_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, DwTile<4>::WIN_BYTES);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_wgrad_tile_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DwTile<2>::WIN_BYTES);
                 attr = true;
             }
-            hipLaunchKernelGGL(dw3x3_wgrad_tile_kernel, dim3((unsigned)gx, nslices), dim3(DW_THREADS), dwt::WIN_BYTES, st, x, (const u32x4*)dy,
-                               (float*)ws, N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
+            if (narrow)
+                hipLaunchKernelGGL(dw3x3_wgrad_tile_kernel<2>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwTile<2>::WIN_BYTES, st, x,
+                                   (const u32x4*)dy, (float*)ws, N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
+            else
+                hipLaunchKernelGGL(dw3x3_wgrad_tile_kernel<4>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwTile<4>::WIN_BYTES, st, x,
+                                   (const u32x4*)dy, (float*)ws, N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
         } else if (stride == 1) {
             constexpr int TW = 4;
             const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
