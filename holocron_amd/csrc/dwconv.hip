@@ -150,29 +150,37 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_fwd_kernel(const u32x4* __re
 // tile's DMA wait with the other's arithmetic.  Same tap order per output as the strip kernel: bit-identical results.
 // Tile shapes: 8 rows x 32 columns (NSTRIP = 4) for wide maps, 16 x 16 (NSTRIP = 2) for the 14 x 14 / 16 x 16 maps - 256 threads =
 // 8 channel groups x NSTRIP strips of 8 pixels x TH rows either way
-template <int NSTRIP_>
+// GROUPS_ = channel groups (of 8 channels) per slice: 8 (128 bytes per pixel), or 4 for 32-channel layers (8 x 64 tiles: the same
+// 256 threads, no idle lanes)
+template <int NSTRIP_, int GROUPS_ = 8>
 struct DwTile {
-    static constexpr int NSTRIP = NSTRIP_, SW = 8, TW = SW * NSTRIP, TH = 32 / NSTRIP;
-    static constexpr int PITCH_PX = (TW + 2 + 7) / 8 * 8, PX_BYTES = 128, ROW_BYTES = PITCH_PX * PX_BYTES, ROWS = TH + 2;
-    static constexpr int WIN_BYTES = ROWS * ROW_BYTES;     // 51 200 B (8 x 32) / 55 296 B (16 x 16)
-    static constexpr int PIECES_ROW = PITCH_PX / 8, PIECES = ROWS * PIECES_ROW;
+    static constexpr int NSTRIP = NSTRIP_, GROUPS = GROUPS_, SW = 8, TW = SW * NSTRIP, TH = 256 / (GROUPS * NSTRIP);
+    static constexpr int PPP = 64 / GROUPS;                // pixels per 1 KB DMA piece
+    static constexpr int PITCH_PX = (TW + 2 + PPP - 1) / PPP * PPP, PX_BYTES = 16 * GROUPS, ROW_BYTES = PITCH_PX * PX_BYTES, ROWS = TH + 2;
+    static constexpr int WIN_BYTES = ROWS * ROW_BYTES;     // 51 200 B (8 x 32) / 55 296 B (16 x 16) / 51 200 B (8 x 64, 4 groups)
+    static constexpr int PIECES_ROW = PITCH_PX / PPP, PIECES = ROWS * PIECES_ROW;
 };
-template <int NSTRIP_>
+using DwThin = DwTile<8, 4>;
+static bool dw_thin_on() {
+    static const bool on = [] { const char* e = getenv("HC_DW_TILE_THIN"); return !e || atoi(e) != 0; }();
+    return on;
+}
+template <int NSTRIP_, int GROUPS_ = 8>
 __global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_fwd_tile_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                                        u32x4* __restrict__ y, float* __restrict__ stats, int N, int H,
                                                                        int W, int C, const int reps, int tiles_x, int tiles_y) {
-    using G = DwTile<NSTRIP_>;
+    using G = DwTile<NSTRIP_, GROUPS_>;
     constexpr int TH = G::TH, SW = G::SW, NSTRIP = G::NSTRIP, TW = G::TW, ROW_BYTES = G::ROW_BYTES, PX_BYTES = G::PX_BYTES, PIECES = G::PIECES,
-                  PIECES_ROW = G::PIECES_ROW;
+                  PIECES_ROW = G::PIECES_ROW, GR = G::GROUPS, PPP = G::PPP;
     (void)TH;
     extern __shared__ __attribute__((aligned(1024))) char dsm[];
     const int cg = C / 8, slice = blockIdx.y;
-    const int gs = min(8, cg - slice * 8);                 // channel groups of this slice
+    const int gs = min(GR, cg - slice * GR);               // channel groups of this slice
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gl = tid & 7, sidx = (tid >> 3) & (NSTRIP - 1), r = tid / (8 * NSTRIP);
+    const int gl = tid & (GR - 1), sidx = (tid / GR) & (NSTRIP - 1), r = tid / (GR * NSTRIP);
     const bool live = gl < gs;
-    const int cgi = slice * 8 + (live ? gl : 0);
+    const int cgi = slice * GR + (live ? gl : 0);
     float wr[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -195,15 +203,15 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_fwd_tile_kernel(const voi
     const unsigned lds0 = hc_lds_addr(dsm);
     const int ntiles = N * tiles_y * tiles_x;
     // DMA lane constants: lane -> (pixel of the 8-pixel piece, channel group)
-    const int dpx = lane >> 3, dgr = lane & 7;
-    const unsigned choff = (unsigned)((slice * 64 + dgr * 8) * 2);
+    const int dpx = lane / GR, dgr = lane & (GR - 1);
+    const unsigned choff = (unsigned)((slice * GR * 8 + dgr * 8) * 2);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int n = tile / (tiles_y * tiles_x), rem = tile - n * (tiles_y * tiles_x);
         const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
         const int oy0 = ty * TH, ox0 = tx * TW;
         __syncthreads();                                   // everybody is done reading the previous window
         for (int q = wid; q < PIECES; q += 4) {
-            const int wr_ = q / PIECES_ROW, px = (q - wr_ * PIECES_ROW) * 8 + dpx;
+            const int wr_ = q / PIECES_ROW, px = (q - wr_ * PIECES_ROW) * PPP + dpx;
             const int iy = oy0 - 1 + wr_, ix = ox0 - 1 + px;
             const bool ok = dgr < gs && px < TW + 2 && iy >= 0 && iy < H && ix >= 0 && ix < W;
             const unsigned off = (unsigned)(((n * H + iy) * W + ix) * C * 2) + choff;
@@ -256,12 +264,12 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_fwd_tile_kernel(const voi
             for (int e = 0; e < 8; ++e) red[tid * 17 + k * 8 + e] = live ? sv[k][e] : 0.f;
         __syncthreads();
         float* rep = stats + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) % reps) * 2 * C;
-        for (int o = tid; o < 2 * 64; o += DW_THREADS) {
-            const int k = o >> 6, c = o & 63, g = c >> 3, e = c & 7;
+        for (int o = tid; o < 2 * GR * 8; o += DW_THREADS) {
+            const int k = o / (GR * 8), c = o - k * (GR * 8), g = c >> 3, e = c & 7;
             if (g >= gs) continue;
             float sum = 0.f;
-            for (int t = g; t < DW_THREADS; t += 8) sum += red[t * 17 + k * 8 + e];
-            atomicAdd(rep + (size_t)k * C + slice * 64 + c, sum);
+            for (int t = g; t < DW_THREADS; t += GR) sum += red[t * 17 + k * 8 + e];
+            atomicAdd(rep + (size_t)k * C + slice * GR * 8 + c, sum);
         }
     }
 }
@@ -381,22 +389,22 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_wgrad_kernel(const u32x4* __
 // the 8 gradient pixels of its strip (read straight from global memory, 16 bytes each, 128-byte runs over the channel groups) with
 // the 3 x 10 window around them and keeps its 72 running sums for the whole kernel; one LDS reduction over the 32 threads of a channel
 // group and one atomic per (tap, channel) at the end, into the replica slab the strip kernel writes too.
-template <int NSTRIP_>
+template <int NSTRIP_, int GROUPS_ = 8>
 __global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_wgrad_tile_kernel(const void* __restrict__ x, const u32x4* __restrict__ dy,
                                                                          float* __restrict__ dw, int N, int H, int W, int C, const int reps,
                                                                          int tiles_x, int tiles_y) {
-    using G = DwTile<NSTRIP_>;
+    using G = DwTile<NSTRIP_, GROUPS_>;
     constexpr int TH = G::TH, SW = G::SW, NSTRIP = G::NSTRIP, TW = G::TW, ROW_BYTES = G::ROW_BYTES, PX_BYTES = G::PX_BYTES, PIECES = G::PIECES,
-                  PIECES_ROW = G::PIECES_ROW;
+                  PIECES_ROW = G::PIECES_ROW, GR = G::GROUPS, PPP = G::PPP;
     (void)TH;
     extern __shared__ __attribute__((aligned(1024))) char dsm[];
     const int cg = C / 8, slice = blockIdx.y;
-    const int gs = min(8, cg - slice * 8);
+    const int gs = min(GR, cg - slice * GR);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gl = tid & 7, sidx = (tid >> 3) & (NSTRIP - 1), r = tid / (8 * NSTRIP);
+    const int gl = tid & (GR - 1), sidx = (tid / GR) & (NSTRIP - 1), r = tid / (GR * NSTRIP);
     const bool live = gl < gs;
-    const int cgi = slice * 8 + (live ? gl : 0);
+    const int cgi = slice * GR + (live ? gl : 0);
     float acc[9][8];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -412,8 +420,8 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_wgrad_tile_kernel(const v
     }
     const unsigned lds0 = hc_lds_addr(dsm);
     const int ntiles = N * tiles_y * tiles_x;
-    const int dpx = lane >> 3, dgr = lane & 7;
-    const unsigned choff = (unsigned)((slice * 64 + dgr * 8) * 2);
+    const int dpx = lane / GR, dgr = lane & (GR - 1);
+    const unsigned choff = (unsigned)((slice * GR * 8 + dgr * 8) * 2);
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int n = tile / (tiles_y * tiles_x), rem = tile - n * (tiles_y * tiles_x);
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_wgrad_tile_kernel(const v
         const int oy0 = ty * TH, ox0 = tx * TW;
         __syncthreads();
         for (int q = wid; q < PIECES; q += 4) {
-            const int wr_ = q / PIECES_ROW, px = (q - wr_ * PIECES_ROW) * 8 + dpx;
+            const int wr_ = q / PIECES_ROW, px = (q - wr_ * PIECES_ROW) * PPP + dpx;
             const int iy = oy0 - 1 + wr_, ix = ox0 - 1 + px;
             const bool ok = dgr < gs && px < TW + 2 && iy >= 0 && iy < H && ix >= 0 && ix < W;
             const unsigned off = (unsigned)(((n * H + iy) * W + ix) * C * 2) + choff;
@@ -470,12 +478,12 @@ __global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_wgrad_tile_kernel(const v
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[tid * 25 + k * 8 + e] = live ? acc[k0 + k][e] : 0.f;
         __syncthreads();
-        for (int o = tid; o < 3 * 64; o += DW_THREADS) {
-            const int k = o >> 6, c = o & 63, g = c >> 3, e = c & 7;
+        for (int o = tid; o < 3 * GR * 8; o += DW_THREADS) {
+            const int k = o / (GR * 8), c = o - k * (GR * 8), g = c >> 3, e = c & 7;
             if (g >= gs) continue;
             float sum = 0.f;
-            for (int t = g; t < DW_THREADS; t += 8) sum += red[t * 25 + k * 8 + e];
-            atomicAdd(rep + (size_t)(k0 + k) * C + slice * 64 + c, sum);
+            for (int t = g; t < DW_THREADS; t += GR) sum += red[t * 25 + k * 8 + e];
+            atomicAdd(rep + (size_t)(k0 + k) * C + slice * GR * 8 + c, sum);
         }
     }
 }
@@ -719,9 +727,10 @@ int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t
     static const int tile_minc = [] { const char* e = getenv("HC_DW_TILE_MINC"); return e == nullptr ? 32 : atoi(e); }();
     if (stride == 1 && tile_on && W >= tile_minw && H >= 8 && C >= tile_minc && (double)N * H * W * C * 2.0 < 4294967000.0) {
         const bool narrow = W <= 16;                       // 16 x 16 tiles for the 14 x 14 / 16 x 16 maps, 8 x 32 otherwise
-        const int tw = narrow ? DwTile<2>::TW : DwTile<4>::TW, th = narrow ? DwTile<2>::TH : DwTile<4>::TH;
+        const bool thin = !narrow && cg <= 4 && dw_thin_on();              // 32 channels or fewer: 4-group slices, 8 x 64 tiles
+        const int tw = narrow ? DwTile<2>::TW : (thin ? DwThin::TW : DwTile<4>::TW), th = narrow ? DwTile<2>::TH : DwTile<4>::TH;
         const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
-        const int nslices = (cg + 7) / 8;
+        const int nslices = thin ? 1 : (cg + 7) / 8;
         const long ntiles = (long)N * tiles_x * tiles_y;
         long gx = (2 * 256 + nslices - 1) / nslices;       // two resident workgroups per CU over all slices
         if (gx > ntiles) gx = ntiles;
@@ -729,12 +738,16 @@ int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t
         if (!attr) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_fwd_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, DwTile<4>::WIN_BYTES);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_fwd_tile_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DwTile<2>::WIN_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw3x3_fwd_tile_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, DwThin::WIN_BYTES);
             attr = true;
         }
         if (stats != nullptr && hc_get_deterministic() && gx * nslices > hc_get_stat_replicas()) return HC_ERR_ARG;
         if (narrow)
             hipLaunchKernelGGL(dw3x3_fwd_tile_kernel<2>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwTile<2>::WIN_BYTES, st, x, wpk, (u32x4*)y,
                                stats, N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
+        else if (thin)
+            hipLaunchKernelGGL((dw3x3_fwd_tile_kernel<8, 4>), dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwThin::WIN_BYTES, st, x, wpk,
+                               (u32x4*)y, stats, N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
         else
             hipLaunchKernelGGL(dw3x3_fwd_tile_kernel<4>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwTile<4>::WIN_BYTES, st, x, wpk, (u32x4*)y,
                                stats, N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
@@ -788,9 +801,10 @@ int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N
         if (stride == 1 && tile_on && W >= tile_minw && H >= 8 && C >= tile_minc && (double)N * H * W * C * 2.0 < 4294967000.0 &&
             !hc_get_deterministic()) {
             const bool narrow = W <= 16;
-            const int tw = narrow ? DwTile<2>::TW : DwTile<4>::TW, th = narrow ? DwTile<2>::TH : DwTile<4>::TH;
+            const bool thin = !narrow && cg <= 4 && dw_thin_on();
+            const int tw = narrow ? DwTile<2>::TW : (thin ? DwThin::TW : DwTile<4>::TW), th = narrow ? DwTile<2>::TH : DwTile<4>::TH;
             const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
-            const int nslices = (cg + 7) / 8;
+            const int nslices = thin ? 1 : (cg + 7) / 8;
             const long ntiles = (long)N * tiles_x * tiles_y;
             long gx = (2 * 256 + nslices - 1) / nslices;
             if (gx > ntiles) gx = ntiles;
@@ -798,10 +812,14 @@ int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N
             if (!attr) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_wgrad_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, DwTile<4>::WIN_BYTES);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_wgrad_tile_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DwTile<2>::WIN_BYTES);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dw3x3_wgrad_tile_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, DwThin::WIN_BYTES);
                 attr = true;
             }
             if (narrow)
                 hipLaunchKernelGGL(dw3x3_wgrad_tile_kernel<2>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwTile<2>::WIN_BYTES, st, x,
+                                   (const u32x4*)dy, (float*)ws, N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
+            else if (thin)
+                hipLaunchKernelGGL((dw3x3_wgrad_tile_kernel<8, 4>), dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwThin::WIN_BYTES, st, x,
                                    (const u32x4*)dy, (float*)ws, N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
             else
                 hipLaunchKernelGGL(dw3x3_wgrad_tile_kernel<4>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwTile<4>::WIN_BYTES, st, x,

@@ -19,7 +19,10 @@ def test_depthwise_conv_kernels_vs_torch():
     import holocron_amd as h
     from holocron_amd.nn.mbconv_op import padded_conv_bn_act
     g = torch.Generator().manual_seed(3)
-    for (Cc, H, W, stride) in [(24, 9, 7, 1), (40, 12, 10, 2), (162, 6, 5, 1), (16, 5, 5, 2)]:
+    for (Cc, H, W, stride) in [(24, 9, 7, 1), (40, 12, 10, 2), (162, 6, 5, 1), (16, 5, 5, 2),
+                                 # the LDS-tiled kernels (W >= 12, H >= 8, C >= 32 padded): 4-group 8 x 64 tiles, 8 x 32 tiles with a
+                                 # partial channel slice, 16 x 16 tiles - all with ragged edges
+                                 (24, 13, 37, 1), (72, 19, 45, 1), (40, 15, 14, 1)]:
         conv = torch.nn.Conv2d(Cc, Cc, 3, stride, 1, groups=Cc, bias=False)
         bn = torch.nn.BatchNorm2d(Cc)
         conv.weight.data = torch.randn(conv.weight.shape, generator=g) * 0.3
