@@ -161,9 +161,22 @@ struct DwTile {
     static constexpr int PIECES_ROW = PITCH_PX / PPP, PIECES = ROWS * PIECES_ROW;
 };
 using DwThin = DwTile<8, 4>;
-static bool dw_thin_on() {
-    static const bool on = [] { const char* e = getenv("HC_DW_TILE_THIN"); return !e || atoi(e) != 0; }();
+// HC_DW_S2=0: the round-3 stride-2 kernels (A/B); the tiled stride-2 kernels take output maps of at least HC_DW_S2_MINW (default 12) columns
+static int dw_s2_on() {
+    static const int on = [] { const char* e = getenv("HC_DW_S2"); const char* t = getenv("HC_DW_TILE");
+                               return (t != nullptr && atoi(t) == 0) ? 0 : (e == nullptr ? 1 : atoi(e)); }();
     return on;
+}
+static int dw_s2_minw() {
+    static const int v = [] { const char* e = getenv("HC_DW_S2_MINW"); return e == nullptr ? 12 : atoi(e); }();
+    return v;
+}
+// 4-group slices for layers of 32 channels or fewer (HC_DW_TILE_THIN >= 1, the default).  HC_DW_TILE_THIN=2 also splits 72 .. 96
+// channels into 4-group slices: measured SLOWER (96@56 stride 1: 3.62 -> 2.83 TB/s; 96@112 stride 2 no better than the strip kernel) -
+// three workgroups then fetch 64-byte thirds of every 192-byte pixel at different times, and every 128-byte line is fetched twice
+static bool dw_thin(int cg) {
+    static const int mode = [] { const char* e = getenv("HC_DW_TILE_THIN"); return e == nullptr ? 1 : atoi(e); }();
+    return (mode >= 1 && cg <= 4) || (mode >= 2 && cg >= 9 && cg <= 12);
 }
 template <int NSTRIP_, int GROUPS_ = 8>
 __global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_fwd_tile_kernel(const void* __restrict__ x, const float* __restrict__ w,
@@ -319,6 +332,302 @@ __global__ __launch_bounds__(DW_THREADS) void dw3x3_dgrad_s2_kernel(const u32x4*
             }
         }
         dx[p * cg + cgi] = pack8(acc);
+    }
+}
+
+// ---------------------------------------------------------------- stride-2 data gradient, 2 x 2 blocks (round 4)
+// The kernel above decodes one dx pixel per thread and loads the 1, 2 or 4 gradient pixels its parity class touches: 2.25 loads and
+// three integer divisions per 16 bytes written.  Here a thread owns two dx rows (2a, 2a + 1) over 2 SW columns: the 2 x (SW + 1)
+// gradient pixels dy[a .. a + 1][b0 .. b0 + SW] feed all 4 SW outputs (0.625 loads per output at SW = 4), one index decode per strip.
+// Same taps in the same order per output as the kernel above (out-of-range taps add +0): bit-identical.
+template <int SW>
+__global__ __launch_bounds__(DW_THREADS) void dw3x3_dgrad_s2_blk_kernel(const u32x4* __restrict__ dy, const float* __restrict__ w,
+                                                                        u32x4* __restrict__ dx, int N, int H, int W, int OH, int OW, int C) {
+    const int cg = C / 8;
+    const long gtid = (long)blockIdx.x * DW_THREADS + threadIdx.x;
+    const long nthreads = (long)gridDim.x * DW_THREADS;
+    const int cgi = (int)(gtid % cg);
+    float wr[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(w + (size_t)t * C + cgi * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(w + (size_t)t * C + cgi * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wr[t][e] = a[e]; wr[t][4 + e] = b[e]; }
+    }
+    const int strips_w = (OW + SW - 1) / SW;
+    const long nstrips = (long)N * OH * strips_w;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    for (long s = gtid / cg; s < nstrips; s += nthreads / cg) {
+        const unsigned su = (unsigned)s, ru = su / (unsigned)strips_w;
+        const int sw = (int)(su - ru * (unsigned)strips_w);
+        const unsigned nu = ru / (unsigned)OH;
+        const int a = (int)(ru - nu * (unsigned)OH);
+        const long n = nu;
+        const int b0 = sw * SW;
+        u32x4 gp[2][SW + 1];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const bool rok = a + rr < OH;
+            const u32x4* grow = dy + ((n * OH + (rok ? a + rr : a)) * (long)OW) * cg + cgi;
+#pragma unroll
+            for (int j = 0; j <= SW; ++j) gp[rr][j] = (rok && b0 + j < OW) ? grow[(long)(b0 + j) * cg] : zero4;
+        }
+        float g[2][SW + 1][8];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int j = 0; j <= SW; ++j) unpack8(gp[rr][j], g[rr][j]);
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int ih = 2 * a + pr;
+            if (ih >= H) continue;
+            u32x4* orow = dx + ((n * H + ih) * (long)W) * cg + cgi;
+#pragma unroll
+            for (int jj = 0; jj < 2 * SW; ++jj) {
+                const int iw = 2 * b0 + jj;
+                if (iw >= W) break;
+                const int pc = jj & 1, jb = jj >> 1;
+                float acc[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int t = pr + 1 - kh;               // ih + 1 - kh = 2 a + t
+                    if (t < 0 || (t & 1)) continue;
+                    const int rr = t >> 1;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int u = pc + 1 - kw;
+                        if (u < 0 || (u & 1)) continue;
+                        const int cj = jb + (u >> 1);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] += wr[kh * 3 + kw][e] * g[rr][cj][e];
+                    }
+                }
+                orow[(long)iw * cg] = pack8(acc);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- forward / weight gradient, stride 2, LDS-TILED (round 4)
+// A workgroup owns a slice of GROUPS channel groups and walks 8 x TW output tiles (TW = 16 at 8 groups, 32 at 4 groups; 4 outputs per
+// thread): the 17 x (2 TW + 1) input window goes to LDS by DMA as one linear run of pixels (no row pitch: 72 704 / 71 680 bytes, two
+// workgroups per CU), 1.1 fetched input bytes per input byte used, and a thread's 3 x 9 window is 27 ds_read_b128.  Tap order per output
+// as dw3x3_fwd_kernel<2, 2>: bit-identical forward.
+template <int GROUPS_>
+struct DwTileS2 {
+    static constexpr int GROUPS = GROUPS_, SW = 4, NSTRIP = 32 / GROUPS, TH = 8, TW = SW * NSTRIP;
+    static constexpr int WINW = 2 * TW + 1, WINH = 2 * TH + 1, WINPX = WINW * WINH, PPP = 64 / GROUPS, PX_BYTES = 16 * GROUPS;
+    static constexpr int PIECES = (WINPX + PPP - 1) / PPP, WIN_BYTES = PIECES * 1024;
+};
+using DwS2Wide = DwTileS2<8>;
+using DwS2Thin = DwTileS2<4>;
+
+template <int GROUPS_>
+__global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_fwd_s2_tile_kernel(const void* __restrict__ x, const float* __restrict__ w,
+                                                                          u32x4* __restrict__ y, float* __restrict__ stats, int N, int H,
+                                                                          int W, int OH, int OW, int C, const int reps, int tiles_x,
+                                                                          int tiles_y) {
+    using G = DwTileS2<GROUPS_>;
+    constexpr int TH = G::TH, SW = G::SW, NSTRIP = G::NSTRIP, TW = G::TW, WINW = G::WINW, WINPX = G::WINPX, PX_BYTES = G::PX_BYTES,
+                  PIECES = G::PIECES, GR = G::GROUPS, PPP = G::PPP;
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];
+    const int cg = C / 8, slice = blockIdx.y;
+    const int gs = min(GR, cg - slice * GR);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gl = tid & (GR - 1), sidx = (tid / GR) & (NSTRIP - 1), r = tid / (GR * NSTRIP);
+    const bool live = gl < gs;
+    const int cgi = slice * GR + (live ? gl : 0);
+    float wr[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(w + (size_t)t * C + cgi * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(w + (size_t)t * C + cgi * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wr[t][e] = a[e]; wr[t][4 + e] = b[e]; }
+    }
+    float sv[2][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sv[0][e] = sv[1][e] = 0.f;
+    u32x4 rs;
+    {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(x);
+        rs[0] = __builtin_amdgcn_readfirstlane((unsigned)v);
+        rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32) & 0xffffu);
+        rs[2] = __builtin_amdgcn_readfirstlane((unsigned)((long)N * H * W * C * 2));
+        rs[3] = 0x00020000u;
+    }
+    const unsigned lds0 = hc_lds_addr(dsm);
+    const int ntiles = N * tiles_y * tiles_x;
+    const int dpx = lane / GR, dgr = lane & (GR - 1);
+    const unsigned choff = (unsigned)((slice * GR * 8 + dgr * 8) * 2);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / (tiles_y * tiles_x), rem = tile - n * (tiles_y * tiles_x);
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        __syncthreads();
+        for (int q = wid; q < PIECES; q += 4) {
+            const int idx = q * PPP + dpx;
+            const int wr_ = idx / WINW, px = idx - wr_ * WINW;
+            const int iy = 2 * oy0 - 1 + wr_, ix = 2 * ox0 - 1 + px;
+            const bool ok = dgr < gs && idx < WINPX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const unsigned off = (unsigned)(((n * H + iy) * W + ix) * C * 2) + choff;
+            hc_dma16(rs, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(q * 1024)), ok ? off : HC_OOB);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int oy = oy0 + r;
+        if (live && oy < OH) {
+            float acc[SW][8];
+#pragma unroll
+            for (int j = 0; j < SW; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+            const char* base = dsm + ((2 * r) * WINW + 2 * sidx * SW) * PX_BYTES + gl * 16;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int c = 0; c < 2 * SW + 1; ++c) {
+                    float f[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(base + (kh * WINW + c) * PX_BYTES), f);
+#pragma unroll
+                    for (int j = 0; j < SW; ++j) {
+                        const int kw = c - 2 * j;
+                        if (kw < 0 || kw > 2) continue;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[j][e] += wr[kh * 3 + kw][e] * f[e];
+                    }
+                }
+            }
+            u32x4* orow = y + ((long)(n * OH + oy) * OW) * cg + cgi;
+#pragma unroll
+            for (int j = 0; j < SW; ++j) {
+                const int ox = ox0 + sidx * SW + j;
+                if (ox >= OW) break;
+                orow[(long)ox * cg] = pack8(acc[j]);
+                if (stats != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { sv[0][e] += acc[j][e]; sv[1][e] += acc[j][e] * acc[j][e]; }
+                }
+            }
+        }
+    }
+    if (stats != nullptr) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(dsm);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[tid * 17 + k * 8 + e] = live ? sv[k][e] : 0.f;
+        __syncthreads();
+        float* rep = stats + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) % reps) * 2 * C;
+        for (int o = tid; o < 2 * GR * 8; o += DW_THREADS) {
+            const int k = o / (GR * 8), c = o - k * (GR * 8), g = c >> 3, e = c & 7;
+            if (g >= gs) continue;
+            float sum = 0.f;
+            for (int t = g; t < DW_THREADS; t += GR) sum += red[t * 17 + k * 8 + e];
+            atomicAdd(rep + (size_t)k * C + slice * GR * 8 + c, sum);
+        }
+    }
+}
+
+template <int GROUPS_>
+__global__ __launch_bounds__(DW_THREADS, 2) void dw3x3_wgrad_s2_tile_kernel(const void* __restrict__ x, const u32x4* __restrict__ dy,
+                                                                            float* __restrict__ dw, int N, int H, int W, int OH, int OW,
+                                                                            int C, const int reps, int tiles_x, int tiles_y) {
+    using G = DwTileS2<GROUPS_>;
+    constexpr int TH = G::TH, SW = G::SW, NSTRIP = G::NSTRIP, TW = G::TW, WINW = G::WINW, WINPX = G::WINPX, PX_BYTES = G::PX_BYTES,
+                  PIECES = G::PIECES, GR = G::GROUPS, PPP = G::PPP;
+    extern __shared__ __attribute__((aligned(1024))) char dsm[];
+    const int cg = C / 8, slice = blockIdx.y;
+    const int gs = min(GR, cg - slice * GR);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gl = tid & (GR - 1), sidx = (tid / GR) & (NSTRIP - 1), r = tid / (GR * NSTRIP);
+    const bool live = gl < gs;
+    const int cgi = slice * GR + (live ? gl : 0);
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    u32x4 rs;
+    {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(x);
+        rs[0] = __builtin_amdgcn_readfirstlane((unsigned)v);
+        rs[1] = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32) & 0xffffu);
+        rs[2] = __builtin_amdgcn_readfirstlane((unsigned)((long)N * H * W * C * 2));
+        rs[3] = 0x00020000u;
+    }
+    const unsigned lds0 = hc_lds_addr(dsm);
+    const int ntiles = N * tiles_y * tiles_x;
+    const int dpx = lane / GR, dgr = lane & (GR - 1);
+    const unsigned choff = (unsigned)((slice * GR * 8 + dgr * 8) * 2);
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / (tiles_y * tiles_x), rem = tile - n * (tiles_y * tiles_x);
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        __syncthreads();
+        for (int q = wid; q < PIECES; q += 4) {
+            const int idx = q * PPP + dpx;
+            const int wr_ = idx / WINW, px = idx - wr_ * WINW;
+            const int iy = 2 * oy0 - 1 + wr_, ix = 2 * ox0 - 1 + px;
+            const bool ok = dgr < gs && idx < WINPX && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const unsigned off = (unsigned)(((n * H + iy) * W + ix) * C * 2) + choff;
+            hc_dma16(rs, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(q * 1024)), ok ? off : HC_OOB);
+        }
+        const int oy = oy0 + r;
+        u32x4 gp[SW];
+        const u32x4* grow = dy + ((long)(n * OH + (oy < OH ? oy : 0)) * OW) * cg + cgi;
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+            const int ox = ox0 + sidx * SW + j;
+            gp[j] = (live && oy < OH && ox < OW) ? grow[(long)ox * cg] : zero4;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (live && oy < OH) {
+            const char* base = dsm + ((2 * r) * WINW + 2 * sidx * SW) * PX_BYTES + gl * 16;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int c = 0; c < 2 * SW + 1; ++c) {
+                    float f[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(base + (kh * WINW + c) * PX_BYTES), f);
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int j2 = c - kw;
+                        if (j2 < 0 || (j2 & 1) || (j2 >> 1) >= SW) continue;
+                        float g[8];
+                        unpack8(gp[j2 >> 1], g);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[kh * 3 + kw][e] += g[e] * f[e];
+                    }
+                }
+            }
+        }
+    }
+    float* red = reinterpret_cast<float*>(dsm);
+    float* rep = dw + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) % reps) * 9 * C;
+#pragma unroll
+    for (int k0 = 0; k0 < 9; k0 += 3) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[tid * 25 + k * 8 + e] = live ? acc[k0 + k][e] : 0.f;
+        __syncthreads();
+        for (int o = tid; o < 3 * GR * 8; o += DW_THREADS) {
+            const int k = o / (GR * 8), c = o - k * (GR * 8), g = c >> 3, e = c & 7;
+            if (g >= gs) continue;
+            float sum = 0.f;
+            for (int t = g; t < DW_THREADS; t += GR) sum += red[t * 25 + k * 8 + e];
+            atomicAdd(rep + (size_t)(k0 + k) * C + slice * GR * 8 + c, sum);
+        }
     }
 }
 
@@ -727,10 +1036,10 @@ int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t
     static const int tile_minc = [] { const char* e = getenv("HC_DW_TILE_MINC"); return e == nullptr ? 32 : atoi(e); }();
     if (stride == 1 && tile_on && W >= tile_minw && H >= 8 && C >= tile_minc && (double)N * H * W * C * 2.0 < 4294967000.0) {
         const bool narrow = W <= 16;                       // 16 x 16 tiles for the 14 x 14 / 16 x 16 maps, 8 x 32 otherwise
-        const bool thin = !narrow && cg <= 4 && dw_thin_on();              // 32 channels or fewer: 4-group slices, 8 x 64 tiles
+        const bool thin = !narrow && dw_thin(cg);              // 32 channels or fewer: 4-group slices, 8 x 64 tiles
         const int tw = narrow ? DwTile<2>::TW : (thin ? DwThin::TW : DwTile<4>::TW), th = narrow ? DwTile<2>::TH : DwTile<4>::TH;
         const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
-        const int nslices = thin ? 1 : (cg + 7) / 8;
+        const int nslices = thin ? (cg + 3) / 4 : (cg + 7) / 8;
         const long ntiles = (long)N * tiles_x * tiles_y;
         long gx = (2 * 256 + nslices - 1) / nslices;       // two resident workgroups per CU over all slices
         if (gx > ntiles) gx = ntiles;
@@ -756,6 +1065,27 @@ int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t
         const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
         hipLaunchKernelGGL((dw3x3_fwd_kernel<1, TW>), dim3(dw_blocks(items, cg, 2)), dim3(DW_THREADS), lds, st, (const u32x4*)x, wpk,
                            (u32x4*)y, stats, N, H, W, OH, OW, C, hc_get_stat_replicas());
+    } else if (dw_s2_on() && OW >= dw_s2_minw() && OH >= 8 && C >= tile_minc && (double)N * H * W * C * 2.0 < 4294967000.0) {
+        const bool thin = dw_thin(cg);
+        const int tw = thin ? DwS2Thin::TW : DwS2Wide::TW, th = DwS2Wide::TH;
+        const int tiles_x = (OW + tw - 1) / tw, tiles_y = (OH + th - 1) / th;
+        const int nslices = thin ? (cg + 3) / 4 : (cg + 7) / 8;
+        const long ntiles = (long)N * tiles_x * tiles_y;
+        long gx = (2 * 256 + nslices - 1) / nslices;
+        if (gx > ntiles) gx = ntiles;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_fwd_s2_tile_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, DwS2Wide::WIN_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_fwd_s2_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, DwS2Thin::WIN_BYTES);
+            attr = true;
+        }
+        if (stats != nullptr && hc_get_deterministic() && gx * nslices > hc_get_stat_replicas()) return HC_ERR_ARG;
+        if (thin)
+            hipLaunchKernelGGL(dw3x3_fwd_s2_tile_kernel<4>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwS2Thin::WIN_BYTES, st, x, wpk,
+                               (u32x4*)y, stats, N, H, W, OH, OW, C, hc_get_stat_replicas(), tiles_x, tiles_y);
+        else
+            hipLaunchKernelGGL(dw3x3_fwd_s2_tile_kernel<8>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwS2Wide::WIN_BYTES, st, x, wpk,
+                               (u32x4*)y, stats, N, H, W, OH, OW, C, hc_get_stat_replicas(), tiles_x, tiles_y);
     } else {
         constexpr int TW = 2;
         const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
@@ -777,6 +1107,19 @@ int hc_dw3x3_dgrad(const void* dy, const float* wpk, const float* wpk_flipped, v
     if (wpk == nullptr) return HC_ERR_ARG;
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const int cg = C / 8;
+    if (dw_s2_on() && OW >= 4) {
+        static const int sw2 = [] { const char* e = getenv("HC_DW_DGRAD_S2_SW"); return e == nullptr ? 4 : atoi(e); }();
+        if (sw2 == 2) {
+            const long items = (long)N * OH * ((OW + 1) / 2) * cg;
+            hipLaunchKernelGGL(dw3x3_dgrad_s2_blk_kernel<2>, dim3(dw_blocks(items, cg, 4)), dim3(DW_THREADS), 0, (hipStream_t)stream,
+                               (const u32x4*)dy, wpk, (u32x4*)dx, N, H, W, OH, OW, C);
+        } else {
+            const long items = (long)N * OH * ((OW + 3) / 4) * cg;
+            hipLaunchKernelGGL(dw3x3_dgrad_s2_blk_kernel<4>, dim3(dw_blocks(items, cg, 4)), dim3(DW_THREADS), 0, (hipStream_t)stream,
+                               (const u32x4*)dy, wpk, (u32x4*)dx, N, H, W, OH, OW, C);
+        }
+        return hc_launch_status();
+    }
     hipLaunchKernelGGL(dw3x3_dgrad_s2_kernel, dim3(dw_blocks((long)N * H * W * cg, cg, 4)), dim3(DW_THREADS), 0, (hipStream_t)stream,
                        (const u32x4*)dy, wpk, (u32x4*)dx, N, H, W, OH, OW, C);
     return hc_launch_status();
@@ -801,10 +1144,10 @@ int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N
         if (stride == 1 && tile_on && W >= tile_minw && H >= 8 && C >= tile_minc && (double)N * H * W * C * 2.0 < 4294967000.0 &&
             !hc_get_deterministic()) {
             const bool narrow = W <= 16;
-            const bool thin = !narrow && cg <= 4 && dw_thin_on();
+            const bool thin = !narrow && dw_thin(cg);
             const int tw = narrow ? DwTile<2>::TW : (thin ? DwThin::TW : DwTile<4>::TW), th = narrow ? DwTile<2>::TH : DwTile<4>::TH;
             const int tiles_x = (W + tw - 1) / tw, tiles_y = (H + th - 1) / th;
-            const int nslices = thin ? 1 : (cg + 7) / 8;
+            const int nslices = thin ? (cg + 3) / 4 : (cg + 7) / 8;
             const long ntiles = (long)N * tiles_x * tiles_y;
             long gx = (2 * 256 + nslices - 1) / nslices;
             if (gx > ntiles) gx = ntiles;
@@ -829,6 +1172,27 @@ int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N
             const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
             hipLaunchKernelGGL((dw3x3_wgrad_kernel<1, TW>), dim3(dw_blocks(items, cg, 4)), dim3(DW_THREADS), lds, st, (const u32x4*)x,
                                (const u32x4*)dy, (float*)ws, N, H, W, OH, OW, C, hc_get_stat_replicas());
+        } else if (dw_s2_on() && OW >= dw_s2_minw() && OH >= 8 && C >= tile_minc && (double)N * H * W * C * 2.0 < 4294967000.0 &&
+                   !hc_get_deterministic()) {
+            const bool thin = dw_thin(cg);
+            const int tw = thin ? DwS2Thin::TW : DwS2Wide::TW, th = DwS2Wide::TH;
+            const int tiles_x = (OW + tw - 1) / tw, tiles_y = (OH + th - 1) / th;
+            const int nslices = thin ? (cg + 3) / 4 : (cg + 7) / 8;
+            const long ntiles = (long)N * tiles_x * tiles_y;
+            long gx = (2 * 256 + nslices - 1) / nslices;
+            if (gx > ntiles) gx = ntiles;
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_wgrad_s2_tile_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, DwS2Wide::WIN_BYTES);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw3x3_wgrad_s2_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, DwS2Thin::WIN_BYTES);
+                attr = true;
+            }
+            if (thin)
+                hipLaunchKernelGGL(dw3x3_wgrad_s2_tile_kernel<4>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwS2Thin::WIN_BYTES, st, x,
+                                   (const u32x4*)dy, (float*)ws, N, H, W, OH, OW, C, hc_get_stat_replicas(), tiles_x, tiles_y);
+            else
+                hipLaunchKernelGGL(dw3x3_wgrad_s2_tile_kernel<8>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwS2Wide::WIN_BYTES, st, x,
+                                   (const u32x4*)dy, (float*)ws, N, H, W, OH, OW, C, hc_get_stat_replicas(), tiles_x, tiles_y);
         } else {
             constexpr int TW = 2;
             const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
