@@ -236,6 +236,7 @@ SIGNATURES = {
     "hc_ce_fwd_bwd": (c_int32, [c_void_p] * 4 + [c_int32, c_int32, c_float, c_void_p]),
     "hc_ce_mean_fwd": (c_int32, [c_void_p] * 4 + [c_int32, c_int32, c_float, c_int64, c_void_p]),
     "hc_ce_mean_bwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_float, c_int64, c_void_p]),
+    "hc_ce_mean_aux_floats": (c_int64, [c_int32]),
     "hc_poly_loss_hard_fwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int64, c_int32, c_float, c_void_p]),
     "hc_poly_loss_hard_bwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int64, c_float, c_void_p]),
     "hc_poly_loss_soft_fwd": (c_int32, [c_void_p] * 4 + [c_int32, c_int32, c_int64, c_int32, c_float, c_void_p]),

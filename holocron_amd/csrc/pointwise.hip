@@ -408,6 +408,113 @@ __global__ __launch_bounds__(1024) void ce_mean_fwd_kernel(const float* __restri
         aux[0] = c;
     }
 }
+// ---- the same criterion for wide class counts (K > 64: 1000-class heads).  The thread-per-row kernels above walk a row serially
+// with a 4 K-byte stride between lanes: 398 us forward + 324 us backward at 256 x 1000.  Here a WAVE owns a row (coalesced 16-byte
+// loads, two passes: max + sum of logits, then the exponential sum), writes the row's log-sum-exp and its two partial sums to aux,
+// and a single-workgroup kernel adds the rows in a fixed order.  aux = {valid rows, lse[N], {nll_n, smooth_n}[N]}.
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void ce_rows_fwd_kernel(const float* __restrict__ logits, const long* __restrict__ target,
+                                                          float* __restrict__ aux, int N, int K, long ignore_index) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float* lse_out = aux + 1;
+    float* part = aux + 1 + N;
+    const long tg = target[n];
+    if (tg == ignore_index) {
+        if (lane == 0) { lse_out[n] = 0.f; part[2 * n] = 0.f; part[2 * n + 1] = 0.f; }
+        return;
+    }
+    const float* px = logits + (long)n * K;
+    float mx = -INFINITY, sx = 0.f, se = 0.f;
+    if ((K & 3) == 0 && (reinterpret_cast<unsigned long long>(logits) & 15ull) == 0) {
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(px);
+        for (int i = lane; i < K / 4; i += 64) {
+            const f32x4 v = p4[i];
+            mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+            sx += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        mx = wave_max(mx);
+        for (int i = lane; i < K / 4; i += 64) {
+            const f32x4 v = p4[i];
+            se += (expf(v[0] - mx) + expf(v[1] - mx)) + (expf(v[2] - mx) + expf(v[3] - mx));
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) { const float v = px[k]; mx = fmaxf(mx, v); sx += v; }
+        mx = wave_max(mx);
+        for (int k = lane; k < K; k += 64) se += expf(px[k] - mx);
+    }
+    sx = wave_sum(sx);
+    se = wave_sum(se);
+    if (lane == 0) {
+        const float lse = logf(se) + mx;
+        lse_out[n] = lse;
+        part[2 * n] = -(px[tg] - lse);
+        part[2 * n + 1] = -(sx - (float)K * lse);          // - sum_k log p_k
+    }
+}
+__global__ __launch_bounds__(1024) void ce_rows_finish_kernel(const long* __restrict__ target, float* __restrict__ loss,
+                                                              float* __restrict__ aux, int N, int K, float ls, long ignore_index) {
+    __shared__ float s_nll[1024], s_sm[1024], s_cnt[1024];
+    const float* part = aux + 1 + N;
+    float nll = 0.f, sm = 0.f, cnt = 0.f;
+    for (int n = threadIdx.x; n < N; n += 1024) {
+        if (target[n] == ignore_index) continue;
+        nll += part[2 * n];
+        sm += part[2 * n + 1];
+        cnt += 1.f;
+    }
+    s_nll[threadIdx.x] = nll; s_sm[threadIdx.x] = sm; s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s_nll[threadIdx.x] += s_nll[threadIdx.x + w];
+            s_sm[threadIdx.x] += s_sm[threadIdx.x + w];
+            s_cnt[threadIdx.x] += s_cnt[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float c = s_cnt[0];
+        loss[0] = (1.f - ls) * (s_nll[0] / c) + ls * ((s_sm[0] / c) / (float)K);
+        aux[0] = c;
+    }
+}
+__global__ __launch_bounds__(256) void ce_rows_bwd_kernel(const float* __restrict__ logits, const long* __restrict__ target,
+                                                          const float* __restrict__ dloss, const float* __restrict__ aux,
+                                                          float* __restrict__ dlogits, int N, int K, float ls, long ignore_index) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* px = logits + (long)n * K;
+    float* pd = dlogits + (long)n * K;
+    const long tg = target[n];
+    const bool dead = tg == ignore_index;
+    const float lse = aux[1 + n], gs = dead ? 0.f : dloss[0] / aux[0], on = (1.f - ls) * gs, sm = ls / (float)K * gs;
+    if ((K & 3) == 0 && ((reinterpret_cast<unsigned long long>(logits) | reinterpret_cast<unsigned long long>(dlogits)) & 15ull) == 0) {
+        const f32x4* p4 = reinterpret_cast<const f32x4*>(px);
+        f32x4* d4 = reinterpret_cast<f32x4*>(pd);
+        for (int i = lane; i < K / 4; i += 64) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            if (!dead) {
+                const f32x4 v = p4[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = expf(v[e] - lse) * gs - ((long)(4 * i + e) == tg ? on : 0.f) - sm;
+            }
+            d4[i] = o;
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) pd[k] = dead ? 0.f : expf(px[k] - lse) * gs - ((long)k == tg ? on : 0.f) - sm;
+    }
+}
+
 // dlogits[n][k] = dloss * (softmax_k - (1 - ls) [k == target] - ls / K) / valid rows ; rows with the ignored target get zeros
 __global__ void ce_mean_bwd_kernel(const float* __restrict__ logits, const long* __restrict__ target, const float* __restrict__ dloss,
                                    const float* __restrict__ aux, float* __restrict__ dlogits, int N, int K, float ls, long ignore_index) {
@@ -579,14 +686,27 @@ int hc_focal_loss_bwd(const float* x, const int64_t* target, const float* weight
 int hc_ce_mean_fwd(const float* logits, const int64_t* target, float* loss, float* aux, int32_t N, int32_t K, float label_smoothing,
                    int64_t ignore_index, hc_stream_t stream) {
     if (logits == nullptr || target == nullptr || loss == nullptr || aux == nullptr || N <= 0 || K <= 0) return HC_ERR_ARG;
+    if (K > 64) {
+        hipLaunchKernelGGL(ce_rows_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, (const long*)target, aux, N, K,
+                           (long)ignore_index);
+        hipLaunchKernelGGL(ce_rows_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const long*)target, loss, aux, N, K,
+                           label_smoothing, (long)ignore_index);
+        return hc_launch_status();
+    }
     hipLaunchKernelGGL(ce_mean_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, (const long*)target, loss, aux, N, K,
                        label_smoothing, (long)ignore_index);
     return hc_launch_status();
 }
+int64_t hc_ce_mean_aux_floats(int32_t N) { return 1 + 3 * (int64_t)(N > 0 ? N : 0); }
 int hc_ce_mean_bwd(const float* logits, const int64_t* target, const float* dloss, const float* aux, float* dlogits, int32_t N,
                    int32_t K, float label_smoothing, int64_t ignore_index, hc_stream_t stream) {
     if (logits == nullptr || target == nullptr || dloss == nullptr || aux == nullptr || dlogits == nullptr || N <= 0 || K <= 0)
         return HC_ERR_ARG;
+    if (K > 64) {
+        hipLaunchKernelGGL(ce_rows_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, (const long*)target, dloss, aux,
+                           dlogits, N, K, label_smoothing, (long)ignore_index);
+        return hc_launch_status();
+    }
     hipLaunchKernelGGL(ce_mean_bwd_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, logits, (const long*)target, dloss,
                        aux, dlogits, N, K, label_smoothing, (long)ignore_index);
     return hc_launch_status();

@@ -161,8 +161,9 @@ class _CrossEntropyMeanFn(torch.autograd.Function):
         xc = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
         tc = target if (target.dtype == torch.int64 and target.is_contiguous()) else target.long().contiguous()
         N, K = xc.shape
-        out = torch.empty((2,), dtype=torch.float32, device=x.device)          # {loss, valid rows}
-        check(_lib.load().hc_ce_mean_fwd(ptr(xc), ptr(tc), out.data_ptr(), out.data_ptr() + 4, N, K, float(label_smoothing),
+        lib = _lib.load()
+        out = torch.empty((1 + int(lib.hc_ce_mean_aux_floats(N)),), dtype=torch.float32, device=x.device)   # {loss, aux: valid rows, ...}
+        check(lib.hc_ce_mean_fwd(ptr(xc), ptr(tc), out.data_ptr(), out.data_ptr() + 4, N, K, float(label_smoothing),
                                          int(ignore_index), stream()), "hc_ce_mean_fwd")
         ctx.save_for_backward(xc, tc, out)
         ctx.cfg = (float(label_smoothing), int(ignore_index), x.dtype)

@@ -489,8 +489,11 @@ int hc_ce_fwd_bwd(const float* logits, const int64_t* target, float* loss_el, fl
 
 /* The same criterion as the training loop calls it - nn.CrossEntropyLoss(label_smoothing=ls), mean over the rows whose target is
  * not ignore_index (references/classification/train.py:194; torch composes it from ~25 aten launches): forward writes the scalar
- * loss and aux[0] = number of valid rows in one single-workgroup launch (fixed-order sums); backward writes
- * dlogits = dloss[0] * d(mean loss)/dlogits with dloss a DEVICE scalar (the upstream gradient autograd hands over). */
+ * loss and aux[0] = number of valid rows (fixed-order sums: one single-workgroup launch for K <= 64, a wave-per-row launch plus a
+ * single-workgroup sum for wider heads); backward writes dlogits = dloss[0] * d(mean loss)/dlogits with dloss a DEVICE scalar (the
+ * upstream gradient autograd hands over).  aux holds hc_ce_mean_aux_floats(N) = 1 + 3 N floats (the rows' log-sum-exp and partial
+ * sums behind aux[0]) and goes unchanged from forward to backward. */
+int64_t hc_ce_mean_aux_floats(int32_t N);
 int hc_ce_mean_fwd(const float* logits, const int64_t* target, float* loss, float* aux, int32_t N, int32_t K, float label_smoothing,
                    int64_t ignore_index, hc_stream_t stream);
 int hc_ce_mean_bwd(const float* logits, const int64_t* target, const float* dloss, const float* aux, float* dlogits, int32_t N,

@@ -174,7 +174,11 @@ def test_cross_entropy_matches_torch_cpu_fp32():
     import holocron_amd as h
     g = torch.Generator().manual_seed(3)
     for N, K, ls, ign, dt in [(256, 10, 0.1, -100, torch.float32), (37, 1000, 0.0, -100, torch.float32),
-                              (3000, 17, 0.2, 5, torch.float32), (64, 10, 0.1, -100, torch.bfloat16)]:
+                              (3000, 17, 0.2, 5, torch.float32), (64, 10, 0.1, -100, torch.bfloat16),
+                              # wide heads (K > 64): the wave-per-row kernels - ignored rows, K not a multiple of 4, more rows than
+                              # one pass of the single-workgroup sum, bf16 logits
+                              (256, 1000, 0.1, 7, torch.float32), (33, 1001, 0.1, -100, torch.float32),
+                              (5000, 100, 0.1, 3, torch.float32), (64, 1000, 0.1, -100, torch.bfloat16)]:
         x = (torch.randn((N, K), generator=g) * 3).to(dt)
         t = torch.randint(0, K, (N,), generator=g)
         up = torch.rand((), generator=g) + 0.5
@@ -191,6 +195,13 @@ def test_cross_entropy_matches_torch_cpu_fp32():
         assert torch.allclose(xg.grad.float().cpu(), xr.grad, rtol=tol, atol=tol / N), (N, K, (xg.grad.float().cpu() - xr.grad).abs().max())
         if ign >= 0:
             assert bool((xg.grad[t.cuda() == ign] == 0).all())
+    # logits that start 4 bytes into an allocation (no 16-byte loads): same numbers as the aligned copy
+    flat = (torch.randn((1 + 48 * 1000,), generator=g) * 3).cuda()
+    xm, t = flat[1:].view(48, 1000).requires_grad_(True), torch.randint(0, 1000, (48,), generator=g).cuda()
+    xa = flat[1:].clone().view(48, 1000).requires_grad_(True)
+    lm, la = h.nn.functional.cross_entropy(xm, t, 0.1), h.nn.functional.cross_entropy(xa, t, 0.1)
+    gm, ga = torch.autograd.grad(lm, xm)[0], torch.autograd.grad(la, xa)[0]
+    assert abs(float(lm) - float(la)) < 2e-6 and torch.allclose(gm, ga, rtol=1e-6, atol=1e-9)
     # the module routes the common case to the HIP launches and anything else to torch
     crit = h.nn.CrossEntropyLoss(label_smoothing=0.1)
     x = torch.randn((32, 10), generator=g).cuda()
