@@ -1,7 +1,11 @@
 #!/bin/bash
 # Round-4 end measurements.  Everything lands in gpurun_out/final4/ (copied to profiles/r04_*).  PMC passes first: the bench lines
 # read the traffic files they produce (bench.py / scripts/_train_bench.py look for profiles/r04_pmc_*_traffic.json).
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=$R/gpurun_out/final4; mkdir -p $O; rm -rf $O/*
+# SECTIONS="rexnet" (or any subset of: headline rexnet yolov4 fp8 mobileone misc) re-measures one configuration after a change to its kernels.
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=$R/gpurun_out/final4; mkdir -p $O
+SECTIONS=${SECTIONS:-"headline rexnet yolov4 fp8 mobileone misc"}
+want() { case " $SECTIONS " in *" $1 "*) return 0;; esac; return 1; }
+[ "$SECTIONS" = "headline rexnet yolov4 fp8 mobileone misc" ] && rm -rf $O/*
 summ() {  # summ <trace dir> <out prefix> <header>
 python - "$1" "$2" "$3" <<'PY'
 import csv, glob, sys, collections
@@ -31,6 +35,7 @@ trace() {  # trace <tag> <header> <command ...>
   summ $O/t_$tag $O/r04_final_$tag "$hdr"; rm -rf $O/t_$tag
 }
 # ---- headline: PMC traffic + MFMA utilisation, then the bench line, then the eager kernel trace
+if want headline; then
 bash scripts/pmc_families.sh step python bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 > $O/pmc_step.log 2>&1
 cp gpurun_out/pmc_step/traffic.json profiles/r04_pmc_step_traffic.json; cp gpurun_out/pmc_step/traffic.json $O/r04_pmc_step_traffic.json
 bash scripts/pmc_mfma.sh > $O/pmc_mfma.log 2>&1; cp gpurun_out/pmc_mfma/mfma_util.txt $O/r04_mfma_util.txt
@@ -41,22 +46,34 @@ timeout 120 python scripts/bench_ew.py 2>&1 | grep -v amdgpu > $O/r04_final_bn_p
 timeout 200 python scripts/bench_s2.py 2>&1 | grep -v amdgpu > $O/r04_final_conv_s2_shapes.txt
 timeout 120 python scripts/check_rows.py 2>&1 | grep -v amdgpu > $O/r04_final_conv_rows_shapes.txt
 timeout 200 python scripts/bench_wrep.py 2>&1 | grep -v amdgpu > $O/r04_final_wgrad_rep_shapes.txt
+fi
 # ---- secondary configurations: PMC traffic, bench line (graph replay), eager trace
+if want rexnet; then
 bash scripts/pmc_families.sh rexnet python scripts/bench_rexnet.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $O/pmc_rexnet.log 2>&1
 cp gpurun_out/pmc_rexnet/traffic.json profiles/r04_pmc_rexnet_traffic.json; cp gpurun_out/pmc_rexnet/traffic.json $O/r04_pmc_rexnet_traffic.json
 timeout 400 python scripts/bench_rexnet.py --steps 20 --warmup 5 > $O/r04_final_rexnet_bench.json 2> $O/rexnet.err
 trace rexnet "rocprofv3 --kernel-trace --stats -- python scripts/bench_rexnet.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline  (MI355X)" python $R/scripts/bench_rexnet.py --steps 3 --warmup 1 --no-graph --no-cpu-baseline
+timeout 300 python scripts/bench_dw.py 2>&1 | grep -v amdgpu > $O/r04_final_dw_tile_shapes.txt
+fi
+if want yolov4; then
 bash scripts/pmc_families.sh yolov4 python scripts/bench_yolov4.py --batch 16 --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $O/pmc_yolov4.log 2>&1
 cp gpurun_out/pmc_yolov4/traffic.json profiles/r04_pmc_yolov4_traffic.json; cp gpurun_out/pmc_yolov4/traffic.json $O/r04_pmc_yolov4_traffic.json
 timeout 500 python scripts/bench_yolov4.py --batch 16 --steps 10 --warmup 3 > $O/r04_final_yolov4_bench.json 2> $O/yolov4.err
 timeout 500 python scripts/bench_yolov4.py --eval --batch 16 --steps 10 --warmup 3 > $O/r04_final_yolov4_eval_bench.json 2> $O/yolov4_eval.err
 timeout 300 python scripts/bench_bigtile.py 2>&1 | grep -v amdgpu > $O/r04_final_bigtile_family_shapes.txt
 trace yolov4 "rocprofv3 --kernel-trace --stats -- python scripts/bench_yolov4.py --batch 16 --steps 3 --warmup 1 --no-graph --no-cpu-baseline  (MI355X)" python $R/scripts/bench_yolov4.py --batch 16 --steps 3 --warmup 1 --no-graph --no-cpu-baseline
+fi
+if want fp8; then
 bash scripts/pmc_families.sh repvgg_a2_fp8 python scripts/bench_repvgg_fp8.py --steps 2 --warmup 1 > $O/pmc_fp8.log 2>&1
 cp gpurun_out/pmc_repvgg_a2_fp8/traffic.json profiles/r04_pmc_repvgg_a2_fp8_traffic.json; cp gpurun_out/pmc_repvgg_a2_fp8/traffic.json $O/r04_pmc_repvgg_a2_fp8_traffic.json
 timeout 300 python scripts/bench_repvgg_fp8.py > $O/r04_final_repvgg_a2_fp8_bench.json 2> $O/fp8.err
+fi
+if want mobileone; then
 timeout 300 python scripts/bench_mobileone.py > $O/r04_final_mobileone_bench.json 2> $O/mobileone.err
+fi
+if want misc; then
 ls -la $O | head -60
 cut -c1-300 $O/r04_final_bench.json
 timeout 200 python scripts/fixture_fracs.py 2>&1 | grep -v amdgpu > $O/fixture_fracs.txt; tail -1 $O/fixture_fracs.txt
 timeout 400 python -m pytest tests/test_gpu_yolo.py -q -x 2>&1 | tail -5 > $O/yolo_tests.log; cat $O/yolo_tests.log
+fi
