@@ -92,6 +92,15 @@ class RepBnDesc(C.Structure):
                 ("eps", c_float), ("momentum", c_float), ("training", c_int32), ("c_valid", c_int32)]
 
 
+class SeMlpDesc(C.Structure):
+    """hc_se_mlp_desc (include/holocron_hip.h)."""
+    _fields_ = [(n, c_void_p) for n in ("pooled", "w1", "gamma", "beta", "running_mean", "running_var", "num_batches_tracked", "w2",
+                                        "b2", "h1", "part", "stat", "logits", "dl", "g", "part2", "dpool", "dw1", "dgamma", "dbeta",
+                                        "dw2", "db2")] + \
+               [("N", c_int32), ("C", c_int32), ("Cp", c_int32), ("R", c_int32), ("act", c_int32), ("eps", c_float),
+                ("momentum", c_float)]
+
+
 class RepBnBwdDesc(C.Structure):
     _fields_ = [("red", c_void_p), ("save", c_void_p), ("gamma", c_void_p * 3), ("dgamma", c_void_p * 3),
                 ("dbeta", c_void_p * 3), ("bcoef", c_void_p), ("C", c_int32), ("count", c_int64),
@@ -237,6 +246,9 @@ SIGNATURES = {
     "hc_ce_mean_fwd": (c_int32, [c_void_p] * 4 + [c_int32, c_int32, c_float, c_int64, c_void_p]),
     "hc_ce_mean_bwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_float, c_int64, c_void_p]),
     "hc_ce_mean_aux_floats": (c_int64, [c_int32]),
+    "hc_se_mlp_part_floats": (c_int64, [c_int32, c_int32]),
+    "hc_se_mlp_fwd": (c_int32, [c_void_p, c_void_p]),
+    "hc_se_mlp_bwd": (c_int32, [c_void_p, c_void_p]),
     "hc_poly_loss_hard_fwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int64, c_int32, c_float, c_void_p]),
     "hc_poly_loss_hard_bwd": (c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_int64, c_float, c_void_p]),
     "hc_poly_loss_soft_fwd": (c_int32, [c_void_p] * 4 + [c_int32, c_int32, c_int64, c_int32, c_float, c_void_p]),

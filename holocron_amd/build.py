@@ -30,6 +30,7 @@ SOURCES = {
     "optim.hip": [],
     "nhwc_ops.hip": [],
     "dwconv.hip": [],
+    "se_mlp.hip": [],
     "mobileone.hip": [],
     # separate torch kernels in the reference round after every op: no fused multiply-add here
     "pointwise.hip": ["-ffp-contract=off"],

@@ -21,7 +21,8 @@ from ... import _lib
 from ...nn import GlobalAvgPool2d
 from ...nn import init
 from ...nn.convbn_op import act_code, conv_bn_act
-from ...nn.mbconv_op import SeGateFn, _PadChannelsFn, ceil16, padded_conv_bias, padded_conv_bn_act, padded_model_scope
+from ...nn.mbconv_op import (SeGateFn, _PadChannelsFn, ceil16, padded_conv_bias, padded_conv_bn_act, padded_model_scope, se_gate_fused,
+                             se_mlp_fusable)
 from ...nn.repblock_op import POOL
 from ..utils import conv_sequence
 
@@ -52,6 +53,10 @@ class SEBlock(nn.Module):
 
     def forward_gated(self, z: Tensor, act: int) -> Tensor:
         """act(z * sigmoid(mlp(mean(z)))) on a channel-padded activation; ``act`` 0 | 6 (ReLU6)."""
+        mods = list(self.conv)
+        if (len(mods) == 5 and isinstance(mods[4], nn.Sigmoid) and z.is_cuda and z.shape[1] == ceil16(mods[0].in_channels)
+                and se_mlp_fusable(mods[0], mods[1], mods[2], mods[3])):
+            return se_gate_fused(z, mods[0], mods[1], mods[2], mods[3], act)     # the MLP as 2 + 4 launches (csrc/se_mlp.hip)
         return SeGateFn.apply(z, self._gate_logits, act)
 
     def forward(self, x: Tensor) -> Tensor:

@@ -382,6 +382,100 @@ class SeGateFn(torch.autograd.Function):
         return dz, None, None
 
 
+# HC_SE_FUSED=0: the squeeze-excite MLP through the generic conv units inside SeGateFn (A/B; round-3 path)
+_SE_FUSED = __import__("os").environ.get("HC_SE_FUSED", "1") != "0"
+
+
+def se_mlp_fusable(conv1, bn, act, conv2):
+    """The layouts hc_se_mlp_fwd / bwd cover (rexnet.py:38-66 as the reference builds it): 1x1 conv without bias, a training-mode
+    BatchNorm2d with running statistics and a float momentum, ReLU / ReLU6 / no activation, 1x1 conv, fp32 parameters."""
+    ok = (_SE_FUSED and type(conv1) is nn.Conv2d and type(conv2) is nn.Conv2d and type(bn) is nn.BatchNorm2d
+          and conv1.kernel_size == (1, 1) and conv2.kernel_size == (1, 1) and conv1.bias is None and conv1.groups == 1
+          and conv2.groups == 1 and conv1.stride == (1, 1) and conv2.stride == (1, 1) and conv1.padding == (0, 0)
+          and conv2.padding == (0, 0) and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
+          and (act is None or type(act) in (nn.ReLU, nn.ReLU6)) and conv1.out_channels <= 128
+          and conv1.out_channels == conv2.in_channels and conv2.out_channels == conv1.in_channels)
+    return ok and all(p.dtype == torch.float32 for p in (conv1.weight, conv2.weight, bn.weight, bn.bias))
+
+
+class SeGateFusedFn(torch.autograd.Function):
+    """SeGateFn with the MLP as hc_se_mlp_fwd / hc_se_mlp_bwd (csrc/se_mlp.hip): 2 + 4 launches on the pooled vectors instead of the
+    ~28 of the generic units, no private autograd graph.  ``out = act(z * sigmoid(mlp(mean_hw(z))))``."""
+
+    @staticmethod
+    def forward(ctx, z, w1, gamma, beta, w2, b2, bn_bufs, cfg):
+        lib = _lib.load()
+        N, Cp, H, W = z.shape
+        act, mlp_act, eps, momentum = cfg
+        R, Cc = w1.shape[0], w1.shape[1]
+        dev = z.device
+        pooled = torch.empty((N, Cp), dtype=torch.float32, device=dev)
+        check(lib.hc_gap_fwd(ptr(z), ptr(pooled), N, H * W, Cp, stream()), "hc_gap_fwd")
+        nf = int(lib.hc_se_mlp_part_floats(N, R))
+        # one allocation for what the forward hands to the backward: h1 [N][R], part, stat [2][R]
+        save = torch.empty((N * R + nf + 2 * R,), dtype=torch.float32, device=dev)
+        lg = torch.empty((N, Cp), dtype=torch.bfloat16, device=dev)
+        w1c, w2c = w1.detach().contiguous(), w2.detach().contiguous()
+        d = _lib.SeMlpDesc()
+        d.pooled, d.w1, d.gamma, d.beta, d.w2 = ptr(pooled), ptr(w1c), ptr(gamma.detach()), ptr(beta.detach()), ptr(w2c)
+        d.b2 = ptr(b2.detach()) if b2 is not None else None
+        rm, rv, nbt = bn_bufs
+        d.running_mean, d.running_var, d.num_batches_tracked = ptr(rm), ptr(rv), ptr(nbt)
+        d.h1, d.part, d.stat = save.data_ptr(), save.data_ptr() + 4 * N * R, save.data_ptr() + 4 * (N * R + nf)
+        d.logits = ptr(lg)
+        d.N, d.C, d.Cp, d.R, d.act, d.eps, d.momentum = N, Cc, Cp, R, mlp_act, eps, momentum
+        check(lib.hc_se_mlp_fwd(C.byref(d), stream()), "hc_se_mlp_fwd")
+        out = torch.empty_like(z)
+        check(lib.hc_se_scale_fwd(ptr(z), ptr(lg), ptr(out), N, H * W, Cp, act, stream()), "hc_se_scale_fwd")
+        ctx.cfg = (act, mlp_act, eps, momentum, nf, b2 is not None)
+        ctx.save_for_backward(z, lg, pooled, save, w1c, gamma, beta, w2c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, lg, pooled, save, w1c, gamma, beta, w2c = ctx.saved_tensors
+        act, mlp_act, eps, momentum, nf, has_b2 = ctx.cfg
+        lib = _lib.load()
+        N, Cp, H, W = z.shape
+        R, Cc = w1c.shape[0], w1c.shape[1]
+        dev = z.device
+        g = cv.to_cl_bf16(g)
+        if cl_ld(g) != Cp:
+            g = g.contiguous(memory_format=torch.channels_last)
+        dgate = torch.empty((N, Cp), dtype=torch.float32, device=dev)
+        dl = torch.empty((N, Cp), dtype=torch.bfloat16, device=dev)
+        check(lib.hc_se_scale_bwd_gate(ptr(g), ptr(z), ptr(lg), ptr(dgate), ptr(dl), N, H * W, Cp, act, stream()),
+              "hc_se_scale_bwd_gate")
+        scratch = torch.empty((N * R + nf,), dtype=torch.float32, device=dev)
+        dpool = torch.empty((N, Cp), dtype=torch.float32, device=dev)
+        dw1, dw2 = torch.empty_like(w1c), torch.empty_like(w2c)
+        dgb = torch.empty((2, R), dtype=torch.float32, device=dev)
+        db2 = torch.empty((Cc,), dtype=torch.float32, device=dev) if has_b2 else None
+        d = _lib.SeMlpDesc()
+        d.pooled, d.w1, d.gamma, d.beta, d.w2 = ptr(pooled), ptr(w1c), ptr(gamma.detach()), ptr(beta.detach()), ptr(w2c)
+        d.h1, d.part, d.stat = save.data_ptr(), save.data_ptr() + 4 * N * R, save.data_ptr() + 4 * (N * R + nf)
+        d.dl, d.g, d.part2 = ptr(dl), scratch.data_ptr(), scratch.data_ptr() + 4 * N * R
+        d.dpool, d.dw1, d.dw2 = ptr(dpool), ptr(dw1), ptr(dw2)
+        d.dgamma, d.dbeta = dgb.data_ptr(), dgb.data_ptr() + 4 * R
+        d.db2 = ptr(db2) if has_b2 else None
+        d.N, d.C, d.Cp, d.R, d.act, d.eps, d.momentum = N, Cc, Cp, R, mlp_act, eps, momentum
+        check(lib.hc_se_mlp_bwd(C.byref(d), stream()), "hc_se_mlp_bwd")
+        dz = torch.empty_like(z)
+        check(lib.hc_se_scale_bwd_apply(ptr(g), ptr(z), ptr(lg), ptr(dpool), ptr(dz), N, H * W, Cp, act, stream()),
+              "hc_se_scale_bwd_apply")
+        return dz, dw1, dgb[0], dgb[1], dw2, db2, None, None
+
+
+def se_gate_fused(z, conv1, bn, mlp_act_module, conv2, act):
+    """``act(z * sigmoid(conv2(mlp_act(bn(conv1(mean_hw(z)))))))`` on a channel-padded NHWC bf16 tensor (the caller checked
+    se_mlp_fusable)."""
+    R, Cc = conv1.out_channels, conv1.in_channels
+    mlp_act = 0 if mlp_act_module is None else (1 if type(mlp_act_module) is nn.ReLU else 6)
+    cfg = (act, mlp_act, float(bn.eps), float(bn.momentum))
+    return SeGateFusedFn.apply(z, conv1.weight.view(R, Cc), bn.weight, bn.bias, conv2.weight.view(Cc, R), conv2.bias,
+                               (bn.running_mean, bn.running_var, bn.num_batches_tracked), cfg)
+
+
 class _MaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

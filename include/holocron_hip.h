@@ -632,6 +632,47 @@ int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N
 int hc_max_fwd(const void* a, const void* b, void* out, int64_t nelem, hc_stream_t stream);
 int hc_max_bwd(const void* a, const void* b, const void* g, void* da, void* db, int64_t nelem, hc_stream_t stream);
 
+/* The MLP of ReXNet's squeeze-excite block on the pooled vectors (holocron/models/classification/rexnet.py:38-66: the nn.Sequential
+ * of conv_sequence(C, C / r, act, BatchNorm2d, kernel_size=1, bias=False) and conv_sequence(C / r, C, Sigmoid, None, kernel_size=1)
+ * - the sigmoid itself is applied by hc_se_scale_fwd), training-mode BatchNorm over the N rows; the six GEMMs run on the matrix cores
+ * with operands rounded to bf16 (as every convolution of this library), fp32 accumulation, statistics and stored intermediates:
+ *     h1 = pooled W1^T ; h = act(gamma (h1 - mean) rstd + beta) ; logits = h W2^T + b2          (act 0 none | 1 ReLU | 6 ReLU6)
+ * hc_se_mlp_fwd: two launches; writes logits (bf16 [N][Cp], channels [C, Cp) zero), h1 [N][R], the row-tile partial sums `part`
+ * (hc_se_mlp_part_floats(N, R) floats), stat = {mean[R], rstd[R]}, and updates running_mean / running_var (momentum, unbiased variance)
+ * and num_batches_tracked when they are given.  hc_se_mlp_bwd: four launches; from dl (bf16 [N][Cp], the gradient of the logits) and the
+ * tensors the forward saved it writes dpool (fp32 [N][Cp], pad channels zero), dw1 [R][C], dgamma / dbeta [R], dw2 [C][R], db2 [C]
+ * (plain stores, not accumulated); g [N][R] and part2 (same size as part) are scratch.  R <= 128, Cp >= C rounded up to 16 and
+ * Cp % 8 == 0, pooled and dl 16-byte aligned with finite (zero) pad channels.  All sums run in a fixed order. */
+typedef struct {
+    const float* pooled;             /* fp32 [N][Cp]: global average pool of the block input (hc_gap_fwd) */
+    const float* w1;                 /* fp32 [R][C]: first 1x1 conv, no bias */
+    const float* gamma;              /* fp32 [R] BatchNorm weight */
+    const float* beta;               /* fp32 [R] BatchNorm bias */
+    float* running_mean;             /* fp32 [R] or NULL (forward) */
+    float* running_var;              /* fp32 [R] or NULL (forward) */
+    int64_t* num_batches_tracked;    /* or NULL (forward) */
+    const float* w2;                 /* fp32 [C][R]: second 1x1 conv */
+    const float* b2;                 /* fp32 [C] or NULL */
+    float* h1;                       /* fp32 [N][R]: forward output, backward input */
+    float* part;                     /* forward output */
+    float* stat;                     /* fp32 [2][R]: forward output, backward input */
+    void* logits;                    /* bf16 [N][Cp]: forward output */
+    const void* dl;                  /* bf16 [N][Cp]: backward input */
+    float* g;                        /* fp32 [N][R]: backward scratch */
+    float* part2;                    /* backward scratch */
+    float* dpool;                    /* fp32 [N][Cp]: backward output */
+    float* dw1;                      /* fp32 [R][C] */
+    float* dgamma;                   /* fp32 [R] or NULL (both) */
+    float* dbeta;                    /* fp32 [R] */
+    float* dw2;                      /* fp32 [C][R] */
+    float* db2;                      /* fp32 [C] or NULL */
+    int32_t N, C, Cp, R, act;
+    float eps, momentum;
+} hc_se_mlp_desc;
+int64_t hc_se_mlp_part_floats(int32_t N, int32_t R);
+int hc_se_mlp_fwd(const hc_se_mlp_desc* d, hc_stream_t stream);
+int hc_se_mlp_bwd(const hc_se_mlp_desc* d, hc_stream_t stream);
+
 /* Squeeze-excite gate of ReXNet (rexnet.py:63-66) fused with the ReLU6 that follows it (rexnet.py:129):
  * out = act(z * sigmoid(l[n][c])), z NHWC bf16 [N][HW][C], l bf16 [N][C] gate logits, act 0 | 6 (ReLU6).
  * bwd_gate: dgate fp32 [N][C] = sum_hw g*mask*z and dlogits bf16 [N][C] = dgate * s (1 - s);

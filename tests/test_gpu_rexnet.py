@@ -61,6 +61,83 @@ def test_depthwise_conv_kernels_vs_torch(case):
     assert ey < 6e-3 and ex < 3e-2 and ew < 4e-2 and eg < 3e-2 and eb < 3e-2 and em < 2e-3, (ey, ex, ew, eg, eb, em)
 
 
+SE_MLP_CASES = [(5, 20, 32, 3, 6, True), (70, 228, 256, 19, 6, True), (256, 1044, 1088, 87, 6, True), (64, 96, 96, 128, 1, False),
+                (130, 40, 48, 33, 0, True)]
+
+
+@pytest.mark.parametrize("case", SE_MLP_CASES, ids=["N%d_C%d_Cp%d_R%d_act%d_b%d" % c for c in SE_MLP_CASES])
+def test_se_mlp_kernels_vs_torch(case):
+    """hc_se_mlp_fwd / hc_se_mlp_bwd (csrc/se_mlp.hip; reference: the nn.Sequential of SEBlock, rexnet.py:49-61, on the pooled
+    vectors with a training-mode BatchNorm2d) against the same MLP in float64 on the CPU: logits, saved statistics, running
+    statistics, and every gradient.  Ragged row tiles, channel padding, R up to the supported 128, ReLU6 / ReLU / no activation."""
+    import ctypes as C
+
+    from holocron_amd import _lib
+    from holocron_amd._lib import check, stream
+    N, Cc, Cp, R, act, has_b2 = case
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11 + N + Cc + R)
+    # the kernels round their MFMA operands to bf16 (like every convolution of the framework): pooled vectors and weights are given
+    # bf16-representable values here so that the float64 reference sees the same numbers; what is left is the rounding of the hidden
+    # activations and of their gradients
+    pooled = torch.zeros((N, Cp))
+    pooled[:, :Cc] = _bf16(torch.rand((N, Cc), generator=g))
+    w1 = _bf16(torch.randn((R, Cc), generator=g) * (2.0 / Cc ** 0.5))
+    gamma, beta = torch.rand((R,), generator=g) + 0.5, torch.randn((R,), generator=g) * 0.5 + (1.0 if act == 6 else 0.0)
+    w2 = _bf16(torch.randn((Cc, R), generator=g) * (1.0 / R ** 0.5))
+    b2 = torch.randn((Cc,), generator=g) * 0.3 if has_b2 else None
+    rm, rv = torch.randn((R,), generator=g) * 0.1, torch.rand((R,), generator=g) + 0.5
+    dl = torch.zeros((N, Cp))
+    dl[:, :Cc] = torch.randn((N, Cc), generator=g)
+    dl = _bf16(dl)
+    eps, mom = 1e-5, 0.1
+    # float64 reference
+    P, W1, G, B, W2 = (t.double().requires_grad_(True) for t in (pooled[:, :Cc], w1, gamma, beta, w2))
+    B2 = b2.double().requires_grad_(True) if has_b2 else None
+    h1 = P @ W1.t()
+    mean, var = h1.mean(0), h1.var(0, unbiased=False)
+    y = (h1 - mean) / torch.sqrt(var + eps) * G + B
+    h = {0: lambda t: t, 1: torch.relu, 6: lambda t: t.clamp(0, 6)}[act](y)
+    logits = h @ W2.t() + (B2 if has_b2 else 0.0)
+    grads = torch.autograd.grad((logits * dl[:, :Cc].double()).sum(), [P, W1, G, B, W2] + ([B2] if has_b2 else []))
+    rm_ref = (1 - mom) * rm.double() + mom * mean.detach()
+    rv_ref = (1 - mom) * rv.double() + mom * h1.detach().var(0, unbiased=N > 1)
+    # the kernels
+    dev = torch.device("cuda:0")
+    nf = int(lib.hc_se_mlp_part_floats(N, R))
+    t = {k: v.to(dev).contiguous() for k, v in dict(pooled=pooled, w1=w1, gamma=gamma, beta=beta, w2=w2, rm=rm, rv=rv).items()}
+    b2g = b2.to(dev) if has_b2 else None
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    h1g, part, stat = (torch.empty(n, device=dev) for n in (N * R, nf, 2 * R))
+    lg = torch.full((N, Cp), 7.0, dtype=torch.bfloat16, device=dev)
+    d = _lib.SeMlpDesc()
+    d.pooled, d.w1, d.gamma, d.beta, d.w2 = (t[k].data_ptr() for k in ("pooled", "w1", "gamma", "beta", "w2"))
+    d.b2 = b2g.data_ptr() if has_b2 else None
+    d.running_mean, d.running_var, d.num_batches_tracked = t["rm"].data_ptr(), t["rv"].data_ptr(), nbt.data_ptr()
+    d.h1, d.part, d.stat, d.logits = h1g.data_ptr(), part.data_ptr(), stat.data_ptr(), lg.data_ptr()
+    d.N, d.C, d.Cp, d.R, d.act, d.eps, d.momentum = N, Cc, Cp, R, act, eps, mom
+    check(lib.hc_se_mlp_fwd(C.byref(d), stream()), "hc_se_mlp_fwd")
+    assert rel_l2(lg[:, :Cc].float().cpu(), logits.detach().float()) < 8e-3          # bf16 hidden activations, bf16 storage of the logits
+    assert Cp == Cc or float(lg[:, Cc:].float().abs().max()) == 0.0
+    assert rel_l2(h1g.view(N, R).cpu(), h1.detach().float()) < 1e-5
+    assert rel_l2(stat[:R].cpu(), mean.detach().float()) < 1e-5
+    assert rel_l2(stat[R:].cpu(), (1.0 / torch.sqrt(var + eps)).detach().float()) < 1e-4
+    assert rel_l2(t["rm"].cpu(), rm_ref.float()) < 1e-5 and rel_l2(t["rv"].cpu(), rv_ref.float()) < 1e-4 and int(nbt) == 1
+    dlg = dl.to(dev).to(torch.bfloat16)
+    gbuf, part2 = torch.empty(N * R, device=dev), torch.empty(nf, device=dev)
+    dpool = torch.full((N, Cp), 7.0, device=dev)
+    dw1, dw2, dgb = torch.empty((R, Cc), device=dev), torch.empty((Cc, R), device=dev), torch.empty((2, R), device=dev)
+    db2 = torch.empty((Cc,), device=dev) if has_b2 else None
+    d.dl, d.g, d.part2, d.dpool, d.dw1, d.dw2 = (x.data_ptr() for x in (dlg, gbuf, part2, dpool, dw1, dw2))
+    d.dgamma, d.dbeta = dgb.data_ptr(), dgb.data_ptr() + 4 * R
+    d.db2 = db2.data_ptr() if has_b2 else None
+    check(lib.hc_se_mlp_bwd(C.byref(d), stream()), "hc_se_mlp_bwd")
+    got = [dpool[:, :Cc], dw1, dgb[0], dgb[1], dw2] + ([db2] if has_b2 else [])
+    for name, a, b in zip(("dpool", "dw1", "dgamma", "dbeta", "dw2", "db2"), got, grads):
+        assert rel_l2(a.cpu(), b.float()) < 1e-2, (name, rel_l2(a.cpu(), b.float()))
+    assert Cp == Cc or float(dpool[:, Cc:].abs().max()) == 0.0
+
+
 def _run_block_case(c):
     import holocron_amd as h
     from oracle import rexnet as orx
