@@ -740,7 +740,10 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
             return launch_cfg<4, 2, 2, 4, 32, false, 4, 1>(d, st);
         }
     }
-    if (d.srcC % 64 == 0) return launch_bk<64>(d, st);
-    if (d.srcC % 32 == 0) return launch_bk<32>(d, st);
+    // HC_CONV_BK=32 | 16 caps the k-step (A/B: a 192-channel tile with 64-channel k-steps stages 2 x 40 KB - two workgroups need the
+    // whole 160 KB of LDS)
+    static const int bk_cap = [] { const char* e = getenv("HC_CONV_BK"); return e == nullptr ? 64 : atoi(e); }();
+    if (d.srcC % 64 == 0 && bk_cap >= 64) return launch_bk<64>(d, st);
+    if (d.srcC % 32 == 0 && bk_cap >= 32) return launch_bk<32>(d, st);
     return launch_bk<16>(d, st);
 }
