@@ -188,6 +188,8 @@ SIGNATURES = {
     "hc_msbn_bwd_apply": (c_int32, [C.POINTER(MsbnIo), c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
     "hc_dwrep_dgrad": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
     "hc_conv_gather": (c_int32, [C.POINTER(ConvDesc), c_void_p]),
+    "hc_conv_pointwise_supported": (c_int32, [C.POINTER(ConvDesc)]),
+    "hc_conv_pointwise": (c_int32, [C.POINTER(ConvDesc), c_void_p]),
     "hc_conv_small": (c_int32, [C.POINTER(ConvSmallDesc), c_void_p]),
     "hc_conv_small_supported": (c_int32, [C.POINTER(ConvSmallDesc)]),
     "hc_conv_s2_supported": (c_int32, [C.POINTER(ConvS2Desc)]),

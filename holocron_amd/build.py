@@ -17,6 +17,7 @@ ARCH = "gfx950"
 
 SOURCES = {
     "conv_gather.hip": [],
+    "conv_pointwise.hip": [],
     "conv_small.hip": [],
     "conv_resident.hip": [],
     "conv_wgrad.hip": [],

@@ -690,6 +690,13 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
         if (d.resid != nullptr || d.bias != nullptr || d.act != 0 || d.pix_scale != nullptr || d.ch_mult != nullptr) return HC_ERR_ARG;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // narrow 1 x 1 convolutions: the weight-stationary streaming kernel (conv_pointwise.hip).  HC_CONV_PW=0 off; 1: launches WITHOUT
+    // statistics whose output is at least twice as wide as the input (the data gradients of the projections: store-heavy, 1.4-2.7 TB/s
+    // in the gather form); 3: those with statistics too (the expansions forward); 2: everything the kernel supports
+    static const int pw = [] { const char* e = getenv("HC_CONV_PW"); return e == nullptr ? 1 : atoi(e); }();
+    if (pw > 0 && hc_conv_pointwise_supported(dp) &&
+        (pw == 2 || (d.Cout >= 2 * d.srcC && (pw == 3 || d.stats == nullptr))))
+        return hc_conv_pointwise(dp, stream);
     if (d.ch_mult != nullptr) {   // fp8 inference path
         if ((d.srcC % 64) != 0 || (d.Cout % 4) != 0 || d.stats != nullptr || d.resid != nullptr || d.pix_scale != nullptr) return HC_ERR_ARG;
         if ((double)d.N * d.IH * d.IW * d.srcC >= 4294967280.0) return HC_ERR_ARG;

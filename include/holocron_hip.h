@@ -84,6 +84,13 @@ typedef struct {
     int32_t co_split;
 } hc_conv_desc;
 int hc_conv_gather(const hc_conv_desc* d, hc_stream_t stream);
+/* Streaming form for 1 x 1 stride-1 convolutions over at most 128 input channels (the expansion convolutions of rexnet.py:97-103 and
+ * the data gradients of the projections, conv_sequence(..., kernel_size=1) in holocron/models/utils.py:73): weights stationary in
+ * registers, 32-pixel tiles, optional BatchNorm statistics; no bias / residual / activation / second source.  hc_conv_gather routes the
+ * launches this covers here by itself (HC_CONV_PW=0: never, =2: also when the output is narrower than twice the input);
+ * hc_conv_pointwise returns HC_ERR_ARG for a descriptor hc_conv_pointwise_supported rejects. */
+int hc_conv_pointwise_supported(const hc_conv_desc* d);
+int hc_conv_pointwise(const hc_conv_desc* d, hc_stream_t stream);
 
 /* Stride-1 3x3 (+1x1) convolution of a RepBlock (holocron/models/classification/repvgg.py:71-73 and its data gradient) for
  * small channel counts: C <= 48 on large images (persistent software-pipelined workgroups, weights resident in registers, DMA'd

@@ -13,7 +13,7 @@ import csv, glob, collections, json, sys
 O, cmd = sys.argv[1], sys.argv[2]
 def fam(k):
     if "cs2::" in k: return "conv_wgrad" if "wgrad" in k and "reduce" not in k else ("conv_s2" if "reduce" not in k else None)
-    if "conv_gather_kernel" in k: return "conv_gather"
+    if "conv_gather_kernel" in k or "conv_pw_kernel" in k: return "conv_gather"
     if "conv_rows" in k: return "conv_rows"
     if "conv_small" in k or "conv_resident" in k: return "conv_small"
     if ("wgrad" in k or "wrep_kernel" in k) and "reduce" not in k and "dw3x3" not in k: return "conv_wgrad"

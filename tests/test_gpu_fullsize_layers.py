@@ -436,3 +436,50 @@ def test_c3_rexnet_pointwise_vs_fp32_cpu(cfg):
     ew = rel_l2(dw.cpu()[:cout, :cin], torch.nn.grad.conv2d_weight(x, w.shape, dy))
     assert ew < TOL_F32, (cfg, "wgrad", ew)
     print(cfg, f"fwd {e:.2e} dgrad {ed:.2e} wgrad {ew:.2e}")
+
+
+PW_STREAM = [(2, 16, 96, 13, 9), (3, 48, 256, 7, 7), (1, 128, 320, 5, 11), (2, 32, 16, 9, 9), (64, 64, 320, 28, 28), (64, 32, 192, 56, 56)]
+
+
+@pytest.mark.parametrize("cfg", PW_STREAM, ids=["N%d_%d-%d_%dx%d" % c for c in PW_STREAM])
+def test_streaming_pointwise_conv_vs_fp32_cpu(cfg):
+    """hc_conv_pointwise (csrc/conv_pointwise.hip: the weight-stationary 1 x 1 kernel hc_conv_gather routes narrow launches to),
+    called directly: pixel counts that are not multiples of the 32-pixel tile, a last channel group that is partly empty, every
+    k-step count the kernel is built for, with and without BatchNorm statistics; two full-size ReXNet shapes."""
+    import ctypes as C
+
+    from holocron_amd import _lib
+    from holocron_amd._lib import check, ptr, stream
+    from holocron_amd.ops import conv as cv
+    N, Ci, Co, H, W = cfg
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    g = gen(7000 + Ci + Co + H)
+    x = bf16r(torch.rand((N, Ci, H, W), generator=g) - 0.5)
+    w = bf16r(torch.randn((Co, Ci, 1, 1), generator=g) * (2.0 / Ci) ** 0.5)
+    xg, wpk = cv.to_cl_bf16(x.to(dev)), cv.pack_weight(w.to(dev), 0)
+    c = F.conv2d(x, w)
+    outs = []
+    for with_stats in (True, False):
+        y = cv.empty_cl(N, Co, H, W, dev)
+        stats = torch.zeros((_lib.stat_replicas(), 2, Co), device=dev) if with_stats else None
+        d = cv.fwd_desc(N, Ci, H, W, Co, 1, 1, 1, 0)
+        d.src0, d.wpk, d.dst, d.stats = ptr(xg), ptr(wpk), ptr(y), ptr(stats)
+        assert lib.hc_conv_pointwise_supported(C.byref(d)) == 1
+        check(lib.hc_conv_pointwise(C.byref(d), stream()), "hc_conv_pointwise")
+        torch.cuda.synchronize()
+        e = rel_l2(nchw(y), c)
+        assert e < TOL_BF16, (cfg, with_stats, e)
+        if with_stats:
+            _stat_check(stats, c, (cfg, "stats"))
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    # what the kernel does not cover is refused, not mis-computed: 3 x 3, a bias, more than 128 input channels
+    d3 = cv.fwd_desc(N, Ci, H, W, Co, 3, 3, 1, 1)
+    d3.src0, d3.wpk, d3.dst = ptr(xg), ptr(wpk), ptr(outs[0])
+    assert lib.hc_conv_pointwise_supported(C.byref(d3)) == 0
+    dw_ = cv.fwd_desc(N, 144, H, W, Co, 1, 1, 1, 0)
+    dw_.src0, dw_.wpk, dw_.dst = ptr(xg), ptr(wpk), ptr(outs[0])
+    assert lib.hc_conv_pointwise_supported(C.byref(dw_)) == 0
+    assert lib.hc_conv_pointwise(C.byref(dw_), stream()) != 0
+
