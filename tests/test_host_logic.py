@@ -567,3 +567,23 @@ def test_multi_copy_launch_plan_covers_every_element_once():
                     (4000, 80000, 8)]
     assert parallel._copy_pieces([], 8, 3) == []
 
+
+def test_squeeze_excite_mlp_routing_predicate():
+    """nn/mbconv_op.se_mlp_fusable: the fused hc_se_mlp_* launches take exactly the layout the reference builds (rexnet.py:49-61:
+    1x1 conv without bias, training-mode BatchNorm2d, ReLU / ReLU6, 1x1 conv); anything else stays on the generic units."""
+    from torch import nn
+
+    from holocron_amd.models.classification.rexnet import SEBlock
+    from holocron_amd.nn.mbconv_op import se_mlp_fusable
+    m = SEBlock(228, 12, nn.ReLU6(inplace=True), nn.BatchNorm2d).train()
+    c1, bn, act, c2 = list(m.conv)[:4]
+    assert se_mlp_fusable(c1, bn, act, c2)
+    m.eval()
+    assert not se_mlp_fusable(c1, bn, act, c2)                       # running statistics: the generic units
+    m.train()
+    assert not se_mlp_fusable(c1, bn, nn.SiLU(), c2)                 # an activation the kernels do not fuse
+    assert not se_mlp_fusable(nn.Conv2d(228, 19, 1, bias=True), bn, act, c2)
+    assert not se_mlp_fusable(c1, nn.BatchNorm2d(19, momentum=None), act, c2)
+    wide = SEBlock(2400, 12, nn.ReLU6(), nn.BatchNorm2d).train()     # 200 reduced channels: above the kernels' 128
+    assert not se_mlp_fusable(*list(wide.conv)[:4])
+
