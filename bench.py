@@ -3,7 +3,8 @@
 per-GPU batch 256 (BASELINE.json configs[1]); weak scaling over GPUs with RCCL gradient all-reduce.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...                      (starts its own N ranks: parallel.ensure_ranks)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (same job; N must match)
 
 Prints ONE JSON line (rank 0).  `value` is whole-job images/sec with inputs resident in HBM.
 `roofline` is measured live with HIP events on the launch stream in an extra instrumented step
@@ -88,6 +89,10 @@ def cpu_baseline(batch, iters):
 
 def main():
     args = parse()
+    # `bench.py --gpus N` IS the N-rank job: with no launcher around it this process starts the N ranks itself (one per GPU) and
+    # exits with their status; under torchrun WORLD_SIZE must equal --gpus (a mismatch is a mis-launch, not a 1-GPU measurement)
+    from holocron_amd.parallel import ensure_ranks
+    ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     # Only the JSON line may reach stdout: libraries that print from C (RCCL's version banner sits in the
     # stdio buffer until exit, i.e. after our line) are sent to stderr, the result goes to the real fd 1.
     sys.stdout.flush()

@@ -34,6 +34,45 @@ def init_process_group_from_env(backend: Optional[str] = None) -> bool:
     return True
 
 
+def ensure_ranks(gpus: int, script: str, argv: List[str]) -> None:
+    """`script --gpus N` must measure N ranks, wrapper or not (bench.py and the scripts/bench_*.py drivers call this first).
+
+    * launched by torchrun (WORLD_SIZE set): WORLD_SIZE has to equal ``gpus``, anything else is a mis-launch and raises;
+    * ``gpus == 1`` without a launcher: returns, the caller runs single-process;
+    * ``gpus > 1`` without a launcher: this process becomes the launcher - it runs
+      ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script argv...``
+      (one rank per GPU, the driver's own command form), forwards its exit status and never returns.
+
+    The reference trains on one device only (trainer/core.py:90-104), so none of this has a counterpart there."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    if gpus < 1:
+        raise SystemExit(f"--gpus must be >= 1 (got {gpus})")
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != gpus:
+            raise SystemExit(f"--gpus {gpus} disagrees with WORLD_SIZE={ws}: launch with --nproc-per-node {gpus} (or drop the launcher, "
+                             f"`{os.path.basename(script)} --gpus {gpus}` starts its own ranks)")
+        return
+    if gpus == 1:
+        return
+    if torch.cuda.is_available() and torch.cuda.device_count() < gpus:
+        raise SystemExit(f"--gpus {gpus} but only {torch.cuda.device_count()} device(s) visible")
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL fails with the legacy mode)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
     """Make every rank start from rank ``src``'s parameters and buffers."""
     if not dist.is_initialized():

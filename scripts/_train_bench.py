@@ -53,6 +53,8 @@ def best_threads_run(fn, counts=(8, 16, 32, 64)):
 
 def run(a, build_model, make_batch, loss_of, metric, workload, train_gflop_per_img=None, cpu_baseline=None, extra=None, traffic_key=None):
     """build_model() -> nn.Module (CPU); make_batch(rank, device) -> (x, target); loss_of(model, x, target) -> scalar loss."""
+    from holocron_amd.parallel import ensure_ranks
+    ensure_ranks(a.gpus, os.path.abspath(sys.argv[0]), sys.argv[1:])   # --gpus N starts N ranks when no launcher did
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)                      # RCCL prints its banner from C at exit: only the JSON line may reach stdout
