@@ -354,7 +354,7 @@ __global__ void ce_fwd_bwd_kernel(const float* __restrict__ logits, const long* 
     const long tg = target[n];
     float sum_logp = 0.f;
     for (int k = 0; k < K; ++k) sum_logp += px[k] - lse;
-    const float nll = -(px[tg] - lse);
+    const float nll = -(((tg >= 0 && tg < K) ? px[tg] : NAN) - lse);   // class index out of range: NaN loss, no out-of-bounds read
     const float smooth = -sum_logp / (float)K;
     loss_el[n] = (1.f - ls) * nll + ls * smooth;
     if (dlogits != nullptr) {
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(1024) void ce_mean_fwd_kernel(const float* __restri
         const float lse = logf(se) + mx;
         float sum_logp = 0.f;
         for (int k = 0; k < K; ++k) sum_logp += px[k] - lse;
-        nll += -(px[tg] - lse);
+        nll += -(((tg >= 0 && tg < K) ? px[tg] : NAN) - lse);   // class index out of range (torch asserts): NaN loss, no out-of-bounds read
         sm += -sum_logp;
         cnt += 1.f;
     }
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void ce_rows_fwd_kernel(const float* __restric
     if (lane == 0) {
         const float lse = logf(se) + mx;
         lse_out[n] = lse;
-        part[2 * n] = -(px[tg] - lse);
+        part[2 * n] = -(((tg >= 0 && tg < K) ? px[tg] : NAN) - lse);   // out-of-range class index: NaN loss, no out-of-bounds read
         part[2 * n + 1] = -(sx - (float)K * lse);          // - sum_k log p_k
     }
 }

@@ -169,8 +169,10 @@ class ReXNet(nn.Sequential):
         _lib.require_gpu(x)
         POOL.begin(x.device)
         scope = padded_model_scope(self)
-        scope.__enter__()
+        entered = False
         try:
+            scope.__enter__()          # may raise (weight repack): POOL.end() below must still run, the registry must not stay ours
+            entered = True
             mods = list(self.features)
             blocks = [m for m in mods if isinstance(m, ReXBlock)]
             first, last = mods.index(blocks[0]), mods.index(blocks[-1])
@@ -186,7 +188,8 @@ class ReXNet(nn.Sequential):
                 pooled = pooled[:, :tail[0].out_channels]
             return self.head(pooled)
         finally:
-            scope.__exit__(None, None, None)
+            if entered:
+                scope.__exit__(None, None, None)
             POOL.end()
 
 

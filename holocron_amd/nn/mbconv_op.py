@@ -89,7 +89,11 @@ class padded_model_scope:
             units = self.model._hcp_units = {}
         self.prev, _REGISTRY = _REGISTRY, units
         if units:
-            _prepack_units(self.model, units)
+            try:
+                _prepack_units(self.model, units)
+            except BaseException:
+                _REGISTRY = self.prev          # a failed repack must not leave later models registering into this one's dict
+                raise
         return self
 
     def __exit__(self, *exc):
@@ -112,6 +116,15 @@ def _prepack_units(model, units):
     cache = getattr(model, "_hcp_tables", None)
     if cache is None:
         cache = model._hcp_tables = {}
+
+    def upload(arr, dev):
+        # the item table goes up by a pageable host-to-device copy: inside a stream capture that either fails or is recorded as a
+        # memcpy node whose host buffer is gone at replay (the pack kernel would then read garbage pointers) - same rule as
+        # repblock_op.launch_pack_items; a model's SECOND forward is the first to come here, so one eager step is not enough
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("padded conv weight images must be packed once outside stream capture (run two eager steps before "
+                               "GraphedStep.capture(): the first registers the units, the second uploads their item tables)")
+        return torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
     if dense:
         sig = tuple((w.data_ptr(), st.pw[0].data_ptr(), st.pw[1].data_ptr()) for (st, w, _a, _b, _c) in dense)
         ent = cache.get("dense")
@@ -124,7 +137,7 @@ def _prepack_units(model, units):
                     a.w, a.dst, a.Cout, a.Cin, a.KH, a.KW, a.mode, a.tap0, a.T, a.ld = (w.data_ptr(), dst.data_ptr(), Cout, Cin_g, KH, KW, mode,
                                                                                         0, KH * KW, ld)
                 mx = max(mx, w.numel())
-            tab = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dense[0][1].device)
+            tab = upload(arr, dense[0][1].device)
             ent = cache["dense"] = (sig, tab, 2 * len(dense), mx)
         check(lib.hc_pack_conv_weights_multi(ent[1].data_ptr(), ent[2], ent[3], stream()), "hc_pack_conv_weights_multi")
     if dwise:
@@ -137,7 +150,7 @@ def _prepack_units(model, units):
                 for a, (dst, flip) in zip((arr[2 * i], arr[2 * i + 1]), ((st.pw[0], 0), (st.pw[1], 1))):
                     a.w, a.out, a.C, a.Cpad, a.flip = w.data_ptr(), dst.data_ptr(), w.shape[0], coutp, flip
                 mx = max(mx, coutp)
-            tab = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dwise[0][1].device)
+            tab = upload(arr, dwise[0][1].device)
             ent = cache["dw"] = (sig, tab, 2 * len(dwise), mx)
         check(lib.hc_dw3x3_pack_multi(ent[1].data_ptr(), ent[2], ent[3], stream()), "hc_dw3x3_pack_multi")
     for (st, w, _a, _b, _c) in stale:

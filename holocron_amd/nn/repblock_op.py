@@ -438,6 +438,7 @@ class RepBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w3, w1, g3, b3, g1, b1, g0, b0, st, relu):
         lib = _lib.load()
+        cv._WREP.note_forward()       # a queue still armed by a backward pass that died is emptied here
         Cout, Cin = w3.shape[0], w3.shape[1]
         N, _, H, W = x.shape
         dev = x.device

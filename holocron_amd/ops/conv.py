@@ -455,13 +455,12 @@ class _RepWgradQueue:
         Cout, Cin = key[4], key[1]
         task = torch._C._current_graph_task_id()
         if self.armed and task != self.task:
-            # Another graph task submits while the queue is armed.  Either the pass that armed it never ran its final callback (the
-            # engine skips it when backward raises: an OOM the caller retries, KeyboardInterrupt, an error in a hook), or this is a
-            # RE-ENTRANT backward nested inside a pass that is still running (torch.utils.checkpoint(use_reentrant=True), a
-            # backward() inside a custom Function: the task ids run [0, 1, 0]).  The two cannot be told apart here, and dropping the
-            # jobs would leave the zero-filled placeholders of the outer pass in .grad, so the stale jobs are LAUNCHED:
-            # their tuples keep every operand alive, and filling gradients nobody reads any more is harmless.  The queue is then
-            # disarmed, this pass arms it for its own task, and an outer pass that resumes afterwards re-arms it on its next submit.
+            # Another graph task submits while the queue is armed: a RE-ENTRANT backward nested inside a pass that is still running
+            # (torch.utils.checkpoint(use_reentrant=True), a backward() inside a custom Function: the task ids run [0, 1, 0]).  Dropping
+            # the jobs would leave the zero-filled placeholders of the outer pass in .grad, so they are LAUNCHED: their
+            # tuples keep every operand alive.  The queue is then disarmed, this pass arms it for its own task, and the outer pass
+            # re-arms it on its next submit.  (A pass that DIED before its final callback - backward raised - is caught earlier, by
+            # note_forward() in the next forward, and its jobs are dropped there.)
             self._flush_stale()
         dw3 = self._zeros((Cout, Cin, 3, 3), x.device, key)
         dw1 = self._zeros((Cout, Cin, 1, 1), x.device, key)
@@ -478,6 +477,20 @@ class _RepWgradQueue:
             self.armed, self.task = True, task
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
         return dw3, dw1
+
+    def note_forward(self):
+        """Called from RepBlockFn.forward.  A forward that runs while the queue is armed and NO backward pass is executing
+        (`_current_graph_task_id() == -1`; the recomputation of a re-entrant checkpoint runs inside one) means the pass that armed the
+        queue died before its final callback - backward raised and the caller went on.  Its jobs are DROPPED, not launched: the
+        placeholders autograd adopted stay zero, so a retry of the micro-batch without zero_grad accumulates the right gradient into
+        them (launching the stale jobs later, from inside the retry, would count the failed micro-batch twice: ADVICE r4)."""
+        if self.armed and torch._C._current_graph_task_id() == -1:
+            self.jobs = []
+            if self.inflight:
+                torch.cuda.current_stream().wait_stream(self.side)
+                self.inflight, self.side_params = [], set()
+            self.armed, self.task = False, -1
+            self.arena, self.arena_used, self.arena_want, self.arena_first = None, 0, 0, None
 
     def _flush_stale(self):
         sizes = dict(self.arena_sizes)

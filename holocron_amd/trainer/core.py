@@ -111,6 +111,11 @@ class Trainer:
         self.start_epoch = self.epoch = state["epoch"]
         self.step, self.min_loss = state["step"], state["min_loss"]
         self.model.load_state_dict(state["model"])
+        if self._world() > 1:
+            # `load` is a collective under data parallelism (like the constructor): whatever each rank read, every rank continues from
+            # rank 0's parameters and buffers - the construction-time broadcast does not cover a checkpoint loaded afterwards
+            from ..parallel import broadcast_parameters
+            broadcast_parameters(self.model, 0)
         if "optimizer" in state:
             self.optimizer.load_state_dict(state["optimizer"])
             # fit_n_epochs / find_lr / check_setup rebuild the groups with an empty state first thing: keep the loaded one for them

@@ -1,6 +1,8 @@
 """GPU: pointwise / box / NMS / loss / optimizer kernels against golden vectors and the oracle.
 Box indices and NMS results are integer work: bit-exact.  Box arithmetic (fp32, no contraction) is
 bit-exact too except the atan-based aspect term."""
+import os
+
 import pytest
 import torch
 
@@ -212,6 +214,16 @@ def test_cross_entropy_matches_torch_cpu_fp32():
     # two passes agree bit for bit (fixed-order sums)
     a, b = h.nn.functional.cross_entropy(x, t, 0.1), h.nn.functional.cross_entropy(x, t, 0.1)
     assert torch.equal(a, b)
+    # a class index outside [0, K) that is not ignore_index (torch asserts on the device): NaN loss here, never an out-of-bounds read
+    #  - narrow and wide heads
+    for K in (10, 1000):
+        xb = torch.randn((16, K), generator=g).cuda()
+        tb = torch.randint(0, K, (16,), generator=g).cuda()
+        for bad in (K, K + 12345, -1):
+            tb2 = tb.clone()
+            tb2[3] = bad
+            assert torch.isnan(h.nn.functional.cross_entropy(xb, tb2, 0.1)), (K, bad)
+        assert torch.isfinite(h.nn.functional.cross_entropy(xb, tb, 0.1))
 
 
 def test_global_avg_pool_matches_adaptive_avg_pool():
@@ -525,3 +537,33 @@ def test_batched_nms_equals_nms_problem_by_problem():
         want = nms(allb[offs[p]:offs[p + 1]], torch.ones((n,), device="cuda"), 0.5)
         assert nk[p] == want.numel(), (p, n, nk[p], want.numel())
         assert torch.equal(keep[offs[p]:offs[p] + nk[p]].long(), want)
+
+
+def test_batched_nms_bit_exact_vs_oracle_at_eval_bench_sizes():
+    """hc_nms_sorted_batched - the kernel `bench_yolov4.py --eval` times - against `oracle/tv_ops.nms` (the
+    restated torchvision algorithm) DIRECTLY, not through hc_nms_sorted: the 3 x 16 problems of a 608^2 batch of 16 at their maximum
+    sizes (76^2 x 3 = 17 328, 38^2 x 3 = 4 332, 19^2 x 3 = 1 083 candidate boxes), clustered so that suppression chains are long;
+    keep lists are compared index for index."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import tv_ops
+    from holocron_amd.ops.boxes import batched_nms_sorted
+    g = torch.Generator().manual_seed(23)
+    sizes = [n for _ in range(16) for n in (17328, 4332, 1083)]
+    boxes, offs = [], [0]
+    for n in sizes:
+        centres = torch.rand((40, 2), generator=g)                       # 40 objects per image: boxes cluster around them
+        c = centres[torch.randint(0, 40, (n,), generator=g)] + torch.randn((n, 2), generator=g) * 0.02
+        wh = torch.rand((n, 2), generator=g) * 0.15 + 0.03
+        boxes.append(torch.cat([c - wh / 2, c + wh / 2], 1))
+        offs.append(offs[-1] + n)
+    allb = torch.cat(boxes, 0)
+    keep, nkeep = batched_nms_sorted(allb.cuda(), torch.tensor(offs, dtype=torch.int32).cuda(), sizes, 0.5)
+    keep, nk = keep.cpu().long(), nkeep.cpu().tolist()
+    total = 0
+    for p, n in enumerate(sizes):
+        want = tv_ops.nms(allb[offs[p]:offs[p + 1]], torch.ones((n,)), 0.5)      # equal scores: stable order = the given order
+        assert nk[p] == want.numel(), (p, n, nk[p], want.numel())
+        assert torch.equal(keep[offs[p]:offs[p] + nk[p]], want), p
+        total += want.numel()
+    assert 0 < total < sum(sizes) // 4                                   # suppression really happened

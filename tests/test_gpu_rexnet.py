@@ -224,3 +224,37 @@ def test_rexnet1_0x_train_step_matches_reference(golden):
     m.eval()
     with torch.no_grad():
         assert m(gm["x"].cuda()).shape == (4, 10)
+
+
+def test_rexnet_capture_without_two_eager_steps_is_refused():
+    """a ReXNet's SECOND forward uploads the item tables of its padded convs (host-to-device copy).  Under stream capture
+    that copy would be recorded with a host buffer that is gone at replay, so it is refused; after two eager steps capture works."""
+    import holocron_amd as h
+    from holocron_amd import parallel
+    torch.manual_seed(0)
+    m = h.models.rexnet1_0x(num_classes=10, dropout_ratio=0.0).cuda().train()
+    opt = h.optim.AdaBelief(m.parameters(), lr=1e-3)
+    x, t = torch.rand(4, 3, 64, 64).cuda(), torch.randint(0, 10, (4,)).cuda()
+
+    def fwd_bwd():
+        opt.zero_grad(set_to_none=True)
+        F.cross_entropy(m(x).float(), t).backward()
+    fwd_bwd()                                   # forward 1 registers the units
+    opt.step()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with pytest.raises(RuntimeError, match="outside stream capture"):
+        with torch.cuda.stream(s):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                m(x)                            # forward 2 would upload the tables inside the capture
+    torch.cuda.synchronize()
+    fwd_bwd()                                   # eager forward 2: tables uploaded
+    opt.step()
+    gs = parallel.GraphedStep(fwd_bwd, opt, None)
+    gs.capture()
+    before = m.head[1].weight.detach().clone()
+    gs.run()
+    torch.cuda.synchronize()
+    assert not torch.equal(before, m.head[1].weight.detach())
+    gs.release()

@@ -389,6 +389,65 @@ def test_deferred_wgrad_queue_recovers_from_an_aborted_backward(monkeypatch):
     assert torch.equal(w3.grad, torch.ones_like(w3)) and torch.equal(w1.grad, torch.ones_like(w1))
 
 
+def test_aborted_backward_is_not_counted_twice_under_gradient_accumulation(monkeypatch):
+    """a micro-batch whose backward raised and is retried WITHOUT zero_grad.  RepBlockFn.forward calls note_forward(): the
+    queue of the dead pass is emptied by the retry's forward (no backward is running there), so the retry's gradient lands in the
+    zero placeholders once - launching the stale jobs from inside the retry would add the failed micro-batch a second time."""
+    fq = _FakeQueue(monkeypatch)
+    w3 = torch.nn.Parameter(torch.zeros(16, 16, 3, 3))
+    w1 = torch.nn.Parameter(torch.zeros(16, 16, 1, 1))
+    x = torch.ones(2, 16, 4, 4, requires_grad=True)
+    with pytest.raises(RuntimeError, match="boom"):
+        _rep_like(w3, w1, x, fail=True).backward()
+    assert cv._WREP.armed and cv._WREP.jobs
+    cv._WREP.note_forward()                                                # what the retry's first RepBlock forward does
+    assert not cv._WREP.armed and not cv._WREP.jobs
+    fq.launches.clear()
+    _rep_like(w3, w1, x).backward()
+    assert torch.equal(w3.grad, torch.ones_like(w3)) and torch.equal(w1.grad, torch.ones_like(w1))
+    assert len(fq.launches) == 1                                           # the retry's own job only: the dead pass's was dropped
+
+
+def test_note_forward_leaves_a_running_pass_alone(monkeypatch):
+    """The recomputation forward of a re-entrant checkpoint runs INSIDE a backward pass: note_forward() must not drop the outer jobs."""
+    fq = _FakeQueue(monkeypatch)
+    ws = [(torch.nn.Parameter(torch.zeros(16, 16, 3, 3)), torch.nn.Parameter(torch.zeros(16, 16, 1, 1))) for _ in range(2)]
+    x = torch.ones(2, 16, 4, 4, requires_grad=True)
+    seen = []
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            before = len(cv._WREP.jobs)
+            cv._WREP.note_forward()
+            seen.append((before, len(cv._WREP.jobs), cv._WREP.armed))
+            return g
+    y = _rep_like_y(*ws[1], Probe.apply(_rep_like_y(*ws[0], x)))          # backward order: block 1 queues, Probe, block 0 queues
+    y.sum().backward()
+    assert seen == [(1, 1, True)]
+    for w3, w1 in ws:
+        assert torch.equal(w3.grad, torch.ones_like(w3)) and torch.equal(w1.grad, torch.ones_like(w1))
+
+
+def _rep_like_y(w3, w1, x):
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w3, w1):
+            ctx.save_for_backward(x, w3, w1)
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w3, w1 = ctx.saved_tensors
+            dw3, dw1 = cv.rep_block_wgrad(x, g, g, w3, w1, 1, defer=True)
+            return g, dw3, dw1
+    return Fn.apply(x, w3, w1)
+
+
 def test_deferred_wgrad_queue_survives_a_reentrant_backward(monkeypatch):
     """torch.utils.checkpoint(use_reentrant=True) runs a nested backward (a new graph task) inside the outer pass: the jobs the outer
     pass queued before it must still be launched (they were dropped and the zero placeholders stayed in .grad)."""
