@@ -71,6 +71,17 @@ class ConvS2Desc(C.Structure):
                 ("Cout", c_int32), ("x_nchw_f32", c_int32)]
 
 
+class StemDesc(C.Structure):
+    """hc_stem_desc (include/holocron_hip.h)."""
+    _fields_ = [("x", c_void_p), ("w3img", c_void_p), ("w1img", c_void_p), ("N", c_int32), ("H", c_int32), ("W", c_int32)]
+
+
+class StemBwdDesc(C.Structure):
+    """hc_stem_bwd_desc (include/holocron_hip.h)."""
+    _fields_ = [(n, c_void_p) for n in ("coef", "g", "save", "gamma3", "gamma1", "w3", "w1", "dgamma3", "dbeta3", "dgamma1", "dbeta1",
+                                        "dw3", "dw1", "ws")] + [("act", c_int32), ("frozen", c_int32), ("accumulate", c_int32)]
+
+
 class ConvS2DgradDesc(C.Structure):
     _fields_ = [("dy3", c_void_p), ("dy1", c_void_p), ("wimg", c_void_p), ("dx", c_void_p),
                 ("N", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32)]
@@ -288,6 +299,11 @@ SIGNATURES = {
     "hc_im2col_small_fp8": (c_int32, [c_void_p, c_void_p] + [c_int32] * 11 + [c_float, c_void_p]),
     "hc_quantize_fp8": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_int64, c_int32, c_float, c_void_p]),
     "hc_gap_fp8": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "hc_stem_fused_supported": (c_int32, [c_void_p]),
+    "hc_stem_stats": (c_int32, [c_void_p] * 4),
+    "hc_stem_apply": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "hc_stem_bwd_ws_bytes": (c_int64, []),
+    "hc_stem_bwd": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "hc_set_deterministic": (c_int32, [c_int32]),
     "hc_get_deterministic": (c_int32, []),
     "hc_get_stat_replicas": (c_int32, []),

@@ -835,6 +835,426 @@ __global__ __launch_bounds__(256) void s2_stem_wgrad_reduce_kernel(const float* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ stem, fused with its BatchNorm
+// The stem block (repvgg.py:71-73 with in_channels = 3) is the one place where the conv is cheaper to REDO than to store: its input
+// is 0.6 MB per image (fp32 planes), each of its two outputs 1.2 MB per image in bf16, and the BatchNorm passes around it (apply,
+// backward reduce, backward apply) moved y3 / y1 / dy3 / dy1 eleven times per step - 3.4 GB of the step's 19 GB of BatchNorm traffic at
+// batch 256.  Here y3 and y1 never exist in HBM; every pass recomputes the two convs from the image window with the SAME two / one
+// MFMAs per fragment as s2_stem_kernel (same operands in the same k slots: the fp32 results are bit-identical from pass to pass, so
+// the ReLU mask of the backward IS the forward's):
+//   mode 0  statistics  image -> per-channel sum / sum of squares of the fp32 conv results                    154 MB read
+//   mode 1  apply       image -> out = act(a3 c3 + a1 c1 + shift), NHWC bf16 (+ the statistics of `out`)      154 MB read, 308 MB written
+//   mode 2  backward    image, g -> three small matrices from which the WHOLE backward of the block follows    462 MB read
+// against 770 + 924 (conv, apply) + 924 + 1540 + 770 (reduce, apply, weight gradient) = 4.9 GB for the unfused sequence.  BatchNorm
+// normalises the fp32 conv results here (the unfused path normalises their bf16 roundings): one rounding less per branch.
+//
+// Backward in ONE pass.  With dz = g [z > 0] (z recomputed), BatchNorm's backward gives dy_b = A_b dz + B_b c_b + C_b per branch b
+// (A, B, C per channel from the sums sum dz, sum dz c_b: rep_bn_bwd_finalize_kernel), and the conv weight gradient is
+// dW3[co][k] = sum_p dy3[p][co] xw[p][k] over the 27 window entries xw[p][k] of output pixel p.  Because c3 = W3 . xw is LINEAR in
+// the window and the window is only 27 wide, every sum over pixels factors through
+//   G [co][k]  = sum_p dz[p][co] xw[p][k]        48 x 27   (the weight gradient of dz; its centre-tap columns are the 1x1 conv's)
+//   XX[k'][k]  = sum_p xw[p][k'] xw[p][k]        27 x 27   (Gram matrix of the windows)
+//   and the window's pad slot {c0, c1, c2, PAD} set to 1 (its weights are zero, the convs do not see it): column (centre tap, pad) of
+//   G is sum_p dz[p][co] and of XX is sum_p xw[p][k']
+// namely  sum dz c3 = <W3[co], G[co]>,  dW3 = A3 G + B3 (W3 XX) + C3 sum xw,  likewise for the 1x1 conv on the centre-tap block.  The
+// pass therefore needs no second sweep for the weight gradients (the two-sweep form read image + g twice: reduce, then a weight-gradient
+// launch that re-formed dy3 / dy1) and no per-pixel products in the VALU (which bounded that form: 108 VALU operations per 16-pixel
+// fragment at 4 cycles each against 9 MFMAs): dz is masked in place in the LDS gradient tile, G takes 9 and XX 6 MFMAs per 32 pixels -
+// XX's two operands are the SAME registers (the B-operand layout of the window IS the A-operand layout of its transpose).
+// stem_bwd_finalize_kernel turns (G, XX) into dgamma, dbeta, dW3, dW1 in fp32; nothing is rounded to bf16 on the way (the unfused path
+// rounds dy3 / dy1 as MFMA operands), so the result is closer to the fp32 reference, not further.
+// Persistent workgroups walk (image, row block) tiles in XCD-contiguous runs with the next tile's loads in flight.
+struct SfArgs {
+    const float* x;
+    const void* w3img;
+    const void* w1img;
+    const float* coef;       // [4][48]: a3, a1, (unused), shift - hc_rep_bn_finalize's output          modes 1, 2
+    const void* g;           // NHWC bf16 [N][112][112][48]                                              mode 2
+    void* out;               // NHWC bf16                                                                mode 1
+    float* acc0;             // mode 0: stats3 [reps][2][48]; mode 1: statistics of `out` [reps][2][48] or null; mode 2: slabs
+    float* acc1;             // mode 0: stats1
+    int N, H, ntiles, act, reps;
+    int dbg;                 // HC_STEM_DBG timing knock-outs (results are wrong): 1 no G / XX stage, 4 no gradient DMA, 8 no conv stage
+};
+
+constexpr int SF_NT = 15;                                  // mode 2 accumulator tiles per wave: 9 of G (3 co x 3 kh), 6 of XX (kh' <= kh)
+constexpr int SF_SLAB = SF_NT * 256;                       // floats per workgroup slab
+
+template <int MODE>
+struct SfGeo {
+    static constexpr int R = MODE < 2 ? 4 : 2;                 // output rows per tile
+    static constexpr int WSB = (224 + 2) * 8, ROWS = 2 * R + 1;
+    static constexpr int WINB = (ROWS * WSB + 1023) / 1024 * 1024;
+    static constexpr int NPIX = R * 112, NFRAG = NPIX / 16;
+    static constexpr int GB = MODE == 2 ? (NPIX * 96 + 1023) / 1024 * 1024 : 0;       // gradient tile (masked in place: dz)
+    static constexpr int GP = GB / 1024;
+    static constexpr int NG = MODE == 2 ? 2 : 0;               // two gradient buffers: the next tile's is DMA'd while this one is worked on
+    static constexpr int OPITCH = 104, OST = 16 * OPITCH;      // mode 1: one staged fragment per wave
+    static constexpr int USED = WINB + NG * GB + (MODE == 1 ? 4 * OST : 0) + 64;
+    static constexpr int SMEM = (MODE == 2 && USED < 4 * SF_SLAB * 4) ? 4 * SF_SLAB * 4 : USED;      // the end-of-kernel wave reduction reuses the tiles' LDS
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void stem_fused_kernel(const SfArgs a) {
+    using G = SfGeo<MODE>;
+    constexpr int R = G::R, WSB = G::WSB, ROWS = G::ROWS, CO = 48, WOUT = 112, WIN = 224;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 15, g = lane >> 4;
+    const int H = a.H, HO = H / 2, RB = HO / R;
+    char* const sgb = smem + G::WINB;             // gradient tiles [pixel][48] bf16
+
+    // weights of all three 16-channel tiles of both convs (pack mode 6), kept for the workgroup's life
+    const __amdgpu_buffer_rsrc_t rw3 = make_rsrc(a.w3img, 3u * 2u * 1024u);
+    const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(a.w1img, 3u * 1024u);
+    u32x4 a3[3][2], a1[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        a3[t][0] = buf_load16(rw3, (unsigned)(lane * 16), (unsigned)((t * 2 + 0) * 1024));
+        a3[t][1] = buf_load16(rw3, (unsigned)(lane * 16), (unsigned)((t * 2 + 1) * 1024));
+        a1[t] = buf_load16(rw1, (unsigned)(lane * 16), (unsigned)(t * 1024));
+    }
+    // per-lane coefficients of its 12 channels (16 t + 4 g + e)
+    f32x4 ka3[3], ka1[3], ksh[3];
+    if (MODE >= 1) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            ka3[t] = *reinterpret_cast<const f32x4*>(a.coef + 16 * t + 4 * g);
+            ka1[t] = *reinterpret_cast<const f32x4*>(a.coef + CO + 16 * t + 4 * g);
+            ksh[t] = *reinterpret_cast<const f32x4*>(a.coef + 3 * CO + 16 * t + 4 * g);
+        }
+    }
+    // The weights / coefficients must have LANDED before the first prefetch is issued: the compiler's wait-count pass otherwise finds
+    // them behind the prefetch loads in the in-order vmcnt queue and puts `s_waitcnt vmcnt(0)` in front of the fragment loop's MFMAs -
+    // every tile then waits for the NEXT tile's loads (seen in the ISA of the first prefetching version)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        asm volatile("" : "+v"(a3[t][0]), "+v"(a3[t][1]), "+v"(a1[t]));
+        if (MODE >= 1) asm volatile("" : "+v"(ka3[t]), "+v"(ka1[t]), "+v"(ksh[t]));
+    }
+    // running sums: mode 0 {sum c3, sum c3^2, sum c1, sum c1^2}, mode 1 {sum out, sum out^2} of the bf16-rounded output (the identity
+    // BatchNorm of the next block normalises exactly those values)
+    constexpr int NK = MODE == 0 ? 4 : (MODE == 1 ? 2 : 1);
+    f32x4 sm[NK][3];
+    if (MODE <= 1) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) sm[k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 accg[3][3], accx[6];                    // mode 2: G[co tile][kh] (16 co x 16 k slots each), XX[(kh', kh)] for kh' <= kh
+    if (MODE == 2) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) accg[c][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) accx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned lds0 = hc_lds_addr(smem);
+    const u32x4 rsg = hc_raw_rsrc(a.g, MODE == 2 ? (unsigned)a.N * HO * WOUT * CO * 2u : 0u);
+
+    // ---- tile loop.  The NEXT tile's operands are requested before this tile is worked on: the image window into registers (it is
+    // converted to bf16 slots on the way into LDS, after this tile's last read of the window), the gradient tile by DMA into the other
+    // gradient buffer.  Single-buffered, a workgroup spent most of a tile's time waiting for its loads.
+    constexpr int IPR = WIN / 4, NITEM = ROWS * IPR, NIT = (NITEM + 255) / 256;
+    f32x4 v[NIT][3];
+    bool vin[NIT];                                // the item's row lies inside the image (its pad slot is 1 in mode 2)
+    auto request = [&](const int L, const int gbuf) {
+        const int tile = xcd_tile(L, a.ntiles);
+        const int n = tile / RB, r0 = (tile - n * RB) * R;
+        const float* xin = a.x + (size_t)n * 3 * H * WIN;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 256 + tid;
+            const int r = idx / IPR, c4 = idx - r * IPR;
+            const int ih = 2 * r0 - 1 + r;
+            const bool ok = idx < NITEM && ih >= 0;
+            vin[it] = ok;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+                v[it][ci] = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xin + ((size_t)ci * H + ih) * WIN + 4 * c4))
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (MODE == 2 && !(a.dbg & 4)) {                  // gradient tile: R output rows are contiguous in memory -> linear DMA
+            const unsigned base = (unsigned)((n * HO + r0) * WOUT) * (unsigned)(CO * 2);
+            for (int j = wid; j < G::GP; j += 4) {
+                const unsigned off = (unsigned)(j * 1024 + lane * 16);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(G::WINB + gbuf * G::GB + j * 1024));
+                hc_dma16(rsg, dst, off < (unsigned)(G::NPIX * 96) ? base + off : HC_OOB);
+            }
+        }
+    };
+    int gcur = 0;
+    if ((int)blockIdx.x < a.ntiles) request(blockIdx.x, 0);
+#pragma unroll 1
+    for (int L = blockIdx.x; L < a.ntiles; L += gridDim.x) {
+        const int tile = xcd_tile(L, a.ntiles);
+        const int n = tile / RB, r0 = (tile - n * RB) * R;
+        char* const sg = sgb + gcur * G::GB;              // this tile's gradient (masked in place: dz)
+        // window: fp32 planes -> {c0, c1, c2, pad} bf16 slots (slot x = input column x - 1), as in s2_stem_kernel; pad = 0, or 1 inside
+        // the image in mode 2.  Nobody reads the window any more: the previous tile ended on a barrier
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * 256 + tid;
+            const int r = idx / IPR, c4 = idx - r * IPR;
+            const float pad = (MODE == 2 && vin[it]) ? 1.f : 0.f;
+            if (idx < NITEM) {
+                char* wp = smem + r * WSB + (1 + 4 * c4) * 8;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<u32x2*>(wp + 8 * k) = u32x2{pack_bf16x2(v[it][0][k], v[it][1][k]), pack_bf16x2(v[it][2][k], pad)};
+            }
+        }
+        if (tid < ROWS * 2) {                             // left halo slot and the zero slot behind the last pixel
+            const int r = tid >> 1;
+            *reinterpret_cast<u32x2*>(smem + r * WSB + ((tid & 1) ? (WIN + 1) * 8 : 0)) = u32x2{0u, 0u};
+        }
+        if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this tile's gradient has landed
+        __syncthreads();
+        if (L + (int)gridDim.x < a.ntiles) request(L + gridDim.x, gcur ^ 1);
+
+        // ---- the convs of this tile, 16 pixels x 48 channels x 2 per fragment
+#pragma unroll 1
+        for (int f = wid; f < ((a.dbg & 8) ? 0 : G::NFRAG); f += 4) {
+            const int orow = f / (WOUT / 16), fx = f - orow * (WOUT / 16), ox = fx * 16 + px;
+            const char* p0 = smem + (2 * orow + (g >> 1)) * WSB + 16 * ox + 16 * (g & 1);
+            const char* p1 = smem + (2 * orow + 2) * WSB + 16 * ox + 16 * (g & 1);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(p0);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(p1);
+            const int pt = orow * WOUT + ox;              // this lane's pixel of the tile
+            char* ost = smem + G::WINB + wid * G::OST + px * G::OPITCH + g * 8;       // mode 1
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                f32x4 c3 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][0]), b0, c3, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][1]), b1, c3, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[t]), b0, c1, 0, 0, 0);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sm[0][t][e] += c3[e]; sm[1][t][e] += c3[e] * c3[e];
+                        sm[2][t][e] += c1[e]; sm[3][t][e] += c1[e] * c1[e];
+                    }
+                    continue;
+                }
+                // pre-activation: the fma chain of rep_preact<false> (csrc/rep_bn.hip), so that every pass rounds alike
+                float z[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = __builtin_fmaf(ka3[t][e], c3[e], __builtin_fmaf(ka1[t][e], c1[e], ksh[t][e]));
+                if (MODE == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[e] = (a.act == 1 && !(z[e] > 0.f)) ? 0.f : z[e];
+                    const u32x2 pk = u32x2{pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3])};
+                    *reinterpret_cast<u32x2*>(ost + 32 * t) = pk;
+                    if (a.acc0 != nullptr) {
+                        const float r[4] = {bf16lo(pk[0]), bf16hi(pk[0]), bf16lo(pk[1]), bf16hi(pk[1])};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { sm[0][t][e] += r[e]; sm[1][t][e] += r[e] * r[e]; }
+                    }
+                    continue;
+                }
+                // mode 2: dz = g [z > 0], masked in place (two bf16 per word: nothing is re-rounded)
+                if (a.act == 1) {
+                    char* gp = sg + pt * (CO * 2) + 32 * t + 8 * g;
+                    const u32x2 gw = *reinterpret_cast<const u32x2*>(gp);
+                    const unsigned m0 = (z[0] > 0.f ? 0x0000ffffu : 0u) | (z[1] > 0.f ? 0xffff0000u : 0u);
+                    const unsigned m1 = (z[2] > 0.f ? 0x0000ffffu : 0u) | (z[3] > 0.f ? 0xffff0000u : 0u);
+                    *reinterpret_cast<u32x2*>(gp) = u32x2{gw[0] & m0, gw[1] & m1};
+                }
+            }
+            if (MODE == 1) {
+                // the fragment's 16 pixels x 48 channels are 1536 consecutive bytes of `out`: 96 coalesced 16-byte stores
+                bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+                const size_t fbase = (((size_t)n * HO + r0 + orow) * WOUT + fx * 16) * CO;
+                const char* rd = smem + G::WINB + wid * G::OST;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int q = i * 64 + lane, pp = q / 6, c = q - pp * 6;
+                    if (q < 96) {
+                        const char* src = rd + pp * G::OPITCH + c * 16;
+                        const u32x2 lo = *reinterpret_cast<const u32x2*>(src), hi = *reinterpret_cast<const u32x2*>(src + 8);
+                        __builtin_nontemporal_store(u32x4{lo[0], lo[1], hi[0], hi[1]}, reinterpret_cast<u32x4*>(out + fbase + pp * CO + c * 8));
+                    }
+                }
+            }
+        }
+        if (MODE == 2) {
+            __syncthreads();                              // dz of the whole tile is in LDS
+            // G and XX over the tile's pixels, k32 steps dealt to the four waves: A = dz^T (transposing reads of the [pixel][48] tile,
+            // as in s2_stem_wgrad_kernel), B = the window rows; XX multiplies the window registers with themselves
+            const int la = lane & 15, kq = lane >> 4;
+            for (int gstep = wid; gstep < ((a.dbg & 1) ? 0 : G::NPIX / 32); gstep += 4) {
+                const char* pa[2];
+                const char* pbw[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int p = 32 * gstep + 16 * h + 4 * kq + (la >> 2);       // this lane's k-row (output pixel of the tile)
+                    const int ar = p / WOUT, ox = p - ar * WOUT;
+                    pa[h] = sg + p * (CO * 2) + 8 * (la & 3);
+                    pbw[h] = smem + (2 * ar) * WSB + (2 * ox + (la & 3)) * 8;
+                }
+                bf16x8 b[3];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) b[kh] = sw_tr_pair(pbw[0] + kh * WSB, pbw[1] + kh * WSB);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const bf16x8 fz = sw_tr_pair(pa[0] + 32 * c, pa[1] + 32 * c);
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) accg[c][kh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fz, b[kh], accg[c][kh], 0, 0, 0);
+                }
+                accx[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], b[0], accx[0], 0, 0, 0);
+                accx[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], b[1], accx[1], 0, 0, 0);
+                accx[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0], b[2], accx[2], 0, 0, 0);
+                accx[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], b[1], accx[3], 0, 0, 0);
+                accx[4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1], b[2], accx[4], 0, 0, 0);
+                accx[5] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2], b[2], accx[5], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                  // everybody is done with this tile's window and gradient buffer
+        gcur ^= 1;
+    }
+
+    if (MODE == 0 || (MODE == 1 && a.acc0 != nullptr)) {
+        // fold the 16 pixel lanes of a DPP row, lanes px < 4 of every row own channel 16 t + 4 g + px; one slot per wave
+        const size_t slot = (size_t)((blockIdx.x * 4 + wid) % a.reps);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                float m = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s = row16_sum(sm[k][t][e]);
+                    m = px == e ? s : m;
+                }
+                if (px < 4) {
+                    const int ch = 16 * t + 4 * g + px;
+                    if (MODE == 0) atomicAdd((k < 2 ? a.acc0 : a.acc1) + slot * 2 * CO + (k & 1) * CO + ch, m);
+                    else atomicAdd(a.acc0 + slot * 2 * CO + k * CO + ch, m);
+                }
+            }
+    }
+    if (MODE == 2) {
+        // slab of this workgroup: [15 tiles][row][col], D layout: lane (la = column, kq) holds rows 4 kq .. 4 kq + 3.  Tiles 0 .. 8:
+        // G[co tile c][kh] (row = co % 16, col = k slot 4 kw + ci | pad), tiles 9 .. 14: XX (row = slot of kernel row kh', col = slot
+        // of kernel row kh) for (kh', kh) = (0,0) (0,1) (0,2) (1,1) (1,2) (2,2).  The four waves are added through LDS in wave order.
+        const int la = lane & 15, kq = lane >> 4;
+        __syncthreads();
+        float* part = reinterpret_cast<float*>(smem) + wid * SF_SLAB;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[((c * 3 + kh) * 16 + 4 * kq + r) * 16 + la] = accg[c][kh][r];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[((9 + i) * 16 + 4 * kq + r) * 16 + la] = accx[i][r];
+        __syncthreads();
+        float* slab = a.acc0 + (size_t)blockIdx.x * SF_SLAB;
+        const float* all = reinterpret_cast<const float*>(smem);
+        for (int e = tid; e < SF_SLAB; e += 256) slab[e] = ((all[e] + all[SF_SLAB + e]) + all[2 * SF_SLAB + e]) + all[3 * SF_SLAB + e];
+    }
+}
+
+// S[e] = sum over the workgroup slabs, in a fixed order (one workgroup per 16 elements, as s2_stem_wgrad_reduce_kernel)
+__global__ __launch_bounds__(256) void stem_bwd_slab_sum_kernel(const float* __restrict__ ws, int nslab, float* __restrict__ S) {
+    __shared__ float sm[16][17];
+    const int el = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = part;
+    for (; k + 48 < nslab; k += 64) {
+        s0 += ws[(size_t)k * SF_SLAB + e];
+        s1 += ws[(size_t)(k + 16) * SF_SLAB + e];
+        s2 += ws[(size_t)(k + 32) * SF_SLAB + e];
+        s3 += ws[(size_t)(k + 48) * SF_SLAB + e];
+    }
+    for (; k < nslab; k += 16) s0 += ws[(size_t)k * SF_SLAB + e];
+    sm[part][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (part != 0) return;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += sm[q][el];
+    S[e] = v;
+}
+
+// (G, XX) -> everything the block's backward returns.  One workgroup; thread = (co, j) with j = one of the 27 3x3 weights, or a
+// per-channel job.  Weights enter as the bf16 roundings the MFMAs multiplied with (RNE of the fp32 master, like the packer).
+struct SfFin {
+    const float* S;          // [15][16][16]
+    const float* w3;         // fp32 master [48][3][3][3]
+    const float* w1;         // [48][3]
+    const float* save;       // [6][48]: mean3, invstd3, mean1, invstd1, ...
+    const float* gamma3;
+    const float* gamma1;
+    float* dgamma3; float* dbeta3; float* dgamma1; float* dbeta1;
+    float* dw3; float* dw1;
+    float count;
+    int frozen, accumulate;
+};
+__device__ __forceinline__ float sf_bf16r(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+__device__ __forceinline__ float sf_xx(const float* S, int kh1, int s1, int kh2, int s2) {      // XX[(kh1, s1)][(kh2, s2)] (symmetric; tiles kh1 <= kh2)
+    if (kh1 > kh2) { const int t = kh1; kh1 = kh2; kh2 = t; const int u = s1; s1 = s2; s2 = u; }
+    const int tile = 9 + (kh1 == 0 ? kh2 : (kh1 == 1 ? 2 + kh2 : 5));
+    return S[(tile * 16 + s1) * 16 + s2];
+}
+__global__ __launch_bounds__(256) void stem_bwd_finalize_kernel(const SfFin f) {
+    __shared__ float sA[2][48], sB[2][48], sC[2][48];
+    const int tid = threadIdx.x;
+    const float* S = f.S;
+    auto gcol = [&](int co, int kh, int slot) { return S[(((co >> 4) * 3 + kh) * 16 + (co & 15)) * 16 + slot]; };
+    if (tid < 96) {
+        const int b = tid / 48, co = tid - 48 * b;              // branch 0: 3x3, 1: 1x1
+        const float sdz = gcol(co, 1, 7);                        // centre tap, pad slot: sum of dz
+        float sdzy = 0.f;
+        if (b == 0) {
+            for (int ci = 0; ci < 3; ++ci)
+                for (int kh = 0; kh < 3; ++kh)
+                    for (int kw = 0; kw < 3; ++kw) sdzy += sf_bf16r(f.w3[((co * 3 + ci) * 3 + kh) * 3 + kw]) * gcol(co, kh, 4 * kw + ci);
+        } else {
+            for (int ci = 0; ci < 3; ++ci) sdzy += sf_bf16r(f.w1[co * 3 + ci]) * gcol(co, 1, 4 + ci);
+        }
+        const float mean = f.save[(2 * b) * 48 + co], invstd = f.save[(2 * b + 1) * 48 + co];
+        const float gam = (b == 0 ? f.gamma3 : f.gamma1)[co];
+        const float dgamma = invstd * (sdzy - mean * sdz);       // the expressions of rep_bn_bwd_finalize_kernel
+        const float av = gam * invstd;
+        float B = 0.f, Cc = 0.f;
+        if (!f.frozen) {
+            B = -av * invstd * dgamma / f.count;
+            Cc = -av * sdz / f.count - B * mean;
+        }
+        sA[b][co] = av; sB[b][co] = B; sC[b][co] = Cc;
+        float* dg = b == 0 ? f.dgamma3 : f.dgamma1;
+        float* db = b == 0 ? f.dbeta3 : f.dbeta1;
+        if (dg != nullptr) dg[co] = f.accumulate ? dg[co] + dgamma : dgamma;
+        if (db != nullptr) db[co] = f.accumulate ? db[co] + sdz : sdz;
+    }
+    __syncthreads();
+    for (int o = tid; o < 48 * 27 + 48 * 3; o += 256) {
+        if (o < 48 * 27) {
+            const int co = o / 27, j = o - 27 * co, ci = j / 9, kh = (j - 9 * ci) / 3, kw = j - 9 * ci - 3 * kh, slot = 4 * kw + ci;
+            float wxx = 0.f;                                     // sum_k' W3[co][k'] XX[k'][k]
+            for (int ci2 = 0; ci2 < 3; ++ci2)
+                for (int kh2 = 0; kh2 < 3; ++kh2)
+                    for (int kw2 = 0; kw2 < 3; ++kw2)
+                        wxx += sf_bf16r(f.w3[((co * 3 + ci2) * 3 + kh2) * 3 + kw2]) * sf_xx(S, kh2, 4 * kw2 + ci2, kh, slot);
+            const float v = sA[0][co] * gcol(co, kh, slot) + sB[0][co] * wxx + sC[0][co] * sf_xx(S, kh, slot, 1, 7);
+            f.dw3[o] = f.accumulate ? f.dw3[o] + v : v;
+        } else {
+            const int q = o - 48 * 27, co = q / 3, ci = q - 3 * co, slot = 4 + ci;
+            float wxx = 0.f;
+            for (int ci2 = 0; ci2 < 3; ++ci2) wxx += sf_bf16r(f.w1[co * 3 + ci2]) * sf_xx(S, 1, 4 + ci2, 1, slot);
+            const float v = sA[1][co] * gcol(co, 1, slot) + sB[1][co] * wxx + sC[1][co] * sf_xx(S, 1, slot, 1, 7);
+            f.dw1[q] = f.accumulate ? f.dw1[q] + v : v;
+        }
+    }
+}
+
 template <typename K>
 void set_smem(K kern, int smem) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -960,4 +1380,91 @@ extern "C" int hc_conv_s2_fwd(const hc_conv_s2_desc* dp, hc_stream_t stream) {
     }
     if (d.Cout == 48) return rsel ? cs2::launch_layer<48, 48, 112, 1, 1>(a, st) : cs2::launch_layer<48, 48, 112, 2, 1>(a, st);
     return rsel ? cs2::launch_layer<48, 96, 56, 2, 2>(a, st) : cs2::launch_layer<48, 96, 56, 4, 2>(a, st);
+}
+
+// ---- the stem block fused with its BatchNorm passes (stem_fused_kernel): y3 / y1 are never stored
+namespace cs2 {
+constexpr int SF_MAX_GRID = 1024;
+
+template <int MODE>
+int launch_stem_fused(SfArgs& a, hipStream_t st) {
+    using G = SfGeo<MODE>;
+    auto kern = stem_fused_kernel<MODE>;
+    // persistent workgroups = what is RESIDENT (two or three per CU, by registers and LDS): one more per CU would start when the first
+    // finishes and leave most of the chip idle behind it
+    static int resident = 0;
+    if (resident == 0) {
+        set_smem(kern, G::SMEM);
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, G::SMEM) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+        resident = per_cu * prop.multiProcessorCount;
+        if (resident > SF_MAX_GRID) resident = SF_MAX_GRID;
+        resident = resident / 8 * 8;
+    }
+    a.ntiles = a.N * (a.H / 2 / G::R);
+    int grid = resident;
+    static const int genv = env_int("HC_STEM_GRID", 0);       // experiments: workgroups per launch
+    if (genv > 0 && genv <= SF_MAX_GRID) grid = genv;
+    if (grid > a.ntiles) grid = a.ntiles;
+    a.reps = hc_get_stat_replicas();
+    a.dbg = env_int("HC_STEM_DBG", 0);
+    if ((MODE == 0 || (MODE == 1 && a.acc0 != nullptr)) && hc_get_deterministic() && grid * 4 > a.reps) return -1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::SMEM, st, a);
+    return grid;
+}
+
+static bool sf_fill(SfArgs& a, const hc_stem_desc* dp) {
+    if (!hc_stem_fused_supported(dp) || dp->x == nullptr || dp->w3img == nullptr || dp->w1img == nullptr) return false;
+    a = SfArgs{};
+    a.x = dp->x; a.w3img = dp->w3img; a.w1img = dp->w1img; a.N = dp->N; a.H = dp->H;
+    return true;
+}
+}  // namespace cs2
+
+extern "C" int hc_stem_fused_supported(const hc_stem_desc* dp) {
+    static const bool on = cs2::env_int("HC_CONV_S2", 1) != 0 && cs2::env_int("HC_STEM_FUSED", 1) != 0;
+    if (!on || dp == nullptr) return 0;
+    if (dp->N < 1 || dp->W != 224 || dp->H < 16 || dp->H % 16 != 0) return 0;
+    return (double)dp->N * dp->H * dp->W * 12.0 < 4294967000.0;
+}
+
+extern "C" int hc_stem_stats(const hc_stem_desc* dp, float* stats3, float* stats1, hc_stream_t stream) {
+    cs2::SfArgs a;
+    if (!cs2::sf_fill(a, dp) || stats3 == nullptr || stats1 == nullptr) return HC_ERR_ARG;
+    a.acc0 = stats3; a.acc1 = stats1;
+    if (cs2::launch_stem_fused<0>(a, reinterpret_cast<hipStream_t>(stream)) < 0) return HC_ERR_ARG;
+    return hc_launch_status();
+}
+
+extern "C" int hc_stem_apply(const hc_stem_desc* dp, const float* coef, int32_t act, void* out, float* out_stats, hc_stream_t stream) {
+    cs2::SfArgs a;
+    if (!cs2::sf_fill(a, dp) || coef == nullptr || out == nullptr) return HC_ERR_ARG;
+    a.coef = coef; a.act = act; a.out = out; a.acc0 = out_stats;
+    if (cs2::launch_stem_fused<1>(a, reinterpret_cast<hipStream_t>(stream)) < 0) return HC_ERR_ARG;
+    return hc_launch_status();
+}
+
+extern "C" int64_t hc_stem_bwd_ws_bytes(void) { return ((int64_t)cs2::SF_MAX_GRID + 1) * cs2::SF_SLAB * 4; }
+
+extern "C" int hc_stem_bwd(const hc_stem_desc* dp, const hc_stem_bwd_desc* bp, hc_stream_t stream) {
+    cs2::SfArgs a;
+    if (!cs2::sf_fill(a, dp) || bp == nullptr) return HC_ERR_ARG;
+    const hc_stem_bwd_desc& b = *bp;
+    if (b.coef == nullptr || b.g == nullptr || b.save == nullptr || b.gamma3 == nullptr || b.gamma1 == nullptr || b.w3 == nullptr ||
+        b.w1 == nullptr || b.dw3 == nullptr || b.dw1 == nullptr || b.ws == nullptr)
+        return HC_ERR_ARG;
+    a.coef = b.coef; a.act = b.act; a.g = b.g; a.acc0 = reinterpret_cast<float*>(b.ws);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int grid = cs2::launch_stem_fused<2>(a, st);
+    if (grid < 0) return HC_ERR_ARG;
+    float* S = a.acc0 + (size_t)cs2::SF_MAX_GRID * cs2::SF_SLAB;
+    hipLaunchKernelGGL(cs2::stem_bwd_slab_sum_kernel, dim3(cs2::SF_SLAB / 16), dim3(256), 0, st, a.acc0, grid, S);
+    cs2::SfFin f;
+    f.S = S; f.w3 = b.w3; f.w1 = b.w1; f.save = b.save; f.gamma3 = b.gamma3; f.gamma1 = b.gamma1;
+    f.dgamma3 = b.dgamma3; f.dbeta3 = b.dbeta3; f.dgamma1 = b.dgamma1; f.dbeta1 = b.dbeta1; f.dw3 = b.dw3; f.dw1 = b.dw1;
+    f.count = (float)((double)dp->N * (dp->H / 2) * (dp->W / 2)); f.frozen = b.frozen; f.accumulate = b.accumulate;
+    hipLaunchKernelGGL(cs2::stem_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, f);
+    return hc_launch_status();
 }

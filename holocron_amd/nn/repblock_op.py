@@ -19,7 +19,7 @@ import os
 import torch
 
 from .. import _lib
-from .._lib import ConvS2Desc, ConvS2DgradDesc, PackItem, RepBnBwdDesc, RepBnDesc, check, ptr, stream
+from .._lib import ConvS2Desc, ConvS2DgradDesc, PackItem, RepBnBwdDesc, RepBnDesc, StemBwdDesc, StemDesc, check, ptr, stream
 from ..ops import conv as cv
 
 STEM_KPAD = 32
@@ -434,6 +434,22 @@ def block_wgrad(st, src, dy3, dy1, w3, w1, geom, stem_cin=None, defer=False):
     return dw3, dw1
 
 
+def stem_fused_desc(st, src, w3, w1, geom):
+    """hc_stem_desc when the fused stem kernels take this block (the stride-2 stem kernel's geometry at 224 x 224, 48 channels), else
+    None.  ``src`` is the contiguous fp32 NCHW image batch."""
+    N, Cin, H, W, Cout = geom
+    if Cin != 3 or Cout != 48 or st.s2_desc(N, Cin, H, W, Cout) is None or src.dtype != torch.float32 or not src.is_contiguous():
+        return None
+    d = StemDesc()
+    d.N, d.H, d.W = N, H, W
+    if not _lib.load().hc_stem_fused_supported(C.byref(d)):
+        return None
+    st.ensure_packed(w3, w1)
+    i3, i1 = st.s2_images
+    d.x, d.w3img, d.w1img = ptr(src), ptr(i3), ptr(i1)
+    return d
+
+
 class RepBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w3, w1, g3, b3, g1, b1, g0, b0, st, relu):
@@ -465,7 +481,17 @@ class RepBlockFn(torch.autograd.Function):
             raise RuntimeError("RepBlock (HIP) expects contiguous fp32 conv weights")
         R = _lib.stat_replicas()
         stats = POOL.take((2, R, 2, Cout), dev) if st.training else None
-        y3, y1 = block_convs_forward(st, src, w3, w1, (N, Cin, H, W, Cout), stats, Cin if stem else None)
+        # the stem fused with its BatchNorm passes (csrc/conv_s2.hip stem_fused_kernel): both convs are recomputed from the image in
+        # every pass, y3 / y1 never exist in HBM
+        sfd = stem_fused_desc(st, src, w3, w1, (N, Cin, H, W, Cout)) if stem_direct else None
+        if sfd is not None:
+            y3 = y1 = None
+            if st.training:
+                fl = 2.0 * N * OH * OW * Cout * 10 * Cin
+                with cv.profiled("conv_s2", fl, src.numel() * 4.0):
+                    check(lib.hc_stem_stats(C.byref(sfd), ptr(stats[0]), ptr(stats[1]), stream()), "hc_stem_stats")
+        else:
+            y3, y1 = block_convs_forward(st, src, w3, w1, (N, Cin, H, W, Cout), stats, Cin if stem else None)
 
         coef = torch.empty((4, Cout), dtype=torch.float32, device=dev)
         save = torch.empty((6, Cout), dtype=torch.float32, device=dev)
@@ -493,10 +519,15 @@ class RepBlockFn(torch.autograd.Function):
         # backward's reduction target, zeroed with the rest of the arena; re-validated in backward (ZeroPool.claim)
         ctx.red, ctx.red_gen = POOL.take_for_backward((_lib.stat_replicas(), 4, Cout), dev) if st.training else (None, -1)
         tb = N * OH * OW * Cout * 2.0            # bytes of one activation tensor of this block
-        with cv.profiled("bn_elementwise", 0.0, tb * (4 if st.identity else 3)):      # reads y3, y1 [, x], writes out
-            check(lib.hc_rep_apply(ptr(y3), ptr(y1), ptr(src) if st.identity else None, ptr(coef), ptr(out), ptr(out_stats),
-                                   N * OH * OW, Cout, 1 if relu else 0, stream()), "hc_rep_apply")
+        if sfd is not None:
+            with cv.profiled("bn_elementwise", 0.0, src.numel() * 4.0 + tb):          # reads the image, writes out
+                check(lib.hc_stem_apply(C.byref(sfd), ptr(coef), 1 if relu else 0, ptr(out), ptr(out_stats), stream()), "hc_stem_apply")
+        else:
+            with cv.profiled("bn_elementwise", 0.0, tb * (4 if st.identity else 3)):      # reads y3, y1 [, x], writes out
+                check(lib.hc_rep_apply(ptr(y3), ptr(y1), ptr(src) if st.identity else None, ptr(coef), ptr(out), ptr(out_stats),
+                                       N * OH * OW, Cout, 1 if relu else 0, stream()), "hc_rep_apply")
         ctx.st, ctx.relu, ctx.stem, ctx.stem_direct = st, relu, stem, stem_direct
+        ctx.stem_fused = sfd is not None
         ctx.geom = (N, Cin, H, W, Cout, OH, OW)
         ctx.was_training = st.training
         # `out` is not kept for the backward: its ReLU mask is recomputed from (y3, y1, src, coef) by the *_z kernels
@@ -516,9 +547,31 @@ class RepBlockFn(torch.autograd.Function):
         act = 1 if ctx.relu else 0
         xid = src if st.identity else None
 
+        tb = npix * Cout * 2.0
+        if ctx.stem_fused:
+            # the fused stem: ONE pass over (image, g) gives G = dz^T X and the Gram matrix of the conv windows, from which a single-
+            # workgroup kernel forms the BatchNorm parameter gradients and both weight gradients (csrc/conv_s2.hip, mode 2)
+            if ctx.needs_input_grad[0]:
+                raise NotImplementedError("input gradient of the stem block")
+            sfd = stem_fused_desc(st, src, w3, w1, (N, Cin, H, W, Cout))
+            if sfd is None:
+                raise _lib.HipError("the stem's fused backward needs the weight images its forward ran on (HC_STEM_FUSED changed mid-step?)")
+            dgam = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+            dbet = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+            dw3 = torch.empty_like(w3, dtype=torch.float32)
+            dw1 = torch.empty_like(w1, dtype=torch.float32)
+            ws = torch.empty((int(lib.hc_stem_bwd_ws_bytes()),), dtype=torch.uint8, device=dev)
+            b = StemBwdDesc()
+            b.coef, b.g, b.save, b.gamma3, b.gamma1, b.w3, b.w1 = ptr(coef), ptr(g), ptr(save), ptr(g3), ptr(g1), ptr(w3), ptr(w1)
+            b.dgamma3, b.dbeta3, b.dgamma1, b.dbeta1 = ptr(dgam[0]), ptr(dbet[0]), ptr(dgam[1]), ptr(dbet[1])
+            b.dw3, b.dw1, b.ws = ptr(dw3), ptr(dw1), ptr(ws)
+            b.act, b.frozen, b.accumulate = act, 0 if ctx.was_training else 1, 0
+            # family: the weight gradient's (its FLOPs are the conv weight gradients'; the BatchNorm reduce rides in the same pass)
+            with cv.profiled("conv_wgrad", 2.0 * npix * Cout * 10 * Cin, src.numel() * 4.0 + tb):
+                check(lib.hc_stem_bwd(C.byref(sfd), C.byref(b), stream()), "hc_stem_bwd")
+            return (None, dw3, dw1, dgam[0], dbet[0], dgam[1], dbet[1], None, None, None, None)
         red = POOL.claim(ctx.red, ctx.red_gen, (_lib.stat_replicas(), 4, Cout), dev)
         ctx.red = None      # a second backward through this node (retain_graph) gets a fresh buffer
-        tb = npix * Cout * 2.0
         with cv.profiled("bn_elementwise", 0.0, tb * (4 if st.identity else 3)):      # reads g, y3, y1 [, x]
             check(lib.hc_rep_bwd_reduce_z(ptr(g), ptr(coef), act, ptr(y3), ptr(y1), ptr(xid), ptr(red), npix, Cout, stream()),
                   "hc_rep_bwd_reduce_z")

@@ -160,6 +160,50 @@ int64_t hc_conv_s2_stem_wgrad_ws_bytes(void);
 int hc_conv_s2_stem_wgrad(const float* x, const void* dy3, const void* dy1, float* dw3, float* dw1, void* ws, int32_t N, int32_t H,
                           int32_t W, int32_t accumulate, hc_stream_t stream);
 
+/* The stem block (in_channels = 3) FUSED with its BatchNorm passes: the 3x3 and the 1x1 conv are recomputed from the image batch in
+ * every pass instead of being stored (each output is twice the input's size), so y3 / y1 / dy3 / dy1 never exist in HBM.  Together with
+ * hc_rep_bn_finalize these three launches replace, for the first RepBlock of RepVGG (repvgg.py:57-60,71-73: two nn.Conv2d, two
+ * training-mode nn.BatchNorm2d, the python sum and the ReLU), aten::convolution x 2, aten::native_batch_norm x 2, add, relu and their
+ * backward ops (aten::threshold_backward, native_batch_norm_backward x 2, convolution_backward(weight) x 2).
+ * x: NCHW fp32 [N][3][224][224]; w3img / w1img: hc_pack_conv_weights_multi mode 6 images; out / g: NHWC bf16 [N][112][112][48].
+ *   hc_stem_stats: stats3 / stats1 [replicas][2][48] += per-channel sum / sum of squares of the fp32 conv results
+ *   hc_stem_apply: out = act(coef[0] c3 + coef[1] c1 + coef[3])            (coef [4][48] of hc_rep_bn_finalize; act 1 = ReLU);
+ *                  out_stats (or NULL) [replicas][2][48] += sum / sum of squares of the bf16-rounded `out` (the statistics of the
+ *                  next block's identity BatchNorm, like hc_rep_apply)
+ *   hc_stem_bwd:   the whole backward from ONE pass over (x, g): dgamma / dbeta of both BatchNorm layers and dw3 [48][3][3][3],
+ *                  dw1 [48][3][1][1] (= or += with `accumulate`), through G = dz^T X and the Gram matrix X^T X of the 27-wide conv
+ *                  windows (csrc/conv_s2.hip has the algebra); save [6][48] = hc_rep_bn_finalize's means / inverse deviations, w3 / w1
+ *                  the fp32 master weights, `frozen` = eval-mode BatchNorm (dy = a dz), ws: hc_stem_bwd_ws_bytes() of scratch
+ *                  (per-workgroup slabs, added in a fixed order: bit-reproducible). */
+typedef struct {
+    const float* x;
+    const void* w3img;
+    const void* w1img;
+    int32_t N, H, W;
+} hc_stem_desc;
+typedef struct {
+    const float* coef;
+    const void* g;
+    const float* save;
+    const float* gamma3;
+    const float* gamma1;
+    const float* w3;
+    const float* w1;
+    float* dgamma3;
+    float* dbeta3;
+    float* dgamma1;
+    float* dbeta1;
+    float* dw3;
+    float* dw1;
+    void* ws;
+    int32_t act, frozen, accumulate;
+} hc_stem_bwd_desc;
+int hc_stem_fused_supported(const hc_stem_desc* d);
+int hc_stem_stats(const hc_stem_desc* d, float* stats3, float* stats1, hc_stream_t stream);
+int hc_stem_apply(const hc_stem_desc* d, const float* coef, int32_t act, void* out, float* out_stats, hc_stream_t stream);
+int64_t hc_stem_bwd_ws_bytes(void);
+int hc_stem_bwd(const hc_stem_desc* d, const hc_stem_bwd_desc* b, hc_stream_t stream);
+
 /* Weight gradient dW[co][ci][kh][kw] = sum_m dy[m][co] * x[m + tap][ci].
  * Replaces aten::convolution_backward(weight).  Split-K over output pixels: partial fp32
  * slabs go to `ws` (at least hc_conv_wgrad_ws_bytes bytes), then a reduce kernel writes

@@ -116,11 +116,13 @@ class _RepBlockBf16Fn(torch.autograd.Function):
     from the fp32 conv results, normalisation is applied to the bf16-stored values.  Sums are fp32 (here: torch-CPU reductions)."""
 
     @staticmethod
-    def forward(ctx, x, w3, w1, g3, b3, g1, b1, g0, b0, stride, identity, dx_staged, bufs):
+    def forward(ctx, x, w3, w1, g3, b3, g1, b1, g0, b0, stride, identity, dx_staged, bufs, recompute=False):
         w3r, w1r = bf16r(w3), bf16r(w1)
         c3 = F.conv2d(x, w3r, None, stride, 1)
         c1 = F.conv2d(x, w1r, None, stride, 0)
-        y3, y1 = bf16r(c3), bf16r(c1)
+        # `recompute`: the fused stem (csrc/conv_s2.hip stem_fused_kernel) never stores y3 / y1 - every pass redoes the convs and works
+        # on their fp32 results
+        y3, y1 = (c3, c1) if recompute else (bf16r(c3), bf16r(c1))
         n = c3.numel() / c3.shape[1]
         V = lambda t: t.view(1, -1, 1, 1)
         branches = [(c3, y3, g3, b3), (c1, y1, g1, b1)] + ([(x, x, g0, b0)] if identity else [])
@@ -171,14 +173,15 @@ class _RepBlockBf16Fn(torch.autograd.Function):
         dw3 = torch.nn.grad.conv2d_weight(x, w3r.shape, dy3, stride, 1)
         dw1 = torch.nn.grad.conv2d_weight(x, w1r.shape, dy1, stride, 0)
         return (dx, dw3, dw1, dgam[0], dbet[0], dgam[1], dbet[1], dgam[2] if identity else None, dbet[2] if identity else None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
-def rep_block_bf16(x, sd, prefix, stride, identity, training, dx_staged=False):
+def rep_block_bf16(x, sd, prefix, stride, identity, training, dx_staged=False, recompute=False):
     """The reference block (repvgg.py:71-73) with bf16 rounding injected exactly where the HIP path keeps bf16 tensors in HBM
     (x, y3, y1, out and, in backward, g, dy3, dy1, dx_id, dx; packed weights).  Test harness only: it separates kernel bugs from
     legitimate bf16 effects (ReLU-kink flips, tiny-batch BN, sub-ulp centring terms).  ``dx_staged``: the data gradient is
-    staged in bf16 before the identity-branch gradient is added (csrc/conv_small.hip, stride-1 blocks of <= 48 channels)."""
+    staged in bf16 before the identity-branch gradient is added (csrc/conv_small.hip, stride-1 blocks of <= 48 channels).
+    ``recompute``: y3 / y1 are not stored at all (the fused stem at 224 x 224: every pass recomputes the convs in fp32)."""
     if training:
         names = [prefix + ".branches.0.1", prefix + ".branches.1.1"] + ([prefix + ".branches.2"] if identity else [])
         bufs = []
@@ -189,13 +192,13 @@ def rep_block_bf16(x, sd, prefix, stride, identity, training, dx_staged=False):
         b0 = sd[prefix + ".branches.2.bias"] if identity else None
         return _RepBlockBf16Fn.apply(x, sd[prefix + ".branches.0.0.weight"], sd[prefix + ".branches.1.0.weight"],
                                      sd[names[0] + ".weight"], sd[names[0] + ".bias"], sd[names[1] + ".weight"], sd[names[1] + ".bias"],
-                                     g0, b0, stride, identity, dx_staged, bufs)
+                                     g0, b0, stride, identity, dx_staged, bufs, recompute)
     w3 = _round_weight(sd[prefix + ".branches.0.0.weight"])
     w1 = _round_weight(sd[prefix + ".branches.1.0.weight"])
     c3 = F.conv2d(x, w3, None, stride, 1)
     c1 = F.conv2d(x, w1, None, stride, 0)
-    out = _bn_emulated(c3, _RoundBoth.apply(c3), sd, prefix + ".branches.0.1", training)
-    out = out + _bn_emulated(c1, _RoundBoth.apply(c1), sd, prefix + ".branches.1.1", training)
+    out = _bn_emulated(c3, c3 if recompute else _RoundBoth.apply(c3), sd, prefix + ".branches.0.1", training)
+    out = out + _bn_emulated(c1, c1 if recompute else _RoundBoth.apply(c1), sd, prefix + ".branches.1.1", training)
     if identity:
         out = out + _bn_emulated(x, x, sd, prefix + ".branches.2", training)
     return _RoundBoth.apply(F.relu(out))
@@ -227,7 +230,9 @@ def forward(sd, x, num_blocks, chans, training=False, taps=None, emulate_bf16=Fa
         x = bf16r(x)
     for prefix, _, _, stride, identity in layout(num_blocks, chans):
         if emulate_bf16:
-            x = rep_block_bf16(x, sd, prefix, stride, identity, training)
+            # the HIP path's fused stem (3 -> 48 channels at 224 x 224) keeps no y3 / y1: mirror its dispatch rule
+            fused_stem = x.shape[1] == 3 and tuple(x.shape[2:]) == (224, 224) and sd[prefix + ".branches.0.0.weight"].shape[0] == 48
+            x = rep_block_bf16(x, sd, prefix, stride, identity, training, recompute=fused_stem)
         else:
             x = rep_block(x, sd, prefix, stride, identity, training)
         if taps is not None:
