@@ -12,6 +12,9 @@ python - "$O" "$*" <<'PY'
 import csv, glob, collections, json, sys
 O, cmd = sys.argv[1], sys.argv[2]
 def fam(k):
+    if "stem_fused_kernel<1>" in k: return "bn_elementwise"          # the stem's fused passes are filed like bench.py files them
+    if "stem_fused_kernel<2>" in k: return "conv_wgrad"
+    if "stem_bwd_" in k: return None
     if "cs2::" in k: return "conv_wgrad" if "wgrad" in k and "reduce" not in k else ("conv_s2" if "reduce" not in k else None)
     if "conv_gather_kernel" in k or "conv_pw_kernel" in k: return "conv_gather"
     if "conv_rows" in k: return "conv_rows"
