@@ -154,7 +154,7 @@ def main():
         mid_mod = model.features[3][0]
         mid = {id(p) for st in model.features[3:] for p in st.parameters()} | rear
         early_last = next((p for p in reversed(list(model.parameters())) if id(p) not in mid), None)
-        bounds = [front_last] + ([early_last] if early_last is not None and os.environ.get("HC_BENCH_CUTS", "2") == "2" else [])
+        bounds = [front_last] + ([early_last] if early_last is not None else [])
         reducer = parallel.GradReducer(model.parameters(), bucket_mb=256.0, comm_dtype=comm, force=force_dist, new_bucket_at=bounds)
         cut = parallel.BackwardCut(rear_mod)
         if len(bounds) == 2:
@@ -164,14 +164,12 @@ def main():
     x = torch.rand((args.batch, 3, 224, 224), device=dev, generator=g)
     t = torch.randint(0, 10, (args.batch,), device=dev, generator=g)
     loss_buf = torch.zeros((), device=dev)
-    torch_loss = os.environ.get("HC_TORCH_LOSS", "0") == "1"
 
     def seg_fwd_bwd():
         opt.zero_grad(set_to_none=True)
         logits = model(x)
         # the criterion of references/classification/train.py:194 as two HIP launches (torch composes it from ~25 small kernels);
-        # HC_TORCH_LOSS=1 is the A side of the A/B
-        loss = (torch.nn.functional.cross_entropy if torch_loss else h.nn.functional.cross_entropy)(logits, t, label_smoothing=0.1)
+        loss = h.nn.functional.cross_entropy(logits, t, label_smoothing=0.1)
         loss.backward()
         loss_buf.copy_(loss.detach())
 

@@ -610,7 +610,7 @@ int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
     constexpr int smem_k = NS * (BC + BP) * BK * 2 + ((MINB == 1 && (BC * BK / 512) % (WM * WN) != 0) ? WM * WN * 1024 : 0), smem_o = BP * (BC * 2 + 8);
     static_assert(smem_k <= 160 * 1024 && smem_o <= 160 * 1024, "LDS budget");
     constexpr int smem = smem_k > smem_o ? smem_k : smem_o;
-    static const int flags = [] { const char* e = getenv("HC_CONV_STAGED_STORES"); return (e == nullptr || atoi(e) != 0) ? 1 : 0; }();
+    constexpr int flags = 1;                       // staged (16-byte coalesced) epilogue stores
     int maxM = 0;
     for (int c = 0; c < d.nclass; ++c) {
         const int m = d.N * d.cls[c].OHg * d.cls[c].OWg;
@@ -643,7 +643,7 @@ int launch_bk(const hc_conv_desc& d, hipStream_t st) {
     // 46 / 181 pixel tiles) has fewer 128-channel tiles than the 512 workgroup slots of the chip - 64-channel tiles double the
     // workgroups (HC_CONV_FILL=n: below n tiles, default 400; 0 = off).  YOLOv4 608^2 batch 16, same box: 29.19 ms per step without
     // the rule, 29.08 / 28.68 / 28.75 with n = 256 / 400 / 600
-    static const int fill = [] { const char* e = getenv("HC_CONV_FILL"); return e == nullptr ? 400 : atoi(e); }();
+    constexpr int fill = 400;
     if (fill > 0 && C % 64 == 0) {
         long maxM = 0;
         for (int c = 0; c < d.nclass; ++c) {
@@ -732,11 +732,11 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
     // HC_CONV_BIG=0 switches the family off (A/B).  (The four-wave 256 x 256 form of round 3 - 0.42-0.48 of the matrix pipe against
     // 0.53 - is retired: git show 067617d:holocron_amd/csrc/conv_gather.hip.)
     static const int big = [] { const char* e = getenv("HC_CONV_BIG"); return e == nullptr ? 1 : atoi(e); }();
-    static const double big_eff = [] { const char* e = getenv("HC_CONV_BIG_EFF"); return e == nullptr ? 0.70 : atof(e); }();
+    constexpr double big_eff = 0.70;
     if (big && d.nclass == 1 && d.co_split == 0 && d.pix_scale == nullptr && d.srcC % 32 == 0 && d.Cout % 8 == 0) {
         const long M = (long)d.N * d.cls[0].OHg * d.cls[0].OWg;
         const int S = d.cls[0].ntaps * (d.srcC / 32);
-        static const int staged = [] { const char* e = getenv("HC_CONV_STAGED_STORES"); return (e == nullptr || atoi(e) != 0) ? 1 : 0; }();
+        constexpr int staged = 1;
         const int C = d.Cout;
         const int bc = (C > 96 && C <= 128) ? 128 : 256, bp = bc == 128 ? 512 : 256;
         const long ct = (C + bc - 1) / bc, pt = (M + bp - 1) / bp, tiles = ct * pt, rounds = (tiles + 255) / 256;
@@ -749,7 +749,7 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
     }
     // HC_CONV_BK=32 | 16 caps the k-step (A/B: a 192-channel tile with 64-channel k-steps stages 2 x 40 KB - two workgroups need the
     // whole 160 KB of LDS)
-    static const int bk_cap = [] { const char* e = getenv("HC_CONV_BK"); return e == nullptr ? 64 : atoi(e); }();
+    constexpr int bk_cap = 64;                      // k-step cap (32 measured 3 % slower on the ReXNet 1 x 1 layers, round 4)
     if (d.srcC % 64 == 0 && bk_cap >= 64) return launch_bk<64>(d, st);
     if (d.srcC % 32 == 0 && bk_cap >= 32) return launch_bk<32>(d, st);
     return launch_bk<16>(d, st);

@@ -326,7 +326,7 @@ int hc_conv_resident_launch(const hc_conv_small_desc& d, hipStream_t st) {
         case 1: crs::launch<1>(a, smem, st); break;
         case 2: crs::launch<2>(a, smem, st); break;
         case 3: {
-            static const int dbg = getenv("HC_CRS_DBG") ? atoi(getenv("HC_CRS_DBG")) : 0;
+            constexpr int dbg = 0;                     // (the HC_CRS_DBG knock-out knob of round 2 is gone; the DBG template argument stays for experiments)
             switch (dbg) {
                 case 1: crs::launch<3, 1>(a, smem, st); break;
                 case 2: crs::launch<3, 2>(a, smem, st); break;

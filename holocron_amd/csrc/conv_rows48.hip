@@ -305,7 +305,7 @@ void launch1(const Args& a, hipStream_t st) {
 template <int W>
 void launch(Args& a, hipStream_t st) {
     static const int dbg = getenv("HC_CRQ_DBG") ? atoi(getenv("HC_CRQ_DBG")) : 0;
-    static const int delay = getenv("HC_CRQ_DELAY") ? atoi(getenv("HC_CRQ_DELAY")) : 2;
+    constexpr int delay = 2;
     a.nunits = a.d.N * (a.d.H / Geo<W>::UR);
     a.delay = delay;
     const bool dg = (a.d.mode & 1) == 1;

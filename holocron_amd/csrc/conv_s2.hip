@@ -73,134 +73,7 @@ struct Geo {
     static_assert(SMEM <= 160 * 1024, "LDS budget");
 };
 
-template <int CIN, int COUT, int WIN, int R, int CTW>
-__global__ __launch_bounds__(64 * (COUT / (16 * CTW))) void s2_fwd_kernel(const Args a) {
-    using G = Geo<CIN, COUT, WIN, R, CTW>;
-    constexpr int PT = G::PT, S = G::S, S3 = G::S3, S1B = G::S1B, S1 = G::S1, PS = G::PS, WS = G::WS, WOUT = G::WOUT;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const hc_conv_s2_desc& d = a.d;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int px = lane & 15, g = lane >> 4;
-    const int H = d.H, HO = H / 2, RB = HO / R;
-    const int tile = xcd_tile(blockIdx.x, gridDim.x);
-    const int n = tile / RB, r0 = (tile - n * RB) * R;
-    const unsigned lds0 = hc_lds_addr(smem);
-
-    // ---- window DMA: slot (r, x) holds input pixel (2 r0 - 1 + r, x - 1); the pad chunk, the halo and the tail are zero filled
-    {
-        const u32x4 rs = hc_raw_rsrc(d.x, (unsigned)d.N * H * WIN * CIN * 2u);
-        const unsigned img = (unsigned)n * (unsigned)(H * WIN * CIN * 2);
-        for (int j = wid; j < G::NDMA; j += G::NW) {
-            const int J = j * 64 + lane;
-            const int slot = J / G::PSC, c = J - slot * G::PSC;
-            const int r = slot / WS, x = slot - r * WS;
-            const int ih = 2 * r0 - 1 + r;
-            const bool ok = c < PT && slot < G::NSLOT && x >= 1 && ih >= 0;
-            const unsigned off = img + (unsigned)((ih * WIN + x - 1) * CIN * 2 + c * 16);
-            if (!(a.dbg & 4)) hc_dma16(rs, lds0 + (unsigned)(j * 1024), ok ? off : HC_OOB);
-        }
-    }
-
-    // ---- weights of this wave's channels: registers for the whole kernel.  Image (pack modes 5): [co tile][step][64 lanes][8]
-    const __amdgpu_buffer_rsrc_t rw3 = make_rsrc(d.w3img, (unsigned)(COUT / 16 * S3 * 1024));
-    const __amdgpu_buffer_rsrc_t rw1 = make_rsrc(d.w1img, (unsigned)(COUT / 16 * S1 * 1024));
-    u32x4 a3[CTW][S3], a1[CTW][S1];
-#pragma unroll
-    for (int t = 0; t < CTW; ++t) {
-        const int ct = wid * CTW + t;
-#pragma unroll
-        for (int s = 0; s < S3; ++s) a3[t][s] = buf_load16(rw3, (unsigned)(lane * 16), (unsigned)((ct * S3 + s) * 1024));
-#pragma unroll
-        for (int s = 0; s < S1; ++s) a1[t][s] = buf_load16(rw1, (unsigned)(lane * 16), (unsigned)((ct * S1 + s) * 1024));
-    }
-    // byte offset of piece 4 s + g relative to the window slot of (2 orow, 2 ox): tap (tr, tc) -> ((tr WS) + tc) PS + 16 c
-    int boff[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int q = 4 * s + g;
-        const int tap = q < G::NP3 ? q / PT : 4;
-        const int c = q < G::NP3 ? q - tap * PT : q - G::NP3;
-        boff[s] = ((tap / 3) * WS + tap % 3) * PS + c * 16;
-    }
-
-    float st3[CTW][2][4], st1[CTW][2][4];
-#pragma unroll
-    for (int t = 0; t < CTW; ++t)
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) st3[t][k][e] = st1[t][k][e] = 0.f;
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA pieces of this wave (and its weight loads) have landed
-    __syncthreads();                                      // ... everybody's have
-
-    bf16_t* y3 = reinterpret_cast<bf16_t*>(d.y3);
-    bf16_t* y1 = reinterpret_cast<bf16_t*>(d.y1);
-    const size_t obase = ((size_t)n * HO + r0) * WOUT * COUT;
-#pragma unroll 1
-    for (int f = 0; f < G::NFRAG; ++f) {
-        const int p = f * 16 + px;
-        const bool ok = p < G::NPIX;
-        const int pc = ok ? p : G::NPIX - 1;
-        const int orow = pc / WOUT, ox = pc - orow * WOUT;
-        const char* pb = smem + (2 * orow * WS + 2 * ox) * PS;
-        f32x4 acc3[CTW], acc1[CTW];
-#pragma unroll
-        for (int t = 0; t < CTW; ++t) acc3[t] = acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(pb + boff[s]);
-#pragma unroll
-            for (int t = 0; t < CTW; ++t) {
-                if (s < S3) acc3[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a3[t][s]), b, acc3[t], 0, 0, 0);
-                if (s >= S1B) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1[t][s - S1B]), b, acc1[t], 0, 0, 0);
-            }
-        }
-        // lane (px, g) holds channels 16 ct + 4 g + e of pixel p
-#pragma unroll
-        for (int t = 0; t < CTW; ++t) {
-            const int co = 16 * (wid * CTW + t) + 4 * g;
-            if (d.stats3 != nullptr) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v3 = ok ? acc3[t][e] : 0.f, v1 = ok ? acc1[t][e] : 0.f;
-                    st3[t][0][e] += v3; st3[t][1][e] += v3 * v3;
-                    st1[t][0][e] += v1; st1[t][1][e] += v1 * v1;
-                }
-            }
-            if (ok && !(a.dbg & 1)) {
-                const size_t o = obase + (size_t)p * COUT + co;
-                *reinterpret_cast<u32x2*>(y3 + o) = u32x2{pack_bf16x2(acc3[t][0], acc3[t][1]), pack_bf16x2(acc3[t][2], acc3[t][3])};
-                *reinterpret_cast<u32x2*>(y1 + o) = u32x2{pack_bf16x2(acc1[t][0], acc1[t][1]), pack_bf16x2(acc1[t][2], acc1[t][3])};
-            }
-        }
-    }
-    // ---- BatchNorm sums: fold the 16 pixel lanes of every group, lane px == e adds channel 4 g + e into this wave's replica slot
-    if (d.stats3 != nullptr) {
-        const size_t slot = (size_t)((blockIdx.x * G::NW + wid) % a.reps) * 2 * COUT;
-#pragma unroll
-        for (int t = 0; t < CTW; ++t) {
-            const int co = 16 * (wid * CTW + t) + 4 * g;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                float m3 = 0.f, m1 = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float s3 = row16_sum(st3[t][k][e]), s1 = row16_sum(st1[t][k][e]);
-                    m3 = px == e ? s3 : m3;
-                    m1 = px == e ? s1 : m1;
-                }
-                if (px < 4) {
-                    atomicAdd(d.stats3 + slot + k * COUT + co + px, m3);
-                    atomicAdd(d.stats1 + slot + k * COUT + co + px, m1);
-                }
-            }
-        }
-    }
-}
-
-// Persistent form of the same kernel (the default; HC_CONV_S2_V=0 selects the one-block-per-workgroup form above): two workgroups per CU walk the (image, row block) list of their XCD; the
+// Persistent workgroups (the one-row-block-per-workgroup form of round 3 was retired in round 5: 0.14 ms per step slower): two workgroups per CU walk the (image, row block) list of their XCD; the
 // weights are loaded ONCE per workgroup instead of once per row block (48 KB of L2 reads against a 38 - 63 KB window), the window
 // of block i + 1 is DMA'd into the second LDS buffer while block i is multiplied (one barrier per block), two pixel fragments run
 // as independent accumulator chains, and the BatchNorm sums are flushed once per workgroup.
@@ -1261,18 +1134,6 @@ void set_smem(K kern, int smem) {
 }
 
 template <int CIN, int COUT, int WIN, int R, int CTW>
-int launch_layer(const Args& a, hipStream_t st) {
-    using G = Geo<CIN, COUT, WIN, R, CTW>;
-    auto kern = s2_fwd_kernel<CIN, COUT, WIN, R, CTW>;
-    static bool once = false;
-    if (!once) { set_smem(kern, G::SMEM); once = true; }
-    const int grid = a.d.N * (a.d.H / 2 / R);
-    if (a.d.stats3 != nullptr && hc_get_deterministic() && grid * G::NW > a.reps) return HC_ERR_ARG;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::SMEM, st, a);
-    return hc_launch_status();
-}
-
-template <int CIN, int COUT, int WIN, int R, int CTW>
 int launch_persist(const Args& a, hipStream_t st, int wg_per_cu) {
     using G = Geo<CIN, COUT, WIN, R, CTW>;
     auto kern = s2_fwd_persist_kernel<CIN, COUT, WIN, R, CTW>;
@@ -1321,7 +1182,7 @@ extern "C" int hc_conv_s2_supported(const hc_conv_s2_desc* dp) {
 }
 
 extern "C" int hc_conv_s2_dgrad_supported(const hc_conv_s2_dgrad_desc* dp) {
-    static const bool on = cs2::env_int("HC_CONV_S2_DGRAD", 1) != 0 && cs2::env_int("HC_CONV_S2", 1) != 0;
+    static const bool on = cs2::env_int("HC_CONV_S2", 1) != 0;
     if (!on || dp == nullptr) return 0;
     const hc_conv_s2_dgrad_desc& d = *dp;
     if (d.N < 1 || d.H != d.W || d.H % 8 != 0) return 0;
@@ -1344,7 +1205,7 @@ extern "C" int64_t hc_conv_s2_stem_wgrad_ws_bytes(void) { return (int64_t)HC_S2_
 
 extern "C" int hc_conv_s2_stem_wgrad(const float* x, const void* dy3, const void* dy1, float* dw3, float* dw1, void* ws, int32_t N,
                                      int32_t H, int32_t W, int32_t accumulate, hc_stream_t stream) {
-    static const bool on = cs2::env_int("HC_CONV_S2", 1) != 0 && cs2::env_int("HC_CONV_S2_STEM_WGRAD", 1) != 0;
+    static const bool on = cs2::env_int("HC_CONV_S2", 1) != 0;
     if (!on) return HC_ERR_ARG;
     if (x == nullptr || dy3 == nullptr || dy1 == nullptr || dw3 == nullptr || dw1 == nullptr || ws == nullptr) return HC_ERR_ARG;
     if (N < 1 || W != 224 || H != 224 || (double)N * H * W * 12.0 >= 4294967000.0) return HC_ERR_ARG;
@@ -1373,13 +1234,8 @@ extern "C" int hc_conv_s2_fwd(const hc_conv_s2_desc* dp, hc_stream_t stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int rsel = cs2::env_int("HC_CONV_S2_R", 0);       // 0 = default rows per workgroup, 1 = the smaller variant (read per call: tests flip it)
     if (d.x_nchw_f32) return rsel ? cs2::launch_stem<8>(a, st) : cs2::launch_stem<4>(a, st);
-    const int ver = cs2::env_int("HC_CONV_S2_V", 1);          // 1: persistent double-buffered form (default: -0.14 ms per step same-box), 0: one row block per workgroup
-    if (ver == 1) {
-        if (d.Cout == 48) return rsel ? cs2::launch_persist<48, 48, 112, 2, 1>(a, st, 1) : cs2::launch_persist<48, 48, 112, 1, 1>(a, st, 2);
-        return rsel ? cs2::launch_persist<48, 96, 56, 4, 2>(a, st, 1) : cs2::launch_persist<48, 96, 56, 2, 2>(a, st, 2);
-    }
-    if (d.Cout == 48) return rsel ? cs2::launch_layer<48, 48, 112, 1, 1>(a, st) : cs2::launch_layer<48, 48, 112, 2, 1>(a, st);
-    return rsel ? cs2::launch_layer<48, 96, 56, 2, 2>(a, st) : cs2::launch_layer<48, 96, 56, 4, 2>(a, st);
+    if (d.Cout == 48) return rsel ? cs2::launch_persist<48, 48, 112, 2, 1>(a, st, 1) : cs2::launch_persist<48, 48, 112, 1, 1>(a, st, 2);
+    return rsel ? cs2::launch_persist<48, 96, 56, 4, 2>(a, st, 1) : cs2::launch_persist<48, 96, 56, 2, 2>(a, st, 2);
 }
 
 // ---- the stem block fused with its BatchNorm passes (stem_fused_kernel): y3 / y1 are never stored
@@ -1405,8 +1261,6 @@ int launch_stem_fused(SfArgs& a, hipStream_t st) {
     }
     a.ntiles = a.N * (a.H / 2 / G::R);
     int grid = resident;
-    static const int genv = env_int("HC_STEM_GRID", 0);       // experiments: workgroups per launch
-    if (genv > 0 && genv <= SF_MAX_GRID) grid = genv;
     if (grid > a.ntiles) grid = a.ntiles;
     a.reps = hc_get_stat_replicas();
     a.dbg = env_int("HC_STEM_DBG", 0);

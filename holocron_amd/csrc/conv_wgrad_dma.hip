@@ -267,7 +267,7 @@ inline Plan make_plan(const hc_wgrad_desc& d) {
     const int T = d.KH * d.KW;
     if (!((d.KH == 3 && d.KW == 3) || T == 1)) return pl;
     if (d.Cin % 64 || d.Cout % 64 || d.stride < 1) return pl;
-    static const int min_c = getenv("HC_WDMA_MINC") ? atoi(getenv("HC_WDMA_MINC")) : 128;
+    constexpr int min_c = 128;
     if (d.Cin < min_c || d.Cout < min_c) return pl;     // narrower layers: the row-staged tr kernel reads x once, not per tap
     // measured (scripts/bench_layers.py): a 192-wide co tile (3 waves x 1) loses to the row-staged kernel on 192 x 192
     if (d.Cout % 256 != 0 && d.Cout % 192 == 0 && d.Cin <= 192) return pl;

@@ -408,12 +408,12 @@ inline Plan make_plan(const hc_rep_wgrad_desc& d) {
     if (d.OH != (d.IH - 1) / s + 1 || d.OW != (d.IW - 1) / s + 1) return pl;     // the 1x1 branch's output size
     if ((double)d.N * d.IH * d.IW * d.Cin * 2.0 >= 4294967040.0 || (double)d.N * d.OH * d.OW * d.Cout * 2.0 >= 4294967040.0) return pl;
     int MR = 0, NR = 0;
-    static const int tile_env = getenv("HC_WREP_TILE") ? atoi(getenv("HC_WREP_TILE")) : 0;     // 33: force the 48 x 48 tile
+    constexpr int tile_env = 0;
     if (d.Cin % 96 == 0 && d.Cout % 48 == 0 && tile_env != 33) { MR = 6; NR = 3; }
     else if (d.Cin % 64 == 0 && d.Cout % 64 == 0) { MR = 4; NR = 4; }
     else if (d.Cin % 48 == 0 && d.Cout % 48 == 0) { MR = 3; NR = 3; }
     else return pl;
-    static const int max_c = getenv("HC_WREP_MAXC") ? atoi(getenv("HC_WREP_MAXC")) : 512;
+    constexpr int max_c = 512;
     if (d.Cin > max_c || d.Cout > max_c) return pl;       // wide layers: the k-pipelined DMA kernel (conv_wgrad_dma.hip)
     Args& a = pl.a;
     for (int j = 0; j < d.njobs; ++j) { a.x[j] = d.x[j]; a.dy3[j] = d.dy3[j]; a.dy1[j] = d.dy1[j]; }
@@ -430,11 +430,11 @@ inline Plan make_plan(const hc_rep_wgrad_desc& d) {
     a.ROWB = a.XJ * 1024;
     a.SD = round_stride(16 * NR * 2, 1);
     if (a.XJ > 4 * XJW) return pl;
-    static const int pf_env = getenv("HC_WREP_PF") ? atoi(getenv("HC_WREP_PF")) : 0;
-    static const int r_env = getenv("HC_WREP_R") ? atoi(getenv("HC_WREP_R")) : 0;
+    constexpr int pf_env = 0;
+    constexpr int r_env = 0;
     // LDS budget of a workgroup: all of it for the big tiles (one workgroup per CU: 512 registers per lane); the 48 x 48 tile fits
     // two waves per SIMD, and two / three co-resident workgroups overlap one's DMA issue and barriers with the other's MFMAs
-    static const int lds_env = getenv("HC_WREP_LDS") ? atoi(getenv("HC_WREP_LDS")) : 0;
+    constexpr int lds_env = 0;
     const int LDS_MAX = lds_env > 0 ? lds_env : 160 * 1024 - 512;
     // rows per step: best fill of the 32-pixel k-steps, then the longest step; deepest prefetch that fits
     double best = -1.0;
@@ -485,10 +485,10 @@ inline Plan make_plan(const hc_rep_wgrad_desc& d) {
     pl.grid = ((d.njobs * a.nsplit + 7) / 8) * 8 * NT;
     pl.MR = MR;
     pl.NR = NR;
-    static const int hv_env = getenv("HC_WREP_HV") ? atoi(getenv("HC_WREP_HV")) : 0;
+    constexpr int hv_env = 0;
     pl.HV = (MR % 2 == 0 && hv_env != 1) ? 2 : 1;
     // the 48 x 48 tile: when the LDS footprint leaves room for one workgroup per CU only, run it with eight waves (pixel split)
-    static const int pv_env = getenv("HC_WREP_PV") ? atoi(getenv("HC_WREP_PV")) : 0;
+    constexpr int pv_env = 0;
     pl.PV = (pl.HV == 1 && MR == 3 && (a.P32 >> 5) >= 2 && (pv_env == 2 || (pv_env == 0 && per_cu == 1))) ? 2 : 1;
     pl.ok = true;
     return pl;

@@ -280,8 +280,8 @@ inline Plan make_plan_seg(const hc_wgrad_desc& d, int NR, int nseg) {
     if (!(T == 9 && d.KH == 3) && T != 1) return pl;
     // measured on MI355X (scripts/bench_layers.py): beyond 192x256 channels the k-pipelined generic
     // kernel is faster (1280-wide layers re-stage dy once per ci tile here)
-    static const int max_cin = getenv("HC_WTR_CIN") ? atoi(getenv("HC_WTR_CIN")) : 192;     // experiment knobs
-    static const int max_cout = getenv("HC_WTR_COUT") ? atoi(getenv("HC_WTR_COUT")) : 256;
+    constexpr int max_cin = 192;
+    constexpr int max_cout = 256;
     if (d.Cin > max_cin || d.Cout > max_cout) return pl;
     // images wider than a chunk (128 pixels) are cut into column segments, each staged with its own halo
     const int CW = (d.OW + nseg - 1) / nseg;

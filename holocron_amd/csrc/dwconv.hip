@@ -163,19 +163,18 @@ struct DwTile {
 using DwThin = DwTile<8, 4>;
 // HC_DW_S2=0: the round-3 stride-2 kernels (A/B); the tiled stride-2 kernels take output maps of at least HC_DW_S2_MINW (default 12) columns
 static int dw_s2_on() {
-    static const int on = [] { const char* e = getenv("HC_DW_S2"); const char* t = getenv("HC_DW_TILE");
-                               return (t != nullptr && atoi(t) == 0) ? 0 : (e == nullptr ? 1 : atoi(e)); }();
+    static const int on = [] { const char* t = getenv("HC_DW_TILE"); return (t != nullptr && atoi(t) == 0) ? 0 : 1; }();
     return on;
 }
 static int dw_s2_minw() {
-    static const int v = [] { const char* e = getenv("HC_DW_S2_MINW"); return e == nullptr ? 12 : atoi(e); }();
+    constexpr int v = 12;
     return v;
 }
 // 4-group slices for layers of 32 channels or fewer (HC_DW_TILE_THIN >= 1, the default).  HC_DW_TILE_THIN=2 also splits 72 .. 96
 // channels into 4-group slices: measured SLOWER (96@56 stride 1: 3.62 -> 2.83 TB/s; 96@112 stride 2 no better than the strip kernel) -
 // three workgroups then fetch 64-byte thirds of every 192-byte pixel at different times, and every 128-byte line is fetched twice
 static bool dw_thin(int cg) {
-    static const int mode = [] { const char* e = getenv("HC_DW_TILE_THIN"); return e == nullptr ? 1 : atoi(e); }();
+    constexpr int mode = 1;
     return (mode >= 1 && cg <= 4) || (mode >= 2 && cg >= 9 && cg <= 12);
 }
 template <int NSTRIP_, int GROUPS_ = 8>
@@ -1032,8 +1031,8 @@ int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t
     // HC_DW_TILE=0: the strip kernel for every stride-1 launch (A/B); the LDS-tiled kernel takes maps of at least HC_DW_TILE_MINW
     // (default 12) pixels and 32-bit byte offsets
     static const int tile_on = [] { const char* e = getenv("HC_DW_TILE"); return e == nullptr ? 1 : atoi(e); }();
-    static const int tile_minw = [] { const char* e = getenv("HC_DW_TILE_MINW"); return e == nullptr ? 12 : atoi(e); }();
-    static const int tile_minc = [] { const char* e = getenv("HC_DW_TILE_MINC"); return e == nullptr ? 32 : atoi(e); }();
+    constexpr int tile_minw = 12;
+    constexpr int tile_minc = 32;
     if (stride == 1 && tile_on && W >= tile_minw && H >= 8 && C >= tile_minc && (double)N * H * W * C * 2.0 < 4294967000.0) {
         const bool narrow = W <= 16;                       // 16 x 16 tiles for the 14 x 14 / 16 x 16 maps, 8 x 32 otherwise
         const bool thin = !narrow && dw_thin(cg);              // 32 channels or fewer: 4-group slices, 8 x 64 tiles
@@ -1108,7 +1107,7 @@ int hc_dw3x3_dgrad(const void* dy, const float* wpk, const float* wpk_flipped, v
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const int cg = C / 8;
     if (dw_s2_on() && OW >= 4) {
-        static const int sw2 = [] { const char* e = getenv("HC_DW_DGRAD_S2_SW"); return e == nullptr ? 4 : atoi(e); }();
+        constexpr int sw2 = 4;
         if (sw2 == 2) {
             const long items = (long)N * OH * ((OW + 1) / 2) * cg;
             hipLaunchKernelGGL(dw3x3_dgrad_s2_blk_kernel<2>, dim3(dw_blocks(items, cg, 4)), dim3(DW_THREADS), 0, (hipStream_t)stream,
@@ -1139,8 +1138,8 @@ int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N
     if ((long)N * OH * OW > 0) {
         const size_t lds = (size_t)DW_THREADS * 25 * sizeof(float);
         static const int tile_on = [] { const char* e = getenv("HC_DW_TILE"); return e == nullptr ? 1 : atoi(e); }();
-        static const int tile_minw = [] { const char* e = getenv("HC_DW_TILE_MINW"); return e == nullptr ? 12 : atoi(e); }();
-        static const int tile_minc = [] { const char* e = getenv("HC_DW_TILE_MINC"); return e == nullptr ? 32 : atoi(e); }();
+        constexpr int tile_minw = 12;
+        constexpr int tile_minc = 32;
         if (stride == 1 && tile_on && W >= tile_minw && H >= 8 && C >= tile_minc && (double)N * H * W * C * 2.0 < 4294967000.0 &&
             !hc_get_deterministic()) {
             const bool narrow = W <= 16;

@@ -31,8 +31,8 @@ from .repblock_op import POOL
 # 32-channel padding 22.09, padding from 96 channels on 22.84: the 56 x 56 stages are HBM-bound and pay for their padding).  With the
 # LDS-tiled depthwise kernels (64-channel slices: csrc/dwconv.hip) the threshold moved from 200 to 160: 162 -> 192 channels is three
 # whole slices (22.36 -> 22.22 ms same-box).
-_PAD_WIDE_FROM = int(__import__("os").environ.get("HC_PAD_WIDE_FROM", "160"))
-_PAD_WIDE_TO = int(__import__("os").environ.get("HC_PAD_WIDE_TO", "64"))
+_PAD_WIDE_FROM = 160
+_PAD_WIDE_TO = 64
 
 
 def ceil16(c):
@@ -396,7 +396,7 @@ class SeGateFn(torch.autograd.Function):
 
 
 # HC_SE_FUSED=0: the squeeze-excite MLP through the generic conv units inside SeGateFn (A/B; round-3 path)
-_SE_FUSED = __import__("os").environ.get("HC_SE_FUSED", "1") != "0"
+_SE_FUSED = True
 
 
 def se_mlp_fusable(conv1, bn, act, conv2):

@@ -194,7 +194,7 @@ class RepState:
             return self._pack_items_s2(w3, w1, Cout, Cin, dev, stem)
         # small-channel stride-2 blocks and the stem read their input twice (3x3, then 1x1) in HBM-bound launches: stack the two
         # kernels as 2 * Cout weight rows (the 1x1 at the centre tap resp. at its im2col columns) and gather the input once
-        self.stack_fwd = (stem or (self.stride == 2 and Cin <= 48)) and Cout % 4 == 0 and os.environ.get("HC_STACK_FWD", "1") != "0"
+        self.stack_fwd = (stem or (self.stride == 2 and Cin <= 48)) and Cout % 4 == 0
         if self.packed is None or self.packed[0].device != dev:
             if self.stack_fwd:
                 self.packed = (torch.zeros((2 * Cout, 1, STEM_KPAD) if stem else (2 * Cout, 9, Cin), dtype=torch.bfloat16, device=dev),

@@ -268,7 +268,7 @@ class _WgradSide:
 
 
 _SIDE = _WgradSide()
-_SIDE.on = os.environ.get("HC_WGRAD_SIDE_STREAM", "0") == "1"   # process-wide opt-in; see set_wgrad_side_stream
+_SIDE.on = False   # process-wide opt-in: set_wgrad_side_stream(True)
 
 
 def set_wgrad_side_stream(on: bool) -> None:

@@ -1,6 +1,6 @@
 """Big-tile gather-conv family (csrc/conv_gather.hip) against the 128 x 128 form, shape by shape: forward 3x3 / 1x1 convs (with
 BatchNorm statistics) of the YOLOv4 608^2 batch-16, repvgg_a2 and repvgg_a0 stride-1 layers.  The dispatch switch is read once per
-process, so this script re-runs itself: HC_CONV_BIG=0 (128 x 128 form) and HC_CONV_BIG_EFF=0 (family wherever its shape rules allow)
+process, so this script re-runs itself: HC_CONV_BIG=0 (128 x 128 form) and the default (the family wherever its efficiency predicate picks it; the threshold knob of round 4 is gone)
 and prints both times, the launch efficiency the predicate sees, and whether the two results are bit-identical."""
 import json
 import os
@@ -65,10 +65,7 @@ def run(env):
 
 
 def main():
-    if os.environ.get("BIGTILE_AB_FILL"):      # A/B of the small-launch rule instead: 64-channel tiles when the launch underfills the chip
-        a, b = run({"HC_CONV_FILL": "0"}), run({"HC_CONV_FILL": os.environ["BIGTILE_AB_FILL"]})
-    else:
-        a, b = run({"HC_CONV_BIG": "0"}), run({"HC_CONV_BIG": "1", "HC_CONV_BIG_EFF": "0"})
+    a, b = run({"HC_CONV_BIG": "0"}), run({"HC_CONV_BIG": "1"})      # the family under its own dispatch predicate (efficiency >= 0.70)
     print(f"{'shape':<26} {'GFLOP':>7} {'128x128 us':>10} {'TF/s':>6} {'family us':>10} {'TF/s':>6} {'ratio':>6} {'tile':>9} {'eff':>5}  same bits / stats")
     for name, N, Cin, H, Cout, k in SHAPES:
         fl = 2.0 * N * H * H * Cout * Cin * k * k

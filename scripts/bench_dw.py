@@ -88,7 +88,7 @@ if __name__ == "__main__":
     if os.environ.get("DW_CHILD") == "1":
         child()
     else:
-        a, b = run({"HC_DW_TILE": "0"}), run({"HC_DW_TILE": "1", "HC_DW_TILE_MINW": "8", "HC_DW_TILE_MINC": "8"})
+        a, b = run({"HC_DW_TILE": "0"}), run({"HC_DW_TILE": "1"})
         print(f"{'shape':<10} {'MB':>7} {'strip us':>9} {'TB/s':>6} {'tile us':>9} {'TB/s':>6}  same bits")
         for k in a:
             if k.startswith("s2 "):

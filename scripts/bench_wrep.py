@@ -1,6 +1,6 @@
 """Per-shape timing of the fused RepBlock weight-gradient kernel against the two-launch path it replaces, at the repvgg_a0
 batch-256 shapes with the group sizes of the real step.  usage: python scripts/bench_wrep.py [--iters 20]
-Environment knobs (read once per process by the planner): HC_WREP_PF, HC_WREP_R."""
+(The planner's experiment knobs of rounds 2-4 - HC_WREP_PF / _R / _TILE / _HV / _PV / _LDS - were removed in round 5: its choices are what it ships.)"""
 import argparse
 import ctypes as C
 import os

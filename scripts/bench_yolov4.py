@@ -66,6 +66,62 @@ def main():
                 "data": "synthetic", "config": {"workload": f"yolov4 {a.size}^2 bs{a.batch} eval: forward + decode + score filter + NMS "
                                                             "(BASELINE.md section 3 row C4), random-init weights, 80 classes"},
                 "predictors_per_image": npred, "detections_per_image_mean": sum(kept) / len(kept), "detections_img0": kept[0]}
+        # ---- roofline: one instrumented eval pass (HIP events on the launch stream around every conv / BatchNorm launch family, as
+        # in the training benches) + the post-processing as its own family: decode reads the padded logits of every predictor once
+        # (2 B x (5 + nc)) and writes boxes / scores / labels; the batched NMS builds an n x n / 64-word suppression bitmap per
+        # (image, scale) problem from its n candidates (yolov4.py:302-336)
+        from holocron_amd.ops import conv as cv
+        import importlib
+        ymod = importlib.import_module("holocron_amd.models.detection.yolov4")      # (the package attribute `yolov4` is the constructor)
+        real_pp = ymod.post_process_scales
+        pp = {}
+
+        def timed_pp(layers, outs):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = real_pp(layers, outs)
+            e1.record()
+            pp["ev"] = (e0, e1)
+            return r
+        ymod.post_process_scales = timed_pp
+        cv.PROFILE = []
+        try:
+            with torch.no_grad():
+                out = m(x)
+            torch.cuda.synchronize()
+            prof = cv.PROFILE
+        finally:
+            cv.PROFILE = None
+            ymod.post_process_scales = real_pp
+        fam = {}
+        for name, flops, e0, e1, nbytes in prof:
+            f = fam.setdefault(name, [0.0, 0.0, 0, 0.0])
+            f[0] += flops; f[1] += e0.elapsed_time(e1) * 1e-3; f[2] += 1; f[3] += nbytes
+        if "ev" in pp:
+            kept_total = sum(int(o["boxes"].shape[0]) for o in out)
+            dec_bytes = a.batch * npred * ((5 + 80) * 2.0 + 4 * 4 + 4 + 8)           # logits read; boxes, score, label written
+            # candidates per problem are not kept by post_process_scales: bound the bitmap by the predictors that passed the threshold
+            # on average (detections_per_image is a lower bound of the candidates, npred the upper one) - reported as bytes of the
+            # decode only, the NMS part is latency-bound index work (bit-exact integer decisions)
+            fam["post_process"] = [0.0, pp["ev"][0].elapsed_time(pp["ev"][1]) * 1e-3, 1, dec_bytes]
+        MF, HB = 2.5e15, 8.0e12
+        if fam:
+            dom = max(fam, key=lambda k: fam[k][1])
+            fl, sec, nl, nb = fam[dom]
+            t_m, t_h = fl / MF, nb / HB
+            bound = "mfma" if t_m >= t_h else "hbm"
+            line["roofline"] = {"bound": bound, "kernel": dom,
+                                "achieved": (fl / sec / 1e12) if bound == "mfma" else (nb / sec / 1e9),
+                                "peak": MF / 1e12 if bound == "mfma" else HB / 1e9, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                                "frac": max(t_m, t_h) / sec, "traffic": None, "launches_per_pass": nl, "avg_launch_ms": sec / nl * 1e3,
+                                "covered_ms_per_pass": sum(v[1] for v in fam.values()) * 1e3,
+                                "families": {k: {"ms_per_pass": v[1] * 1e3, "launches": v[2], "tflops": v[0] / v[1] / 1e12 if v[1] else 0.0,
+                                                 "gbps": v[3] / v[1] / 1e9 if v[1] else 0.0,
+                                                 "frac": max(v[0] / MF, v[3] / HB) / v[1] if v[1] else 0.0}
+                                             for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])},
+                                "note": "instrumented eager eval pass (HIP events per launch family); post_process = decode + score filter + "
+                                        "sorts + batched NMS incl. its two host waits, priced against the decode's bytes only (the NMS is "
+                                        "latency-bound integer work)"}
         if not a.no_cpu_baseline:
             # the oracle's detect(): the reference's eval path restated on torch-CPU fp32 incl. the restated torchvision NMS
             from oracle import yolov4 as ov

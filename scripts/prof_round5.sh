@@ -75,7 +75,9 @@ cp gpurun_out/pmc_repvgg_a2_fp8/traffic.json profiles/r05_pmc_repvgg_a2_fp8_traf
 timeout 300 python scripts/bench_repvgg_fp8.py > $O/r05_final_repvgg_a2_fp8_bench.json 2> $O/fp8.err
 fi
 if want mobileone; then
-timeout 300 python scripts/bench_mobileone.py > $O/r05_final_mobileone_bench.json 2> $O/mobileone.err
+bash scripts/pmc_families.sh mobileone python scripts/bench_mobileone.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $O/pmc_mobileone.log 2>&1
+cp gpurun_out/pmc_mobileone/traffic.json profiles/r05_pmc_mobileone_traffic.json; cp gpurun_out/pmc_mobileone/traffic.json $O/r05_pmc_mobileone_traffic.json
+timeout 400 python scripts/bench_mobileone.py > $O/r05_final_mobileone_bench.json 2> $O/mobileone.err
 fi
 if want misc; then
 ls -la $O | head -60
