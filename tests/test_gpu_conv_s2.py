@@ -270,3 +270,37 @@ def test_stem_fused_block_matches_the_unfused_block():
         assert rel_l2(gf[n], gu[n]) < (3e-2 if n.endswith("0.weight") else 3e-3), (n, rel_l2(gf[n], gu[n]))
     for k in rf:
         assert rel_l2(rf[k], ru[k]) < 1e-6, k
+
+
+def test_stem_fused_eval_mode_and_frozen_backward_match_the_unfused_block():
+    """Eval-mode BatchNorm (running statistics: no statistics launch, `frozen` backward: dy = a dz) through the fused stem against the
+    unfused sequence on the same block - forward within two bf16 roundings, weight gradients within flip noise."""
+    import holocron_amd as h
+    from holocron_amd.nn import repblock_op as rb
+    torch.manual_seed(11)
+    x = torch.rand((3, 3, 224, 224), device="cuda")
+    r = (torch.rand((3, 48, 112, 112), device="cuda") + 0.5).to(torch.bfloat16).float()
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(12)
+        blk = h.models.RepBlock(3, 48, 2, False).cuda()
+        with torch.no_grad():
+            for m in blk.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.copy_(torch.randn(48, device="cuda") * 0.05)
+                    m.running_var.copy_(torch.rand(48, device="cuda") * 0.05 + 0.02)
+        blk.eval()
+        real = rb.stem_fused_desc
+        if not fused:
+            rb.stem_fused_desc = lambda *a, **k: None
+        try:
+            out = blk(x)
+            (out.float() * r).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            rb.stem_fused_desc = real
+        res.append((out.detach().float(), {n: p.grad.clone() for n, p in blk.named_parameters()}))
+    (of, gf), (ou, gu) = res
+    assert rel_l2(of, ou) < 6e-3
+    for n in gf:
+        assert rel_l2(gf[n], gu[n]) < 3e-2, (n, rel_l2(gf[n], gu[n]))
