@@ -65,6 +65,10 @@ __device__ __forceinline__ void st16(u32x4* p, const u32x4 v) {
     if (NT) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
+// single-branch passes (bn_act_apply / bn_act_bwd_apply): streaming form from 200 MB on.  Step-level A/B, same box, off / 200 / 48 MB:
+// rexnet1_0x 18.36-18.43 / 18.18-18.23 / 18.20-18.24 ms, yolov4 28.65-28.67 / 28.60-28.68 / 28.71-28.75 ms (its 95-190 MB tensors are still in
+// the last-level cache when the pass reads them: the hint costs there)
+static inline bool ba_streaming(long nchunks) { return nchunks * 16 >= 200L * 1000000L; }
 static inline bool ew_streaming(long nchunks) {      // one tensor >= 48 MB
     constexpr long thr = 48;                     // 32 / 96 measured inside the noise (round 4)
     return thr >= 0 && nchunks * 16 >= thr * 1000000L;
@@ -490,7 +494,10 @@ __device__ __forceinline__ float drop_scale(const float* __restrict__ count, lon
 
 // The output (apply) and the incoming gradient (backward) may live inside a wider concat buffer: `ld8` is their
 // channels-per-pixel / 8 (the pointer already includes the channel offset).
-template <bool HAS_RES>
+// U pixels of a thread's channel group per iteration, all their loads requested before the first is used, and (NT) the non-temporal
+// hint for tensors far larger than the last-level cache - what the RepBlock passes have had since round 2.  With one pixel per iteration
+// a thread had one or two 16-byte loads in flight and the passes ran at 4.2-4.4 TB/s on the 257-617 MB tensors of ReXNet (round 5).
+template <bool HAS_RES, bool NT>
 __global__ __launch_bounds__(EW_THREADS) void bn_act_apply_kernel(const u32x4* __restrict__ y, const float* __restrict__ coef,
                                                                   const u32x4* __restrict__ res, int res_cg,
                                                                   const float* __restrict__ keep, const float* __restrict__ count,
@@ -509,24 +516,39 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_apply_kernel(const u32x4* _
     const float dsc = keep != nullptr ? drop_scale(count, npix) : 1.f;
     // a second DropBlock BEHIND the residual add (DarkNet's ResBlock: dropblock(x + conv(x)), darknetv3.py:59-61) rides along too
     const float dsc2 = keep2 != nullptr ? drop_scale(count2, npix) : 1.f;
-    for (long p = gtid / cg; p < npix; p += pstep) {
-        const long q = p * cg + cgi;
-        float fy[8], fr[8], o[8];
-        unpack8(y[q], fy);
-        // the residual may cover only the first res_cg channel groups (ReXBlock: out[:, :Cin] += x, rexnet.py:141)
-        const bool has_r = HAS_RES && cgi < res_cg;
-        if (has_r) unpack8(res[p * res_cg + cgi], fr);
-        const float kp = keep != nullptr ? keep[p] * dsc : 1.f;
-        const float kp2 = keep2 != nullptr ? keep2[p] * dsc2 : 1.f;
+    // the residual may cover only the first res_cg channel groups (ReXBlock: out[:, :Cin] += x, rexnet.py:141)
+    const bool has_r = HAS_RES && cgi < res_cg;
+    constexpr int BA_U = NT ? 4 : 1;                 // streaming tensors: four pixels per iteration; cache-resident ones: the one-pixel loop
+    for (long p0 = gtid / cg; p0 < npix; p0 += BA_U * pstep) {
+        u32x4 vy[BA_U], vr[BA_U];
+        float kp[BA_U], kp2[BA_U];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float z = act_fwd(a[i] * fy[i] + sh[i], act, slope);
-            if (keep != nullptr) z *= kp;
-            if (has_r) z += fr[i];
-            if (keep2 != nullptr) z *= kp2;
-            o[i] = z;
+        for (int u = 0; u < BA_U; ++u) {
+            const long p = p0 + u * pstep;
+            const bool ok = p < npix;
+            const long pc = ok ? p : p0;
+            vy[u] = ld16<NT>(y + pc * cg + cgi);
+            if (has_r) vr[u] = ld16<NT>(res + pc * res_cg + cgi);
+            kp[u] = keep != nullptr ? keep[pc] * dsc : 1.f;
+            kp2[u] = keep2 != nullptr ? keep2[pc] * dsc2 : 1.f;
         }
-        out[p * out_ld8 + cgi] = pack8(o);
+#pragma unroll
+        for (int u = 0; u < BA_U; ++u) {
+            const long p = p0 + u * pstep;
+            if (p >= npix) break;
+            float fy[8], fr[8], o[8];
+            unpack8(vy[u], fy);
+            if (has_r) unpack8(vr[u], fr);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float z = act_fwd(a[i] * fy[i] + sh[i], act, slope);
+                if (keep != nullptr) z *= kp[u];
+                if (has_r) z += fr[i];
+                if (keep2 != nullptr) z *= kp2[u];
+                o[i] = z;
+            }
+            st16<NT>(out + p * out_ld8 + cgi, pack8(o));
+        }
     }
 }
 
@@ -551,6 +573,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32
     float sv[2][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) sv[0][i] = sv[1][i] = 0.f;
+    // (one pixel per iteration: the four-pixel form of the apply kernels measured SLOWER here on every size, 33 -> 46 us at 96 MB)
     for (long p = gtid / cg; p < npix; p += pstep) {
         float fg[8], fy[8];
         unpack8(g[p * g_ld8 + cgi], fg);
@@ -567,6 +590,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32
     block_reduce_flush<2>(sv, cg, C, red + (size_t)(blockIdx.x % reps) * 4 * C, sred, 2);
 }
 
+template <bool NT>
 __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_apply_kernel(const u32x4* __restrict__ g, int g_ld8,
                                                                       const u32x4* __restrict__ y, const float* __restrict__ coef,
                                                                       const float* __restrict__ bc, const float* __restrict__ keep,
@@ -588,24 +612,39 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_apply_kernel(const u32x
     load8f(bc + 2 * C + c0, Cc);
     const float dsc = keep != nullptr ? drop_scale(count, npix) : 1.f;
     const float dsc2 = keep2 != nullptr ? drop_scale(count2, npix) : 1.f;
-    for (long p = gtid / cg; p < npix; p += pstep) {
-        const long q = p * cg + cgi;
-        float fg[8], fy[8], o[8];
-        unpack8(g[p * g_ld8 + cgi], fg);
-        unpack8(y[q], fy);
-        if (keep2 != nullptr) {      // gradient through the DropBlock behind the residual add: what the residual input receives
-            const float kp2 = keep2[p] * dsc2;
+    constexpr int BA_U = NT ? 4 : 1;
+    for (long p0 = gtid / cg; p0 < npix; p0 += BA_U * pstep) {
+        u32x4 vg[BA_U], vy[BA_U];
+        float kp[BA_U], kp2[BA_U];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) fg[i] *= kp2;
-            if (gres != nullptr) gres[q] = pack8(fg);
+        for (int u = 0; u < BA_U; ++u) {
+            const long p = p0 + u * pstep;
+            const long pc = p < npix ? p : p0;
+            vg[u] = ld16<NT>(g + pc * g_ld8 + cgi);
+            vy[u] = ld16<NT>(y + pc * cg + cgi);
+            kp[u] = keep != nullptr ? keep[pc] * dsc : 1.f;
+            kp2[u] = keep2 != nullptr ? keep2[pc] * dsc2 : 1.f;
         }
-        const float kp = keep != nullptr ? keep[p] * dsc : 1.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float dz = fg[i] * kp * act_bwd(a[i] * fy[i] + sh[i], act, slope);
-            o[i] = A[i] * dz + B[i] * fy[i] + Cc[i];
+        for (int u = 0; u < BA_U; ++u) {
+            const long p = p0 + u * pstep;
+            if (p >= npix) break;
+            const long q = p * cg + cgi;
+            float fg[8], fy[8], o[8];
+            unpack8(vg[u], fg);
+            unpack8(vy[u], fy);
+            if (keep2 != nullptr) {      // gradient through the DropBlock behind the residual add: what the residual input receives
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fg[i] *= kp2[u];
+                if (gres != nullptr) st16<NT>(gres + q, pack8(fg));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float dz = fg[i] * kp[u] * act_bwd(a[i] * fy[i] + sh[i], act, slope);
+                o[i] = A[i] * dz + B[i] * fy[i] + Cc[i];
+            }
+            st16<NT>(dy + q, pack8(o));
         }
-        dy[q] = pack8(o);
     }
 }
 
@@ -1163,12 +1202,13 @@ int hc_bn_act_apply_post(const void* y, const float* coef, const void* res, int3
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8);
     hipStream_t st = (hipStream_t)stream;
-    if (res != nullptr)
-        hipLaunchKernelGGL((bn_act_apply_kernel<true>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)y, coef, (const u32x4*)res,
-                           res_C / 8, keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope, keep2, count2);
-    else
-        hipLaunchKernelGGL((bn_act_apply_kernel<false>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)y, coef, (const u32x4*)res,
-                           0, keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope, keep2, count2);
+#define HC_BAA(RS, NTM)                                                                                                          \
+    hipLaunchKernelGGL((bn_act_apply_kernel<RS, NTM>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)y, coef, (const u32x4*)res, \
+                       RS ? res_C / 8 : 0, keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope, keep2, count2)
+    const bool nt = ba_streaming(nchunks);
+    if (res != nullptr) { if (nt) HC_BAA(true, true); else HC_BAA(true, false); }
+    else { if (nt) HC_BAA(false, true); else HC_BAA(false, false); }
+#undef HC_BAA
     return hc_launch_status();
 }
 int hc_bn_act_bwd_reduce(const void* g, int32_t g_ld, const void* y, const float* coef, const float* keep, const float* count,
@@ -1201,8 +1241,11 @@ int hc_bn_act_bwd_apply_post(const void* g, int32_t g_ld, const void* y, const f
     if (gres != nullptr && keep2 == nullptr) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u32x4*)g, g_ld / 8,
-                       (const u32x4*)y, coef, bcoef, keep, count, (u32x4*)dy, (long)npix, C, act, slope, keep2, count2, (u32x4*)gres);
+#define HC_BAB(NTM)                                                                                                          \
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<NTM>), dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u32x4*)g, g_ld / 8, \
+                       (const u32x4*)y, coef, bcoef, keep, count, (u32x4*)dy, (long)npix, C, act, slope, keep2, count2, (u32x4*)gres)
+    if (ba_streaming(nchunks)) HC_BAB(true); else HC_BAB(false);
+#undef HC_BAB
     return hc_launch_status();
 }
 int hc_gap_fwd(const void* x, float* y, int32_t N, int32_t HW, int32_t C, hc_stream_t stream) {
