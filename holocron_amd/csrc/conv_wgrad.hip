@@ -222,12 +222,19 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     if (ci0 + c < Cin) {
         const float* p = ws + ((long)co * T + t) * Cin + ci0 + c;
         int k = k0;
-        for (; k + 8 <= k1; k += 8) {   // 8 independent loads in flight
-            float v[8];
+        for (; k + 16 <= k1; k += 16) {   // 16 independent loads in flight (the launch is a chain of nsplit / 16 memory round trips)
+            float v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(long)(k + u) * slab];
+            for (int u = 0; u < 16; ++u) v[u] = p[(long)(k + u) * slab];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; k + 4 <= k1; k += 4) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p[(long)(k + u) * slab];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
         }
         for (; k < k1; ++k) s += p[(long)k * slab];
     }
