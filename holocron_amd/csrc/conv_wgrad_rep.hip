@@ -82,9 +82,18 @@ constexpr int DJW = 4;   // dy DMA instructions per tensor and wave (stages up t
 // LDS or issues DMA the other feeds the matrix pipe - with one wave per SIMD nothing overlaps unless the instruction stream says so)
 // PV = 2 (the 48 x 48 tile, whose ci blocks do not split evenly): eight waves, the two groups take alternate halves of the 32-pixel
 // k-steps of every step and write their own partial slab (the reduction kernel adds twice as many) - same reason as HV = 2.
+// BIGR (MR = NR = 6: the 96 ci x 96 co x 10-tap tile, round 5): EIGHT waves, two per SIMD, 180 accumulator registers each.  Roles are
+// (tap group of five) x (co half) x (ci half): group 0 = taps (0,0) (0,1) (0,2) (1,0) (1,1) against dy3, group 1 = (1,2) (2,0) (2,1) (2,2)
+// against dy3 + the 1x1 against dy1.  Twice the accumulators per CU of the 96 x 48 tile (which uses 42 % of the register file for them):
+// 18 KB of operands per k32 step for 360 MFMAs instead of 12.3 KB for 180 - the L2 -> LDS fill, not the matrix pipe, bounds the smaller
+// tile.  The first form - four waves at one per SIMD, 360 accumulators each - compiled to 584 v_accvgpr_write + 124
+// v_accvgpr_read per 90 MFMAs (the accumulators do not fit the 256 AGPRs and the allocator shuttles them) and ran at 26 % of the matrix rate.
 template <int MR, int NR, int HV, int PV = 1>
 __global__ __launch_bounds__(256 * HV * PV, (PV == 1 && (HV == 2 || MR * NR <= 9)) ? 2 : 1) void wrep_kernel(const Args a) {
     constexpr int NW = 4 * HV * PV, NT_ = 256 * HV * PV, MH = MR / HV;
+    constexpr bool BIGR = MR == 6 && NR == 6;
+    constexpr int NRW = BIGR ? NR / 2 : NR;                // co blocks of one wave
+    static_assert(!BIGR || (HV == 2 && PV == 1), "the 96 x 96 tile runs on eight waves");
     static_assert(HV == 1 || PV == 1, "one kind of wave-group split at a time");
     static_assert(MR % HV == 0, "ci tile must split evenly over the wave groups");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -328,6 +337,97 @@ __global__ __launch_bounds__(256 * HV * PV, (PV == 1 && (HV == 2 || MR * NR <= 9
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
+    // ---- BIGR: five taps x six ci blocks x three co blocks per wave ----------------------------------------------------
+    auto run5 = [&](auto tg_c) {
+        constexpr int TG = decltype(tg_c)::value;
+        const int ch = (wid >> 1) & 1;                      // co half of this wave (ci half: `half` = wid >> 2)
+        const int kwoff = 32 * MH * half;
+        f32x4 acc[5][MH][NRW];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int m = 0; m < MH; ++m)
+#pragma unroll
+                for (int q = 0; q < NRW; ++q) acc[j][m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int base = (s * Ua) % a.NSLOT;
+        int cstage = 0;
+        const int cohalf = ch * NRW * 32;                   // byte offset of the wave's co blocks inside a staged dy pixel
+        for (int t = 0; t < nsteps; ++t) {
+            wait_vm(a.PF > 1 ? ndma : 0);
+            __syncthreads();
+            if (!(a.dbg & 2)) {
+                issue_x_rows(RS);
+                issue_dy();
+            }
+            const char* dyb = smem + a.off_dy + cstage * a.DSLOT;
+            for (int g = 0; g < nk; ++g) {
+                const int p0 = 32 * g + prow;
+                const int r0 = tab[2 * p0], c0 = tab[2 * p0 + 1], r1 = tab[2 * p0 + 32], c1 = tab[2 * p0 + 33];
+                const int d0 = p0 * a.SD + cq2 + cohalf;
+                bf16x8 fb[NRW];                             // dy3 fragments; group 1 re-loads them from dy1 in front of its last tap (the 1x1)
+#pragma unroll
+                for (int q = 0; q < NRW; ++q) fb[q] = tr_pair(dyb, d0 + 32 * q, d0 + SD16B + 32 * q);
+                // x addresses of the (up to three) kernel rows this group touches
+                int xr0[3], xr1[3];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    int s0 = base + r0 + kh, s1 = base + r1 + kh;
+                    if (s0 >= a.NSLOT) s0 -= a.NSLOT;
+                    if (s1 >= a.NSLOT) s1 -= a.NSLOT;
+                    xr0[kh] = s0 * a.ROWB + c0 + cq2 + kwoff;
+                    xr1[kh] = s1 * a.ROWB + c1 + cq2 + kwoff;
+                }
+                // the 5 x MH (tap, ci block) groups as ONE software pipeline: the x fragment of group i + 1 is requested before the three
+                // MFMAs of group i (left to the compiler every group was read -> wait -> 3 MFMAs: ~180 cycles per 48 of matrix work, and the
+                // two waves of a SIMD together kept its pipe 53 % busy)
+                auto xfrag = [&](const int i) __attribute__((always_inline)) {
+                    const int j = i / MH, m = i - j * MH;
+                    const bool is1 = TG == 1 && j == 4;
+                    const int tap = is1 ? 4 : (TG == 0 ? 0 : 5) + j;
+                    const int kh = tap / 3, kw = tap - 3 * kh;
+                    const int ko = kw == 0 ? 0 : (kw == 1 ? SX1 : SX2);
+                    return tr_pair(smem, xr0[kh] + ko + 32 * m, xr1[kh] + ko + 32 * m);
+                };
+                bf16x8 fa0 = xfrag(0), fa1;
+#pragma unroll
+                for (int i = 0; i < 5 * MH; ++i) {
+                    const int j = i / MH, m = i - j * MH;
+                    if (TG == 1 && j == 4 && m == 0) {          // the 1x1 (centre tap against dy1): swap the dy fragments
+#pragma unroll
+                        for (int q = 0; q < NRW; ++q) fb[q] = tr_pair(dyb + a.DHALF, d0 + 32 * q, d0 + SD16B + 32 * q);
+                    }
+                    if (i + 1 < 5 * MH) {
+                        if (i & 1) fa0 = xfrag(i + 1); else fa1 = xfrag(i + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < NRW; ++q)
+                        acc[j][m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((i & 1) ? fa1 : fa0, fb[q], acc[j][m][q], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            base += RS;
+            if (base >= a.NSLOT) base -= a.NSLOT;
+            if (++cstage > a.PF) cstage = 0;
+        }
+        wait_vm(0);
+        float* ws = a.ws + (size_t)(job * a.nsplit + split) * (size_t)a.Cout * 10u * (size_t)a.Cin;
+#pragma unroll
+        for (int q = 0; q < NRW; ++q) {
+            const int co = co0 + 16 * (ch * NRW + q) + la;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int tap = (TG == 1 && j == 4) ? 9 : (TG == 0 ? j : 5 + j);
+                float* row = ws + ((size_t)co * 10 + tap) * a.Cin + ci0 + 16 * MH * half + 4 * kq;
+#pragma unroll
+                for (int m = 0; m < MH; ++m) *reinterpret_cast<f32x4*>(row + 16 * m) = acc[j][m][q];
+            }
+        }
+    };
+    if (BIGR) {
+        if ((wid & 1) == 0) run5(I0{}); else run5(I1{});
+        return;
+    }
     if (role == 0) run(I0{}, I0{}, I3{}, I0{});
     else if (role == 1) run(I1{}, I0{}, I3{}, I0{});
     else if (role == 2) run(I2{}, I0{}, I2{}, I0{});
@@ -409,7 +509,10 @@ inline Plan make_plan(const hc_rep_wgrad_desc& d) {
     if ((double)d.N * d.IH * d.IW * d.Cin * 2.0 >= 4294967040.0 || (double)d.N * d.OH * d.OW * d.Cout * 2.0 >= 4294967040.0) return pl;
     int MR = 0, NR = 0;
     constexpr int tile_env = 0;
-    if (d.Cin % 96 == 0 && d.Cout % 48 == 0 && tile_env != 33) { MR = 6; NR = 3; }
+    // 96 x 96 where both widths allow (RepVGG-A0's 96- and 192-wide stages): half the x re-reads of the 96 x 48 tile per output; same-box
+    // step 9.91-10.00 ms against 10.00-10.07 with the 96 x 48 tile everywhere (profiles/r05_wgrad_rep_big_tile.txt)
+    if (d.Cin % 96 == 0 && d.Cout % 96 == 0 && tile_env != 33) { MR = 6; NR = 6; }
+    else if (d.Cin % 96 == 0 && d.Cout % 48 == 0 && tile_env != 33) { MR = 6; NR = 3; }
     else if (d.Cin % 64 == 0 && d.Cout % 64 == 0) { MR = 4; NR = 4; }
     else if (d.Cin % 48 == 0 && d.Cout % 48 == 0) { MR = 3; NR = 3; }
     else return pl;
@@ -430,8 +533,6 @@ inline Plan make_plan(const hc_rep_wgrad_desc& d) {
     a.ROWB = a.XJ * 1024;
     a.SD = round_stride(16 * NR * 2, 1);
     if (a.XJ > 4 * XJW) return pl;
-    constexpr int pf_env = 0;
-    constexpr int r_env = 0;
     // LDS budget of a workgroup: all of it for the big tiles (one workgroup per CU: 512 registers per lane); the 48 x 48 tile fits
     // two waves per SIMD, and two / three co-resident workgroups overlap one's DMA issue and barriers with the other's MFMAs
     constexpr int lds_env = 0;
@@ -440,17 +541,19 @@ inline Plan make_plan(const hc_rep_wgrad_desc& d) {
     double best = -1.0;
     int bestR = 0, bestPF = 0;
     for (int R = 1; R <= a.PO && R * d.OW <= 128; ++R) {
-        if (r_env > 0 && R != r_env) continue;
         const int P = R * d.OW, P32 = (P + 31) / 32 * 32;
         const int DJ = (P32 * (a.SD / 16) + 63) / 64;
-        if (DJ > 4 * DJW) continue;
+        if (DJ > (MR % 2 == 0 ? 8 : 4) * DJW) continue;       // eight waves issue the DMA of the even-MR tiles (HV = 2)
         for (int PF = 2; PF >= 1; --PF) {
-            if (pf_env > 0 && PF != pf_env) continue;
             const int NSLOT = (R - 1) * s + 3 + PF * R * s;
             const long bytes = (long)NSLOT * a.ROWB + (long)(PF + 1) * 2 * DJ * 1024 + P32 * 8 + 1024;
             if (bytes > LDS_MAX) continue;
             // PF = 2 only pays while a step is short (HBM latency not covered by one step of MFMAs)
-            const double score = (double)P / P32 + 1e-3 * P + (PF == 2 && P32 <= 64 ? 0.05 : 0.0) - (PF == 2 && P32 > 64 ? 0.5 : 0.0);
+            // the 96 x 96 tile: the longest well-filled step wins whatever the depth (its fill floor is 295 us of a 670 us launch; measured
+            // on 192@14: R / PF = 4 / 2 686-702 us, 4 / 1 687-696, 5 / 1 763, 6 / 1 669, 3 / 2 867, 2 / 2 786)
+            const bool bigr = MR == 6 && NR == 6;
+            const double score = bigr ? (double)P / P32 + 1e-3 * P
+                                      : (double)P / P32 + 1e-3 * P + (PF == 2 && P32 <= 64 ? 0.05 : 0.0) - (PF == 2 && P32 > 64 ? 0.5 : 0.0);
             if (score > best) { best = score; bestR = R; bestPF = PF; }
         }
     }
@@ -539,7 +642,8 @@ extern "C" int hc_rep_wgrad(const hc_rep_wgrad_desc* dp, hc_stream_t stream) {
     if (!pl.ok) return HC_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
-    if (pl.MR == 6) rc = pl.HV == 2 ? wrep::launch<6, 3, 2>(pl, st) : wrep::launch<6, 3, 1>(pl, st);
+    if (pl.MR == 6 && pl.NR == 6) rc = wrep::launch<6, 6, 2>(pl, st);
+    else if (pl.MR == 6) rc = pl.HV == 2 ? wrep::launch<6, 3, 2>(pl, st) : wrep::launch<6, 3, 1>(pl, st);
     else if (pl.MR == 4) rc = pl.HV == 2 ? wrep::launch<4, 4, 2>(pl, st) : wrep::launch<4, 4, 1>(pl, st);
     else rc = pl.PV == 2 ? wrep::launch<3, 3, 1, 2>(pl, st) : wrep::launch<3, 3, 1>(pl, st);
     if (rc != HC_OK) return rc;
