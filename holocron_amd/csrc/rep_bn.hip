@@ -813,6 +813,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, bf16_t* __restri
 // (ci, tap) and the bf16 destination is written in runs along ITS fastest axis (ci for the forward image, co for the
 // data-gradient image) through an LDS tile: a thread-per-output-element walk reads the data-gradient image with a stride of
 // Cin * KK floats (one cache line per lane), which made this kernel 20x slower than its traffic.
+constexpr int PK_BATCH = 5;       // 16-byte source loads a thread keeps in flight
 constexpr int PK_MAXKK = 9;
 constexpr int PK_TILE = 16 * 64 * PK_MAXKK;      // floats: 16 x 64 (co x ci or ci x co) x taps
 // mode 0: tiles of 16 co x 64 ci, written [co][tap][ci] (rows of ld >= Cin; the padding is left untouched)
@@ -830,10 +831,37 @@ __device__ __forceinline__ void pack_tiles(const hc_pack_item& it, bf16_t* __res
         const int co0 = (tl / nci) * TCO, ci0 = (tl % nci) * TCI;
         const int cw = min(TCI, it.Cin - ci0) * KK;   // valid floats of a row
         __syncthreads();
+        // whole tiles of 16-byte-aligned rows: 16-byte loads, ALL of a thread's (nine for a 3x3 tile) issued in batches of five before their LDS stores.
+        // The dword form (six in flight per thread) ran the RepVGG-A0 pack at 1.5 TB/s: 296 MB in 198 us, 2 % of the step.
+        const bool vin = KKC != 0 && cw == run && co0 + TCO <= it.Cout && ((it.Cin * KK) & 3) == 0 && ((reinterpret_cast<size_t>(it.w) & 15) == 0);
+        if (vin) {
+            constexpr int RUN4 = KKC ? TCI * KKC / 4 : 1, NV = (TCO * RUN4 + 255) / 256;
+#pragma unroll 1
+            for (int k0 = 0; k0 < NV; k0 += PK_BATCH) {           // batches: all nine at once cost 168 registers and a workgroup per CU
+                f32x4 v[PK_BATCH];
+#pragma unroll
+                for (int k = 0; k < PK_BATCH; ++k) {
+                    const int e = threadIdx.x + 256 * (k0 + k);
+                    const int r = e / RUN4, c = 4 * (e - r * RUN4);
+                    if (e < TCO * RUN4)
+                        v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(it.w + ((long)(co0 + r) * it.Cin + ci0) * KK + c));
+                }
+#pragma unroll
+                for (int k = 0; k < PK_BATCH; ++k) {
+                    const int e = threadIdx.x + 256 * (k0 + k);
+                    const int r = e / RUN4, c = 4 * (e - r * RUN4);
+                    if (e < TCO * RUN4) {
+                        float* d = tile + r * lrun + c;
+                        d[0] = v[k][0]; d[1] = v[k][1]; d[2] = v[k][2]; d[3] = v[k][3];
+                    }
+                }
+            }
+        } else {
 #pragma unroll 6
-        for (int e = threadIdx.x; e < TCO * run; e += 256) {      // unrolled: six independent loads in flight per thread
-            const int r = e / run, c = e - r * run;
-            if (co0 + r < it.Cout && c < cw) tile[r * lrun + c] = it.w[((long)(co0 + r) * it.Cin + ci0) * KK + c];
+            for (int e = threadIdx.x; e < TCO * run; e += 256) {      // unrolled: six independent loads in flight per thread
+                const int r = e / run, c = e - r * run;
+                if (co0 + r < it.Cout && c < cw) tile[r * lrun + c] = it.w[((long)(co0 + r) * it.Cin + ci0) * KK + c];
+            }
         }
         __syncthreads();
         // 16-byte stores: a thread gathers EIGHT consecutive destination elements from the tile (the one-element form issued a 2-byte
@@ -876,13 +904,78 @@ __device__ __forceinline__ void pack_tiles(const hc_pack_item& it, bf16_t* __res
     }
 }
 
+// modes 3 / 4 (row-unit images of conv_rows.hip) through an LDS tile: one unit = 48 row channels x one k32 block x all taps.  The fp32
+// source is read in 16-byte pieces along its contiguous runs (mode 3: a co row's 32 ci x taps; mode 4: a co row's 48 ci x taps), kept as
+// bf16 in LDS (27 KB), and every tap's 48 x 32 block of the image leaves as 3 KB of contiguous 16-byte stores (the lane's eight k values
+// of one MFMA fragment row).  The element walk wrote 2 bytes per lane at scattered addresses: the fourteen 192-channel blocks of
+// RepVGG-A0 alone kept the pack at 1.3 TB/s.  Pieces past the channel count (C = 48: the second k block is half empty) are written as
+// zeros, which is what the image holds there anyway.
+template <int MODE, int KK, int nk>                                // nk: valid k channels of the unit's k32 block (32; 16 in the last block when C % 32 = 16)
+__device__ __forceinline__ void pack_rows_unit(const hc_pack_item& it, bf16_t* __restrict__ wpk, float* __restrict__ tile_f, const int w48,
+                                               const int kblk) {
+    bf16_t* tile = reinterpret_cast<bf16_t*>(tile_f);
+    const int C = it.Cout, KB = (C + 31) >> 5;
+    constexpr int NR = MODE == 3 ? 48 : 32;                        // LDS rows: mode 3 one per row channel, mode 4 one per k channel
+    constexpr int LS = (MODE == 3 ? 32 : 48) * KK + 2;             // LDS row stride in elements (an odd number of dwords)
+    static_assert(NR * LS * 2 <= (PK_TILE + 64) * 4, "tile buffer too small");
+    constexpr int rows = MODE == 3 ? 48 : nk;
+    constexpr int run4 = (MODE == 3 ? nk : 48) * KK / 4;               // 16-byte pieces per source run
+    __syncthreads();
+    constexpr int NV = (rows * run4 + 255) / 256;
+#pragma unroll 1
+    for (int k0 = 0; k0 < NV; k0 += PK_BATCH) {
+        f32x4 v[PK_BATCH];
+#pragma unroll
+        for (int k = 0; k < PK_BATCH; ++k) {
+            const int e = threadIdx.x + 256 * (k0 + k);
+            const int r = e / run4, c4 = e - r * run4;
+            if (r < rows) {
+                const long src = MODE == 3 ? ((long)(48 * w48 + r) * C + 32 * kblk) * KK : ((long)(32 * kblk + r) * C + 48 * w48) * KK;
+                v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(it.w + src) + c4);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PK_BATCH; ++k) {
+            const int e = threadIdx.x + 256 * (k0 + k);
+            const int r = e / run4, c4 = e - r * run4;
+            if (r < rows) {
+                bf16_t* d = tile + r * LS + 4 * c4;
+                d[0] = f32_to_bf16(v[k][0]); d[1] = f32_to_bf16(v[k][1]); d[2] = f32_to_bf16(v[k][2]); d[3] = f32_to_bf16(v[k][3]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < KK * 48 * 4; o += 256) {
+        const int g = o & 3, q = o >> 2, rp = q % 48, t = q / 48;
+        const int f = rp >> 4, gq = (rp & 15) >> 2, i = rp & 3;
+        const int c = f < 2 ? 8 * gq + 4 * f + i : 32 + 4 * gq + i;            // row channel whose image row is 48 w + rp
+        unsigned short h[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int kk = 16 * (x >> 2) + 4 * g + (x & 3);
+            const bf16_t b = MODE == 3 ? tile[c * LS + kk * KK + t] : tile[kk * LS + c * KK + t];
+            h[x] = kk < nk ? __builtin_bit_cast(unsigned short, b) : (unsigned short)0;
+        }
+        u32x4 pk;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) pk[x] = (unsigned)h[2 * x] | ((unsigned)h[2 * x + 1] << 16);
+        const int tap = it.tap0 + (MODE == 3 ? t : KK - 1 - t);
+        *reinterpret_cast<u32x4*>(wpk + (((long)tap * KB + kblk) * C + 48 * w48 + rp) * 32 + 8 * g) = pk;
+    }
+}
 // Work units of an item: its LDS tiles (modes 0 / 1, kernels up to 3x3) or chunks of PK_CHUNK source elements (element-wise modes).
 // The grid is ONE dimension of a few thousand workgroups that walk the flat unit list (the former (tiles, items) grid launched
 // 512 x 108 workgroups of which 50 000 had nothing to do; removing them did not change the 175 us of the RepVGG-A0 pack, whose time
 // is in the two 59 MB passes over the 1280 x 1280 x 3 x 3 tensor).
 constexpr int PK_CHUNK = 8192;
+__device__ __forceinline__ bool pack_rows_tiled(const hc_pack_item& it) {
+    const int KK = it.KH * it.KW;
+    return (it.mode == 3 || it.mode == 4) && (KK == 9 || KK == 1) && it.Cout == it.Cin && it.Cout % 48 == 0 &&
+           ((reinterpret_cast<size_t>(it.w) | reinterpret_cast<size_t>(it.dst)) & 15) == 0;
+}
 __device__ __forceinline__ int pack_units(const hc_pack_item& it) {
     const int KK = it.KH * it.KW;
+    if (pack_rows_tiled(it)) return (it.Cout / 48) * ((it.Cout + 31) >> 5);
     if (it.mode >= 2 || KK > PK_MAXKK) return (int)(((long)it.Cout * it.Cin * KK + PK_CHUNK - 1) / PK_CHUNK);
     return it.mode == 0 ? ((it.Cout + 15) / 16) * ((it.Cin + 63) / 64) : ((it.Cout + 63) / 64) * ((it.Cin + 15) / 16);
 }
@@ -909,7 +1002,17 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const hc_pack_it
         bf16_t* wpk = reinterpret_cast<bf16_t*>(it.dst);
         const long total = (long)it.Cout * it.Cin * KK;
         const long o0 = (long)tl * PK_CHUNK, o1 = o0 + PK_CHUNK < total ? o0 + PK_CHUNK : total;
-        if (it.mode >= 3) {                          // row-unit images: walk the source (16-byte runs on both sides)
+        if (pack_rows_tiled(it)) {
+            const int KB = (it.Cout + 31) >> 5, w48 = tl / KB, kblk = tl - w48 * KB;
+            const bool full = it.Cout - 32 * kblk >= 32;
+            if (it.mode == 3) {
+                if (KK == 9) { if (full) pack_rows_unit<3, 9, 32>(it, wpk, tile, w48, kblk); else pack_rows_unit<3, 9, 16>(it, wpk, tile, w48, kblk); }
+                else { if (full) pack_rows_unit<3, 1, 32>(it, wpk, tile, w48, kblk); else pack_rows_unit<3, 1, 16>(it, wpk, tile, w48, kblk); }
+            } else {
+                if (KK == 9) { if (full) pack_rows_unit<4, 9, 32>(it, wpk, tile, w48, kblk); else pack_rows_unit<4, 9, 16>(it, wpk, tile, w48, kblk); }
+                else { if (full) pack_rows_unit<4, 1, 32>(it, wpk, tile, w48, kblk); else pack_rows_unit<4, 1, 16>(it, wpk, tile, w48, kblk); }
+            }
+        } else if (it.mode >= 3) {                   // row-unit images: walk the source (16-byte runs on both sides)
             for (long o = o0 + threadIdx.x; o < o1; o += 256) {
                 const int t = (int)(o % KK);
                 const long r = o / KK;

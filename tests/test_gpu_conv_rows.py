@@ -52,6 +52,30 @@ def test_rows_image_layout(C):
                 assert got[rows_index(ci, co, 9, C)] == w1b[co, ci, 0, 0]
 
 
+@pytest.mark.parametrize("C", [48, 96, 192, 240])
+def test_rows_image_multi_pack_is_the_single_pack(C):
+    """hc_pack_conv_weights_multi builds the row-unit images through LDS tiles (48 row channels x one k32 block x all taps per unit,
+    16-byte loads and stores); hc_pack_conv_weight walks the elements.  Same bits, including the zero half of the last k block when
+    C is not a multiple of 32."""
+    from holocron_amd.ops import conv as cv
+    from holocron_amd.nn.repblock_op import launch_pack_items
+    g = torch.Generator(device="cuda").manual_seed(C)
+    w3 = torch.randn(C, C, 3, 3, device="cuda", generator=g)
+    w1 = torch.randn(C, C, 1, 1, device="cuda", generator=g)
+    for mode in (3, 4):
+        ref = cv.rows_image(C, "cuda"); ref.zero_()
+        cv.pack_weight(w3, mode, out=ref, tap0=0, T=10)
+        cv.pack_weight(w1, mode, out=ref, tap0=9, T=10)
+        got = cv.rows_image(C, "cuda"); got.zero_()
+        launch_pack_items([(w3, got, C, C, 3, 3, mode, 0, 10), (w1, got, C, C, 1, 1, mode, 9, 10)])
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (C, mode)
+        got.fill_(1.0)            # the tiles own the padding of their pieces: stale values there must not survive a repack
+        launch_pack_items([(w3, got, C, C, 3, 3, mode, 0, 10), (w1, got, C, C, 1, 1, mode, 9, 10)])
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), (C, mode)
+
+
 @pytest.mark.parametrize("N,C,H,W", [(2, 192, 14, None), (256, 192, 14, None), (3, 96, 28, None), (256, 96, 28, None), (5, 192, 28, None),
                                      (2, 96, 56, None), (3, 48, 112, None), (64, 48, 56, None),
                                      # the family form (round 4): any width up to 16 (192 channels) / 32 (96 channels) pixels, any height
