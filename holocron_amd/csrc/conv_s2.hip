@@ -1078,8 +1078,15 @@ __device__ __forceinline__ float sf_xx(const float* S, int kh1, int s1, int kh2,
 }
 __global__ __launch_bounds__(256) void stem_bwd_finalize_kernel(const SfFin f) {
     __shared__ float sA[2][48], sB[2][48], sC[2][48];
+    // the sums and the (bf16-rounded) weights once into LDS: every output below is a 27-term dot product over them, and out of global
+    // memory each term was a dependent L2 round trip (16 us for 1.4 k outputs at the very end of the backward pass)
+    __shared__ float sS[SF_NT * 256], sw3[48 * 27], sw1[48 * 3];
     const int tid = threadIdx.x;
-    const float* S = f.S;
+    for (int i = tid; i < SF_NT * 256 / 4; i += 256) reinterpret_cast<f32x4*>(sS)[i] = reinterpret_cast<const f32x4*>(f.S)[i];
+    for (int i = tid; i < 48 * 27; i += 256) sw3[i] = sf_bf16r(f.w3[i]);
+    if (tid < 48 * 3) sw1[tid] = sf_bf16r(f.w1[tid]);
+    __syncthreads();
+    const float* S = sS;
     auto gcol = [&](int co, int kh, int slot) { return S[(((co >> 4) * 3 + kh) * 16 + (co & 15)) * 16 + slot]; };
     if (tid < 96) {
         const int b = tid / 48, co = tid - 48 * b;              // branch 0: 3x3, 1: 1x1
@@ -1088,9 +1095,9 @@ __global__ __launch_bounds__(256) void stem_bwd_finalize_kernel(const SfFin f) {
         if (b == 0) {
             for (int ci = 0; ci < 3; ++ci)
                 for (int kh = 0; kh < 3; ++kh)
-                    for (int kw = 0; kw < 3; ++kw) sdzy += sf_bf16r(f.w3[((co * 3 + ci) * 3 + kh) * 3 + kw]) * gcol(co, kh, 4 * kw + ci);
+                    for (int kw = 0; kw < 3; ++kw) sdzy += sw3[((co * 3 + ci) * 3 + kh) * 3 + kw] * gcol(co, kh, 4 * kw + ci);
         } else {
-            for (int ci = 0; ci < 3; ++ci) sdzy += sf_bf16r(f.w1[co * 3 + ci]) * gcol(co, 1, 4 + ci);
+            for (int ci = 0; ci < 3; ++ci) sdzy += sw1[co * 3 + ci] * gcol(co, 1, 4 + ci);
         }
         const float mean = f.save[(2 * b) * 48 + co], invstd = f.save[(2 * b + 1) * 48 + co];
         const float gam = (b == 0 ? f.gamma3 : f.gamma1)[co];
@@ -1115,13 +1122,13 @@ __global__ __launch_bounds__(256) void stem_bwd_finalize_kernel(const SfFin f) {
             for (int ci2 = 0; ci2 < 3; ++ci2)
                 for (int kh2 = 0; kh2 < 3; ++kh2)
                     for (int kw2 = 0; kw2 < 3; ++kw2)
-                        wxx += sf_bf16r(f.w3[((co * 3 + ci2) * 3 + kh2) * 3 + kw2]) * sf_xx(S, kh2, 4 * kw2 + ci2, kh, slot);
+                        wxx += sw3[((co * 3 + ci2) * 3 + kh2) * 3 + kw2] * sf_xx(S, kh2, 4 * kw2 + ci2, kh, slot);
             const float v = sA[0][co] * gcol(co, kh, slot) + sB[0][co] * wxx + sC[0][co] * sf_xx(S, kh, slot, 1, 7);
             f.dw3[o] = f.accumulate ? f.dw3[o] + v : v;
         } else {
             const int q = o - 48 * 27, co = q / 3, ci = q - 3 * co, slot = 4 + ci;
             float wxx = 0.f;
-            for (int ci2 = 0; ci2 < 3; ++ci2) wxx += sf_bf16r(f.w1[co * 3 + ci2]) * sf_xx(S, 1, 4 + ci2, 1, slot);
+            for (int ci2 = 0; ci2 < 3; ++ci2) wxx += sw1[co * 3 + ci2] * sf_xx(S, 1, 4 + ci2, 1, slot);
             const float v = sA[1][co] * gcol(co, 1, slot) + sB[1][co] * wxx + sC[1][co] * sf_xx(S, 1, slot, 1, 7);
             f.dw1[q] = f.accumulate ? f.dw1[q] + v : v;
         }

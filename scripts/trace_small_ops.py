@@ -1,0 +1,54 @@
+"""Where do the small torch kernels of the headline step come from?  One eager repvgg_a0 step under torch.profiler with Python stacks:
+every op that launches a fill / copy / torch elementwise kernel, grouped by its innermost holocron_amd / bench frame."""
+import collections
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import holocron_amd as h
+from torch.profiler import profile, ProfilerActivity
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = h.models.repvgg_a0(num_classes=10).to(dev).train()
+opt = h.optim.AdaBelief(model.parameters(), lr=1e-3, betas=(0.95, 0.99), eps=1e-6, weight_decay=0.0)
+x = torch.rand((256, 3, 224, 224), device=dev)
+t = torch.randint(0, 10, (256,), device=dev)
+loss_buf = torch.zeros((), device=dev)
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    loss = h.nn.functional.cross_entropy(model(x), t, label_smoothing=0.1)
+    loss.backward()
+    loss_buf.copy_(loss.detach())
+    opt.step()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    step()
+    torch.cuda.synchronize()
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+by = collections.Counter()
+kern = collections.Counter()
+for ev in prof.events():
+    if ev.device_type.name == "CUDA" if hasattr(ev.device_type, "name") else False:
+        continue
+    ks = [k for k in ev.kernels] if hasattr(ev, "kernels") else []
+    if not ks:
+        continue
+    names = ",".join(sorted({k.name[:48] for k in ks}))
+    if not any(s in names for s in ("Fill", "copy", "Memcpy", "Memset", "elementwise", "reduce_kernel", "at::")):
+        continue
+    where = "?"
+    for fr in ev.stack or []:
+        if root in fr and "site-packages" not in fr and "dist-packages" not in fr:
+            where = fr.replace(root + "/", "")
+            break
+    by[(ev.name, names, where)] += 1
+for (name, names, where), n in sorted(by.items(), key=lambda kv: -kv[1]):
+    print(f"{n:4d}  {name:28s} {names:50s} {where}")
