@@ -15,6 +15,10 @@
 //     (1,1)).  A wave's taps share their dy fragments, and nobody re-reads a neighbour's x fragments: 2*(3*MR + NR) transposing
 //     LDS reads per 3*MR*NR MFMAs instead of 2*(9*MR + NR) per 9*MR*NR/WAVES.  Eight-wave variants (two ci halves or two pixel
 //     halves) rotate the roles of the second group by two so that every SIMD carries one 3-tap and one 2-tap wave.
+//   * the 96 x 96 tile (MR = NR = 6; the 96- and 192-wide stages, round 5) deals differently: EIGHT waves = two tap groups of five
+//     (taps 0-4 against dy3 | taps 5-8 against dy3 + the 1x1 against dy1) x two co halves x two ci halves, 5 x 3 x 3 MFMAs and 180
+//     accumulator registers per wave and k32 step (`run5`).  Twice the accumulators per CU halve the L2 -> LDS ingest per MFMA, which
+//     bounded the 96 x 48 tile (its DMA alone took 504 of its 744 us on the fourteen 192 @ 14 x 14 blocks; here 295 of 670).
 //   * operands stream HBM/L2 -> LDS by DMA (buffer_load ... lds) in their natural NHWC layout, one step (R output rows)
 //     ahead of the MFMAs, no staging registers.  The batch is walked as ONE tall image: image n owns virtual input rows
 //     [n*PI, (n+1)*PI), PI = s*(OH+1), row 0 = the zero halo row (out-of-range DMA -> zeros), and virtual output rows

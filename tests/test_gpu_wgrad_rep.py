@@ -21,9 +21,12 @@ CASES = [
     (3, 48, 10, 14, 48, 1, 2),       # non-square, two blocks in one launch
     (2, 48, 16, 16, 96, 2, 1),
     (2, 48, 15, 13, 48, 2, 1),       # odd sizes with stride 2
-    (2, 96, 12, 12, 96, 1, 3),       # (6, 3) tile
-    (2, 96, 28, 28, 192, 2, 1),
-    (5, 192, 14, 14, 192, 1, 2),     # 2 x 4 tiles
+    (2, 96, 12, 12, 96, 1, 3),       # (6, 6) tile: 96 ci x 96 co x 10 taps, eight waves (round 5)
+    (2, 96, 28, 28, 192, 2, 1),      # (6, 6), stride 2
+    (5, 192, 14, 14, 192, 1, 2),     # (6, 6), 2 x 2 tiles
+    (3, 192, 9, 11, 96, 1, 1),       # (6, 6), odd map, 2 x 1 tiles
+    (2, 96, 12, 12, 144, 1, 2),      # (6, 3) tile of rounds 2-4: 96 | Cin, 48 | Cout only
+    (2, 192, 14, 14, 48, 1, 1),      # (6, 3), 2 x 1 tiles
     (2, 64, 9, 9, 128, 1, 1),        # (4, 4) tile
     (1, 128, 56, 56, 64, 1, 1),
     (9, 48, 7, 7, 48, 1, 1),         # steps that span several images

@@ -254,13 +254,14 @@ def test_fused_weight_gradient_planner():
         return list(out), int(lib.hc_rep_wgrad_ws_bytes(C.byref(d)))
 
     p192, ws192 = plan(256, 192, 14, 192, 1, 14)
-    assert p192[0:2] == [6, 3] and p192[6] <= 160 * 1024 and p192[2] * 14 <= 128
+    assert p192[0:2] == [6, 6] and p192[6] <= 160 * 1024 and p192[2] * 14 <= 128     # the 96 x 96 tile where both widths allow it
     p1, ws1 = plan(256, 192, 14, 192, 1, 1)
     assert p1[4] > p192[4]                                   # one block alone needs a deeper pixel split than 14 grouped ones
     assert ws192 % (4 * 192 * 10 * 192) == 0 and ws1 % (4 * 192 * 10 * 192) == 0
     p48, ws48 = plan(256, 48, 112, 48, 1, 1)
     assert p48[0:2] == [3, 3] and p48[6] <= 160 * 1024 and ws48 % (4 * 48 * 10 * 48) == 0
-    assert plan(256, 96, 28, 192, 2, 1)[0][0:2] == [6, 3] and plan(256, 64, 16, 64, 1, 2)[0][0:2] == [4, 4]
+    assert plan(256, 96, 28, 192, 2, 1)[0][0:2] == [6, 6] and plan(256, 64, 16, 64, 1, 2)[0][0:2] == [4, 4]
+    assert plan(256, 96, 28, 144, 1, 1)[0][0:2] == [6, 3]    # 96 | Cin, 48 | Cout only: the 96 x 48 tile of rounds 2-4
     assert plan(256, 1280, 7, 1280, 1, 1) is None and plan(256, 40, 14, 48, 1, 1) is None and plan(4, 48, 14, 48, 3, 1) is None
     assert _WREP._desc((4, 48, 14, 14, 48, 1), 17).njobs == 17 and plan(4, 48, 14, 48, 1, 17) is None     # more than 16 blocks per launch
 
