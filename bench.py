@@ -45,6 +45,16 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary BASELINE configs (C3 rexnet1_0x, C4 yolov4 train / eval, C5 repvgg_a2 fp8) that rank 0 "
+                         "runs after the headline's timed region at N = 1 and reports under `secondary`")
+    ap.add_argument("--secondary-steps", type=int, default=10)
+    ap.add_argument("--deterministic", action="store_true",
+                    help="bit-reproducible steps (holocron_amd.set_deterministic: single-writer statistics slots); for A/B checks of the "
+                         "step's code paths, not for the headline number")
+    ap.add_argument("--loss-tail", type=int, default=0,
+                    help="after the timed region run this many more steps and report each one's loss (config.loss_tail): the loss "
+                         "trajectory of two runs with the same flags must agree bit for bit under --deterministic")
     ap.add_argument("--comm-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="dtype of the gradient all-reduce at N > 1 (fp32 = the reference's gradient precision; bf16 halves the "
                          "bytes on xGMI but moves an AdaBelief update by ~2e-2, tests/test_parallel_gloo.py)")
@@ -87,6 +97,45 @@ def cpu_baseline(batch, iters):
                       f"1 warm-up + {iters} timed iterations on the best of the tried thread counts"}
 
 
+SECONDARY = [   # (key, BASELINE.json config, script under scripts/, extra arguments)
+    ("rexnet1_0x_train_bs256", "configs[2]", "bench_rexnet.py", []),
+    ("yolov4_train_bs16_608", "configs[3]", "bench_yolov4.py", []),
+    ("yolov4_eval_bs16_608", "configs[3] (eval: forward + decode + NMS)", "bench_yolov4.py", ["--eval"]),
+    ("repvgg_a2_fp8_infer_bs1024", "configs[4]", "bench_repvgg_fp8.py", []),
+]
+
+
+def run_secondary(steps, timeout_s=420):
+    """The other single-GPU BASELINE configs, each by its own driver under scripts/ (same timing contract as this file: W untimed
+    steps, K timed steps between synchronisations, one JSON line) in a fresh process AFTER the headline's timed region, so that the
+    driver's record carries them.  CPU baselines are skipped here (they are in the per-config lines committed
+    under profiles/); a failed or slow config is reported as such, never silently dropped."""
+    import subprocess
+    out = {}
+    for key, cfg, script, extra in SECONDARY:
+        cmd = [sys.executable, os.path.join(ROOT, "scripts", script), "--steps", str(steps), "--warmup", "3", "--no-cpu-baseline"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+            line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+            if r.returncode != 0 or line is None:
+                out[key] = {"baseline_config": cfg, "error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+                continue
+            j = json.loads(line)
+            roof = j.get("roofline") or {}
+            out[key] = {"baseline_config": cfg, "metric": j.get("metric"), "value": j.get("value"), "unit": j.get("unit"),
+                        "ms_per_step": j.get("ms_per_step"), "steps": j.get("steps"), "dtype": j.get("dtype"),
+                        "mode": (j.get("config") or {}).get("mode"),
+                        "roofline": {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic")},
+                        "mfma_fraction_whole_step": j.get("mfma_fraction_whole_step", j.get("mfma_fraction")),
+                        "wall_s": round(time.perf_counter() - t0, 1)}
+        except subprocess.TimeoutExpired:
+            out[key] = {"baseline_config": cfg, "error": f"timeout after {timeout_s} s"}
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"baseline_config": cfg, "error": f"{type(e).__name__}: {str(e)[:200]}"}
+    return out
+
+
 def main():
     args = parse()
     # `bench.py --gpus N` IS the N-rank job: with no launcher around it this process starts the N ranks itself (one per GPU) and
@@ -122,6 +171,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1)
 
+    if args.deterministic:
+        h.set_deterministic(True)
     torch.manual_seed(0)
     model = getattr(h.models, args.arch)(num_classes=10).to(dev).train()
     headline = args.arch == "repvgg_a0"
@@ -256,6 +307,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     final_loss = float(loss_buf.item())
+    loss_tail = []
+    for _ in range(args.loss_tail):          # untimed: every rank runs them (they hold collectives at N > 1)
+        run_step()
+        loss_tail.append(float(loss_buf.item()))
 
     # ---- roofline: instrumented eager step, HIP events on the launch stream -----------------------
     roof = None
@@ -355,13 +410,18 @@ def main():
                                f"{args.arch} bf16 train step (fwd+bwd+AdaBelief), synthetic 224^2, bs={args.batch} per MI355X (side measurement, "
                                "not a BASELINE config), random-init weights, 10 classes, CE label_smoothing 0.1",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "mode": graph_note,
-                   "final_loss": final_loss},
+                   "final_loss": final_loss, **({"loss_tail": loss_tail, "deterministic": bool(args.deterministic)} if loss_tail else {})},
         "mfma_fraction_whole_step": (TRAIN_GFLOP_PER_IMG * 1e9 * imgs / dt / MFMA_BF16_PEAK / world) if headline else None,
         "conv_mfma_fraction": conv_frac,
         "roofline": roof,
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_iters)
+    if world == 1 and headline and not args.no_secondary and not force_dist:
+        # release this process's device memory first: the secondary drivers are separate processes on the same GPU
+        del gstep, model, opt, x
+        torch.cuda.empty_cache()
+        out["secondary"] = run_secondary(args.secondary_steps)
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.barrier()

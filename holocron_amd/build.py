@@ -19,7 +19,6 @@ SOURCES = {
     "conv_gather.hip": [],
     "conv_pointwise.hip": [],
     "conv_small.hip": [],
-    "conv_resident.hip": [],
     "conv_wgrad.hip": [],
     "conv_wgrad_tr.hip": [],
     "conv_wgrad_dma.hip": [],

@@ -641,7 +641,7 @@ int launch_bk(const hc_conv_desc& d, hipStream_t st) {
     if (C <= 96) return launch_cfg<3, 1, 1, 4, BK>(d, st);
     // ... unless the launch would leave most of the chip idle: a layer with few pixels (YOLOv4's 19 x 19 and 38 x 38 maps at batch 16:
     // 46 / 181 pixel tiles) has fewer 128-channel tiles than the 512 workgroup slots of the chip - 64-channel tiles double the
-    // workgroups (HC_CONV_FILL=n: below n tiles, default 400; 0 = off).  YOLOv4 608^2 batch 16, same box: 29.19 ms per step without
+    // workgroups (below `fill` = 400 tiles).  YOLOv4 608^2 batch 16, same box: 29.19 ms per step without
     // the rule, 29.08 / 28.68 / 28.75 with n = 256 / 400 / 600
     constexpr int fill = 400;
     if (fill > 0 && C % 64 == 0) {
@@ -722,7 +722,7 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
     // wide layers - a ragged last channel tile is allowed while at most 15 % of the tile rows are padding - and on 128 x 512 tiles for
     // 97-128 output channels.  One workgroup per CU: it pays when the tiles fill the 256 CUs in whole rounds or in many rounds, so the
     // predicate is the EFFICIENCY of the launch, (useful channels / tile channels) x (useful pixels / tile pixels) x (tiles / CU
-    // slots of the rounds they take), against HC_CONV_BIG_EFF (default 0.70).  Measured per shape against the 128 x 128 form
+    // slots of the rounds they take), against `big_eff` = 0.70.  Measured per shape against the 128 x 128 form
     // (scripts/bench_bigtile.py, forward + statistics, us):
     //     128 @ 76 x 76 batch 16 (eff 0.71)   54.0 -> 51.8      256 -> 512 @ 38 x 38 batch 16 (0.71)   83.4 -> 76.8
     //     128 @ 28 x 28 batch 256 (0.77)     104.3 -> 98.6      256 @ 14 x 14 batch 256 (0.77)         88.6 -> 73.6
@@ -747,7 +747,7 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
             return launch_cfg<4, 2, 2, 4, 32, false, 4, 1>(d, st);
         }
     }
-    // HC_CONV_BK=32 | 16 caps the k-step (A/B: a 192-channel tile with 64-channel k-steps stages 2 x 40 KB - two workgroups need the
+    // `bk_cap` caps the k-step (a 192-channel tile with 64-channel k-steps stages 2 x 40 KB - two workgroups need the
     // whole 160 KB of LDS)
     constexpr int bk_cap = 64;                      // k-step cap (32 measured 3 % slower on the ReXNet 1 x 1 layers, round 4)
     if (d.srcC % 64 == 0 && bk_cap >= 64) return launch_bk<64>(d, st);

@@ -1288,7 +1288,10 @@ extern "C" int hc_stem_fused_supported(const hc_stem_desc* dp) {
     static const bool on = cs2::env_int("HC_CONV_S2", 1) != 0 && cs2::env_int("HC_STEM_FUSED", 1) != 0;
     if (!on || dp == nullptr) return 0;
     if (dp->N < 1 || dp->W != 224 || dp->H < 16 || dp->H % 16 != 0) return 0;
-    return (double)dp->N * dp->H * dp->W * 12.0 < 4294967000.0;
+    // 32-bit buffer descriptors / byte offsets: the fp32 image (12 B per pixel) AND, for the apply / backward passes, the bf16 output and
+    // gradient of 48 channels per output pixel (2 x the image's bytes: the tighter bound - ADVICE r5)
+    return (double)dp->N * dp->H * dp->W * 12.0 < 4294967000.0 &&
+           (double)dp->N * (dp->H / 2) * (dp->W / 2) * 48.0 * 2.0 < 4294967000.0;
 }
 
 extern "C" int hc_stem_stats(const hc_stem_desc* dp, float* stats3, float* stats1, hc_stream_t stream) {

@@ -778,30 +778,21 @@ void launch_pipe_mode(const Args& a, int grid, int smem, hipStream_t st) {
 
 }  // namespace csm
 
-// image-resident variant for 64 .. 256 channels on small maps (conv_resident.hip); HC_CONV_RESIDENT=0 routes those shapes back to
-// the gather-conv
-bool hc_conv_resident_supported(const hc_conv_small_desc& d);
-int hc_conv_resident_launch(const hc_conv_small_desc& d, hipStream_t st);
+// (the image-resident 8-wave kernel for 64 .. 256 channels of round 2, conv_resident.hip, is retired: the row-unit kernel below
+// replaced it on every shape it served - git show 1f81691:holocron_amd/csrc/conv_resident.hip)
 // row-unit kernel for 192 @ 14x14 and 96 @ 28x28 (conv_rows.hip); HC_CONV_ROWS=0 disables it
 bool hc_conv_rows_supported(const hc_conv_small_desc& d);
 int hc_conv_rows_launch(const hc_conv_small_desc& d, hipStream_t st);
 // streaming row-unit kernel for 48 channels @ 112 / 56 (conv_rows48.hip); HC_CONV_ROWS48=0 disables it
 bool hc_conv_rows48_supported(const hc_conv_small_desc& d);
 int hc_conv_rows48_launch(const hc_conv_small_desc& d, hipStream_t st);
-static bool resident_enabled() {
-    return true;
-}
-
 extern "C" int hc_conv_small(const hc_conv_small_desc* dp, hc_stream_t stream) {
     if (dp == nullptr) return HC_ERR_ARG;
     const hc_conv_small_desc& d = *dp;
     if (d.mode & HC_CONV_SMALL_ROWS_IMAGE)
         return d.C >= 64 ? hc_conv_rows_launch(d, reinterpret_cast<hipStream_t>(stream))
                          : hc_conv_rows48_launch(d, reinterpret_cast<hipStream_t>(stream));
-    if (d.C >= 64) {
-        if (!resident_enabled() || !hc_conv_resident_supported(d)) return HC_ERR_ARG;
-        return hc_conv_resident_launch(d, reinterpret_cast<hipStream_t>(stream));
-    }
+    if (d.C >= 64) return HC_ERR_ARG;          // 64+ channels: the row-unit image (HC_CONV_SMALL_ROWS_IMAGE) or the gather-conv
     if (d.srcA == nullptr || d.w3 == nullptr || d.w1 == nullptr || d.out3 == nullptr) return HC_ERR_ARG;
     if ((d.mode & 1) == 1 && d.srcB == nullptr) return HC_ERR_ARG;
     if ((d.mode & 1) == 0 && d.out1 == nullptr) return HC_ERR_ARG;
@@ -844,7 +835,7 @@ extern "C" int hc_conv_small_trace(unsigned long long* out) {
 extern "C" int hc_conv_small_supported(const hc_conv_small_desc* dp) {
     if (dp == nullptr) return 0;
     if (dp->mode & HC_CONV_SMALL_ROWS_IMAGE) return (hc_conv_rows_supported(*dp) || hc_conv_rows48_supported(*dp)) ? 1 : 0;
-    if (dp->C >= 64) return (resident_enabled() && hc_conv_resident_supported(*dp)) ? 1 : 0;
+    if (dp->C >= 64) return 0;
     csm::Args a;
     int smem = 0;
     return csm::make_args(*dp, a, smem) ? 1 : 0;

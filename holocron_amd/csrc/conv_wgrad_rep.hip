@@ -592,8 +592,7 @@ inline Plan make_plan(const hc_rep_wgrad_desc& d) {
     pl.grid = ((d.njobs * a.nsplit + 7) / 8) * 8 * NT;
     pl.MR = MR;
     pl.NR = NR;
-    constexpr int hv_env = 0;
-    pl.HV = (MR % 2 == 0 && hv_env != 1) ? 2 : 1;
+    pl.HV = (MR % 2 == 0) ? 2 : 1;
     // the 48 x 48 tile: when the LDS footprint leaves room for one workgroup per CU only, run it with eight waves (pixel split)
     constexpr int pv_env = 0;
     pl.PV = (pl.HV == 1 && MR == 3 && (a.P32 >> 5) >= 2 && (pv_env == 2 || (pv_env == 0 && per_cu == 1))) ? 2 : 1;
@@ -647,8 +646,8 @@ extern "C" int hc_rep_wgrad(const hc_rep_wgrad_desc* dp, hc_stream_t stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int rc;
     if (pl.MR == 6 && pl.NR == 6) rc = wrep::launch<6, 6, 2>(pl, st);
-    else if (pl.MR == 6) rc = pl.HV == 2 ? wrep::launch<6, 3, 2>(pl, st) : wrep::launch<6, 3, 1>(pl, st);
-    else if (pl.MR == 4) rc = pl.HV == 2 ? wrep::launch<4, 4, 2>(pl, st) : wrep::launch<4, 4, 1>(pl, st);
+    else if (pl.MR == 6) rc = wrep::launch<6, 3, 2>(pl, st);          // even MR: always the eight-wave (HV = 2) form
+    else if (pl.MR == 4) rc = wrep::launch<4, 4, 2>(pl, st);
     else rc = pl.PV == 2 ? wrep::launch<3, 3, 1, 2>(pl, st) : wrep::launch<3, 3, 1>(pl, st);
     if (rc != HC_OK) return rc;
     const int ns = pl.a.nsplit * pl.PV;

@@ -161,7 +161,7 @@ struct DwTile {
     static constexpr int PIECES_ROW = PITCH_PX / PPP, PIECES = ROWS * PIECES_ROW;
 };
 using DwThin = DwTile<8, 4>;
-// HC_DW_S2=0: the round-3 stride-2 kernels (A/B); the tiled stride-2 kernels take output maps of at least HC_DW_S2_MINW (default 12) columns
+// the tiled stride-2 kernels take output maps of at least 12 columns (the round-3 strip kernels below that)
 static int dw_s2_on() {
     static const int on = [] { const char* t = getenv("HC_DW_TILE"); return (t != nullptr && atoi(t) == 0) ? 0 : 1; }();
     return on;

@@ -23,7 +23,7 @@ from .convbn_op import ConvState, act_code, as_cl_view, cl_ld
 from .repblock_op import POOL
 
 
-# Wide layers travel with their channel count padded to a multiple of 64 instead of 16 (HC_PAD_WIDE_FROM, default 160 channels;
+# Wide layers travel with their channel count padded to a multiple of 64 instead of 16 (from 160 channels on;
 # 0 = always 16).  The gather-conv's k-step is the largest of 64 / 32 / 16 channels that divides the padded count: ReXNet's late
 # widths (228, 300, 366, 432, 840, 906, 972 -> 240, 304, 368, 432, 848, 912, 976) are all = 16 mod 32, so every 1 x 1 convolution
 # over them ran 15-61 sixteen-channel steps, each a DMA round trip for a quarter of the MFMA work of a 64-channel step.  Padding those
@@ -37,7 +37,7 @@ _PAD_WIDE_TO = 64
 
 def ceil16(c):
     """Channels per pixel an activation of ``c`` logical channels travels with: a multiple of 16 (the smallest k-step of the MFMA
-    gather-conv; the name is from when that was the only rule), of 64 from HC_PAD_WIDE_FROM channels on."""
+    gather-conv; the name is from when that was the only rule), of 64 from 160 channels on."""
     if _PAD_WIDE_FROM and c >= _PAD_WIDE_FROM:
         return (c + _PAD_WIDE_TO - 1) // _PAD_WIDE_TO * _PAD_WIDE_TO
     return (c + 15) // 16 * 16
@@ -395,7 +395,7 @@ class SeGateFn(torch.autograd.Function):
         return dz, None, None
 
 
-# HC_SE_FUSED=0: the squeeze-excite MLP through the generic conv units inside SeGateFn (A/B; round-3 path)
+# (round 3 ran the squeeze-excite MLP through the generic conv units inside SeGateFn; its A/B switch is retired)
 _SE_FUSED = True
 
 

@@ -6,6 +6,7 @@ surface (reference ``state_dict`` layout, SURVEY.md §5 checkpoint row) and are 
 kernel layout lazily (cached on parameter version + optimizer epoch).
 """
 import ctypes as C
+import functools
 import os
 
 import torch
@@ -121,6 +122,12 @@ def dgrad_desc(N, Cin, H, W, Cout, branches, stride):
 
 
 PROFILE = None  # bench.py sets this to a list: (family, algorithmic flops, start event, end event, algorithmic bytes)
+PROFILE_TAGS = None  # scripts/layer_table.py: a list that receives one shape tag per PROFILE entry, in the same order
+
+
+def _tag(text):
+    if PROFILE_TAGS is not None:
+        PROFILE_TAGS.append(text)
 
 
 class profiled:
@@ -145,6 +152,7 @@ class profiled:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             PROFILE.append((self.family, self.flops, self.e0, e1, self.nbytes))
+            _tag("%s %.1fMB" % (self.family, self.nbytes / 1e6))
         return False
 
 
@@ -169,6 +177,9 @@ def launch_conv(d, src0, wpk, dst, src1=None, resid=None, stats=None, bias=None,
         e1.record()
         nbytes = sum(t.numel() * t.element_size() for t in (src0, src1, wpk, dst, resid, dst2) if t is not None)
         PROFILE.append(("conv_gather", _desc_flops(d) if flops is None else flops, e0, e1, nbytes))
+        _tag("%s N%d %d@%dx%d -> %d@%dx%d taps%d%s%s" % ("fwd" if d.nclass == 1 and d.cls[0].istep >= 1 and stats is not None else "conv", d.N, d.srcC,
+                                                      d.IH, d.IW, d.Cout, d.OH, d.OW, d.cls[0].ntaps, " cls%d" % d.nclass if d.nclass > 1 else "",
+                                                      " +resid" if resid is not None else ""))
         return
     check(_lib.load().hc_conv_gather(C.byref(d), stream()), "hc_conv_gather")
 
@@ -350,6 +361,7 @@ def conv_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, out=None, accumulate=False
         e1.record()
         nbytes = sum(t.numel() * t.element_size() for t in (x, dy, out))
         PROFILE.append(("conv_wgrad", 2.0 * N * OH * OW * Cout * KH * KW * Cin if flops is None else flops, e0, e1, nbytes))
+        _tag("wgrad N%d %d@%dx%d -> %d@%dx%d k%d s%d" % (N, Cin, H, W, Cout, OH, OW, KH, stride))
         return out
     if not WGRAD_KNOCKOUT:
         check(lib.hc_conv_wgrad(C.byref(d), stream()), "hc_conv_wgrad")
@@ -359,6 +371,11 @@ def conv_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad, out=None, accumulate=False
 # HC_WGRAD_KNOCKOUT=1: timing experiment - the conv weight-gradient launches (hc_conv_wgrad, hc_rep_wgrad) are skipped, so a step's time
 # is its main-stream critical path (gradients are wrong; VERDICT r4 item 3c: what the weight gradients cost that is NOT hidden)
 WGRAD_KNOCKOUT = os.environ.get("HC_WGRAD_KNOCKOUT", "0") == "1"
+if WGRAD_KNOCKOUT:
+    import warnings
+    warnings.warn("HC_WGRAD_KNOCKOUT=1: every conv weight-gradient launch is SKIPPED - weight gradients stay zero and training is wrong. "
+                  "This is a timing experiment (scripts/prof_round*.sh), never a training mode.", RuntimeWarning, stacklevel=1)
+    print("holocron_amd: HC_WGRAD_KNOCKOUT=1 - conv weight gradients are NOT computed (timing experiment)", file=__import__("sys").stderr)
 
 
 # ------------------------------------------------------------------ RepBlock weight gradients: fused, grouped, deferred
@@ -385,6 +402,8 @@ class _RepWgradQueue:
         self.jobs = []
         self.armed = False
         self.task = -1              # autograd graph task the queued jobs (and the pending flush callback) belong to
+        self.parked = {}            # task id -> jobs of a pass that another pass interrupted (re-entrant backward) or outlived (dead pass)
+        self.cb_tasks = set()       # graph tasks whose final callback is queued
         self.support = {}
         self.enabled = os.environ.get("HC_WREP_DEFER", "1") != "0"
         # HC_WREP_SIDE=1: a group is launched on a second HIP stream as soon as the backward pass moves on to another block shape, so
@@ -453,6 +472,7 @@ class _RepWgradQueue:
                 flops = 2.0 * N * d.OH * d.OW * Cout * 10 * Cin * len(grp)
                 nb = len(grp) * (2 * N * H * W * Cin + 4 * N * d.OH * d.OW * Cout + 40 * Cout * Cin)
                 PROFILE.append(("conv_wgrad", flops, e0, e1, nb))
+                _tag("wrep x%d N%d %d@%dx%d -> %d s%d" % (len(grp), N, Cin, H, W, Cout, stride))
             elif not WGRAD_KNOCKOUT:
                 check(lib.hc_rep_wgrad(C.byref(d), stream()), "hc_rep_wgrad")
 
@@ -461,13 +481,14 @@ class _RepWgradQueue:
         Cout, Cin = key[4], key[1]
         task = torch._C._current_graph_task_id()
         if self.armed and task != self.task:
-            # Another graph task submits while the queue is armed: a RE-ENTRANT backward nested inside a pass that is still running
-            # (torch.utils.checkpoint(use_reentrant=True), a backward() inside a custom Function: the task ids run [0, 1, 0]).  Dropping
-            # the jobs would leave the zero-filled placeholders of the outer pass in .grad, so they are LAUNCHED: their
-            # tuples keep every operand alive.  The queue is then disarmed, this pass arms it for its own task, and the outer pass
-            # re-arms it on its next submit.  (A pass that DIED before its final callback - backward raised - is caught earlier, by
-            # note_forward() in the next forward, and its jobs are dropped there.)
-            self._flush_stale()
+            # Another graph task submits while the queue is armed.  Either a RE-ENTRANT backward nested inside a pass that is still
+            # running (torch.utils.checkpoint(use_reentrant=True), a backward() inside a custom Function: the task ids run [0, 1, 0]),
+            # or the armed pass DIED before its final callback (backward raised) and this is a retry on the retained graph with no
+            # forward in between.  The two cannot be told apart here, so the armed pass's jobs are PARKED under its task id - neither
+            # launched (a dead pass would be counted twice under gradient accumulation: ADVICE r4 / r5) nor dropped (a live outer
+            # pass would leave zero placeholders in .grad: ADVICE r3).  A live pass takes them back on its next submit or launches them
+            # from its final callback; a dead pass never comes back and its parked jobs go with the next forward (note_forward).
+            self._park()
         dw3 = self._zeros((Cout, Cin, 3, 3), x.device, key)
         dw1 = self._zeros((Cout, Cin, 1, 1), x.device, key)
         # The queue must not hold the gradient TENSORS: AccumulateGrad only adopts a gradient it holds the sole reference to
@@ -481,8 +502,32 @@ class _RepWgradQueue:
                           dw1.untyped_storage(), dw1.data_ptr(), dw1.storage_offset(), w3, w1))
         if not self.armed:
             self.armed, self.task = True, task
-            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+            back = self.parked.pop(task, None)
+            if back:                                 # the outer pass of a re-entrant backward goes on: its parked jobs rejoin the queue
+                self.jobs = back + self.jobs
+            if task not in self.cb_tasks:            # one final callback per graph task
+                self.cb_tasks.add(task)
+                torch.autograd.Variable._execution_engine.queue_callback(functools.partial(self._final, task))
         return dw3, dw1
+
+    def _park(self):
+        self.join()
+        if self.jobs:
+            self.parked.setdefault(self.task, []).extend(self.jobs)
+        self.jobs = []
+        self.armed, self.task = False, -1
+        self.arena, self.arena_used, self.arena_want, self.arena_first = None, 0, 0, None   # (a partial pass records no arena size)
+
+    def _final(self, task):
+        """Final callback of graph task ``task`` (runs only when that pass completed)."""
+        self.cb_tasks.discard(task)
+        if self.armed and self.task == task:
+            self.flush()
+            return
+        jobs = self.parked.pop(task, None)           # the pass queued jobs, was interrupted by a nested pass and submitted nothing after it
+        if jobs:
+            self._launch_groups(jobs)
+            self._fix_clones([jobs])
 
     def note_forward(self):
         """Called from RepBlockFn.forward.  A forward that runs while the queue is armed and NO backward pass is executing
@@ -490,18 +535,14 @@ class _RepWgradQueue:
         queue died before its final callback - backward raised and the caller went on.  Its jobs are DROPPED, not launched: the
         placeholders autograd adopted stay zero, so a retry of the micro-batch without zero_grad accumulates the right gradient into
         them (launching the stale jobs later, from inside the retry, would count the failed micro-batch twice: ADVICE r4)."""
-        if self.armed and torch._C._current_graph_task_id() == -1:
+        if (self.armed or self.parked) and torch._C._current_graph_task_id() == -1:
             self.jobs = []
+            self.parked, self.cb_tasks = {}, set()
             if self.inflight:
                 torch.cuda.current_stream().wait_stream(self.side)
                 self.inflight, self.side_params = [], set()
             self.armed, self.task = False, -1
             self.arena, self.arena_used, self.arena_want, self.arena_first = None, 0, 0, None
-
-    def _flush_stale(self):
-        sizes = dict(self.arena_sizes)
-        self.flush()
-        self.arena_sizes = sizes                # a partial pass must not shrink the arena the next full pass gets
 
     def _launch_on_side(self):
         jobs, self.jobs = self.jobs, []
@@ -712,5 +753,6 @@ def _launch_small(d, flops, nbytes=0):
         check(_lib.load().hc_conv_small(C.byref(d), stream()), "hc_conv_small")
         e1.record()
         PROFILE.append(("conv_rows" if (d.mode & ROWS_IMAGE) else "conv_small", flops, e0, e1, nbytes))
+        _tag("%s N%d %d@%dx%d -> %d mode%d" % ("conv_rows" if (d.mode & ROWS_IMAGE) else "conv_small", d.N, d.C, d.H, d.W, d.Cout, d.mode))
         return
     check(_lib.load().hc_conv_small(C.byref(d), stream()), "hc_conv_small")

@@ -107,19 +107,53 @@ class Trainer:
         torch.save(state, output_file)
 
     def load(self, state: Dict[str, Any]) -> None:
-        """core.py:123-133 (+ the optimizer state when the checkpoint has one)"""
-        self.start_epoch = self.epoch = state["epoch"]
-        self.step, self.min_loss = state["step"], state["min_loss"]
+        """core.py:123-133 (+ the optimizer state when the checkpoint has one).
+
+        Under data parallelism ``load`` is a COLLECTIVE, like the constructor: EVERY rank must call it (``save`` is the opposite - it
+        writes on rank 0 only - so do not mirror its ``if rank == 0`` around ``load``: the other ranks would wait in the broadcast
+        forever).  Whatever file each rank read, all ranks continue from RANK 0's checkpoint: parameters, buffers, epoch / step /
+        min_loss and the optimizer state (moments and step counters) are broadcast from rank 0, and a rank whose checkpoint has an
+        optimizer state where rank 0's has none (or the reverse) raises instead of training on with diverging moments."""
+        dp = self._world() > 1
+        meta = [state["epoch"], state["step"], state["min_loss"], "optimizer" in state]
+        if dp:
+            import torch.distributed as dist
+            mine = meta[3]
+            dist.broadcast_object_list(meta, src=0)
+            if mine != meta[3]:
+                raise RuntimeError("Trainer.load: this rank's checkpoint %s an optimizer state and rank 0's %s"
+                                   % ("has" if mine else "lacks", "has one" if meta[3] else "has none"))
+        self.start_epoch = self.epoch = meta[0]
+        self.step, self.min_loss = meta[1], meta[2]
         self.model.load_state_dict(state["model"])
-        if self._world() > 1:
-            # `load` is a collective under data parallelism (like the constructor): whatever each rank read, every rank continues from
-            # rank 0's parameters and buffers - the construction-time broadcast does not cover a checkpoint loaded afterwards (ADVICE r4)
+        if dp:
             from ..parallel import broadcast_parameters
             broadcast_parameters(self.model, 0)
         if "optimizer" in state:
             self.optimizer.load_state_dict(state["optimizer"])
+            if dp:
+                self._broadcast_optimizer_state()
             # fit_n_epochs / find_lr / check_setup rebuild the groups with an empty state first thing: keep the loaded one for them
-            self._pending_opt_state = state["optimizer"]
+            self._pending_opt_state = self.optimizer.state_dict() if dp else state["optimizer"]
+
+    def _broadcast_optimizer_state(self) -> None:
+        """Rank 0's optimizer state on every rank: tensors in (group, parameter, key) order, python scalars as one object list."""
+        import torch.distributed as dist
+        scalars, slots = [], []
+        for group in self.optimizer.param_groups:
+            for p in group["params"]:
+                st = self.optimizer.state.get(p, {})
+                for k in sorted(st):
+                    v = st[k]
+                    if torch.is_tensor(v):
+                        dist.broadcast(v, src=0)
+                    else:
+                        scalars.append(v)
+                        slots.append((st, k))
+        if scalars:
+            dist.broadcast_object_list(scalars, src=0)
+            for (st, k), v in zip(slots, scalars):
+                st[k] = v
 
     # ---------------------------------------------------------------- ranks
     @staticmethod

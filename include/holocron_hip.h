@@ -95,7 +95,7 @@ int hc_conv_pointwise(const hc_conv_desc* d, hc_stream_t stream);
 /* Stride-1 3x3 (+1x1) convolution of a RepBlock (holocron/models/classification/repvgg.py:71-73 and its data gradient) for
  * small channel counts: C <= 48 on large images (persistent software-pipelined workgroups, weights resident in registers, DMA'd
  * row window with halo, XCD-grouped tiles) and 64 <= C <= 256 on maps that fit one image into LDS (image-resident kernel).
- * Environment (experiments / tests): HC_CONV_SMALL_PIPE=0 non-pipelined kernel, HC_CONV_SMALL_GRID=n grid cap, HC_CONV_RESIDENT=0.
+ * Environment (experiments / tests): HC_CONV_SMALL_PIPE=0 non-pipelined kernel, HC_CONV_SMALL_GRID=n grid cap.
  * mode 0: out3 = W3 (*) srcA, out1 = W1 . srcA (+ optional BN statistics, replicated like hc_conv_desc);
  * mode 1: out3 = W3 (*) srcA + W1 . srcB + resid  (RepBlock data gradient; srcA = dy3, srcB = dy1).
  * w3/w1 are packed bf16 rows [out channel][tap][C] with the given row strides (elements).

@@ -215,39 +215,3 @@ def test_conv_small_many_tiles_per_workgroup(grid, pipe, monkeypatch):
         test_conv_small_forward_and_dgrad(*args)
 
 
-def test_resident_image_conv_forward_and_dgrad():
-    """hc_conv_small on 64..256 channels (conv_resident.hip: the image resident in LDS): fused 3x3 + 1x1 forward with BatchNorm
-    statistics, and the two-source data gradient with residual, against fp32 torch on the same bf16 inputs."""
-    import torch.nn.functional as F
-    from holocron_amd.ops import conv as cv
-    from holocron_amd import _lib
-    g = torch.Generator().manual_seed(21)
-    for (N, Cc, H, W) in [(3, 192, 14, 14), (2, 64, 9, 7), (5, 128, 16, 16), (2, 256, 5, 6)]:
-        sf = cv.conv_small_desc(N, H, W, Cc, Cc, 0)
-        sd = cv.conv_small_desc(N, H, W, Cc, Cc, 1)
-        assert sf is not None and sd is not None, (N, Cc, H, W)
-        x = torch.randn((N, Cc, H, W), generator=g).to(torch.bfloat16).float()
-        w3 = (torch.randn((Cc, Cc, 3, 3), generator=g) * (2.0 / (9 * Cc)) ** 0.5).to(torch.bfloat16).float()
-        w1 = (torch.randn((Cc, Cc, 1, 1), generator=g) * (2.0 / Cc) ** 0.5).to(torch.bfloat16).float()
-        y3r, y1r = F.conv2d(x, w3, padding=1), F.conv2d(x, w1)
-        xg = cv.to_cl_bf16(x.cuda())
-        wp3, wp1 = cv.pack_weight(w3.cuda(), 0), cv.pack_weight(w1.cuda(), 0)
-        y3, y1 = cv.empty_cl(N, Cc, H, W, "cuda"), cv.empty_cl(N, Cc, H, W, "cuda")
-        stats = torch.zeros((2, _lib.stat_replicas(), 2, Cc), device="cuda")
-        cv.launch_conv_small_fwd(sf, xg, wp3, wp1, y3, y1, stats[0], stats[1])
-        assert rel_l2(y3.float().cpu(), y3r) < 4e-3 and rel_l2(y1.float().cpu(), y1r) < 4e-3
-        for st, yr in ((stats[0], y3r), (stats[1], y1r)):
-            s = st.sum(0).cpu()
-            assert torch.allclose(s[0], yr.sum((0, 2, 3)), rtol=2e-3, atol=2e-2 * float(yr.abs().mean()) * N * H * W ** 0.5)
-            assert torch.allclose(s[1], (yr * yr).sum((0, 2, 3)), rtol=2e-3)
-        # data gradient: dx = conv3x3^T(dy3) + conv1x1^T(dy1) + resid
-        dy3 = torch.randn((N, Cc, H, W), generator=g).to(torch.bfloat16).float()
-        dy1 = torch.randn((N, Cc, H, W), generator=g).to(torch.bfloat16).float()
-        res = torch.randn((N, Cc, H, W), generator=g).to(torch.bfloat16).float()
-        dxr = F.conv_transpose2d(dy3, w3, padding=1) + F.conv_transpose2d(dy1, w1) + res
-        wpd = torch.zeros((Cc, 10, Cc), dtype=torch.bfloat16, device="cuda")
-        cv.pack_weight(w3.cuda(), 1, out=wpd, tap0=0, T=10)
-        cv.pack_weight(w1.cuda(), 1, out=wpd, tap0=9, T=10)
-        dx = cv.empty_cl(N, Cc, H, W, "cuda")
-        cv.launch_conv_small_dgrad(sd, cv.to_cl_bf16(dy3.cuda()), cv.to_cl_bf16(dy1.cuda()), wpd, dx, resid=cv.to_cl_bf16(res.cuda()))
-        assert rel_l2(dx.float().cpu(), dxr) < 4e-3, (N, Cc, H, W, rel_l2(dx.float().cpu(), dxr))

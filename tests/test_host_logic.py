@@ -170,15 +170,15 @@ def test_mixup_and_metrics_host_contract():
 
 def test_small_channel_conv_planner_accepts_and_rejects():
     """hc_conv_small_supported is pure host code (LDS budget, DMA instruction counts, tile geometry): the RepVGG-A0 shapes the
-    persistent / image-resident kernels are built for are accepted, everything else falls back to the gather-conv (None)."""
+    persistent kernel is built for are accepted, everything else falls back to the row-unit image or the gather-conv (None)."""
     from holocron_amd.ops import conv as cv
     ok = [(256, 112, 112, 48, 48, 0), (256, 112, 112, 48, 48, 1), (256, 56, 56, 48, 48, 0), (256, 56, 56, 48, 48, 1),
-          (4, 30, 30, 32, 48, 0), (2, 17, 17, 16, 64, 0), (1, 3, 128, 48, 40, 0),       # persistent kernel: C <= 48, W <= 128
-          (256, 14, 14, 192, 192, 0), (256, 14, 14, 192, 192, 1), (8, 16, 16, 64, 64, 1)]   # image-resident kernel: 64 .. 256 channels
+          (4, 30, 30, 32, 48, 0), (2, 17, 17, 16, 64, 0), (1, 3, 128, 48, 40, 0)]       # persistent kernel: C <= 48, W <= 128
     no = [(2, 20, 200, 48, 48, 0),      # wider than a 128-pixel tile
           (2, 20, 112, 40, 48, 0),      # C not a multiple of 16
           (2, 20, 112, 48, 72, 0),      # more than 64 output channels in the persistent kernel
-          (2, 28, 28, 96, 96, 0), (2, 40, 40, 96, 96, 0),   # 96 channels: map too large to keep an image in LDS
+          (2, 28, 28, 96, 96, 0), (2, 40, 40, 96, 96, 0),   # 64+ channels without the row-unit image flag: no kernel (round 6:
+          (256, 14, 14, 192, 192, 0), (8, 16, 16, 64, 64, 1),  # the image-resident kernel of round 2 is retired)
           (2, 7, 7, 1280, 1280, 0)]
     for a in ok:
         d = cv.conv_small_desc(*a)
@@ -216,8 +216,8 @@ def test_weight_gradient_workspace_planner():
 def test_row_unit_conv_planner_accepts_and_rejects():
     """hc_conv_small_supported with HC_CONV_SMALL_ROWS_IMAGE (host code): the row-unit kernel takes 192 channels on maps up to 16 pixels
     wide and 96 channels up to 32, any height (round 4: a predicate - the two 224 x 224 stages keep their tuned instantiations, every
-    other width / height runs the family form), forward and data gradient; without the flag the same shapes still resolve to the older
-    kernels (or to the gather-conv)."""
+    other width / height runs the family form), forward and data gradient; without the flag the same shapes resolve to the
+    gather-conv."""
     from holocron_amd.ops import conv as cv
     R = cv.ROWS_IMAGE
     for a in [(256, 14, 14, 192, 192, R), (256, 14, 14, 192, 192, R | 1), (256, 28, 28, 96, 96, R), (3, 28, 28, 96, 96, R | 1),
@@ -232,7 +232,7 @@ def test_row_unit_conv_planner_accepts_and_rejects():
               (4, 112, 112, 48, 48, R | 1),     # its data gradient stays on the persistent kernel unless HC_CONV_ROWS48=2
               (4, 110, 112, 48, 48, R), (4, 28, 28, 48, 48, R), (4, 60, 56, 48, 48, R)]:
         assert cv.conv_small_desc(*a) is None, a
-    assert cv.conv_small_desc(256, 14, 14, 192, 192, 0) is not None        # image-resident kernel, its own weight format
+    assert cv.conv_small_desc(256, 14, 14, 192, 192, 0) is None            # (the image-resident kernel of round 2 is retired)
     assert cv.rows_image(192, "cpu").shape == (60, 192, 32) and cv.rows_image(96, "cpu").shape == (30, 96, 32)
     assert cv.rows_image(48, "cpu").shape == (20, 48, 32) and float(cv.rows_image(48, "cpu").abs().sum()) == 0.0   # zero-filled K padding
 
@@ -343,6 +343,7 @@ class _FakeQueue:
                         a[:] = 1.0
         monkeypatch.setattr(q, "launch", launch)
         q.jobs, q.armed, q.task = [], False, -1
+        q.parked, q.cb_tasks = {}, set()
 
 
 def _rep_like(w3, w1, x, fail=False):
@@ -384,10 +385,58 @@ def test_deferred_wgrad_queue_recovers_from_an_aborted_backward(monkeypatch):
     fq.launches.clear()
     _rep_like(w3, w1, x).backward()                  # the retry must not inherit `armed` (it would train on zero gradients)
     assert not cv._WREP.armed and not cv._WREP.jobs
-    # the stale job is launched into buffers nobody reads (it cannot be told from the outer pass of a re-entrant backward, whose jobs
-    # must not be lost: ADVICE r3), then the retry's own
-    assert len(fq.launches) == 2 and all(n == 1 for _, n, _ in fq.launches)
+    # the stale job is PARKED under the dead pass's task id (it cannot be told from the outer pass of a re-entrant backward, whose jobs
+    # must not be lost: ADVICE r3) and never launched; only the retry's own job runs
+    assert len(fq.launches) == 1 and all(n == 1 for _, n, _ in fq.launches)
     assert torch.equal(w3.grad, torch.ones_like(w3)) and torch.equal(w1.grad, torch.ones_like(w1))
+    assert cv._WREP.parked                           # ... until the next forward outside a backward pass drops it
+    cv._WREP.note_forward()
+    assert not cv._WREP.parked and not cv._WREP.cb_tasks
+
+
+def test_retained_graph_retry_without_a_forward_is_not_counted_twice(monkeypatch):
+    """backward raised, and the caller retries on the RETAINED graph - no forward in between, no zero_grad (gradient
+    accumulation).  The dead pass's job must not be launched from inside the retry: its placeholders were adopted as .grad, the
+    retry accumulates its own gradient onto them, and a launch of the stale job would add the failed micro-batch a second time."""
+    fq = _FakeQueue(monkeypatch)
+    w3 = torch.nn.Parameter(torch.zeros(16, 16, 3, 3))
+    w1 = torch.nn.Parameter(torch.zeros(16, 16, 1, 1))
+    x = torch.ones(2, 16, 4, 4, requires_grad=True)
+    boom = {"on": True}
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w3, w1):
+            ctx.save_for_backward(x, w3, w1)
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w3, w1 = ctx.saved_tensors
+            dw3, dw1 = cv.rep_block_wgrad(x, g, g, w3, w1, 1, defer=True)
+            return g, dw3, dw1
+
+    class MaybeBoom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            if boom["on"]:
+                raise RuntimeError("boom")
+            return g
+    loss = Fn.apply(MaybeBoom.apply(Fn.apply(x, w3, w1)), w3, w1).sum()
+    with pytest.raises(RuntimeError, match="boom"):
+        loss.backward(retain_graph=True)             # the last Fn queued one job, then the pass died
+    assert cv._WREP.armed and len(cv._WREP.jobs) == 1
+    boom["on"] = False
+    fq.launches.clear()
+    loss.backward()                                  # same graph, new graph task, no forward: both Fn nodes queue again
+    assert not cv._WREP.armed and not cv._WREP.jobs
+    assert sum(n for _, n, _ in fq.launches) == 2    # the retry's two jobs; the dead pass's parked job was not launched
+    # w3 is used by two nodes: gradient = 2 (one per node), exactly once each
+    assert torch.equal(w3.grad, 2 * torch.ones_like(w3)) and torch.equal(w1.grad, 2 * torch.ones_like(w1))
 
 
 def test_aborted_backward_is_not_counted_twice_under_gradient_accumulation(monkeypatch):

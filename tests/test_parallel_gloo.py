@@ -473,3 +473,55 @@ def _worker_trainer(rank, world, port):
 
 def test_trainer_world2_keeps_replicas_identical():
     mp.spawn(_worker_trainer, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _worker_trainer_load(rank, world, port):
+    """Trainer.load under data parallelism is a collective: ranks that read DIFFERENT checkpoints all continue from rank 0's - weights,
+    epoch / step / min_loss and the optimizer's moments (only the weights were broadcast, the moments diverged)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import warnings
+    from holocron_amd.trainer import ClassificationTrainer
+    torch.manual_seed(3)
+    model = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(12, 8), torch.nn.ReLU(), torch.nn.Linear(8, 6))
+    g = torch.Generator().manual_seed(rank)
+    train = _ListLoader([(torch.randn(4, 3, 2, 2, generator=g), torch.randint(0, 6, (4,), generator=g)) for _ in range(2)])
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr = ClassificationTrainer(model, train, _ListLoader(train[:1]), torch.nn.CrossEntropyLoss(), opt, gpu=None,
+                                   output_file=os.path.join("/tmp", f"hc_trainer_load_{port}_{rank}.pth"))
+        # a per-rank checkpoint: different weights, different moments, different counters
+        gg = torch.Generator().manual_seed(100 + rank)
+        ck_model = {k: torch.randn(v.shape, generator=gg) for k, v in model.state_dict().items()}
+        ck_opt = {"state": {i: {"step": torch.tensor(float(5 + rank)), "exp_avg": torch.randn(p.shape, generator=gg),
+                                "exp_avg_sq": torch.rand(p.shape, generator=gg)} for i, p in enumerate(model.parameters())},
+                  "param_groups": opt.state_dict()["param_groups"]}
+        tr.load({"epoch": 3 + rank, "step": 40 + rank, "min_loss": 0.5 + rank, "model": ck_model, "optimizer": ck_opt})
+    assert (tr.epoch, tr.step, tr.min_loss) == (3, 40, 0.5)
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()]
+                     + [v.flatten() for st in opt.state.values() for k, v in sorted(st.items()) if torch.is_tensor(v)])
+    ref = flat.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(flat, ref) and len(opt.state) == 4
+    # the state that _reset_opt re-installs in fit_n_epochs is rank 0's too
+    pend = torch.cat([v.flatten() for st in tr._pending_opt_state["state"].values() for k, v in sorted(st.items()) if torch.is_tensor(v)])
+    pref = pend.clone()
+    dist.broadcast(pref, src=0)
+    assert torch.equal(pend, pref)
+    # a rank without an optimizer state where rank 0 has one is an error on that rank, not a silent divergence
+    st = {"epoch": 1, "step": 1, "min_loss": 1.0, "model": ck_model}
+    if rank == 0:
+        st["optimizer"] = ck_opt
+    if rank == 1:
+        with pytest.raises(RuntimeError, match="optimizer state"):
+            tr.load(st)
+    else:
+        meta = [1, 1, 1.0, True]
+        dist.broadcast_object_list(meta, src=0)          # rank 0's side of the aborted collective
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_load_world2_is_a_collective_from_rank0():
+    mp.spawn(_worker_trainer_load, args=(2, _free_port()), nprocs=2, join=True)
