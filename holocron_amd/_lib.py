@@ -46,6 +46,16 @@ class WgradDesc(C.Structure):
                 ("beta", c_int32), ("co_valid", c_int32), ("ci_valid", c_int32)]
 
 
+HC_WGRAD_MAX_JOBS = 16
+
+
+class WgradGroupDesc(C.Structure):
+    _fields_ = [("x", c_void_p * HC_WGRAD_MAX_JOBS), ("dy", c_void_p * HC_WGRAD_MAX_JOBS), ("dw", c_void_p * HC_WGRAD_MAX_JOBS),
+                ("ws", c_void_p),
+                ("njobs", c_int32), ("N", c_int32), ("IH", c_int32), ("IW", c_int32), ("Cin", c_int32), ("OH", c_int32), ("OW", c_int32),
+                ("Cout", c_int32), ("KH", c_int32), ("KW", c_int32), ("stride", c_int32), ("pad", c_int32), ("beta", c_int32)]
+
+
 class DwPackItem(C.Structure):
     _fields_ = [("w", c_void_p), ("out", c_void_p), ("C", c_int32), ("Cpad", c_int32), ("flip", c_int32), ("pad_", c_int32)]
 
@@ -211,6 +221,9 @@ SIGNATURES = {
     "hc_conv_s2_stem_wgrad": (c_int32, [c_void_p] * 6 + [c_int32] * 4 + [c_void_p]),
     "hc_conv_wgrad_ws_bytes": (c_int64, [C.POINTER(WgradDesc)]),
     "hc_conv_wgrad": (c_int32, [C.POINTER(WgradDesc), c_void_p]),
+    "hc_conv_wgrad_group_supported": (c_int32, [C.POINTER(WgradGroupDesc)]),
+    "hc_conv_wgrad_group_ws_bytes": (c_int64, [C.POINTER(WgradGroupDesc)]),
+    "hc_conv_wgrad_group": (c_int32, [C.POINTER(WgradGroupDesc), c_void_p]),
     "hc_rep_wgrad_supported": (c_int32, [C.POINTER(RepWgradDesc)]),
     "hc_rep_wgrad_ws_bytes": (c_int64, [C.POINTER(RepWgradDesc)]),
     "hc_rep_wgrad_plan": (c_int32, [C.POINTER(RepWgradDesc), c_void_p]),

@@ -658,6 +658,16 @@ int launch_bk(const hc_conv_desc& d, hipStream_t st) {
     return launch_cfg<2, 2, 2, 2, BK>(d, st);
 }
 
+// SHORT k-loops (1 x 1 convolutions over at most 256 channels: 2-8 k32 steps): a workgroup's life is its prologue, two to eight
+// steps and the epilogue (statistics, staged stores), none of which overlap inside one workgroup.  Four co-resident workgroups per CU
+// (k32 stages: 24-32 KB of LDS each, at most 128 registers) cover one another's latencies instead of two.
+int launch_short(const hc_conv_desc& d, hipStream_t st) {
+    const int C = d.Cout;
+    if (C <= 64) return launch_cfg<1, 2, 2, 2, 32, false, 2, 4>(d, st);
+    if (C % 128 != 0 && C % 64 == 0) return launch_cfg<1, 2, 2, 2, 32, false, 2, 4>(d, st);
+    return launch_cfg<2, 2, 2, 2, 32, false, 2, 4>(d, st);
+}
+
 // fp8 inference: the descriptor arrives with srcC in channels (= bytes); the kernel sees it in 2-byte units
 int launch_fp8(const hc_conv_desc& din, hipStream_t st) {
     hc_conv_desc d = din;
@@ -747,6 +757,10 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
             return launch_cfg<4, 2, 2, 4, 32, false, 4, 1>(d, st);
         }
     }
+    static const int short_on = [] { const char* e = getenv("HC_CONV_SHORT"); return e == nullptr ? 0 : atoi(e); }();
+    if (short_on && d.nclass == 1 && d.cls[0].ntaps == 1 && d.srcC % 32 == 0 && d.srcC <= short_on && d.co_split == 0 && d.pix_scale == nullptr &&
+        d.Cout % 8 == 0)
+        return launch_short(d, st);
     // `bk_cap` caps the k-step (a 192-channel tile with 64-channel k-steps stages 2 x 40 KB - two workgroups need the
     // whole 160 KB of LDS)
     constexpr int bk_cap = 64;                      // k-step cap (32 measured 3 % slower on the ReXNet 1 x 1 layers, round 4)

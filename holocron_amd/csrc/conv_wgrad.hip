@@ -250,6 +250,38 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     }
 }
 
+// Grouped form: blockIdx.z = job; job j's slabs start at ws + j * nsplit * slab and its gradient is dws.p[j] (= or +=, fixed order)
+struct WgradGroupPtrs { float* p[HC_WGRAD_MAX_JOBS]; };
+__global__ void wgrad_reduce_group_kernel(const float* __restrict__ ws, const WgradGroupPtrs dws, int nsplit, int Cout, int T, int Cin,
+                                          int beta) {
+    extern __shared__ float sm[];  // [T][64]
+    const int co = blockIdx.x, ci0 = blockIdx.y * 64, job = blockIdx.z;
+    const int t = threadIdx.x / 64, c = threadIdx.x % 64;
+    const long slab = (long)Cout * T * Cin;
+    float s = 0.f;
+    if (ci0 + c < Cin) {
+        const float* p = ws + (long)job * nsplit * slab + ((long)co * T + t) * Cin + ci0 + c;
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)(k + u) * slab];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nsplit; ++k) s += p[(long)k * slab];
+    }
+    sm[t * 64 + c] = s;
+    __syncthreads();
+    const int j = threadIdx.x;
+    const int cl = j / T, tt = j - cl * T;
+    if (ci0 + cl < Cin) {
+        float* o = dws.p[job] + ((long)co * Cin + ci0 + cl) * T + tt;
+        const float v = sm[tt * 64 + cl];
+        *o = beta ? *o + v : v;
+    }
+}
+
 // the split range goes over several workgroups when the (co, ci tile) grid alone cannot fill the chip
 static inline int launch_wgrad_reduce(const hc_wgrad_desc& d, int nsplit, hipStream_t st) {
     const int T = d.KH * d.KW;
@@ -332,6 +364,53 @@ int generic_dispatch(const hc_wgrad_desc& d, hipStream_t st, bool plan_only, int
 }
 
 }  // namespace
+
+// ---- grouped launch of same-shaped layers (conv_wgrad_dma.hip) --------------------------------------------------------------
+int wgrad_dma_group_nsplit(const hc_wgrad_desc& d, int njobs);
+int wgrad_dma_group_launch(const hc_wgrad_desc& d, const void* const* xs, const void* const* dys, int njobs, hipStream_t st, int* nsplit_out);
+
+static bool group_template(const hc_wgrad_group_desc* g, hc_wgrad_desc& d) {
+    if (g == nullptr || g->njobs < 1 || g->njobs > HC_WGRAD_MAX_JOBS) return false;
+    d = hc_wgrad_desc{};
+    d.x = g->x[0]; d.dy = g->dy[0]; d.dw = g->dw[0]; d.ws = g->ws;
+    d.N = g->N; d.IH = g->IH; d.IW = g->IW; d.Cin = g->Cin; d.OH = g->OH; d.OW = g->OW; d.Cout = g->Cout;
+    d.KH = g->KH; d.KW = g->KW; d.stride = g->stride; d.pad = g->pad; d.beta = g->beta;
+    if ((d.Cin % 8) != 0 || (d.Cout % 8) != 0 || d.stride < 1 || d.KH * d.KW > 16) return false;
+    if ((double)d.N * d.IH * d.IW * d.Cin * 2.0 >= 4294967280.0 || (double)d.N * d.OH * d.OW * d.Cout * 2.0 >= 4294967280.0) return false;
+    return true;
+}
+
+extern "C" int hc_conv_wgrad_group_supported(const hc_wgrad_group_desc* g) {
+    hc_wgrad_desc d;
+    if (!group_template(g, d)) return 0;
+    return wgrad_dma_group_nsplit(d, g->njobs) > 0 ? 1 : 0;
+}
+
+extern "C" int64_t hc_conv_wgrad_group_ws_bytes(const hc_wgrad_group_desc* g) {
+    hc_wgrad_desc d;
+    if (!group_template(g, d)) return -1;
+    const int ns = wgrad_dma_group_nsplit(d, g->njobs);
+    if (ns <= 0) return -1;
+    return (int64_t)g->njobs * ns * d.Cout * d.KH * d.KW * d.Cin * 4;
+}
+
+extern "C" int hc_conv_wgrad_group(const hc_wgrad_group_desc* g, hc_stream_t stream) {
+    hc_wgrad_desc d;
+    if (!group_template(g, d) || g->ws == nullptr) return HC_ERR_ARG;
+    for (int j = 0; j < g->njobs; ++j)
+        if (g->x[j] == nullptr || g->dy[j] == nullptr || g->dw[j] == nullptr) return HC_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int ns = 0;
+    const int rc = wgrad_dma_group_launch(d, g->x, g->dy, g->njobs, st, &ns);
+    if (rc < 0) return HC_ERR_ARG;            // shape outside the DMA kernel's plan: the caller launches the layers one by one
+    if (rc != HC_OK) return rc;
+    const int T = d.KH * d.KW;
+    WgradGroupPtrs pp;
+    for (int j = 0; j < HC_WGRAD_MAX_JOBS; ++j) pp.p[j] = j < g->njobs ? g->dw[j] : nullptr;
+    hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(d.Cout, (d.Cin + 63) / 64, g->njobs), dim3(64 * T), 64 * T * sizeof(float), st,
+                       reinterpret_cast<const float*>(g->ws), pp, ns, d.Cout, T, d.Cin, d.beta);
+    return hc_launch_status();
+}
 
 extern "C" int64_t hc_conv_wgrad_ws_bytes(const hc_wgrad_desc* d) {
     if (d == nullptr) return -1;

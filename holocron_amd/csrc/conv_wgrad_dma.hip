@@ -32,6 +32,9 @@ namespace wdm {
 
 struct Args {
     hc_wgrad_desc d;
+    const void* xs[HC_WGRAD_MAX_JOBS];    // per-job operands of a grouped launch (same-shaped layers): job = blockIdx.y / nsplit
+    const void* dys[HC_WGRAD_MAX_JOBS];
+    int njobs, nsplit;
     int M;                       // output pixels
     int total_steps, steps_per_split;
     int n_co_tiles, n_ci_tiles, n_tg;
@@ -84,7 +87,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const Args a) {
     const int cot = b % a.n_co_tiles;
     const int cit = b / a.n_co_tiles;
     const int co0 = cot * 64 * WM, ci0 = cit * 64 * WN;
-    const int split = blockIdx.y;
+    const int jb = (int)blockIdx.y / a.nsplit;            // wave-uniform: which of the group's layers
+    const int split = (int)blockIdx.y - jb * a.nsplit;
     const int T = d.KH * d.KW;
     const int kh = (TG == 1) ? 0 : tg;               // 3x3: one kernel row per group; 1x1: the only tap
     const int tap0 = tg * TG;
@@ -94,8 +98,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const Args a) {
     if (s_end > a.total_steps) s_end = a.total_steps;
     const int nsteps = s_end - s_begin;
 
-    const u32x4 rsx = raw_rsrc(d.x, (unsigned)d.N * d.IH * d.IW * d.Cin * 2u);
-    const u32x4 rsy = raw_rsrc(d.dy, (unsigned)d.N * d.OH * d.OW * d.Cout * 2u);
+    const u32x4 rsx = raw_rsrc(a.xs[jb], (unsigned)d.N * d.IH * d.IW * d.Cin * 2u);
+    const u32x4 rsy = raw_rsrc(a.dys[jb], (unsigned)d.N * d.OH * d.OW * d.Cout * 2u);
 
     // ---- pixel table of one k-step: lanes 0..31 of wave 0 walk the pixels 32 at a time (no divisions in the loop) ----
     int tn = 0, toh = 0, tow = 0, tstep = 0;         // (n, oh, ow) of this lane's pixel at table step `tstep`
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_dma_kernel(const Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (co < d.Cout) ws[(((long)split * d.Cout + co) * T + tap0 + t) * d.Cin + ci] = acc[t][mb][nb][r];
+                    if (co < d.Cout) ws[(((long)(jb * a.nsplit + split) * d.Cout + co) * T + tap0 + t) * d.Cin + ci] = acc[t][mb][nb][r];
                 }
             }
 }
@@ -259,9 +263,10 @@ struct Plan {
     int WM, WN, TG, nsplit;
 };
 
-inline Plan make_plan(const hc_wgrad_desc& d) {
+inline Plan make_plan(const hc_wgrad_desc& d, const void* const* xs = nullptr, const void* const* dys = nullptr, int njobs = 1) {
     Plan pl{};
     pl.ok = false;
+    if (njobs < 1 || njobs > HC_WGRAD_MAX_JOBS) return pl;
     static const int enable = getenv("HC_WDMA") ? atoi(getenv("HC_WDMA")) : 1;
     if (!enable) return pl;
     const int T = d.KH * d.KW;
@@ -282,6 +287,11 @@ inline Plan make_plan(const hc_wgrad_desc& d) {
     pl.TG = T == 1 ? 1 : 3;
     Args& a = pl.a;
     a.d = d;
+    a.njobs = njobs;
+    for (int j = 0; j < HC_WGRAD_MAX_JOBS; ++j) {
+        a.xs[j] = j < njobs ? (xs != nullptr ? xs[j] : d.x) : nullptr;
+        a.dys[j] = j < njobs ? (dys != nullptr ? dys[j] : d.dy) : nullptr;
+    }
     a.M = d.N * d.OH * d.OW;
     a.total_steps = (a.M + 31) / 32;
     a.n_co_tiles = d.Cout / (64 * WM);
@@ -318,7 +328,10 @@ int launch(Plan& pl, hipStream_t st, bool do_launch) {
     // stays; the model is what a single-stream caller wants (HC_WDMA_NSPLIT=n > 0 forces n).
     const int slots = 256 * occ;
     static const int forced = getenv("HC_WDMA_NSPLIT") ? atoi(getenv("HC_WDMA_NSPLIT")) : -1;
-    int nsplit = slots / tiles;
+    // a GROUP of same-shaped layers fills the chip with its tiles x jobs: the split-K factor - and with it the fp32 slab traffic,
+    // which for YOLOv4's mid layers (3-6 tiles, 40-85 splits of a 0.6-2.4 MB slab) is several times the layer's own bytes - drops by
+    // the group size
+    int nsplit = slots / (tiles * a.njobs);
     if (forced == 0) {
         const double step_us = 0.055 * (2 * TG * 4);
         const double slab_steps = ((double)a.d.Cout * a.d.KH * a.d.KW * a.d.Cin * 8.0 / 4.0e6) / step_us;
@@ -335,8 +348,9 @@ int launch(Plan& pl, hipStream_t st, bool do_launch) {
     if (nsplit > a.total_steps) nsplit = a.total_steps;
     a.steps_per_split = (a.total_steps + nsplit - 1) / nsplit;
     pl.nsplit = (a.total_steps + a.steps_per_split - 1) / a.steps_per_split;
+    a.nsplit = pl.nsplit;
     if (!do_launch) return HC_OK;
-    hipLaunchKernelGGL(kern, dim3(tiles, pl.nsplit), dim3(64 * WM * WN), smem, st, a);
+    hipLaunchKernelGGL(kern, dim3(tiles, pl.nsplit * a.njobs), dim3(64 * WM * WN), smem, st, a);
     return hc_launch_status();
 }
 
@@ -356,6 +370,22 @@ int wgrad_dma_nsplit(const hc_wgrad_desc& d) {
     if (!pl.ok) return 0;
     if (wdm::dispatch(pl, nullptr, false) != HC_OK) return 0;
     return pl.nsplit;
+}
+
+// grouped form: njobs same-shaped layers in one launch; slab (job, split) at ws + (job * nsplit + split) * Cout T Cin floats
+int wgrad_dma_group_nsplit(const hc_wgrad_desc& d, int njobs) {
+    wdm::Plan pl = wdm::make_plan(d, nullptr, nullptr, njobs);
+    if (!pl.ok) return 0;
+    if (wdm::dispatch(pl, nullptr, false) != HC_OK) return 0;
+    return pl.nsplit;
+}
+
+int wgrad_dma_group_launch(const hc_wgrad_desc& d, const void* const* xs, const void* const* dys, int njobs, hipStream_t st, int* nsplit_out) {
+    wdm::Plan pl = wdm::make_plan(d, xs, dys, njobs);
+    if (!pl.ok) return -1;
+    const int rc = wdm::dispatch(pl, st, true);
+    *nsplit_out = pl.nsplit;
+    return rc;
 }
 
 int wgrad_dma_launch(const hc_wgrad_desc& d, hipStream_t st, int* nsplit_out) {

@@ -174,26 +174,29 @@ __global__ void box_pairwise_bwd_kernel(const float* __restrict__ b1, const floa
 }
 
 // ---------------------------------------------------------------- NMS (torchvision.ops.nms semantics)
-// pass 1: mask[i][w] bit b set  <=>  j = 64*w + b > i  and  IoU(i, j) > thr
+// pass 1: mask[i][w] bit b set  <=>  j = 64*w + b > i  and  IoU(i, j) > thr.  A workgroup = four waves = four column blocks of one
+// row block (a wave per 64 x 64 tile, its column boxes in its own LDS slice): a quarter of the workgroups of the one-wave form, whose
+// launch was dominated by dispatching 3.5 M workgroups most of which (below the diagonal, past a small problem's end) exit at once.
 __device__ __forceinline__ void nms_mask_body(const float* __restrict__ boxes, int n, float thr, unsigned long long* __restrict__ mask,
-                                              int nw, const int rb, const int cb) {
-    if (cb < rb) return;  // only j > i matters
-    const int lane = threadIdx.x;
-    __shared__ float sb[64 * 4];
-    const int jn = min(64, n - cb * 64);
+                                              int nw, const int rb, const int cb0) {
+    __shared__ float sb[4][64 * 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cb = cb0 + wv;
+    const bool active = cb >= rb && cb < nw;             // only j > i matters
+    const int jn = active ? min(64, n - cb * 64) : 0;
     if (lane < jn) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sb[lane * 4 + e] = boxes[(long)(cb * 64 + lane) * 4 + e];
+        for (int e = 0; e < 4; ++e) sb[wv][lane * 4 + e] = boxes[(long)(cb * 64 + lane) * 4 + e];
     }
     __syncthreads();
     const int i = rb * 64 + lane;
-    if (i >= n) return;
+    if (!active || i >= n) return;
     const float x1 = boxes[(long)i * 4], y1 = boxes[(long)i * 4 + 1], x2 = boxes[(long)i * 4 + 2], y2 = boxes[(long)i * 4 + 3];
     const float iarea = (x2 - x1) * (y2 - y1);
     unsigned long long bits = 0;
     const int start = (rb == cb) ? lane + 1 : 0;
     for (int b = start; b < jn; ++b) {
-        const float bx1 = sb[b * 4], by1 = sb[b * 4 + 1], bx2 = sb[b * 4 + 2], by2 = sb[b * 4 + 3];
+        const float bx1 = sb[wv][b * 4], by1 = sb[wv][b * 4 + 1], bx2 = sb[wv][b * 4 + 2], by2 = sb[wv][b * 4 + 3];
         const float xx1 = fmaxf(x1, bx1), yy1 = fmaxf(y1, by1);
         const float xx2 = fminf(x2, bx2), yy2 = fminf(y2, by2);
         const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
@@ -204,74 +207,94 @@ __device__ __forceinline__ void nms_mask_body(const float* __restrict__ boxes, i
     }
     mask[(long)i * nw + cb] = bits;
 }
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr,
-                                                       unsigned long long* __restrict__ mask, int nw) {
-    nms_mask_body(boxes, n, thr, mask, nw, blockIdx.y, blockIdx.x);
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float* __restrict__ boxes, int n, float thr,
+                                                        unsigned long long* __restrict__ mask, int nw) {
+    if ((int)blockIdx.x * 4 + 3 < (int)blockIdx.y) return;      // the whole workgroup is below the diagonal
+    nms_mask_body(boxes, n, thr, mask, nw, blockIdx.y, blockIdx.x * 4);
 }
 // Batched form: blockIdx.z = problem; problem p owns boxes [off[p], off[p + 1]) and the mask words at ws + ws_off[p]
-__global__ __launch_bounds__(64) void nms_mask_batched_kernel(const float* __restrict__ boxes, const int* __restrict__ off, float thr,
-                                                               unsigned long long* __restrict__ ws, const long* __restrict__ ws_off) {
+__global__ __launch_bounds__(256) void nms_mask_batched_kernel(const float* __restrict__ boxes, const int* __restrict__ off, float thr,
+                                                                unsigned long long* __restrict__ ws, const long* __restrict__ ws_off) {
     const int p = blockIdx.z;
     const int o = off[p], n = off[p + 1] - o;
     const int nw = (n + 63) / 64;
-    if ((int)blockIdx.x >= nw || (int)blockIdx.y >= nw) return;
-    nms_mask_body(boxes + (long)o * 4, n, thr, ws + ws_off[p], nw, blockIdx.y, blockIdx.x);
+    if ((int)blockIdx.x * 4 >= nw || (int)blockIdx.y >= nw || (int)blockIdx.x * 4 + 3 < (int)blockIdx.y) return;
+    nms_mask_body(boxes + (long)o * 4, n, thr, ws + ws_off[p], nw, blockIdx.y, blockIdx.x * 4);
 }
-// pass 2: one workgroup walks the sorted boxes 64 at a time.  Wave 0 resolves the intra-block
-// dependency chain on the diagonal word with scalar code; then all threads OR the rows of the
-// kept boxes into the running "removed" bitmap held in LDS.
+// pass 2: one workgroup of sixteen waves walks the sorted boxes 64 at a time, in a two-stage pipeline (round 6; the serial form of
+// rounds 1-5 - one lane group looping over the kept rows with dependent loads, everyone else waiting - was 3.2 of the 13 ms of a
+// YOLOv4 608^2 eval pass):
+//   wave 0, iteration b:      resolves the dependency chain of block b on its diagonal word (only boxes still alive are visited:
+//                             find-first-set + v_readlane of the row, all scalar), appends the kept indices (one lane per kept box,
+//                             prefix popcount), publishes the block's kept list, and ORs the kept rows' word b + 1 into `removed`
+//                             itself (one row per lane, butterfly OR) - the one word it needs at iteration b + 1;
+//   waves 1-15, iteration b:  OR the rows kept in block b - 1 into the words >= b + 1 of `removed` (four row groups x 240 word slots,
+//                             up to four independent 8-byte loads per thread in flight, ds_or_b64 into LDS).
+// One barrier per iteration; every decision is a boolean function of the mask, so the result is the serial scan's bit for bit.
 __device__ __forceinline__ void nms_scan_body(const unsigned long long* __restrict__ mask, int n, int nw, int* __restrict__ keep,
                                               int* __restrict__ nkeep) {
     extern __shared__ unsigned long long removed[];  // nw words
-    __shared__ unsigned long long kept_sh;
-    __shared__ int count_sh;
+    __shared__ unsigned char klist[2][64];
+    __shared__ int kcnt[2];
     const int tid = threadIdx.x;
     for (int w = tid; w < nw; w += 1024) removed[w] = 0ull;
-    if (tid == 0) count_sh = 0;
+    if (tid < 2) kcnt[tid] = 0;
     __syncthreads();
-    for (int blk = 0; blk < nw; ++blk) {
-        const int base = blk * 64;
-        const int cnt = min(64, n - base);
+    int count = 0;                                   // wave 0: kept so far (uniform)
+    for (int blk = 0; blk < nw; ++blk) {             // (the rows kept in the last block have no later words to mark)
         if (tid < 64) {
-            const unsigned long long diag = (tid < cnt) ? mask[(long)(base + tid) * nw + blk] : 0ull;
-            unsigned long long rem = removed[blk];
-            unsigned long long kept = 0ull;
-            for (int b = 0; b < cnt; ++b) {
-                const unsigned long long row = __shfl(diag, b);
-                if (!((rem >> b) & 1ull)) {
+            if (blk < nw) {
+                const int lane = tid;
+                const int base = blk * 64;
+                const int cnt = min(64, n - base);
+                const unsigned long long diag = (lane < cnt) ? mask[(long)(base + lane) * nw + blk] : 0ull;
+                const unsigned lo = (unsigned)diag, hi = (unsigned)(diag >> 32);
+                const unsigned long long valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+                unsigned long long cand = ~removed[blk] & valid, kept = 0ull;
+                while (cand != 0ull) {
+                    const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)cand) - 1);
                     kept |= 1ull << b;
-                    rem |= row;
+                    const unsigned long long row = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, b) << 32) |
+                                                   (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)lo, b);
+                    cand &= ~(row | (1ull << b));          // row b holds only boxes behind b
+                }
+                const int kc = __popcll(kept);
+                if ((kept >> lane) & 1ull) {
+                    const int pos = __popcll(kept & ((1ull << lane) - 1ull));
+                    keep[count + pos] = base + lane;
+                    klist[blk & 1][pos] = (unsigned char)lane;
+                }
+                if (lane == 0) kcnt[blk & 1] = kc;
+                count += kc;
+                // the word the next iteration starts from: rows kept in THIS block, word blk + 1
+                if (blk + 1 < nw) {
+                    unsigned long long v = ((kept >> lane) & 1ull) ? mask[(long)(base + lane) * nw + blk + 1] : 0ull;
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) v |= __shfl_xor(v, o);
+                    if (lane == 0 && v != 0ull) atomicOr(&removed[blk + 1], v);
                 }
             }
-            if (tid == 0) {
-                kept_sh = kept;
-                int c = count_sh;
-                unsigned long long k = kept;
-                while (k) {
-                    const int b = __ffsll((long long)k) - 1;
-                    keep[c++] = base + b;
-                    k &= k - 1;
-                }
-                count_sh = c;
-            }
-        }
-        __syncthreads();
-        const unsigned long long kept = kept_sh;
-        if (kept != 0ull) {
-            for (int w = blk + 1 + tid; w < nw; w += 1024) {
+        } else if (blk >= 1) {
+            const int pb = blk - 1;                  // rows kept in block pb -> words >= pb + 2 = blk + 1
+            const int kc = kcnt[pb & 1];
+            const int t = tid - 64, slot = t % 240, rg = t / 240;       // 960 threads = 4 row groups x 240 word slots
+            const long rbase = (long)pb * 64;
+            const unsigned char* kl = klist[pb & 1];
+            for (int w = blk + 1 + slot; w < nw && kc > 0; w += 240) {
                 unsigned long long acc = 0ull;
-                unsigned long long k = kept;
-                while (k) {
-                    const int b = __ffsll((long long)k) - 1;
-                    acc |= mask[(long)(base + b) * nw + w];
-                    k &= k - 1;
+                int j = rg;
+                for (; j + 12 < kc; j += 16) {
+                    const unsigned long long a0 = mask[(rbase + kl[j]) * nw + w], a1 = mask[(rbase + kl[j + 4]) * nw + w],
+                                             a2 = mask[(rbase + kl[j + 8]) * nw + w], a3 = mask[(rbase + kl[j + 12]) * nw + w];
+                    acc |= (a0 | a1) | (a2 | a3);
                 }
-                removed[w] |= acc;
+                for (; j < kc; j += 4) acc |= mask[(rbase + kl[j]) * nw + w];
+                if (acc != 0ull) atomicOr(&removed[w], acc);
             }
         }
         __syncthreads();
     }
-    if (tid == 0) nkeep[0] = count_sh;
+    if (tid == 0) nkeep[0] = count;
 }
 __global__ __launch_bounds__(1024) void nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int nw,
                                                          int* __restrict__ keep, int* __restrict__ nkeep) {
@@ -644,7 +667,7 @@ int hc_nms_sorted(const float* boxes, int32_t n, float iou_thr, void* ws, int32_
     if (boxes == nullptr || ws == nullptr || keep == nullptr) return HC_ERR_ARG;
     const int nw = (n + 63) / 64;
     if ((size_t)nw * 8 > 60000) return HC_ERR_ARG;  // bitmap must fit LDS (n <= 480000)
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nw, nw), dim3(64), 0, st, boxes, n, iou_thr, (unsigned long long*)ws, nw);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((nw + 3) / 4, nw), dim3(256), 0, st, boxes, n, iou_thr, (unsigned long long*)ws, nw);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), nw * 8, st, (const unsigned long long*)ws, n, nw, keep, nkeep);
     return hc_launch_status();
 }
@@ -659,7 +682,7 @@ int hc_nms_sorted_batched(const float* boxes, const int32_t* off, int32_t nprob,
     if (boxes == nullptr || ws == nullptr || ws_off == nullptr || keep == nullptr || nprob > 65535) return HC_ERR_ARG;
     const int nw = (nmax + 63) / 64;
     if ((size_t)nw * 8 > 60000 || nw > 65535) return HC_ERR_ARG;
-    hipLaunchKernelGGL(nms_mask_batched_kernel, dim3(nw, nw, nprob), dim3(64), 0, st, boxes, off, iou_thr, (unsigned long long*)ws,
+    hipLaunchKernelGGL(nms_mask_batched_kernel, dim3((nw + 3) / 4, nw, nprob), dim3(256), 0, st, boxes, off, iou_thr, (unsigned long long*)ws,
                        (const long*)ws_off);
     hipLaunchKernelGGL(nms_scan_batched_kernel, dim3(nprob), dim3(1024), nw * 8, st, (const unsigned long long*)ws, (const long*)ws_off,
                        off, keep, nkeep);

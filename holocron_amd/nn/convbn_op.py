@@ -81,6 +81,7 @@ class ConvBnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, gamma, beta, res, st, meta, out_holder=None, link=None):
         lib = _lib.load()
+        cv._WCONV.note_forward()       # a weight-gradient queue still armed by a backward pass that died is emptied here
         out = None if out_holder is None else out_holder[0]
         # ``link`` couples the two units of a residual block whose shortcut is the block INPUT (DarkNet ResBlock): the unit that adds
         # the residual ("sink") parks the residual's gradient in link["grad"] instead of returning it, and the unit that consumes the
@@ -217,7 +218,7 @@ class ConvBnActFn(torch.autograd.Function):
                 dw = torch.empty_like(w, dtype=torch.float32)
                 check(lib.hc_unpack_im2col_grad(ptr(dwc), ptr(dw), Cout, Cin, KH, KW, Kpad, 0, stream()), "hc_unpack_im2col_grad")
             else:
-                dw = cv.conv_wgrad(src, dy, Cin, Cout, KH, KW, stride, pad)
+                dw = cv.conv_wgrad_unit(src, dy, w, Cin, Cout, KH, KW, stride, pad)
             side.produced(dw)
         gr = (gres if gres is not None else g) if ctx.has_res else None
         if gr is not None and ctx.link is not None and ctx.link.get("role") == "sink" and ctx.link.get("armed"):
@@ -374,7 +375,7 @@ class ConvBiasActFn(torch.autograd.Function):
                 dw = torch.empty_like(w, dtype=torch.float32)
                 check(lib.hc_unpack_im2col_grad(ptr(dwc), ptr(dw), Cout, Cin, KH, KW, Kpad, 0, stream()), "hc_unpack_im2col_grad")
             else:
-                dw = cv.conv_wgrad(src, dy, Cin, Cout, KH, KW, stride, pad)
+                dw = cv.conv_wgrad_unit(src, dy, w, Cin, Cout, KH, KW, stride, pad)
             side.produced(dw)
         return dx, dw, db, None, None
 

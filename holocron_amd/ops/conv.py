@@ -12,7 +12,7 @@ import os
 import torch
 
 from .. import _lib
-from .._lib import ConvDesc, ConvSmallDesc, RepWgradDesc, WgradDesc, check, ptr, stream, tap
+from .._lib import ConvDesc, ConvSmallDesc, RepWgradDesc, WgradDesc, WgradGroupDesc, check, ptr, stream, tap
 
 _WEIGHTS_EPOCH = [0]  # bumped by holocron_amd.optim after every raw-pointer parameter update
 
@@ -581,6 +581,8 @@ class _RepWgradQueue:
         for jobs in job_lists:
             for (_, x, _, _, s3, p3, o3, s1, p1, o1, w3, w1) in jobs:
                 for w, st, p, off in ((w3, s3, p3, o3), (w1, s1, p1, o1)):
+                    if w is None:
+                        continue
                     g = w.grad
                     if g is not None and g.data_ptr() != p:
                         g.add_(torch.empty(0, dtype=torch.float32, device=x.device).set_(st, off, g.shape))
@@ -605,17 +607,111 @@ class _RepWgradQueue:
 _WREP = _RepWgradQueue()
 
 
+class _ConvWgradQueue(_RepWgradQueue):
+    """The same deferral for the PLAIN conv units (conv_sequence: conv -> BatchNorm -> activation, nn/convbn_op.py): the weight
+    gradients of a backward pass are queued and launched at its end, same-shaped layers in ONE ``hc_conv_wgrad_group`` launch pair.
+    The DarkNet / CSP / YOLO stacks repeat a handful of conv shapes 4-9 times per step (the ResBlocks of a CSP stage); one such layer
+    has 3-6 weight-gradient tiles and on its own needs 40-85 split-K slabs to fill the chip - its fp32 partial sums are several times
+    its operands.  Grouped, tiles x jobs fill the chip and the split factor drops by the group size.  Arming, parking, the zero
+    placeholders and the end-of-pass flush are the RepBlock queue's (one weight per job instead of two); layers whose shape the
+    grouped kernel does not take are launched one by one at the flush."""
+
+    def __init__(self):
+        super().__init__()
+        self.enabled = os.environ.get("HC_WGRAD_DEFER", "1") != "0"
+        self.side_on = False
+
+    @staticmethod
+    def _gdesc(key, njobs=1):
+        N, Cin, H, W, Cout, KH, KW, stride, pad = key
+        d = WgradGroupDesc()
+        d.njobs, d.N, d.IH, d.IW, d.Cin, d.Cout, d.stride, d.pad = njobs, N, H, W, Cin, Cout, stride, pad
+        d.KH, d.KW = KH, KW
+        d.OH, d.OW = conv_out_size(H, KH, stride, pad), conv_out_size(W, KW, stride, pad)
+        return d
+
+    def supported(self, key):
+        ok = self.support.get(key)
+        if ok is None:
+            d = self._gdesc(key)
+            d.x[0] = d.dy[0] = d.dw[0] = 1        # (the support query looks at the geometry only)
+            ok = self.support[key] = bool(_lib.load().hc_conv_wgrad_group_supported(C.byref(d)))
+        return ok
+
+    def launch(self, key, jobs, accumulate=False):
+        """``jobs`` = (x, dy, _, dw pointer, _) of shape ``key``: groups of up to 16 through the grouped kernel."""
+        lib = _lib.load()
+        N, Cin, H, W, Cout, KH, KW, stride, pad = key
+        for i in range(0, len(jobs), _lib.HC_WGRAD_MAX_JOBS):
+            grp = jobs[i:i + _lib.HC_WGRAD_MAX_JOBS]
+            d = self._gdesc(key, len(grp))
+            d.beta = 1 if accumulate else 0
+            for j, (x, dy, _, p, _) in enumerate(grp):
+                d.x[j], d.dy[j], d.dw[j] = ptr(x), ptr(dy), p
+            nbytes = lib.hc_conv_wgrad_group_ws_bytes(C.byref(d))
+            if nbytes < 0:
+                raise _lib.HipError("hc_conv_wgrad_group: unsupported shape %s" % (key,))
+            ws = torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=grp[0][0].device)
+            d.ws = ptr(ws)
+            if PROFILE is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(lib.hc_conv_wgrad_group(C.byref(d), stream()), "hc_conv_wgrad_group")
+                e1.record()
+                flops = 2.0 * N * d.OH * d.OW * Cout * KH * KW * Cin * len(grp)
+                nb = len(grp) * (2 * N * H * W * Cin + 2 * N * d.OH * d.OW * Cout + 4 * Cout * Cin * KH * KW)
+                PROFILE.append(("conv_wgrad", flops, e0, e1, nb))
+                _tag("wgrad x%d N%d %d@%dx%d -> %d@%dx%d k%d s%d" % (len(grp), N, Cin, H, W, Cout, d.OH, d.OW, KH, stride))
+            elif not WGRAD_KNOCKOUT:
+                check(lib.hc_conv_wgrad_group(C.byref(d), stream()), "hc_conv_wgrad_group")
+
+    def submit1(self, key, x, dy, w):
+        """Queue one layer; returns the zero-filled (to be accumulated into) gradient tensor for autograd."""
+        Cout, Cin, KH, KW = key[4], key[1], key[5], key[6]
+        task = torch._C._current_graph_task_id()
+        if self.armed and task != self.task:
+            self._park()
+        dw = self._zeros((Cout, Cin, KH, KW), x.device, key)
+        self.jobs.append((key, x, dy, None, dw.untyped_storage(), dw.data_ptr(), dw.storage_offset(), None, 0, 0, w, None))
+        if not self.armed:
+            self.armed, self.task = True, task
+            back = self.parked.pop(task, None)
+            if back:
+                self.jobs = back + self.jobs
+            if task not in self.cb_tasks:
+                self.cb_tasks.add(task)
+                torch.autograd.Variable._execution_engine.queue_callback(functools.partial(self._final, task))
+        return dw
+
+
+_WCONV = _ConvWgradQueue()
+
+
+def conv_wgrad_unit(x, dy, w, Cin, Cout, KH, KW, stride, pad):
+    """dW of a plain conv unit from inside its backward node: queued for the grouped end-of-pass launch when nothing can read the
+    gradient before the pass ends (``_may_defer``) and the grouped kernel takes the shape, else computed now (``conv_wgrad``)."""
+    N, _, H, W = x.shape
+    if (_WCONV.enabled and not _SIDE.on and torch._C._current_graph_task_id() != -1 and tuple(w.shape) == (Cout, Cin, KH, KW)
+            and w.dtype == torch.float32):
+        key = (N, Cin, H, W, Cout, KH, KW, stride, pad)
+        if _WCONV.supported(key) and _may_defer(w):
+            return _WCONV.submit1(key, x, dy, w)
+    return conv_wgrad(x, dy, Cin, Cout, KH, KW, stride, pad)
+
+
 def flush_deferred_wgrads() -> None:
     """Launch every weight gradient that is still queued (call before reading ``.grad`` from inside a backward pass)."""
-    if _WREP.jobs or _WREP.inflight:
-        jobs, _WREP.jobs = _WREP.jobs, []
-        arena = (_WREP.arena, _WREP.arena_used, _WREP.arena_want, _WREP.arena_first)
-        sizes = dict(_WREP.arena_sizes)
-        _WREP.jobs = jobs
-        _WREP.flush()
-        # a mid-pass flush must not drop the arena of the pass that is still running (nor record its partial size)
-        _WREP.arena, _WREP.arena_used, _WREP.arena_want, _WREP.arena_first = arena
-        _WREP.arena_sizes = sizes
+    for q in (_WREP, _WCONV):
+        if q.jobs or q.inflight:
+            arena = (q.arena, q.arena_used, q.arena_want, q.arena_first)
+            sizes = dict(q.arena_sizes)
+            task, cbs = q.task, set(q.cb_tasks)
+            q.flush()
+            # a mid-pass flush must not drop the arena of the pass that is still running (nor record its partial size); the pass's final
+            # callback is still queued: the next submit of the pass re-arms without queueing a second one
+            q.arena, q.arena_used, q.arena_want, q.arena_first = arena
+            q.arena_sizes = sizes
+            q.cb_tasks = cbs
 
 
 _FLUSH_AWARE = {}    # id(parameter) -> ids of its post-accumulate hooks that call flush_deferred_wgrads() before reading .grad
@@ -642,6 +738,7 @@ def set_deferred_wgrads(on: bool) -> None:
     if not on:
         flush_deferred_wgrads()
     _WREP.enabled = bool(on)
+    _WCONV.enabled = bool(on)
 
 
 def _may_defer(*params) -> bool:

@@ -223,6 +223,26 @@ typedef struct {
 int64_t hc_conv_wgrad_ws_bytes(const hc_wgrad_desc* d);
 int hc_conv_wgrad(const hc_wgrad_desc* d, hc_stream_t stream);
 
+/* The weight gradients of up to HC_WGRAD_MAX_JOBS SAME-SHAPED conv layers in one launch pair (aten::convolution_backward(weight) of
+ * each; the conv_sequence units of the DarkNet / CSP / YOLO stacks, holocron/models/utils.py:73 under darknetv4.py:38-115 and
+ * yolov4.py:31-229, repeat a handful of shapes 4-9 times per step).  One layer of those stacks has 3-6 output tiles, so on its own it
+ * needs 40-85 split-K slabs to fill 256 CUs and its fp32 partial sums outweigh its operands several times; a group fills the chip
+ * with tiles x jobs and the split factor drops by the group size.  x[j] NHWC bf16 [N][IH][IW][Cin], dy[j] NHWC bf16 [N][OH][OW][Cout],
+ * dw[j] fp32 OIHW (= when beta == 0, += when 1); ws: hc_conv_wgrad_group_ws_bytes().  Slabs are reduced in a fixed order.
+ * hc_conv_wgrad_group_supported: 0 for shapes outside the DMA kernel's plan (Cin, Cout multiples of 64 from 128 on, 3x3 or 1x1) - call
+ * hc_conv_wgrad per layer then. */
+#define HC_WGRAD_MAX_JOBS 16
+typedef struct {
+    const void* x[HC_WGRAD_MAX_JOBS];
+    const void* dy[HC_WGRAD_MAX_JOBS];
+    float* dw[HC_WGRAD_MAX_JOBS];
+    void* ws;
+    int32_t njobs, N, IH, IW, Cin, OH, OW, Cout, KH, KW, stride, pad, beta;
+} hc_wgrad_group_desc;
+int hc_conv_wgrad_group_supported(const hc_wgrad_group_desc* d);
+int64_t hc_conv_wgrad_group_ws_bytes(const hc_wgrad_group_desc* d);
+int hc_conv_wgrad_group(const hc_wgrad_group_desc* d, hc_stream_t stream);
+
 /* Both weight gradients of a RepBlock (repvgg.py:57-60: a 3x3 / pad 1 and a 1x1 / pad 0 conv on the same input with the same
  * stride; aten::convolution_backward(weight) of both) in ONE launch from ONE staging of x, for up to HC_WREP_MAX_JOBS blocks of
  * the same shape at a time (csrc/conv_wgrad_rep.hip).  x[j] NHWC bf16 [N][IH][IW][Cin], dy3[j] / dy1[j] NHWC bf16

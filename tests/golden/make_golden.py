@@ -771,8 +771,39 @@ def gen_nms():
     save("nms.pt", cases)
 
 
+def gen_whole_models():
+    """One training step of rexnet1_0x and mobileone_s0 on a batch whose LAST stage still holds 16 x 4 x 4 = 256 positions per channel
+    (16 images of 128 x 128), so that batch-statistics BatchNorm is well conditioned down to the head and a whole-model comparison means
+    something (with the 4-image / 2 x 2-map fixtures above it amplifies rounding to the 10-100 % level).  The weights
+    are reproducible from the seed (the mirror draws the same RNG stream as the reference); the inputs are stored as bytes."""
+    import importlib
+    g = torch.Generator().manual_seed(97)
+    out = {}
+    for name, seed, mod, ctor, kw in (("rexnet1_0x", 151, "rexnet", "rexnet1_0x", {"dropout_ratio": 0.0}),
+                                      ("mobileone_s0", 161, "mobileone", "mobileone_s0", {})):
+        rm = importlib.import_module("ref_holocron.models.classification." + mod)
+        torch.manual_seed(seed)
+        m = getattr(rm, ctor)(num_classes=10, **kw)
+        x8 = torch.randint(0, 256, (16, 3, 128, 128), generator=g, dtype=torch.uint8)
+        x = bf16r(x8.float() / 255.0)
+        t = torch.randint(0, 10, (16,), generator=g)
+        m.train()
+        logits = m(x)
+        loss = torch.nn.functional.cross_entropy(logits, t)
+        loss.backward()
+        params = dict(m.named_parameters())
+        # full gradients of every tensor up to 4096 elements (BatchNorm affine, biases, depthwise taps, narrow convs) + the head
+        keep = {n: p.grad.clone() for n, p in params.items() if p.numel() <= 4096 or n.startswith("head")}
+        running = {k: v.clone() for k, v in m.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+        out[name] = {"seed": seed, "num_classes": 10, "kwargs": kw, "x8": x8, "target": t, "logits": logits.detach(), "loss": loss.detach(),
+                     "grads": keep, "grad_norms": {n: float(p.grad.norm()) for n, p in params.items()},
+                     "grad_abs_max": {n: float(p.grad.abs().max()) for n, p in params.items()},
+                     "running_sample": {k: running[k] for k in list(running)[:8] + list(running)[-8:]}}
+    save("whole_models.pt", out)
+
+
 if __name__ == "__main__":
-    gens = {"boxes": gen_boxes, "functional": gen_functional, "optim": gen_optim, "repblock": gen_repblock,
+    gens = {"whole_models": gen_whole_models, "boxes": gen_boxes, "functional": gen_functional, "optim": gen_optim, "repblock": gen_repblock,
             "repvgg_small": gen_repvgg_small, "darknet": gen_darknet, "losses": gen_losses, "yolo": gen_yolo, "rexnet": gen_rexnet, "convs": gen_convs, "optim2": gen_optim2, "nms": gen_nms, "mobileone": gen_mobileone, "optim3": gen_optim3, "yolo_v1": gen_yolo_v1, "mixup": gen_mixup}
     for name in (sys.argv[1:] or list(gens)):
         gens[name]()

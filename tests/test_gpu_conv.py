@@ -215,3 +215,35 @@ def test_conv_small_many_tiles_per_workgroup(grid, pipe, monkeypatch):
         test_conv_small_forward_and_dgrad(*args)
 
 
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,k,jobs", [(2, 128, 128, 19, 3, 3), (2, 256, 128, 16, 1, 5), (1, 128, 256, 24, 3, 16), (3, 256, 128, 9, 3, 2)])
+def test_grouped_wgrad_matches_single_launches(N, Cin, Cout, H, k, jobs):
+    """hc_conv_wgrad_group (same-shaped layers in one launch pair, round 6) against hc_conv_wgrad layer by layer and against fp32
+    autograd on the same bf16 operands; `beta` accumulates into the destination."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from holocron_amd import _lib
+    from holocron_amd.ops import conv as cv
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(Cin + Cout + H + k)
+    xs = [bf16r(torch.randn((N, Cin, H, H), generator=g)) for _ in range(jobs)]
+    dys = [bf16r(torch.randn((N, Cout, H, H), generator=g)) for _ in range(jobs)]
+    key = (N, Cin, H, H, Cout, k, k, 1, k // 2)
+    assert cv._WCONV.supported(key)
+    xg = [cv.to_cl_bf16(t.cuda()) for t in xs]
+    dg = [cv.to_cl_bf16(t.cuda()) for t in dys]
+    outs = [torch.full((Cout, Cin, k, k), 0.5, dtype=torch.float32, device="cuda") for _ in range(jobs)]
+    cv._WCONV.launch(key, [(a, b, None, o.data_ptr(), 0) for a, b, o in zip(xg, dg, outs)], accumulate=True)
+    torch.cuda.synchronize()
+    for j in range(jobs):
+        single = cv.conv_wgrad(xg[j], dg[j], Cin, Cout, k, k, 1, k // 2)
+        w = torch.zeros((Cout, Cin, k, k), requires_grad=True)
+        (ref,) = torch.autograd.grad((F.conv2d(xs[j], w, None, 1, k // 2) * dys[j]).sum(), w)
+        got = outs[j].cpu() - 0.5
+        assert rel_l2(got, ref) < 2e-4, (j, rel_l2(got, ref))
+        assert rel_l2(got, single.cpu()) < 2e-5, (j, rel_l2(got, single.cpu()))
+    # the same group twice is the same bits (fixed-order slab sums)
+    outs2 = [torch.full((Cout, Cin, k, k), 0.5, dtype=torch.float32, device="cuda") for _ in range(jobs)]
+    cv._WCONV.launch(key, [(a, b, None, o.data_ptr(), 0) for a, b, o in zip(xg, dg, outs2)], accumulate=True)
+    assert all(torch.equal(a, b) for a, b in zip(outs, outs2))

@@ -112,20 +112,15 @@ def test_mobileone_s0_train_step_and_reparametrize(golden):
     assert errs[0] < 1e-2 and errs[1] < 3e-2 and errs[2] < 0.15, errs
     logits = m(x)
     assert logits.shape == gm["logits"].shape and logits.dtype == torch.float32
-    # 23 BatchNorm'd blocks down to 2x2 maps of 4 images are chaotic (a 1e-3 input perturbation moves the fp32 reference's
-    # logits by 55 %): the logits are only sanity-checked, the stage outputs are compared where the depth still allows it
-    assert bool(torch.isfinite(logits).all()) and rel_l2(logits.float().cpu(), gm["logits"]) < 1.5
+    # SMOKE only beyond the stage means above (4 images, 2 x 2 maps at the end): finiteness and the loss in the right place.  The
+    # whole-model PARITY check - every block in situ against the oracle, free-running logits against the emulating oracle with a
+    # yardstick - is tests/test_gpu_whole_models.py on the 16 x 128 x 128 fixture
+    assert bool(torch.isfinite(logits).all())
     loss = F.cross_entropy(logits, t)
     assert abs(float(loss.detach()) - float(gm["loss"])) < 0.25 * max(1.0, float(gm["loss"]))
     loss.backward()
     params = dict(m.named_parameters())
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in params.values())
-    ratios = []
-    for n, gn in gm["grad_norms"].items():
-        if gn > 1e-3 and not _scale_only(params[n]):
-            ratios.append(float(params[n].grad.norm()) / gn)
-    ratios = torch.tensor(ratios)
-    assert 0.7 < float(ratios.median()) < 1.4, float(ratios.median())
     for k, v in gm["running_sample"].items():
         assert rel_l2(m.state_dict()[k].cpu(), v) < 0.2, k
     # reparametrize: no BatchNorm left, same eval output

@@ -1,6 +1,10 @@
 """bench.py's N > 1 code path on one GPU (HC_FORCE_DIST=1: process group of one rank over RCCL, GradReducer, three hipGraphs with the
 all-reduces between them) against its single-graph path: in deterministic mode the two loss trajectories must agree BIT FOR BIT - the
 fp32 wire, the bucket pack / unpack and the cut backward change where the work is launched from, never a value.
+Both arms run with HC_WREP_DEFER=0: the deferred RepBlock weight gradients are GROUPED per backward call, and the cut backward of the
+N > 1 path ends a call (and a group) at each cut - same-shaped blocks then land in groups of other sizes, whose split-K factor and
+therefore fp32 summation order differ.  That is a rounding-order difference, not a value difference, but AdaBelief's first steps are
+sign-like and amplify it to 5e-3 of the loss within a dozen steps; without grouping every launch of the two arms is the same launch.
 (Runs late: each arm is a fresh process with its own process group.)"""
 import json
 import os
@@ -17,6 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _bench(force_dist):
     env = dict(os.environ)
     env["HC_FORCE_DIST"] = "1" if force_dist else "0"
+    env["HC_WREP_DEFER"] = "0"
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env["MASTER_PORT"] = "29541"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--profile-steps", "1",

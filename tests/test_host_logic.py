@@ -696,3 +696,74 @@ def test_squeeze_excite_mlp_routing_predicate():
     wide = SEBlock(2400, 12, nn.ReLU6(), nn.BatchNorm2d).train()     # 200 reduced channels: above the kernels' 128
     assert not se_mlp_fusable(*list(wide.conv)[:4])
 
+
+
+# ------------------------------------------------------------------ deferred, grouped weight gradients of the plain conv units (round 6)
+def test_conv_unit_wgrad_queue_groups_same_shaped_layers(monkeypatch):
+    """ops.conv._ConvWgradQueue on CPU tensors (the launch replaced by `+= njobs-th of 1`): same-shaped layers of one backward pass go
+    out as ONE grouped launch at the end of the pass, other shapes as their own, gradients land in the tensors autograd adopted."""
+    import numpy as np
+    q = cv._WCONV
+    launches = []
+    monkeypatch.setattr(q, "support", {})
+    monkeypatch.setattr(q, "supported", lambda key: True)
+
+    def launch(key, jobs, accumulate=False):
+        launches.append((key, len(jobs), accumulate))
+        Cout, Cin, KH, KW = key[4], key[1], key[5], key[6]
+        for (_, _, _, p, _) in jobs:
+            a = np.ctypeslib.as_array((ctypes.c_float * (Cout * Cin * KH * KW)).from_address(p))
+            a += 1.0
+    monkeypatch.setattr(q, "launch", launch)
+    q.jobs, q.armed, q.task, q.parked, q.cb_tasks = [], False, -1, {}, set()
+
+    def unit(x, w):
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w):
+                ctx.save_for_backward(x, w)
+                return x * 1.0
+
+            @staticmethod
+            def backward(ctx, g):
+                x, w = ctx.saved_tensors
+                Cout, Cin, KH, KW = w.shape
+                return g, cv.conv_wgrad_unit(x, g, w, Cin, Cout, KH, KW, 1, KH // 2)
+        return Fn.apply(x, w)
+    ws = [torch.nn.Parameter(torch.zeros(16, 16, 3, 3)) for _ in range(3)] + [torch.nn.Parameter(torch.zeros(16, 16, 1, 1))]
+    x = torch.ones(2, 16, 4, 4, requires_grad=True)
+    y = x
+    for w in ws:
+        y = unit(y, w)
+    y.sum().backward()
+    assert not q.armed and not q.jobs
+    assert sorted((k[5], n, acc) for k, n, acc in launches) == [(1, 1, True), (3, 3, True)]
+    for w in ws:
+        assert torch.equal(w.grad, torch.ones_like(w))
+    # a parameter that already has a gradient (accumulation), or a hook that reads gradients inside the pass: computed at once
+    launches.clear()
+    seen = []
+    monkeypatch.setattr(cv, "conv_wgrad", lambda x, dy, Cin, Cout, KH, KW, s, p, **kw: (seen.append((Cout, KH)) or torch.ones(Cout, Cin, KH, KW)))
+    y = unit(x, ws[0])
+    y.sum().backward()
+    assert seen == [(16, 3)] and not launches and torch.equal(ws[0].grad, 2 * torch.ones_like(ws[0]))
+    # flush_deferred_wgrads() from inside a pass launches what is queued so far; the pass's later layers still arrive
+    for w in ws:
+        w.grad = None
+    launches.clear()
+
+    class Peek(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            cv.flush_deferred_wgrads()
+            seen.append(("mid", float(ws[1].grad.sum())))
+            return g
+    y = unit(Peek.apply(unit(x, ws[0])), ws[1])
+    y.sum().backward()
+    assert ("mid", float(ws[1].numel())) in seen
+    assert torch.equal(ws[0].grad, torch.ones_like(ws[0])) and torch.equal(ws[1].grad, torch.ones_like(ws[1]))
+    assert len(launches) == 2 and not q.armed and not q.jobs and not q.cb_tasks
