@@ -29,7 +29,8 @@ class ConvDesc(C.Structure):
                 ("N", c_int32), ("IH", c_int32), ("IW", c_int32), ("srcC", c_int32),
                 ("OH", c_int32), ("OW", c_int32), ("Cout", c_int32), ("T", c_int32), ("nclass", c_int32),
                 ("cls", ConvClass * 4), ("pix_scale", c_void_p), ("pix_shift", c_void_p), ("ch_coef", c_void_p),
-                ("ch_mult", c_void_p), ("dst2", c_void_p), ("stats2", c_void_p), ("co_split", c_int32)]
+                ("ch_mult", c_void_p), ("dst2", c_void_p), ("stats2", c_void_p), ("co_split", c_int32),
+                ("ch_scale", c_void_p), ("act_slope", C.c_float), ("resid_after_act", c_int32)]
 
 
 class ConvSmallDesc(C.Structure):

@@ -432,9 +432,67 @@ def conv_bn_act(x, conv, bn, act=None, residual=None, drop=None, out=None, post_
     dp2 = None
     if post_drop is not None and post_drop.training and post_drop.drop_prob > 0:
         dp2 = (float(post_drop.drop_prob), int(post_drop.block_size))
+    if (not bn.training and not torch.is_grad_enabled() and dp is None and dp2 is None and bn.running_mean is not None
+            and _INFER_FUSED and (out is None or cl_ld(out) == conv.out_channels)):
+        return _conv_bn_act_infer(x, conv, bn, code, slope, residual, st, out)
     meta = (conv.stride[0], conv.padding[0], code, slope,
             (bn.running_mean, bn.running_var, bn.num_batches_tracked), bn.eps, momentum, bn.training, dp, dp2)
     return ConvBnActFn.apply(x, conv.weight, bn.weight, bn.bias, residual, st, meta, None if out is None else [out], link)
+
+
+# HC_INFER_FUSED=0: eval-mode units run conv -> finalize -> apply like the training path (A/B)
+_INFER_FUSED = __import__("os").environ.get("HC_INFER_FUSED", "1") != "0"
+
+
+def _conv_bn_act_infer(x, conv, bn, code, slope, residual, st, out):
+    """INFERENCE form of the unit (eval mode, no autograd, no DropBlock): ONE gather-conv launch whose epilogue applies the BatchNorm
+    of the running statistics (per-channel scale and shift, fp32, on the fp32 accumulator), the activation and the residual
+    (models/utils.py:73-84 in eval mode; north_star's "fused conv+BN+activation epilogues").  The training path needs batch statistics
+    between the conv and the normalisation and keeps its three launches; here the unnormalised conv output is never stored and the
+    BatchNorm launches (finalize + apply, a third of an eval pass's launches in YOLOv4) are gone.  Scale / shift are cached on the
+    unit, keyed on the versions of the four BatchNorm tensors and the optimizer epoch."""
+    w = conv.weight
+    Cout, Cin, KH, KW = w.shape
+    N, _, H, W = x.shape
+    dev = x.device
+    stride, pad = conv.stride[0], conv.padding[0]
+    key = (bn.weight.data_ptr(), bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, cv.weights_epoch(),
+           float(bn.eps), str(dev))
+    if getattr(st, "infer_key", None) != key:
+        with torch.no_grad():
+            a = (bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + bn.eps)).contiguous()
+            st.infer_scale = a
+            st.infer_shift = (bn.bias.detach().float() - bn.running_mean.detach().float() * a).contiguous()
+        st.infer_key = key
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        raise RuntimeError("conv_bn_act (HIP) expects contiguous fp32 conv weights")
+    if (Cin % 16) != 0:
+        K = Cin * KH * KW
+        Kpad = (K + 15) // 16 * 16
+        src = cv.im2col_small(x, KH, KW, stride, pad, Kpad)
+        wpk = st.fwd_cache.get((w,), lambda: cv.pack_weight_im2col(w, Kpad))
+        dkey = ("c", N, src.shape[2], src.shape[3], Kpad, Cout)
+        if dkey not in st.desc:
+            st.desc[dkey] = cv.fwd_desc(N, Kpad, src.shape[2], src.shape[3], Cout, 1, 1, 1, 0)
+        flops = 2.0 * N * st.desc[dkey].OH * st.desc[dkey].OW * Cout * K
+    else:
+        src = cv.to_cl_bf16(x)
+        wpk = st.fwd_cache.get((w,), lambda: cv.pack_weight(w, 0))
+        dkey = ("f", N, Cin, H, W, Cout, KH, KW, stride, pad)
+        if dkey not in st.desc:
+            st.desc[dkey] = cv.fwd_desc(N, Cin, H, W, Cout, KH, KW, stride, pad)
+        flops = None
+    fd = st.desc[dkey]
+    if out is None:
+        out = cv.empty_cl(N, Cout, fd.OH, fd.OW, dev)
+    elif tuple(out.shape) != (N, Cout, fd.OH, fd.OW):
+        raise _lib.HipError("conv_bn_act: `out` must be an NHWC bf16 view of shape %s" % ((N, Cout, fd.OH, fd.OW),))
+    resc = None if residual is None else cv.to_cl_bf16(residual)
+    if resc is not None and cl_ld(resc) != Cout:
+        resc = resc.contiguous(memory_format=torch.channels_last)
+    cv.launch_conv(fd, src, wpk, out, resid=resc, bias=st.infer_shift, act=code, flops=flops, ch_scale=st.infer_scale,
+                   act_slope=slope, resid_after_act=True)
+    return out
 
 
 def _is_act(m):

@@ -165,11 +165,14 @@ def _desc_flops(d):
 
 
 def launch_conv(d, src0, wpk, dst, src1=None, resid=None, stats=None, bias=None, act=0, flops=None, dst2=None, stats2=None,
-                co_split=0):
-    """``dst2`` / ``stats2`` / ``co_split``: two convolutions of ``src0`` in one launch (stacked weight rows, hc_conv_desc.co_split)."""
+                co_split=0, ch_scale=None, act_slope=0.0, resid_after_act=False):
+    """``dst2`` / ``stats2`` / ``co_split``: two convolutions of ``src0`` in one launch (stacked weight rows, hc_conv_desc.co_split).
+    ``ch_scale`` (+ ``bias``, ``act``, ``act_slope``, ``resid_after_act``): the inference epilogue of a conv -> BatchNorm -> activation
+    unit (running statistics folded into a per-channel scale and shift)."""
     d.src0, d.src1, d.wpk, d.dst = ptr(src0), ptr(src1), ptr(wpk), ptr(dst)
     d.resid, d.stats, d.bias, d.act = ptr(resid), ptr(stats), ptr(bias), act
     d.dst2, d.stats2, d.co_split = ptr(dst2), ptr(stats2), co_split
+    d.ch_scale, d.act_slope, d.resid_after_act = ptr(ch_scale), float(act_slope), 1 if resid_after_act else 0
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

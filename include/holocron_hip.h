@@ -82,6 +82,15 @@ typedef struct {
     void* dst2;
     float* stats2;
     int32_t co_split;
+    /* INFERENCE epilogue of a conv_sequence unit (holocron/models/utils.py:73-84 in eval mode: conv -> BatchNorm2d with running
+     * statistics -> activation): when ch_scale != NULL the fp32 accumulator becomes v * ch_scale[co] + bias[co] (bias = the
+     * BatchNorm shift; required with ch_scale) BEFORE the activation - the whole unit is one launch and the conv output is never
+     * stored unnormalised.  act_slope: negative slope of act == 3 (0 = the 0.1 of the other callers).  resid_after_act != 0 adds
+     * `resid` AFTER the activation (DarkNet's ResBlock: x + act(bn(conv)), darknetv3.py:59-61) instead of before it.  bf16 path
+     * only, not with co_split / pix_scale / ch_mult. */
+    const float* ch_scale;   /* fp32 [Cout] */
+    float act_slope;
+    int32_t resid_after_act;
 } hc_conv_desc;
 int hc_conv_gather(const hc_conv_desc* d, hc_stream_t stream);
 /* Streaming form for 1 x 1 stride-1 convolutions over at most 128 input channels (the expansion convolutions of rexnet.py:97-103 and

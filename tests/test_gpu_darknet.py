@@ -106,3 +106,45 @@ def test_conv_bn_act_activations_vs_torch(act):
     assert rel_l2(cg.weight.grad.cpu(), gr[1]) < 3e-2
     # d(gamma) is a cancelling sum over only 4*7*7 bf16-stored values per channel
     assert rel_l2(bg.weight.grad.cpu(), gr[2]) < 8e-2 and rel_l2(bg.bias.grad.cpu(), gr[3]) < 3e-2
+
+
+@pytest.mark.parametrize("act", ["mish", "leaky0.01", "none"])
+@pytest.mark.parametrize("cin,cout,k,stride,res", [(64, 64, 3, 1, True), (32, 96, 1, 1, False), (128, 256, 3, 2, False), (3, 32, 3, 1, False)])
+def test_inference_unit_is_one_launch_and_matches_fp32_eval(act, cin, cout, k, stride, res):
+    """Eval mode under no_grad: conv -> BatchNorm(running statistics) -> activation [+ residual] runs as ONE gather-conv launch with
+    the normalisation in its epilogue (round 6).  Checked against torch-CPU fp32 eval of the same modules (models/utils.py:73-84) and
+    against the three-launch path the same unit takes with autograd on."""
+    import torch.nn.functional as F
+    from torch import nn
+    from holocron_amd.nn import convbn_op as cb
+    from holocron_amd.ops import conv as cv
+    torch.manual_seed(cin + cout + k)
+    conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False)
+    conv.weight.data = conv.weight.data.to(torch.bfloat16).float()
+    bn = nn.BatchNorm2d(cout)
+    bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.uniform_(-0.5, 0.5)
+    bn.running_mean.uniform_(-0.3, 0.3); bn.running_var.uniform_(0.5, 2.0)
+    a = {"mish": nn.Mish(), "leaky0.01": nn.LeakyReLU(0.01), "none": None}[act]
+    x = torch.randn(3, cin, 20, 20).to(torch.bfloat16).float()
+    r = torch.randn(3, cout, 20, 20).to(torch.bfloat16).float() if res else None
+    conv.eval(); bn.eval()
+    with torch.no_grad():
+        ref = bn(conv(x))
+        if a is not None:
+            ref = a(ref)
+        if r is not None:
+            ref = ref + r
+    conv, bn = conv.cuda(), bn.cuda()
+    cv.PROFILE, cv.PROFILE_TAGS = [], []
+    try:
+        with torch.no_grad():
+            got = cb.conv_bn_act(x.cuda(), conv, bn, a, residual=None if r is None else r.cuda())
+        torch.cuda.synchronize()
+        fams = [p[0] for p in cv.PROFILE]
+    finally:
+        cv.PROFILE = cv.PROFILE_TAGS = None
+    assert [f for f in fams if f != "stem_im2col"] == ["conv_gather"], fams          # no BatchNorm launch
+    assert rel_l2(got.float().cpu(), ref) < 3e-3, rel_l2(got.float().cpu(), ref)   # one bf16 store of an fp32 result
+    three = cb.conv_bn_act(x.cuda().requires_grad_(True), conv, bn, a, residual=None if r is None else r.cuda())
+    assert rel_l2(three.float().cpu(), ref) < 6e-3
+    assert rel_l2(got.float().cpu(), three.float().cpu()) < 6e-3
