@@ -350,7 +350,7 @@ def main():
         # HBM bytes per launch from the PMC passes over this same command (scripts/pmc_step.sh; the counters cannot be read from
         # inside the process): taken from this round's committed file when there is one, else null
         traffic, traffic_src = None, None
-        for cand in ("r05_pmc_step_traffic.json", "r04_pmc_step_traffic.json", "r03_pmc_step_traffic.json", "r02_pmc_step_traffic.json"):
+        for cand in ("r06_pmc_step_traffic.json", "r05_pmc_step_traffic.json", "r04_pmc_step_traffic.json", "r03_pmc_step_traffic.json", "r02_pmc_step_traffic.json"):
             pmc_file = os.path.join(ROOT, "profiles", cand)
             if headline and args.batch == 256 and os.path.exists(pmc_file) and traffic is None:
                 with open(pmc_file) as fh:

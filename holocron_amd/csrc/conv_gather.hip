@@ -692,6 +692,9 @@ int launch_bk(const hc_conv_desc& d, hipStream_t st) {
 // (k32 stages: 24-32 KB of LDS each, at most 128 registers) cover one another's latencies instead of two.
 int launch_short(const hc_conv_desc& d, hipStream_t st) {
     const int C = d.Cout;
+    // (k64 steps - 128-byte rows, which the L2 serves at 53 B/clk/CU against 28 for the 64-byte rows of a k32 step,
+    // scripts/probes/fill_probe.hip - fit only three workgroups per CU and measured SLOWER: YOLOv4 26.26 -> 26.84 ms, rexnet1_0x
+    // 17.87 -> 18.00 ms, same box, two pairs.  Occupancy is what covers these launches, not the row width.)
     if (C <= 64) return launch_cfg<1, 2, 2, 2, 32, false, 2, 4>(d, st);
     if (C % 128 != 0 && C % 64 == 0) return launch_cfg<1, 2, 2, 2, 32, false, 2, 4>(d, st);
     return launch_cfg<2, 2, 2, 2, 32, false, 2, 4>(d, st);
@@ -783,6 +786,9 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
         const double ceff = (double)C / (double)(ct * bc);
         const double eff = ceff * ((double)M / (double)(pt * bp)) * ((double)tiles / (double)(rounds * 256));
         if (staged && S >= 16 && ceff >= 0.85 && eff >= big_eff) {
+            // (128-byte rows - BK = 64 - leave room for two stages only, one step ahead: YOLOv4 26.81 / 26.83 against 26.78 / 26.88 ms,
+            // the headline 10.33 against 10.35 ms on one box: no difference, as in round 3.  Three stages of 128-byte rows need a
+            // 256 x 128 tile whose waves read 1.25 fragments per MFMA instead of 0.75.)
             if (bc == 128) return launch_cfg<4, 2, 1, 8, 32, false, 4, 1>(d, st);
             return launch_cfg<4, 2, 2, 4, 32, false, 4, 1>(d, st);
         }

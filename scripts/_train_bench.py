@@ -191,7 +191,7 @@ def run(a, build_model, make_batch, loss_of, metric, workload, train_gflop_per_i
             traffic = traffic_src = None
             if traffic_key is not None:
                 import json as _json
-                for rnd in ("r05", "r04", "r03"):
+                for rnd in ("r06", "r05", "r04", "r03"):
                     pf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", f"{rnd}_pmc_{traffic_key}_traffic.json")
                     if traffic is None and os.path.exists(pf):
                         with open(pf) as fh:

@@ -84,7 +84,7 @@ def main():
         cv.PROFILE = None
     peak = 5.0e15     # dense fp8 through v_mfma_scale_f32_32x32x64_f8f6f4 (MI355X_MICROARCH.md: 4.6-4.7 PF measured at K = 128)
     traffic = src = None
-    for rnd in ("r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         pf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", rnd + "_pmc_repvgg_a2_fp8_traffic.json")
         if traffic is None and os.path.exists(pf):
             with open(pf) as fh:

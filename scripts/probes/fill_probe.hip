@@ -24,6 +24,29 @@ __device__ __forceinline__ void dma16(const u32x4 rsrc, unsigned lds_off, unsign
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // share: 0 = every workgroup its own region, 1 = the workgroups of an XCD (blockIdx % 8) share one region (weights-like)
+// Row mode: one DMA instruction fetches 1024 / rowb rows of `rowb` contiguous bytes each, `pitch` bytes apart (a k-slice of an NHWC
+// tensor: rowb = 2 BK bytes of a pixel whose channels span `pitch` bytes) - what the conv kernels' staging really issues.
+template <int DEPTH>
+__global__ __launch_bounds__(1024) void fill_rows_kernel(const char* src, unsigned region, int share, int iters, int rowb, int pitch,
+                                                         unsigned* sink) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const size_t rbase = (size_t)(share ? (blockIdx.x & 7) : blockIdx.x) * region;
+    const u32x4 rs = raw_rsrc(src + rbase, region);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem + (unsigned)wid * DEPTH * 1024u;
+    const int lpr = rowb / 16, rows = 64 / lpr;              // lanes per row, rows per instruction
+    unsigned off = ((unsigned)(wid * rows + lane / lpr) * (unsigned)pitch + (unsigned)(lane % lpr) * 16u) % region;
+    const unsigned stride = (unsigned)(nw * rows) * (unsigned)pitch;
+    for (int i = 0; i < iters; ++i) {
+        wait_vm<DEPTH - 1>();
+        dma16(rs, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(i % DEPTH) * 1024u), off);
+        off += stride;
+        if (off >= region) off -= region;
+    }
+    wait_vm<0>();
+    if (*reinterpret_cast<unsigned*>(smem + wid * DEPTH * 1024 + lane * 4) == 0x12345678u) sink[0] = 1;
+}
+
 template <int DEPTH, bool TO_LDS>
 __global__ __launch_bounds__(1024) void fill_kernel(const char* src, unsigned region, int share, int iters, unsigned* sink) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -83,7 +106,46 @@ double run(const char* src, unsigned region, int share, int waves, int wgs, int 
     return (double)wgs * waves * iters * 1024.0 / (ms * 1e-3);
 }
 
-int main() {
+double run_rows(const char* src, unsigned region, int share, int waves, int wgs, int iters, int rowb, int pitch) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    unsigned* sink; hipMalloc(&sink, 4);
+    auto k = fill_rows_kernel<4>;
+    const int smem = waves * 4 * 1024;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(k, dim3(wgs), dim3(64 * waves), smem, 0, src, region, share, iters, rowb, pitch, sink);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(wgs), dim3(64 * waves), smem, 0, src, region, share, iters, rowb, pitch, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipFree(sink);
+    return (double)wgs * waves * iters * 1024.0 / (ms * 1e-3);
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1) {          // ./fill_probe rows: the row-strided table only
+        const size_t total = (size_t)1 << 30;
+        char* src; hipMalloc(&src, total);
+        hipMemset(src, 1, total);
+        printf("%-34s %6s %6s %6s %10s %12s %10s\n", "source (L2-resident)", "rowB", "pitch", "waves", "TB/s chip", "GB/s per CU", "B/clk/CU");
+        for (int share = 1; share >= 0; --share)
+            for (int rowb : {1024, 256, 128, 64, 32})
+                for (int pitch : {0, 256, 512, 2560}) {
+                    const int pt = pitch == 0 ? rowb : pitch;
+                    if (pt < rowb) continue;
+                    for (int waves : {4, 8}) {
+                        const unsigned region = share ? (1u << 20) : (256u << 10);
+                        const double bps = run_rows(src, region, share, waves, 256, 4096, rowb, pt);
+                        printf("%-34s %6d %6d %6d %10.2f %12.1f %10.1f\n", share ? "1 MB shared per XCD" : "256 KB private per WG (64 MB: MALL)", rowb, pt, waves,
+                               bps / 1e12, bps / 256 / 1e9, bps / 256 / 2.4e9);
+                    }
+                }
+        hipFree(src);
+        return 0;
+    }
     const size_t total = (size_t)3 << 30;
     char* src; hipMalloc(&src, total);
     hipMemset(src, 1, total);
