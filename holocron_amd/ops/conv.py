@@ -622,6 +622,9 @@ class _ConvWgradQueue(_RepWgradQueue):
     def __init__(self):
         super().__init__()
         self.enabled = os.environ.get("HC_WGRAD_DEFER", "1") != "0"
+        # (a complete group launched on a second stream beside the rest of the pass - the RepBlock queue's HC_WREP_SIDE idea with a
+        # "group is complete" trigger - measured SLOWER on YOLOv4: 26.67 / 26.69 -> 27.53 / 27.56 ms, same box; the weight-gradient
+        # kernels and the main stream's passes compete for the same fill paths.  Removed; the groups run behind the pass.)
         self.side_on = False
 
     @staticmethod
