@@ -435,7 +435,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
             }
         }
         __syncthreads();
-        float* rep = d.stats + (size_t)(blockIdx.x % reps) * 2 * Cout;
+        float* rep = d.stats + (size_t)(bx % reps) * 2 * Cout;
         for (int i = tid; i < 2 * BC; i += NT) {
             const int which = i / BC, c = i - which * BC;
             if (cbase + c < Cout) {
@@ -446,8 +446,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
                 const int cg_ = cbase + c;
                 if (!BIG && d.co_split > 0) {      // stacked convolutions: each has its own statistics array
                     const int C1 = d.co_split, C2 = Cout - d.co_split;
-                    if (cg_ < C1) atomicAdd(d.stats + (size_t)(blockIdx.x % reps) * 2 * C1 + which * C1 + cg_, v);
-                    else atomicAdd(d.stats2 + (size_t)(blockIdx.x % reps) * 2 * C2 + which * C2 + (cg_ - C1), v);
+                    if (cg_ < C1) atomicAdd(d.stats + (size_t)(bx % reps) * 2 * C1 + which * C1 + cg_, v);
+                    else atomicAdd(d.stats2 + (size_t)(bx % reps) * 2 * C2 + which * C2 + (cg_ - C1), v);
                 } else {
                     atomicAdd(rep + which * Cout + cbase + c, v);
                 }

@@ -323,6 +323,17 @@ def _conv_passes(N, cin, H, cout, k, stride, seed, dev):
         ew = rel_l2(dw.cpu(), torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad))
         assert ew < TOL_F32, ("wgrad", ew)
         out.update(dgrad=ed, wgrad=ew)
+        # the grouped launch the training step really takes for this shape (round 6: same-shaped layers of a backward pass in one
+        # hc_conv_wgrad_group launch pair): three jobs at the group's split factor, every one against the fp32 reference
+        key = (N, cin, H, H, cout, k, k, stride, pad)
+        if cv._WCONV.supported(key):
+            outs = [torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev) for _ in range(3)]
+            cv._WCONV.launch(key, [(src, dyg, None, o.data_ptr(), 0) for o in outs], accumulate=False)
+            torch.cuda.synchronize()
+            ref_w = torch.nn.grad.conv2d_weight(x, w.shape, dy, stride, pad)
+            eg = max(rel_l2(o.cpu(), ref_w) for o in outs)
+            assert eg < TOL_F32, ("grouped wgrad", eg)
+            out.update(wgrad_group=eg)
     else:   # Cin = 3: explicit im2col, the weight gradient is a GEMM over the column tensor
         K = cin * k * k
         Kpad = (K + 15) // 16 * 16
