@@ -497,7 +497,10 @@ __device__ __forceinline__ float drop_scale(const float* __restrict__ count, lon
 // U pixels of a thread's channel group per iteration, all their loads requested before the first is used, and (NT) the non-temporal
 // hint for tensors far larger than the last-level cache - what the RepBlock passes have had since round 2.  With one pixel per iteration
 // a thread had one or two 16-byte loads in flight and the passes ran at 4.2-4.4 TB/s on the 257-617 MB tensors of ReXNet (round 5).
-template <bool HAS_RES, bool NT>
+// ACT: the activation code as a COMPILE-TIME constant (round 6).  With the runtime switch the compiler kept a chain of scalar compares
+// and branches around every one of a thread's eight elements (108-114 s_cbranch per kernel body, two v_exp_f32 per element in the
+// text): the small, cache-resident tensors of YOLOv4 (280 launches of 10-19 us per step) were issue-bound on that chain.
+template <bool HAS_RES, bool NT, int ACT>
 __global__ __launch_bounds__(EW_THREADS) void bn_act_apply_kernel(const u32x4* __restrict__ y, const float* __restrict__ coef,
                                                                   const u32x4* __restrict__ res, int res_cg,
                                                                   const float* __restrict__ keep, const float* __restrict__ count,
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_apply_kernel(const u32x4* _
             if (has_r) unpack8(vr[u], fr);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float z = act_fwd(a[i] * fy[i] + sh[i], act, slope);
+                float z = act_fwd(a[i] * fy[i] + sh[i], ACT, slope);
                 if (keep != nullptr) z *= kp[u];
                 if (has_r) z += fr[i];
                 if (keep2 != nullptr) z *= kp2[u];
@@ -552,6 +555,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_apply_kernel(const u32x4* _
     }
 }
 
+template <int ACT>
 __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32x4* __restrict__ g, int g_ld8,
                                                                        const u32x4* __restrict__ y, const float* __restrict__ coef,
                                                                        const float* __restrict__ keep, const float* __restrict__ count,
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32
         const float kp = (keep != nullptr ? keep[p] * dsc : 1.f) * (keep2 != nullptr ? keep2[p] * dsc2 : 1.f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float dz = fg[i] * kp * act_bwd(a[i] * fy[i] + sh[i], act, slope);
+            const float dz = fg[i] * kp * act_bwd(a[i] * fy[i] + sh[i], ACT, slope);
             sv[0][i] += dz;
             sv[1][i] += dz * fy[i];
         }
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_reduce_kernel(const u32
     block_reduce_flush<2>(sv, cg, C, red + (size_t)(blockIdx.x % reps) * 4 * C, sred, 2);
 }
 
-template <bool NT>
+template <bool NT, int ACT>
 __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_apply_kernel(const u32x4* __restrict__ g, int g_ld8,
                                                                       const u32x4* __restrict__ y, const float* __restrict__ coef,
                                                                       const float* __restrict__ bc, const float* __restrict__ keep,
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_act_bwd_apply_kernel(const u32x
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float dz = fg[i] * kp[u] * act_bwd(a[i] * fy[i] + sh[i], act, slope);
+                const float dz = fg[i] * kp[u] * act_bwd(a[i] * fy[i] + sh[i], ACT, slope);
                 o[i] = A[i] * dz + B[i] * fy[i] + Cc[i];
             }
             st16<NT>(dy + q, pack8(o));
@@ -1305,12 +1309,20 @@ int hc_bn_act_apply_post(const void* y, const float* coef, const void* res, int3
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8);
     hipStream_t st = (hipStream_t)stream;
-#define HC_BAA(RS, NTM)                                                                                                          \
-    hipLaunchKernelGGL((bn_act_apply_kernel<RS, NTM>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)y, coef, (const u32x4*)res, \
+    if (act < 0 || act > 6) return HC_ERR_ARG;
+#define HC_BAA(RS, NTM, A)                                                                                                       \
+    hipLaunchKernelGGL((bn_act_apply_kernel<RS, NTM, A>), dim3(blocks), dim3(EW_THREADS), 0, st, (const u32x4*)y, coef, (const u32x4*)res, \
                        RS ? res_C / 8 : 0, keep, count, (u32x4*)out, out_ld / 8, (long)npix, C, act, slope, keep2, count2)
+#define HC_BAA_ACT(RS, NTM)                                                                                                      \
+    switch (act) {                                                                                                               \
+        case 0: HC_BAA(RS, NTM, 0); break; case 1: HC_BAA(RS, NTM, 1); break; case 2: HC_BAA(RS, NTM, 2); break;                  \
+        case 3: HC_BAA(RS, NTM, 3); break; case 4: HC_BAA(RS, NTM, 4); break; case 5: HC_BAA(RS, NTM, 5); break;                  \
+        default: HC_BAA(RS, NTM, 6); break;                                                                                       \
+    }
     const bool nt = ba_streaming(nchunks);
-    if (res != nullptr) { if (nt) HC_BAA(true, true); else HC_BAA(true, false); }
-    else { if (nt) HC_BAA(false, true); else HC_BAA(false, false); }
+    if (res != nullptr) { if (nt) HC_BAA_ACT(true, true) else HC_BAA_ACT(true, false) }
+    else { if (nt) HC_BAA_ACT(false, true) else HC_BAA_ACT(false, false) }
+#undef HC_BAA_ACT
 #undef HC_BAA
     return hc_launch_status();
 }
@@ -1325,9 +1337,16 @@ int hc_bn_act_bwd_reduce_post(const void* g, int32_t g_ld, const void* y, const 
     if ((keep == nullptr) != (count == nullptr) || (keep2 == nullptr) != (count2 == nullptr)) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8, 16);
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(blocks), dim3(EW_THREADS), EW_THREADS * 17 * sizeof(float), (hipStream_t)stream,
-                       (const u32x4*)g, g_ld / 8, (const u32x4*)y, coef, keep, count, red, (long)npix, C, act, slope, hc_get_stat_replicas(),
-                       keep2, count2);
+    if (act < 0 || act > 6) return HC_ERR_ARG;
+#define HC_BAR(A)                                                                                                                  \
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<A>, dim3(blocks), dim3(EW_THREADS), EW_THREADS * 17 * sizeof(float), (hipStream_t)stream, \
+                       (const u32x4*)g, g_ld / 8, (const u32x4*)y, coef, keep, count, red, (long)npix, C, act, slope, hc_get_stat_replicas(), \
+                       keep2, count2)
+    switch (act) {
+        case 0: HC_BAR(0); break; case 1: HC_BAR(1); break; case 2: HC_BAR(2); break; case 3: HC_BAR(3); break;
+        case 4: HC_BAR(4); break; case 5: HC_BAR(5); break; default: HC_BAR(6); break;
+    }
+#undef HC_BAR
     return hc_launch_status();
 }
 int hc_bn_act_bwd_apply(const void* g, int32_t g_ld, const void* y, const float* coef, const float* bcoef, const float* keep,
@@ -1344,10 +1363,17 @@ int hc_bn_act_bwd_apply_post(const void* g, int32_t g_ld, const void* y, const f
     if (gres != nullptr && keep2 == nullptr) return HC_ERR_ARG;
     const long nchunks = (long)npix * (C / 8);
     const int blocks = ew_blocks(nchunks, C / 8);
-#define HC_BAB(NTM)                                                                                                          \
-    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<NTM>), dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u32x4*)g, g_ld / 8, \
+    if (act < 0 || act > 6) return HC_ERR_ARG;
+#define HC_BAB(NTM, A)                                                                                                       \
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<NTM, A>), dim3(blocks), dim3(EW_THREADS), 0, (hipStream_t)stream, (const u32x4*)g, g_ld / 8, \
                        (const u32x4*)y, coef, bcoef, keep, count, (u32x4*)dy, (long)npix, C, act, slope, keep2, count2, (u32x4*)gres)
-    if (ba_streaming(nchunks)) HC_BAB(true); else HC_BAB(false);
+#define HC_BAB_ACT(NTM)                                                                                                      \
+    switch (act) {                                                                                                           \
+        case 0: HC_BAB(NTM, 0); break; case 1: HC_BAB(NTM, 1); break; case 2: HC_BAB(NTM, 2); break; case 3: HC_BAB(NTM, 3); break; \
+        case 4: HC_BAB(NTM, 4); break; case 5: HC_BAB(NTM, 5); break; default: HC_BAB(NTM, 6); break;                         \
+    }
+    if (ba_streaming(nchunks)) HC_BAB_ACT(true) else HC_BAB_ACT(false)
+#undef HC_BAB_ACT
 #undef HC_BAB
     return hc_launch_status();
 }
