@@ -502,6 +502,25 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
     // per-channel scale / shift of the epilogue (inference BatchNorm, bias): ONE coalesced read per workgroup into an LDS table behind
     // the output staging area.  Read from global memory inside the store loop they were eight dependent loads per accumulator quad
     // that the compiler cannot hoist past the stores: ~20 us per launch, more than the BatchNorm launches the fused epilogue replaces.
+    // the activation of an accumulator quad: ONE uniform test per quad in front of a constant-folded body (Mish first: the inference
+    // epilogue of the YOLO stacks).  apply_act's switch evaluated per element is a chain of scalar compares and branches around every
+    // value - 64 chains per thread of a 128 x 128 tile, ~8 us per launch.
+    auto act_quad = [&](float (&q4)[4]) __attribute__((always_inline)) {
+        if (d.act == 0) return;
+        if (d.act == 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q4[e] = apply_act(q4[e], 4);
+        } else if (d.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q4[e] = apply_act(q4[e], 1);
+        } else if (d.act == 3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q4[e] = apply_act(q4[e], 3, aslope);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q4[e] = apply_act(q4[e], d.act, aslope);
+        }
+    };
     constexpr int COEF_OFF = (BP * OPITCH + 15) / 16 * 16;
     float* ctab = reinterpret_cast<float*>(smem + COEF_OFF);
     const bool has_coef = d.ch_scale != nullptr || d.bias != nullptr;
@@ -551,10 +570,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
                         v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]);
                         v[2] += bf16lo(rv[1]); v[3] += bf16hi(rv[1]);
                     }
-                    if (d.act != 0) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], d.act, aslope);
-                    }
+                    act_quad(v);
                     if (resid != nullptr && res_after) {
                         const u32x2 rv = *reinterpret_cast<const u32x2*>(resid + pofs + co);
                         v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]);
@@ -579,10 +595,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
                         v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]);
                         v[2] += bf16lo(rv[1]); v[3] += bf16hi(rv[1]);
                     }
-                    if (d.act != 0) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], d.act, aslope);
-                    }
+                    act_quad(v);
                     if (resid != nullptr && res_after) {
                         const u32x2 rv = *reinterpret_cast<const u32x2*>(resid + pofs + co);
                         v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]);
