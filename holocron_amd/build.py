@@ -16,7 +16,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 SOURCES = {
-    "conv_gather.hip": [],
+    # the epilogue's store loop is fully unrolled over the tile's accumulator quads (24-32 copies of its body); past LLVM's default
+    # pragma-unroll budget the loop stays rolled, the accumulator indices become dynamic and the 96-384 accumulator registers of a wave
+    # move to SCRATCH (round 6: the 192-channel tile lost 50 % that way when the inference epilogue grew the body -
+    # tests/test_host_logic.py::test_gather_conv_accumulators_stay_in_registers keeps watch)
+    "conv_gather.hip": ["-mllvm", "-pragma-unroll-threshold=131072"],
     "conv_pointwise.hip": [],
     "conv_small.hip": [],
     "conv_wgrad.hip": [],

@@ -502,25 +502,6 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
     // per-channel scale / shift of the epilogue (inference BatchNorm, bias): ONE coalesced read per workgroup into an LDS table behind
     // the output staging area.  Read from global memory inside the store loop they were eight dependent loads per accumulator quad
     // that the compiler cannot hoist past the stores: ~20 us per launch, more than the BatchNorm launches the fused epilogue replaces.
-    // the activation of an accumulator quad: ONE uniform test per quad in front of a constant-folded body (Mish first: the inference
-    // epilogue of the YOLO stacks).  apply_act's switch evaluated per element is a chain of scalar compares and branches around every
-    // value - 64 chains per thread of a 128 x 128 tile, ~8 us per launch.
-    auto act_quad = [&](float (&q4)[4]) __attribute__((always_inline)) {
-        if (d.act == 0) return;
-        if (d.act == 4) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) q4[e] = apply_act(q4[e], 4);
-        } else if (d.act == 1) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) q4[e] = apply_act(q4[e], 1);
-        } else if (d.act == 3) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) q4[e] = apply_act(q4[e], 3, aslope);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) q4[e] = apply_act(q4[e], d.act, aslope);
-        }
-    };
     constexpr int COEF_OFF = (BP * OPITCH + 15) / 16 * 16;
     float* ctab = reinterpret_cast<float*>(smem + COEF_OFF);
     const bool has_coef = d.ch_scale != nullptr || d.bias != nullptr;
@@ -565,16 +546,17 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
                     for (int e = 0; e < 4; ++e) v[e] = v[e] * cs[e] + cb[e];
                 }
                 if (staged) {
-                    if (resid != nullptr && !res_after) {
+                    float r4[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (resid != nullptr) {
                         const u32x2 rv = *reinterpret_cast<const u32x2*>(resid + pofs + co);
-                        v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]);
-                        v[2] += bf16lo(rv[1]); v[3] += bf16hi(rv[1]);
+                        r4[0] = bf16lo(rv[0]); r4[1] = bf16hi(rv[0]); r4[2] = bf16lo(rv[1]); r4[3] = bf16hi(rv[1]);
                     }
-                    act_quad(v);
-                    if (resid != nullptr && res_after) {
-                        const u32x2 rv = *reinterpret_cast<const u32x2*>(resid + pofs + co);
-                        v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]);
-                        v[2] += bf16lo(rv[1]); v[3] += bf16hi(rv[1]);
+                    if (d.act != 0) {              // (training units: no activation here, the residual order does not matter)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = apply_act(res_after ? v[e] : v[e] + r4[e], d.act, aslope) + (res_after ? r4[e] : 0.f);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += r4[e];
                     }
                     u32x2 o;
                     o[0] = pack_bf16x2(v[0], v[1]);
@@ -590,16 +572,17 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
                     o[1] = pack_bf16x2(v[2], v[3]);
                     *reinterpret_cast<u32x2*>(dp) = o;
                 } else if ((Cout & 3) == 0) {
-                    if (resid != nullptr && !res_after) {
+                    float r4[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (resid != nullptr) {
                         const u32x2 rv = *reinterpret_cast<const u32x2*>(resid + pofs + co);
-                        v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]);
-                        v[2] += bf16lo(rv[1]); v[3] += bf16hi(rv[1]);
+                        r4[0] = bf16lo(rv[0]); r4[1] = bf16hi(rv[0]); r4[2] = bf16lo(rv[1]); r4[3] = bf16hi(rv[1]);
                     }
-                    act_quad(v);
-                    if (resid != nullptr && res_after) {
-                        const u32x2 rv = *reinterpret_cast<const u32x2*>(resid + pofs + co);
-                        v[0] += bf16lo(rv[0]); v[1] += bf16hi(rv[0]);
-                        v[2] += bf16lo(rv[1]); v[3] += bf16hi(rv[1]);
+                    if (d.act != 0) {              // (training units: no activation here, the residual order does not matter)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = apply_act(res_after ? v[e] : v[e] + r4[e], d.act, aslope) + (res_after ? r4[e] : 0.f);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += r4[e];
                     }
                     u32x2 o;
                     o[0] = pack_bf16x2(v[0], v[1]);

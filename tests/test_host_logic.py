@@ -767,3 +767,22 @@ def test_conv_unit_wgrad_queue_groups_same_shaped_layers(monkeypatch):
     assert ("mid", float(ws[1].numel())) in seen
     assert torch.equal(ws[0].grad, torch.ones_like(ws[0])) and torch.equal(ws[1].grad, torch.ones_like(ws[1]))
     assert len(launches) == 2 and not q.armed and not q.jobs and not q.cb_tasks
+
+
+def test_gather_conv_accumulators_stay_in_registers(tmp_path):
+    """Compile-time guard (hipcc cross-compiles without a GPU): no instantiation of the gather-conv kernel may use scratch memory.  Its
+    epilogue is a fully unrolled loop over the accumulator quads; when the loop body outgrows the compiler's pragma-unroll budget the
+    accumulators are indexed dynamically and move to scratch - the kernel still computes the right values, 1.5 x slower (round 6: the
+    192-channel tile, found only by the headline's family timings)."""
+    import re
+    import subprocess
+    from holocron_amd import build as hb
+    src = os.path.join(hb.CSRC, "conv_gather.hip")
+    cmd = [hb.HIPCC] + hb.COMMON + hb.SOURCES["conv_gather.hip"] + ["-c", src, "-o", str(tmp_path / "cg.o"), "-Rpass-analysis=kernel-resource-usage"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    scratch = re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)
+    assert len(names) == len(scratch) and len(names) >= 20
+    bad = [(n[:60], s) for n, s in zip(names, scratch) if "conv_gather_kernel" in n and s != "0"]
+    assert not bad, bad
