@@ -58,6 +58,10 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
     const hc_conv_class& cl = d.cls[blockIdx.z];
     const int OHg = cl.OHg, OWg = cl.OWg;
     const int M = d.N * OHg * OWg;
+    // the class grid IS the output grid (every stride-1 forward conv and data gradient): output pixel index = m, no (n, i, j) decode - two
+    // integer divisions per store of the epilogue's staged loop otherwise, ~1 us per workgroup whose whole life may be 10 us (1 x 1 layers).
+    // Same box, two pairs (with the pure-1x1 prologue below): YOLOv4 26.17 -> 25.60 ms, rexnet1_0x 17.25 -> 16.89 ms
+    const bool lin_out = cl.ostep == 1 && cl.oy0 == 0 && cl.ox0 == 0 && OHg == d.OH && OWg == d.OW;
     // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), so a plain
     // (pixel tile, channel tile) grid puts every channel tile that is in flight on every XCD and the weight tiles thrash the
     // 4 MB L2s.  Give XCD k the k-th contiguous run of the channel-tile-major list instead: the workgroups that share an L2 share
@@ -93,12 +97,19 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
     // Per staged row: byte offset of (tap offset (0,0), this lane's logical chunk) and a bitmask of
     // the taps whose source pixel is inside the image -> the per-step address is one add + select.
     unsigned x_base[XJ], x_vmask[XJ];
+    // a pure 1 x 1 (one tap at offset (0, 0), source grid = class grid): source pixel = m, always inside the image - no decode
+    const bool lin_in = cl.ntaps == 1 && (cl.tap[0] & 0xffff) == 0 && cl.istep == 1 && IH == OHg && IW == OWg;
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
         const int row = (wid + j * NW) * RPI + lrow;
         const int m = pbase + row;
         const bool ok = (wid + j * NW < XQ) && (m < M);
         const int mm = ok ? m : 0;
+        if (lin_in) {
+            x_base[j] = (unsigned)mm * (unsigned)srcC * 2u + (unsigned)((lpc ^ ((row / (16 / NC)) % NC)) * 16);
+            x_vmask[j] = ok ? 1u : 0u;
+            continue;
+        }
         const int n = mm / (OHg * OWg);
         const int rem = mm - n * (OHg * OWg);
         const int oi = rem / OWg, oj = rem - oi * OWg;
@@ -517,10 +528,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
     for (int nr = 0; nr < NR; ++nr) {
         const int m = pbase + (wn * NR + nr) * 32 + lr;
         if (m >= M) continue;
-        const int n = m / (OHg * OWg);
-        const int rem = m - n * (OHg * OWg);
-        const int oi = rem / OWg, oj = rem - oi * OWg;
-        const long pix = ((long)n * d.OH + (oi * cl.ostep + cl.oy0)) * d.OW + (oj * cl.ostep + cl.ox0);
+        long pix = m;
+        if (!lin_out) {
+            const int n = m / (OHg * OWg);
+            const int rem = m - n * (OHg * OWg);
+            const int oi = rem / OWg, oj = rem - oi * OWg;
+            pix = ((long)n * d.OH + (oi * cl.ostep + cl.oy0)) * d.OW + (oj * cl.ostep + cl.ox0);
+        }
         const long pofs = pix * Cout;
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
@@ -609,10 +623,13 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
             const int pl = i / CPR, ch = i - pl * CPR;
             const int m = pbase + pl, co = cbase + ch * 8;
             if (m >= M || co >= Cout) continue;
-            const int n = m / (OHg * OWg);
-            const int rem = m - n * (OHg * OWg);
-            const int oi = rem / OWg, oj = rem - oi * OWg;
-            const long pix = ((long)n * d.OH + (oi * cl.ostep + cl.oy0)) * d.OW + (oj * cl.ostep + cl.ox0);
+            long pix = m;
+            if (!lin_out) {
+                const int n = m / (OHg * OWg);
+                const int rem = m - n * (OHg * OWg);
+                const int oi = rem / OWg, oj = rem - oi * OWg;
+                pix = ((long)n * d.OH + (oi * cl.ostep + cl.oy0)) * d.OW + (oj * cl.ostep + cl.ox0);
+            }
             const u32x2 lo = *reinterpret_cast<const u32x2*>(ost + pl * OPITCH + ch * 16);
             const u32x2 hi = *reinterpret_cast<const u32x2*>(ost + pl * OPITCH + ch * 16 + 8);
             const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
