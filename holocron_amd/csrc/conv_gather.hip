@@ -812,6 +812,14 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
     if (short_on && d.nclass == 1 && d.cls[0].ntaps == 1 && d.srcC % 32 == 0 && d.srcC <= short_on && d.co_split == 0 && d.pix_scale == nullptr &&
         d.Cout % 8 == 0)
         return launch_short(d, st);
+    // ... and ANY launch whose longest parity class has at most 36 k32 steps (taps x channels <= 1152: the 3 x 3 layers over <= 128
+    // channels, the stride-2 data gradients of the 304^2 / 608^2 maps): YOLOv4 26.36 -> 26.10 ms and 26.3 -> 25.75 ms on two boxes
+    // (taps x channels <= 640: 26.14; <= 2304: 25.9; <= 4608: 26.35 = none); headline and rexnet1_0x unchanged
+    if (short_on && d.srcC % 32 == 0 && d.co_split == 0 && d.pix_scale == nullptr && d.Cout % 8 == 0) {
+        int mt = 0;
+        for (int c = 0; c < d.nclass; ++c) mt = d.cls[c].ntaps > mt ? d.cls[c].ntaps : mt;
+        if (mt > 1 && mt * d.srcC <= 1152) return launch_short(d, st);
+    }
     // `bk_cap` caps the k-step (a 192-channel tile with 64-channel k-steps stages 2 x 40 KB - two workgroups need the
     // whole 160 KB of LDS)
     constexpr int bk_cap = 64;                      // k-step cap (32 measured 3 % slower on the ReXNet 1 x 1 layers, round 4)
