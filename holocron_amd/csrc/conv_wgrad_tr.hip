@@ -288,7 +288,7 @@ inline Plan make_plan_seg(const hc_wgrad_desc& d, int NR, int nseg) {
     // ci tile = 16*MR: the largest supported MR that divides Cin/16
     const int c16 = d.Cin / 16;
     int MR = 0;
-    for (int m : {8, 6, 4, 3, 2})
+    for (int m : {8, 6, 4, 3, 2, 1})       // (1: 16-channel inputs - ReXNet's first expansion 16 -> 96 @ 112 ran the generic kernel at 1.5 TB/s)
         if (c16 % m == 0) { MR = m; break; }
     if (MR == 0) return pl;
     int TG = T;
@@ -408,9 +408,11 @@ static int dispatch(wtr::Plan& pl, hipStream_t st, bool do_launch) {
     if (pl.MR == M && pl.NR == N && pl.TG == G) \
         return pl.a.nseg > 1 ? wtr::launch<M, N, G, true>(pl, st, do_launch) : wtr::launch<M, N, G, false>(pl, st, do_launch);
     if (T == 1) {
+        WTR_CASE(1, 1, 1) WTR_CASE(1, 2, 1)
         WTR_CASE(2, 1, 1) WTR_CASE(3, 1, 1) WTR_CASE(4, 1, 1) WTR_CASE(6, 1, 1) WTR_CASE(8, 1, 1)
         WTR_CASE(2, 2, 1) WTR_CASE(3, 2, 1) WTR_CASE(4, 2, 1) WTR_CASE(6, 2, 1) WTR_CASE(8, 2, 1)
     } else {
+        WTR_CASE(1, 1, 9) WTR_CASE(1, 2, 9)
         WTR_CASE(2, 1, 9) WTR_CASE(3, 1, 9) WTR_CASE(4, 1, 9) WTR_CASE(6, 1, 3) WTR_CASE(8, 1, 3)
         WTR_CASE(2, 2, 9) WTR_CASE(3, 2, 3) WTR_CASE(4, 2, 3) WTR_CASE(6, 2, 3) WTR_CASE(8, 2, 1)
     }

@@ -121,7 +121,9 @@ def test_dual_branch_dgrad_matches_autograd(N, Cin, Cout, H, W, stride):
 
 
 @pytest.mark.parametrize("N,Cin,Cout,H,W,k,stride", [(2, 16, 48, 12, 12, 3, 1), (3, 48, 48, 11, 9, 3, 2), (2, 64, 192, 9, 9, 3, 1),
-                                                       (2, 192, 64, 8, 8, 1, 1), (4, 32, 96, 7, 7, 1, 2), (2, 136, 200, 6, 6, 3, 1)])
+                                                       (2, 192, 64, 8, 8, 1, 1), (4, 32, 96, 7, 7, 1, 2), (2, 136, 200, 6, 6, 3, 1),
+                                                       # 16 input channels: the transposing kernel's 16-channel tile (round 6; ReXNet's 16 -> 96 expansion)
+                                                       (2, 16, 96, 20, 20, 1, 1), (3, 16, 32, 9, 9, 1, 2), (1, 16, 160, 10, 10, 3, 1), (2, 16, 144, 130, 7, 1, 1)])
 def test_wgrad_matches_autograd(N, Cin, Cout, H, W, k, stride):
     from holocron_amd.ops import conv as cv
     torch.manual_seed(Cin * 3 + Cout)
