@@ -806,12 +806,23 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
             return launch_cfg<4, 2, 2, 4, 32, false, 4, 1>(d, st);
         }
     }
-    // HC_CONV_SHORT=n: 1 x 1 convolutions over at most n channels take the short-loop form (0 = never).  Default 1024: rexnet1_0x
-    // 18.27 -> 17.74 ms per step (same box; n = 256: 17.80), YOLOv4 26.31 -> 26.19 ms
+    // HC_CONV_SHORT=n: 1 x 1 convolutions over at most n channels MAY take the short-loop form (0 = never).  Which do is decided by
+    // the per-shape tables of one YOLOv4 and one rexnet1_0x step, each on one box (profiles/r06_short_form_by_shape.txt):
+    //   <= 128 channels: always (31 -> 24 us on 128@76 -> 128, 222 -> 150 us on 64@304 -> 128, 196 -> 97 us on 32@56 -> 192);
+    //   129-256 channels: when the launch has >= 11 M output elements (HC_CONV_SHORT_WORK) - wins on YOLOv4's 76 x 76 maps, on
+    //     256@38 -> 512 (34 -> 26 us) and on rexnet's 160 / 192@7 -> 896..1088 (50 -> 28 us), LOSES on 256@38 -> 256 (18 -> 26 us);
+    //   above: only with <= 128 output channels (rexnet's 14 x 14 projections: 51 -> 44 us on 704 -> 128); 512 / 1024 -> 256..1024 on
+    //     19 x 19 / 38 x 38 maps lose 30-40 % (1024@19 -> 512: 28 -> 40 us): 16-32 k32 steps are a loop the classic form's 128-byte rows
+    //     feed better, and those grids have too few tiles for four workgroups per CU to matter.
+    // HC_CONV_SHORT_ALL=1: every 1 x 1 launch up to n channels (the rule before this table)
     static const int short_on = [] { const char* e = getenv("HC_CONV_SHORT"); return e == nullptr ? 1024 : atoi(e); }();
+    static const double short_work = [] { const char* e = getenv("HC_CONV_SHORT_WORK"); return e == nullptr ? 11.0e6 : atof(e); }();
+    static const bool short_all = [] { const char* e = getenv("HC_CONV_SHORT_ALL"); return e != nullptr && atoi(e) != 0; }();
     if (short_on && d.nclass == 1 && d.cls[0].ntaps == 1 && d.srcC % 32 == 0 && d.srcC <= short_on && d.co_split == 0 && d.pix_scale == nullptr &&
-        d.Cout % 8 == 0)
-        return launch_short(d, st);
+        d.Cout % 8 == 0) {
+        const double work = (double)d.N * d.cls[0].OHg * d.cls[0].OWg * d.Cout;
+        if (short_all || d.srcC <= 128 || (d.srcC <= 256 ? work >= short_work : d.Cout <= 128)) return launch_short(d, st);
+    }
     // ... and ANY launch whose longest parity class has at most 36 k32 steps (taps x channels <= 1152: the 3 x 3 layers over <= 128
     // channels, the stride-2 data gradients of the 304^2 / 608^2 maps): YOLOv4 26.36 -> 26.10 ms and 26.3 -> 25.75 ms on two boxes
     // (taps x channels <= 640: 26.14; <= 2304: 25.9; <= 4608: 26.35 = none); headline and rexnet1_0x unchanged

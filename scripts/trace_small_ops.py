@@ -1,25 +1,42 @@
-"""Where do the small torch kernels of the headline step come from?  One eager repvgg_a0 step under torch.profiler with Python stacks:
-every op that launches a fill / copy / torch elementwise kernel, grouped by its innermost holocron_amd / bench frame."""
+"""Where do the small torch kernels of a training step come from?  One eager step (repvgg_a0 by default, `yolov4` as first argument for
+the YOLOv4 608^2 batch-16 step) under torch.profiler with Python stacks: every op that launches a fill / copy / torch elementwise
+kernel, grouped by its innermost holocron_amd / bench frame."""
 import collections
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import holocron_amd as h
 from torch.profiler import profile, ProfilerActivity
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-model = h.models.repvgg_a0(num_classes=10).to(dev).train()
-opt = h.optim.AdaBelief(model.parameters(), lr=1e-3, betas=(0.95, 0.99), eps=1e-6, weight_decay=0.0)
-x = torch.rand((256, 3, 224, 224), device=dev)
-t = torch.randint(0, 10, (256,), device=dev)
+which = sys.argv[1] if len(sys.argv) > 1 else "repvgg_a0"
 loss_buf = torch.zeros((), device=dev)
+if which == "yolov4":
+    import bench_yolov4 as by_
+    from holocron_amd.models.detection.yolov4 import PackedTargets
+    model = h.models.detection.yolov4(pretrained_backbone=False, num_classes=80).to(dev).train()
+    g_ = torch.Generator().manual_seed(0)
+    x = torch.rand((16, 3, 608, 608), generator=g_).to(dev)
+    tg = PackedTargets(by_.targets(16, g_, dev), dev)
+
+    def loss_of():
+        return sum(v.sum() for v in model(x, tg).values())
+else:
+    model = h.models.repvgg_a0(num_classes=10).to(dev).train()
+    x = torch.rand((256, 3, 224, 224), device=dev)
+    t = torch.randint(0, 10, (256,), device=dev)
+
+    def loss_of():
+        return h.nn.functional.cross_entropy(model(x), t, label_smoothing=0.1)
+opt = h.optim.AdaBelief(model.parameters(), lr=1e-3, betas=(0.95, 0.99), eps=1e-6, weight_decay=0.0)
 
 
 def step():
     opt.zero_grad(set_to_none=True)
-    loss = h.nn.functional.cross_entropy(model(x), t, label_smoothing=0.1)
+    loss = loss_of()
     loss.backward()
     loss_buf.copy_(loss.detach())
     opt.step()
