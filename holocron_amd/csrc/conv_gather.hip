@@ -685,7 +685,7 @@ int launch_bk(const hc_conv_desc& d, hipStream_t st) {
     // 46 / 181 pixel tiles) has fewer 128-channel tiles than the 512 workgroup slots of the chip - 64-channel tiles double the
     // workgroups (below `fill` = 400 tiles).  YOLOv4 608^2 batch 16, same box: 29.19 ms per step without
     // the rule, 29.08 / 28.68 / 28.75 with n = 256 / 400 / 600
-    constexpr int fill = 400;
+    static const int fill = [] { const char* e = getenv("HC_CONV_FILL"); return e == nullptr ? 400 : atoi(e); }();
     if (fill > 0 && C % 64 == 0) {
         long maxM = 0;
         for (int c = 0; c < d.nclass; ++c) {
@@ -758,6 +758,29 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
         if ((double)d.N * d.IH * d.IW * d.srcC >= 4294967280.0) return HC_ERR_ARG;
         return launch_fp8(d, st);
     }
+    // SHORT-LOOP form for multi-tap launches whose longest parity class has at most 36 k32 steps (taps x channels <= 1152: the 3 x 3
+    // layers over <= 128 channels, the stride-2 data gradients of the 304^2 / 608^2 maps): YOLOv4 26.36 -> 26.10 ms and 26.3 -> 25.75 ms
+    // on two boxes (taps x channels <= 640: 26.14; <= 2304: 25.9; <= 4608: 26.35 = none); headline and rexnet1_0x unchanged.  It is
+    // asked BEFORE the big tile: on 128@76 x 76 (3 x 3, batch 16) the big tile was dispatched at 61 / 53 us forward / data gradient
+    // where this form takes 48 / 45 us (per-shape table, profiles/r06_dispatch_by_shape.txt); 3 x 3 over 256 channels loses in this
+    // form (256@38: 49 -> 66 us).  HC_CONV_SHORT_FIRST=0 restores the old order.
+    static const int short_gate = [] { const char* e = getenv("HC_CONV_SHORT"); return e == nullptr ? 1024 : atoi(e); }();
+    static const int short_taps = [] { const char* e = getenv("HC_CONV_SHORT_TAPS"); return e == nullptr ? 1152 : atoi(e); }();
+    static const int short_first = [] { const char* e = getenv("HC_CONV_SHORT_FIRST"); return e == nullptr ? 1 : atoi(e); }();
+    static const double short_work_mt = [] { const char* e = getenv("HC_CONV_SHORT_WORK_MT"); return e == nullptr ? 11.0e6 : atof(e); }();
+    auto short_multitap = [&]() {
+        if (!(short_gate && d.srcC % 32 == 0 && d.co_split == 0 && d.pix_scale == nullptr && d.Cout % 8 == 0)) return false;
+        int mt = 0;
+        double work = 0.0;
+        for (int c = 0; c < d.nclass; ++c) {
+            mt = d.cls[c].ntaps > mt ? d.cls[c].ntaps : mt;
+            work += (double)d.N * d.cls[c].OHg * d.cls[c].OWg * d.Cout;
+        }
+        // ... and up to twice that loop length when the launch is large (>= 11 M outputs, as for the 1 x 1 rule below): 3 x 3 over 256
+        // channels, 256@38 -> 512: 85 -> 79 us, 256@76 -> 128: 83 -> 74 us (both from the big tile); 256@38 -> 256 stays (49 -> 66 us)
+        return mt > 1 && (mt * d.srcC <= short_taps || (mt * d.srcC <= 2 * short_taps && work >= short_work_mt));
+    };
+    if (short_first && short_multitap()) return launch_short(d, st);
     // Big-tile form (256 x 256, see the kernel): one workgroup per CU, so it only pays when the tile count fills whole rounds of the
     // 256 CUs (RepVGG-A0's 1280-channel layers at batch 256: 49 x 5 = 245 tiles).  HC_CONV_BIG=0 sends these layers back to the
     // 128 x 128 tile (same-box A/B), =2 picks the four-wave form.  Measured on those layers (scripts/bench_block1280.py, us per
@@ -823,14 +846,7 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
         const double work = (double)d.N * d.cls[0].OHg * d.cls[0].OWg * d.Cout;
         if (short_all || d.srcC <= 128 || (d.srcC <= 256 ? work >= short_work : d.Cout <= 128)) return launch_short(d, st);
     }
-    // ... and ANY launch whose longest parity class has at most 36 k32 steps (taps x channels <= 1152: the 3 x 3 layers over <= 128
-    // channels, the stride-2 data gradients of the 304^2 / 608^2 maps): YOLOv4 26.36 -> 26.10 ms and 26.3 -> 25.75 ms on two boxes
-    // (taps x channels <= 640: 26.14; <= 2304: 25.9; <= 4608: 26.35 = none); headline and rexnet1_0x unchanged
-    if (short_on && d.srcC % 32 == 0 && d.co_split == 0 && d.pix_scale == nullptr && d.Cout % 8 == 0) {
-        int mt = 0;
-        for (int c = 0; c < d.nclass; ++c) mt = d.cls[c].ntaps > mt ? d.cls[c].ntaps : mt;
-        if (mt > 1 && mt * d.srcC <= 1152) return launch_short(d, st);
-    }
+    if (!short_first && short_multitap()) return launch_short(d, st);
     // `bk_cap` caps the k-step (a 192-channel tile with 64-channel k-steps stages 2 x 40 KB - two workgroups need the
     // whole 160 KB of LDS)
     constexpr int bk_cap = 64;                      // k-step cap (32 measured 3 % slower on the ReXNet 1 x 1 layers, round 4)

@@ -1,5 +1,6 @@
-"""Joins the per-shape rows of `scripts/layer_table.py` runs made with different HC_CONV_SHORT settings (one box) into one table:
-which 1 x 1 / short-loop gather-conv shapes prefer the four-workgroups-per-CU form.  usage: short_form_table.py prefix (files prefix_N.txt)"""
+"""Joins the per-shape conv_gather rows of `scripts/layer_table.py` runs made under different dispatch settings (one box) into one
+table: which shapes prefer which form.  usage: short_form_table.py file1 file2 ... (column = file name)"""
+import os
 import re
 import sys
 
@@ -14,11 +15,15 @@ def load(f):
     return d
 
 
-pre = sys.argv[1]
-keys = (0, 128, 256, 1024)
-T = {s: load(f'{pre}_{s}.txt') for s in keys}
+files = sys.argv[1:]
+T = [load(f) for f in files]
+names = [os.path.basename(f).replace('.txt', '')[-9:] for f in files]
 rows = sorted(T[0], key=lambda k: -T[0][k][0] * T[0][k][1])
-print(f"{'shape (us per launch at HC_CONV_SHORT = ...)':62s}  n      0    128    256   1024")
+print(f"{'shape (us per launch)':62s}  n " + " ".join(f"{n:>9s}" for n in names))
+tot = [0.0] * len(T)
 for k in rows:
-    if all(k in T[s] for s in T):
-        print(f"{k:62s} {T[0][k][0]:2d} " + " ".join(f"{T[s][k][1]:6.1f}" for s in keys))
+    if all(k in t for t in T):
+        print(f"{k:62s} {T[0][k][0]:2d} " + " ".join(f"{t[k][1]:9.1f}" for t in T))
+        for i, t in enumerate(T):
+            tot[i] += t[k][0] * t[k][1]
+print(f"{'total us per step over the common rows':62s}    " + " ".join(f"{v:9.0f}" for v in tot))
