@@ -44,9 +44,11 @@ typedef __attribute__((ext_vector_type(8))) int hc_i32x8;
 template <int MR, int NR, int WM, int WN, int BK, bool FP8, int NS = 2, int MINB = 2>
 __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const hc_conv_desc d, const int reps, const int flags) {
     static_assert(!FP8 || BK == 32, "fp8: 64 one-byte channels per k-step");
-    constexpr bool BIG = MINB == 1;       // one workgroup per CU: asm-issued DMA, skewed fragment schedule, pruned epilogue
-    static_assert(!BIG || !FP8, "the big-tile form is bf16 only");
-    static_assert(BIG || NS == 2, "the classic form is double-buffered");
+    // BIG = the deep-pipeline loop (asm-issued DMA NS - 1 steps ahead, skewed fragment schedule, pruned epilogue): the big tiles with one
+    // workgroup per CU (MINB = 1) and, since round 6, the classic 128 x 64 / 128 x 128 tiles with two (NS = 3 / 4, MINB = 2) for
+    // launches with long k-loops and few tiles - see `launch_deep`
+    constexpr bool BIG = NS > 2;
+    static_assert(!BIG || !FP8, "the deep-pipeline form is bf16 only");
     constexpr int NT = 64 * WM * WN;
     constexpr int BC = 32 * MR * WM;  // output-channel tile (A rows)
     constexpr int BP = 32 * NR * WN;  // output-pixel tile (B cols)
@@ -647,7 +649,7 @@ template <int MR, int NR, int WM, int WN, int BK, bool FP8 = false, int NS = 2, 
 int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
     constexpr int BC = 32 * MR * WM, BP = 32 * NR * WN;
     // k-loop stages (+ the big-tile form's scratch slots for padding weight pieces) / output staging
-    constexpr int smem_k = NS * (BC + BP) * BK * 2 + ((MINB == 1 && (BC * BK / 512) % (WM * WN) != 0) ? WM * WN * 1024 : 0), smem_o = BP * (BC * 2 + 8);
+    constexpr int smem_k = NS * (BC + BP) * BK * 2 + ((NS > 2 && (BC * BK / 512) % (WM * WN) != 0) ? WM * WN * 1024 : 0), smem_o = BP * (BC * 2 + 8);
     static_assert(smem_k <= 160 * 1024 && smem_o <= 160 * 1024, "LDS budget");
     constexpr int smem_c = (smem_o + 15) / 16 * 16 + 2 * BC * 4;          // output staging + the epilogue's scale / shift table
     static_assert(smem_c <= 160 * 1024, "LDS budget");
@@ -711,6 +713,28 @@ int launch_short(const hc_conv_desc& d, hipStream_t st) {
     if (C <= 64) return launch_cfg<1, 2, 2, 2, 32, false, 2, 4>(d, st);
     if (C % 128 != 0 && C % 64 == 0) return launch_cfg<1, 2, 2, 2, 32, false, 2, 4>(d, st);
     return launch_cfg<2, 2, 2, 2, 32, false, 2, 4>(d, st);
+}
+
+// LONG k-loops on FEW tiles (YOLOv4's 3 x 3 layers over 256-1024 channels on 19 x 19 / 38 x 38 maps at batch 16: 72-288 k32 steps, 46-181
+// pixel tiles): the classic form keeps ONE step of DMA in flight, and with one or two workgroups on a CU a step then costs an L2 / Infinity
+// Cache round trip (~2000 clocks per k64 step measured on 1024@19 -> 512: 135 us, 0.16 of peak) however small the tile's MFMA work is
+// (256 clocks).  Same tiles, same two workgroups per CU, but the big-tile form's loop: stages issued NS - 1 steps ahead with counted
+// waits, pieces inside the MFMA stream.
+// Per-shape table (profiles/r06_deep_by_shape.txt, us per launch, YOLOv4 batch 16): 1024@19 -> 512 3 x 3 135 -> 92, 512@19 -> 512 3 x 3 73 -> 53,
+// 256@38 -> 512@19 46 -> 35, 2048@19 -> 512 1 x 1 46 -> 37 - the launches of at most 512 such workgroups.  With more (256@38 -> 256 3 x 3:
+// 724) the 74 KB of three k64 stages make two rounds of what the classic form (49 KB: three per CU) runs in one: 48 -> 53-57 us in this
+// form, as in every variant tried for them (128 x 128 tiles with four k32 stages, two per CU: 53; 128 x 64 with four k32 stages, three per
+// CU: 57; 128 x 128 with three k64 stages, one per CU: 77) - those launches keep the classic form (-1).
+int launch_deep(const hc_conv_desc& d, hipStream_t st) {
+    const int C = d.Cout;
+    long maxM = 0;
+    for (int c = 0; c < d.nclass; ++c) {
+        const long m = (long)d.N * d.cls[c].OHg * d.cls[c].OWg;
+        if (m > maxM) maxM = m;
+    }
+    const long wg64 = ((maxM + 127) / 128) * ((C + 63) / 64) * d.nclass;
+    if ((C <= 64 || C % 64 == 0) && wg64 <= 512) return launch_cfg<1, 2, 2, 2, 64, false, 3, 2>(d, st);
+    return -1;
 }
 
 // fp8 inference: the descriptor arrives with srcC in channels (= bytes); the kernel sees it in 2-byte units
@@ -847,6 +871,21 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
         if (short_all || d.srcC <= 128 || (d.srcC <= 256 ? work >= short_work : d.Cout <= 128)) return launch_short(d, st);
     }
     if (!short_first && short_multitap()) return launch_short(d, st);
+    // HC_CONV_DEEP=0 switches the deep-pipeline loop on the classic tile off (A/B); it is asked for launches with at least 16 k32 steps in
+    // every parity class (HC_CONV_DEEP_S; 32: 10 109 against 10 015 us of gather-conv per YOLOv4 step)
+    static const int deep = [] { const char* e = getenv("HC_CONV_DEEP"); return e == nullptr ? 1 : atoi(e); }();
+    static const int deep_s = [] { const char* e = getenv("HC_CONV_DEEP_S"); return e == nullptr ? 16 : atoi(e); }();
+    if (deep && d.co_split == 0 && d.pix_scale == nullptr && d.srcC % 64 == 0 && d.Cout % 8 == 0) {
+        int ms = 1 << 30;
+        for (int c = 0; c < d.nclass; ++c) {
+            const int sc = d.cls[c].ntaps * (d.srcC / 32);
+            ms = sc < ms ? sc : ms;
+        }
+        if (ms >= deep_s) {
+            const int rc = launch_deep(d, st);
+            if (rc != -1) return rc;
+        }
+    }
     // `bk_cap` caps the k-step (a 192-channel tile with 64-channel k-steps stages 2 x 40 KB - two workgroups need the
     // whole 160 KB of LDS)
     constexpr int bk_cap = 64;                      // k-step cap (32 measured 3 % slower on the ReXNet 1 x 1 layers, round 4)
