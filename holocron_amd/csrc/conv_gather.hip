@@ -57,25 +57,37 @@ __global__ __launch_bounds__(64 * WM * WN, MINB) void conv_gather_kernel(const h
     constexpr int STAGE = (BC + BP) * BK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const hc_conv_class& cl = d.cls[blockIdx.z];
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), so a plain
+    // (pixel tile, channel tile) grid puts every channel tile that is in flight on every XCD and the weight tiles thrash the
+    // 4 MB L2s.  Give XCD k the k-th contiguous run of the channel-tile-major list instead: the workgroups that share an L2 share
+    // one weight tile and walk neighbouring pixel tiles.  flags & 2: the parity classes of a stride-2 data gradient (grid z) are the
+    // FASTEST index of that list - the four classes of a pixel tile read the same source pixels, and with z slowest a source tensor too
+    // large for the caches is streamed four times (64@304 -> 32@608: 4 x 189 MB of reads for 378 MB of stores, 340 -> 303 us).  Only
+    // then: the classes use different weight taps, and on the smaller maps (128@152 -> 64@304 and below) mixing them costs 7-12 %.
+    int bx, by, bz = blockIdx.z;
+    if (gridDim.z > 1 && (flags & 2) != 0) {
+        const int gx = gridDim.x, ncls = gridDim.z;
+        const int T = gx * gridDim.y * ncls, L = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
+        const int q = T >> 3, r = T & 7, xcd = L & 7, j = L >> 3;
+        int tile = xcd * q + (xcd < r ? xcd : r) + j;
+        bz = tile % ncls;
+        tile /= ncls;
+        by = tile / gx;
+        bx = tile - by * gx;
+    } else {      // per class plane (the classes have 1 / 2 / 2 / 4 taps: one run of a z-major list per XCD would leave the XCDs unevenly loaded)
+        const int gx = gridDim.x, T = gx * gridDim.y, L = blockIdx.y * gx + blockIdx.x;
+        const int q = T >> 3, r = T & 7, xcd = L & 7, j = L >> 3;
+        const int tile = xcd * q + (xcd < r ? xcd : r) + j;
+        by = tile / gx;
+        bx = tile - by * gx;
+    }
+    const hc_conv_class& cl = d.cls[bz];
     const int OHg = cl.OHg, OWg = cl.OWg;
     const int M = d.N * OHg * OWg;
     // the class grid IS the output grid (every stride-1 forward conv and data gradient): output pixel index = m, no (n, i, j) decode - two
     // integer divisions per store of the epilogue's staged loop otherwise, ~1 us per workgroup whose whole life may be 10 us (1 x 1 layers).
     // Same box, two pairs (with the pure-1x1 prologue below): YOLOv4 26.17 -> 25.60 ms, rexnet1_0x 17.25 -> 16.89 ms
     const bool lin_out = cl.ostep == 1 && cl.oy0 == 0 && cl.ox0 == 0 && OHg == d.OH && OWg == d.OW;
-    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), so a plain
-    // (pixel tile, channel tile) grid puts every channel tile that is in flight on every XCD and the weight tiles thrash the
-    // 4 MB L2s.  Give XCD k the k-th contiguous run of the channel-tile-major list instead: the workgroups that share an L2 share
-    // one weight tile and walk neighbouring pixel tiles.
-    int bx = blockIdx.x, by = blockIdx.y;
-    {
-        const int gx = gridDim.x, T = gx * gridDim.y, L = by * gx + bx;
-        const int q = T >> 3, r = T & 7, xcd = L & 7, j = L >> 3;
-        const int tile = xcd * q + (xcd < r ? xcd : r) + j;
-        by = tile / gx;
-        bx = tile - by * gx;
-    }
     const int pbase = bx * BP;
     if (pbase >= M) return;
     const int cbase = by * BC;
@@ -654,7 +666,10 @@ int launch_cfg(const hc_conv_desc& d, hipStream_t st) {
     constexpr int smem_c = (smem_o + 15) / 16 * 16 + 2 * BC * 4;          // output staging + the epilogue's scale / shift table
     static_assert(smem_c <= 160 * 1024, "LDS budget");
     constexpr int smem = smem_k > smem_c ? smem_k : smem_c;
-    constexpr int flags = 1;                       // staged (16-byte coalesced) epilogue stores
+    // bit 0: staged (16-byte coalesced) epilogue stores; bit 1: parity classes fastest in the tile order (sources of at least
+    // HC_CONV_CLSFAST MB, default 128; 0 = never)
+    static const double clsfast_mb = [] { const char* e = getenv("HC_CONV_CLSFAST"); return e == nullptr ? 128.0 : atof(e); }();
+    const int flags = 1 | ((d.nclass > 1 && clsfast_mb > 0 && (double)d.N * d.IH * d.IW * d.srcC * 2.0 >= clsfast_mb * 1e6) ? 2 : 0);
     int maxM = 0;
     for (int c = 0; c < d.nclass; ++c) {
         const int m = d.N * d.cls[c].OHg * d.cls[c].OWg;
@@ -710,6 +725,10 @@ int launch_short(const hc_conv_desc& d, hipStream_t st) {
     // (k64 steps - 128-byte rows, which the L2 serves at 53 B/clk/CU against 28 for the 64-byte rows of a k32 step,
     // scripts/probes/fill_probe.hip - fit only three workgroups per CU and measured SLOWER: YOLOv4 26.26 -> 26.84 ms, rexnet1_0x
     // 17.87 -> 18.00 ms, same box, two pairs.  Occupancy is what covers these launches, not the row width.)
+    // <= 32 output channels: a 32-channel x 256-pixel tile (the 64-channel tile multiplies 32 rows of zero-filled weights and idles half
+    // of the staged store loop).  HC_CONV_C32=0: the 64-channel tile (A/B)
+    static const int c32 = [] { const char* e = getenv("HC_CONV_C32"); return e == nullptr ? 1 : atoi(e); }();
+    if (c32 && C <= 32) return launch_cfg<1, 2, 1, 4, 32, false, 2, 4>(d, st);
     if (C <= 64) return launch_cfg<1, 2, 2, 2, 32, false, 2, 4>(d, st);
     if (C % 128 != 0 && C % 64 == 0) return launch_cfg<1, 2, 2, 2, 32, false, 2, 4>(d, st);
     return launch_cfg<2, 2, 2, 2, 32, false, 2, 4>(d, st);
