@@ -728,6 +728,8 @@ int launch_short(const hc_conv_desc& d, hipStream_t st) {
     // <= 32 output channels: a 32-channel x 256-pixel tile (the 64-channel tile multiplies 32 rows of zero-filled weights and idles half
     // of the staged store loop).  HC_CONV_C32=0: the 64-channel tile (A/B)
     static const int c32 = [] { const char* e = getenv("HC_CONV_C32"); return e == nullptr ? 1 : atoi(e); }();
+    // (k64 stages - 128-byte rows - for the multi-tap launches of this form, per shape: 64@304 -> 32 3 x 3 175 -> 236 us, 64@152 3 x 3 69 -> 82 us,
+    // 128@76 3 x 3 47 -> 50 / 68 us with 64- / 128-channel tiles: worse on every shape, profiles/r06_dispatch_by_shape.txt)
     if (c32 && C <= 32) return launch_cfg<1, 2, 1, 4, 32, false, 2, 4>(d, st);
     if (C <= 64) return launch_cfg<1, 2, 2, 2, 32, false, 2, 4>(d, st);
     if (C % 128 != 0 && C % 64 == 0) return launch_cfg<1, 2, 2, 2, 32, false, 2, 4>(d, st);

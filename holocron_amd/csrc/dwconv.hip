@@ -173,6 +173,18 @@ static int dw_s2_minw() {
 // 4-group slices for layers of 32 channels or fewer (HC_DW_TILE_THIN >= 1, the default).  HC_DW_TILE_THIN=2 also splits 72 .. 96
 // channels into 4-group slices: measured SLOWER (96@56 stride 1: 3.62 -> 2.83 TB/s; 96@112 stride 2 no better than the strip kernel) -
 // three workgroups then fetch 64-byte thirds of every 192-byte pixel at different times, and every 128-byte line is fetched twice
+inline int dw_blocks_exact(long items, int cg, int per_thread) {      // no fill-the-chip floor: `per_thread` items per thread
+    int a = cg, b = DW_THREADS;
+    while (b) { int t = a % b; a = b; b = t; }
+    const int unit = cg / a;
+    long want = (items + (long)DW_THREADS * per_thread - 1) / ((long)DW_THREADS * per_thread);
+    if (want < 1) want = 1;
+    return (int)(((want + unit - 1) / unit) * unit);
+}
+static int dw_row7() {        // HC_DW_ROW7=n: whole rows of the 5..7-pixel-wide maps, n rows per thread (0: strips of four, A/B)
+    static const int on = [] { const char* e = getenv("HC_DW_ROW7"); return e == nullptr ? 2 : atoi(e); }();
+    return on;
+}
 static bool dw_thin(int cg) {
     constexpr int mode = 1;
     return (mode >= 1 && cg <= 4) || (mode >= 2 && cg >= 9 && cg <= 12);
@@ -1059,6 +1071,12 @@ int hc_dw3x3_fwd(const void* x, const float* wpk, void* y, float* stats, int32_t
         else
             hipLaunchKernelGGL(dw3x3_fwd_tile_kernel<4>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwTile<4>::WIN_BYTES, st, x, wpk, (u32x4*)y,
                                stats, N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
+    } else if (stride == 1 && OW > 4 && OW <= 7 && dw_row7()) {
+        // 7 x 7 maps (ReXNet's last stage): one thread per output ROW - 3 x 7 loads for 7 outputs where strips of 4 + 3 take 3 x (6 + 5)
+        constexpr int TW = 7;
+        const long items = (long)N * OH * cg;
+        hipLaunchKernelGGL((dw3x3_fwd_kernel<1, TW>), dim3(dw_blocks_exact(items, cg, dw_row7())), dim3(DW_THREADS), lds, st, (const u32x4*)x, wpk,
+                           (u32x4*)y, stats, N, H, W, OH, OW, C, hc_get_stat_replicas());
     } else if (stride == 1) {
         constexpr int TW = 4;
         const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;
@@ -1166,6 +1184,12 @@ int hc_dw3x3_wgrad(const void* x, const void* dy, void* ws, float* dw, int32_t N
             else
                 hipLaunchKernelGGL(dw3x3_wgrad_tile_kernel<4>, dim3((unsigned)gx, nslices), dim3(DW_THREADS), DwTile<4>::WIN_BYTES, st, x,
                                    (const u32x4*)dy, (float*)ws, N, H, W, C, hc_get_stat_replicas(), tiles_x, tiles_y);
+        } else if (stride == 1 && OW > 4 && OW <= 7 && dw_row7()) {
+            constexpr int TW = 7;
+            const long items = (long)N * OH * cg;
+            // (rows per thread, rexnet1_0x bs 256 one box: 2 -> 16.62 ms per step, 4 -> 16.67, 7 -> 16.82, 14 -> 17.15; strips of four: 16.72)
+            hipLaunchKernelGGL((dw3x3_wgrad_kernel<1, TW>), dim3(dw_blocks_exact(items, cg, dw_row7())), dim3(DW_THREADS), lds, st, (const u32x4*)x,
+                               (const u32x4*)dy, (float*)ws, N, H, W, OH, OW, C, hc_get_stat_replicas());
         } else if (stride == 1) {
             constexpr int TW = 4;
             const long items = (long)N * OH * ((OW + TW - 1) / TW) * cg;

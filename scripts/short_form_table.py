@@ -1,21 +1,26 @@
-"""Joins the per-shape conv_gather rows of `scripts/layer_table.py` runs made under different dispatch settings (one box) into one
+"""Joins the per-shape rows of one kernel family (--family=conv_gather by default) of `scripts/layer_table.py` runs made under different dispatch settings (one box) into one
 table: which shapes prefer which form.  usage: short_form_table.py file1 file2 ... (column = file name)"""
 import os
 import re
 import sys
 
 
+FAMILY = 'conv_gather'
+
+
 def load(f):
     d = {}
     for ln in open(f):
-        if ln.startswith('conv_gather') and 'taps' in ln:
-            m = re.match(r'conv_gather\s+(.*?taps\d+.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)', ln)
-            if m:
-                d[m.group(1).strip()] = (int(m.group(2)), float(m.group(3)))
+        if ln.startswith(FAMILY + ' ') and not ln.startswith('#'):
+            parts = re.split(r'\s{2,}', ln.strip())
+            if len(parts) >= 4 and parts[2].isdigit():
+                d[parts[1]] = (int(parts[2]), float(parts[3]))
     return d
 
 
 files = sys.argv[1:]
+if files and files[0].startswith('--family='):
+    FAMILY = files.pop(0).split('=', 1)[1]
 T = [load(f) for f in files]
 names = [os.path.basename(f).replace('.txt', '')[-9:] for f in files]
 rows = sorted(T[0], key=lambda k: -T[0][k][0] * T[0][k][1])
