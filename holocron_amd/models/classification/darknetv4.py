@@ -7,6 +7,7 @@ Same module tree and ``state_dict`` keys as the reference (``features.stem.*``,
 the concat buffer.
 """
 from collections import OrderedDict
+import os
 from typing import Any, Callable, List, Optional, Tuple, Union
 
 import torch
@@ -18,7 +19,7 @@ from ...nn.convbn_op import prepack_model_convs, run_conv_sequence
 from ...nn.functional import drop_plan_scope
 from ...nn.init import init_module
 from ...nn.repblock_op import POOL
-from ...ops.nhwc import cat_buffer, cat_cl, chunk2_cl
+from ...ops.nhwc import cat_buffer, cat_cl, chunk2_cl, slice_of, split_keep_cl
 from ..utils import conv_sequence
 from .darknetv3 import ResBlock
 
@@ -52,10 +53,21 @@ class CSPStage(nn.Module):
         )
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = run_conv_sequence(self.base_layer, x)
-        x1, x2 = chunk2_cl(x)
-        N, half, H, W = x2.shape
-        buf, (_, p2) = cat_buffer(N, [half, half], H, W, x.device)
+        if os.environ.get("HC_CSP_SPLIT", "1") == "0":          # A/B: three copies (x -> a, x -> b, a -> buffer)
+            x = run_conv_sequence(self.base_layer, x)
+            x1, x2 = chunk2_cl(x)
+            N, half, H, W = x2.shape
+            buf, (_, p2) = cat_buffer(N, [half, half], H, W, x.device)
+            y2 = run_conv_sequence(self.main, x2, out=p2)
+            return run_conv_sequence(self.transition, cat_cl([x1, y2], buf))
+        # the base layer writes straight into the concat buffer of the transition: its first half is already where the concat wants
+        # it, the second is copied out for the main path, whose output then takes its place (ops/nhwc.py: split_keep_cl)
+        N, _, H, W = x.shape
+        H2, W2 = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        half = self.transition[0].in_channels // 2
+        buf, (_, p2) = cat_buffer(N, [half, half], H2, W2, x.device)
+        x = run_conv_sequence(self.base_layer, x, out=slice_of(buf, 0, 2 * half))
+        x1, x2 = split_keep_cl(x)
         y2 = run_conv_sequence(self.main, x2, out=p2)
         return run_conv_sequence(self.transition, cat_cl([x1, y2], buf))
 

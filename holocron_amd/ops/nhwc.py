@@ -116,6 +116,34 @@ class _Chunk2Fn(torch.autograd.Function):
         return dx
 
 
+class _SplitKeepFn(torch.autograd.Function):
+    """``x.chunk(2, dim=1)`` of an ``x`` that already lives in the concat buffer its FIRST half is headed for (CSPStage: the first
+    half of the base layer's output is concatenated with what the main path makes of the second): the first half is handed out in
+    place, only the second - which the main path overwrites in the buffer and needs for its own backward - is copied out.  One
+    activation-sized copy per stage instead of three (x -> a, x -> b, a -> buffer)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, Ct, H, W = x.shape
+        h = Ct // 2
+        if _ld(x) != Ct:
+            raise _lib.HipError("split_keep_cl: dense NHWC bf16 input expected")
+        a = slice_of(x, 0, h)
+        b = empty_cl(N, h, H, W, x.device)
+        check(_lib.load().hc_nhwc_copy(ptr(x), Ct, h, ptr(b), h, 0, N * H * W, h, stream()), "hc_nhwc_copy")
+        return a, b
+
+    backward = _Chunk2Fn.backward
+
+
+def split_keep_cl(x: torch.Tensor):
+    """``x.chunk(2, dim=1)``: (first half IN PLACE as a slice of ``x``, second half as a dense copy)."""
+    _lib.require_gpu(x)
+    if x.shape[1] % 16:
+        raise _lib.HipError("split_keep_cl: channel count must be a multiple of 16")
+    return _SplitKeepFn.apply(x)
+
+
 def chunk2_cl(x: torch.Tensor):
     """``x.chunk(2, dim=1)`` as two dense NHWC tensors (darknetv4.py:114)."""
     _lib.require_gpu(x)
