@@ -9,6 +9,7 @@ A concat is a buffer allocated up front whose channel slices are handed to the p
 and its backward hands out slices of the incoming gradient, which the fused BN/activation backward kernels read
 in place (``g_ld``).
 """
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -50,6 +51,9 @@ def _copy(src, dst, Cc):
     check(_lib.load().hc_nhwc_copy(ptr(src), _ld(src), 0, ptr(dst), _ld(dst), 0, N * H * W, Cc, stream()), "hc_nhwc_copy")
 
 
+_CAT_GRADS = {}        # data_ptr of a concat gradient's first slice -> the whole gradient buffer (see _CatFn.backward)
+
+
 class _CatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, holder, *parts):
@@ -78,6 +82,11 @@ class _CatFn(torch.autograd.Function):
         for Cc in ctx.chans:
             outs.append(slice_of(g, c0, Cc))
             c0 += Cc
+        # the gradient buffer itself, for a consumer that can finish its own result in it (_SplitKeepFn.backward); a handful of
+        # entries at most, dropped when used
+        if len(_CAT_GRADS) >= 8:
+            _CAT_GRADS.clear()
+        _CAT_GRADS[outs[0].data_ptr()] = g
         return (None, *outs)
 
 
@@ -133,7 +142,20 @@ class _SplitKeepFn(torch.autograd.Function):
         check(_lib.load().hc_nhwc_copy(ptr(x), Ct, h, ptr(b), h, 0, N * H * W, h, stream()), "hc_nhwc_copy")
         return a, b
 
-    backward = _Chunk2Fn.backward
+    @staticmethod
+    def backward(ctx, ga, gb):
+        # ga is normally the first half of the gradient of the concat [x1 | main(x2)], whose second half every reader (the main
+        # path's last unit) is done with by now: the gradient of x is that buffer with gb copied over its second half - one copy,
+        # not two.  Anything else (a dense ga, another layout): the two-copy path of _Chunk2Fn.
+        N, h, H, W = ga.shape
+        g = _CAT_GRADS.pop(ga.data_ptr(), None)
+        if (g is not None and tuple(g.shape) == (N, 2 * h, H, W) and _ld(g) == 2 * h and g.data_ptr() == ga.data_ptr()
+                and _ld(ga) == 2 * h and os.environ.get("HC_CSP_SPLIT", "1") != "2"):
+            if _ld(gb) is None:
+                gb = to_cl_bf16(gb)
+            check(_lib.load().hc_nhwc_copy(ptr(gb), _ld(gb), 0, ptr(g), 2 * h, h, N * H * W, h, stream()), "hc_nhwc_copy")
+            return g
+        return _Chunk2Fn.backward(ctx, ga, gb)
 
 
 def split_keep_cl(x: torch.Tensor):
