@@ -3,6 +3,7 @@
 // upsample+cat, holocron/nn/modules/downsample.py:154-167 SPP).  All are pure HBM traffic: a thread moves
 // 16-byte chunks (8 channels); source and destination carry their own channels-per-pixel ("ld") and
 // channel offset so that a concat is written in place by its producers instead of by an extra pass.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/holocron_hip.h"
 
@@ -153,14 +154,13 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const u32x4* __restrict__ 
                 const int k0 = r <= 2 ? 0 : (r <= 4 ? 1 : 2);
                 for (int k = k0; k < 3; ++k) {
                     const u32x2 pk = idx[((long)k * npix + q) * c8 + c];
-                    bool any = false;
+                    // any byte equal to `code`?  The exact zero-byte test on pk ^ code-in-every-byte: ten operations for the 99 % of
+                    // (q, k) that miss instead of eight shift-mask-compare triples (the walk is VALU-bound: 231 us per launch before)
+                    const unsigned int x0 = pk[0] ^ (code * 0x01010101u), x1 = pk[1] ^ (code * 0x01010101u);
+                    if ((((x0 - 0x01010101u) & ~x0) | ((x1 - 0x01010101u) & ~x1)) & 0x80808080u) {} else continue;
                     bool hit[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        hit[e] = ((pk[e >> 2] >> (8 * (e & 3))) & 0xffu) == code;
-                        any |= hit[e];
-                    }
-                    if (!any) continue;
+                    for (int e = 0; e < 8; ++e) hit[e] = ((pk[e >> 2] >> (8 * (e & 3))) & 0xffu) == code;
                     float f[8];
                     unpack8(g[q * 4 * c8 + (k + 1) * c8 + c], f);
 #pragma unroll
@@ -170,6 +170,100 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const u32x4* __restrict__ 
         }
         dx[p * c8 + c] = pack8(acc);
     }
+}
+
+// ---------------------------------------------------------------- SPP forward, LDS-tiled with integer keys (round 6)
+// Both window walks are VALU-bound, not memory-bound: 169 positions x 8 channels x (compare + two selects) x 1-3 pools is ~8 k lane
+// operations per (pixel, channel group), 3 G per launch of YOLOv4's 16 x 512 x 19 x 19 map = 86 us of the chip's 64 lanes per CU and
+// clock however the operands arrive (142 us measured from global memory, 162 us from an LDS tile with the same loop).  This kernel
+// changes the arithmetic: a workgroup stages one image x SPP_G channel groups in LDS as 32-bit KEYS, (order-preserving map of the
+// bf16 value) << 16, with a 6-pixel halo of the smallest key; in the window loop a position costs one OR (key | 255 - code) and one
+// integer MAX per pool: the largest key is the largest value and, among equal values, the smallest code = the first maximum in
+// row-major window order, torch's rule.  (-0 is keyed as +0: they compare equal in float, and a tie between them must go to the
+// first, not to +0; the stored maximum is then +0 where the walk may store -0 - equal as numbers.  NaNs sort above +inf.)
+constexpr int SPP_G = 2;
+__device__ __forceinline__ unsigned int spp_key(unsigned int b) {        // b: bf16 bits; monotone in the value
+    if ((b & 0x7fffu) == 0u) b = 0u;
+    return ((b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u)) << 16;
+}
+__device__ __forceinline__ unsigned int spp_unkey(unsigned int k) {      // back to bf16 bits
+    const unsigned int b = k >> 16;
+    return (b & 0x8000u) ? (b & 0x7fffu) : (~b & 0xffffu);
+}
+__global__ __launch_bounds__(256) void spp_fwd_tile_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ out, u32x2* __restrict__ idx,
+                                                           int N, int H, int W, int c8) {
+    extern __shared__ __attribute__((aligned(16))) char spp_smem[];
+    u32x4* tile = reinterpret_cast<u32x4*>(spp_smem);          // [H + 12][W + 12][SPP_G][2]: eight keys per (pixel, channel group)
+    const int TW = W + 12, TH = H + 12;
+    const int n = blockIdx.y, cg0 = blockIdx.x * SPP_G;
+    const int ng = (c8 - cg0) < SPP_G ? (c8 - cg0) : SPP_G;
+    const int tid = threadIdx.x;
+    const unsigned int kmin = spp_key(0xff80u);                 // -inf
+    for (int i = tid; i < TH * TW * SPP_G; i += 256) {
+        const int g = i % SPP_G, t = i / SPP_G, tx = t % TW, ty = t / TW;
+        const int yy = ty - 6, xx = tx - 6;
+        u32x4 lo = {kmin, kmin, kmin, kmin}, hi = lo;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W && g < ng) {
+            const u32x4 v = x[((long)(n * H + yy) * W + xx) * c8 + cg0 + g];
+            lo = u32x4{spp_key(v[0] & 0xffffu), spp_key(v[0] >> 16), spp_key(v[1] & 0xffffu), spp_key(v[1] >> 16)};
+            hi = u32x4{spp_key(v[2] & 0xffffu), spp_key(v[2] >> 16), spp_key(v[3] & 0xffffu), spp_key(v[3] >> 16)};
+        }
+        tile[2 * i] = lo;
+        tile[2 * i + 1] = hi;
+    }
+    __syncthreads();
+    const long npix = (long)N * H * W;
+    for (int i = tid; i < H * W * SPP_G; i += 256) {
+        const int g = i % SPP_G, pp = i / SPP_G, w = pp % W, h = pp / W;
+        if (g >= ng) continue;
+        unsigned int m[3][8];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[k][e] = 0u;
+        const u32x4* ctr = tile + (((h + 6) * TW + (w + 6)) * SPP_G + g) * 2;
+#pragma unroll
+        for (int dy = -6; dy <= 6; ++dy) {
+            const u32x4* row = ctr + dy * TW * SPP_G * 2;
+#pragma unroll
+            for (int dx = -6; dx <= 6; ++dx) {
+                const u32x4 lo = row[dx * SPP_G * 2], hi = row[dx * SPP_G * 2 + 1];
+                const unsigned int tag = 255u - (unsigned int)((dy + 6) * 13 + (dx + 6));
+                const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
+                const int r = ady > adx ? ady : adx;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned int key = (e < 4 ? lo[e & 3] : hi[e & 3]) | tag;
+                    m[2][e] = key > m[2][e] ? key : m[2][e];
+                    if (r <= 4) m[1][e] = key > m[1][e] ? key : m[1][e];
+                    if (r <= 2) m[0][e] = key > m[0][e] ? key : m[0][e];
+                }
+            }
+        }
+        const long p = (long)(n * H + h) * W + w;
+        const int c = cg0 + g;
+        const long ob = p * 4 * c8 + c;
+        out[ob] = x[p * c8 + c];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = spp_unkey(m[k][2 * q]) | (spp_unkey(m[k][2 * q + 1]) << 16);
+            out[ob + (k + 1) * c8] = o;
+            u32x2 pk;
+            pk[0] = (255u - (m[k][0] & 0xffu)) | ((255u - (m[k][1] & 0xffu)) << 8) | ((255u - (m[k][2] & 0xffu)) << 16) | ((255u - (m[k][3] & 0xffu)) << 24);
+            pk[1] = (255u - (m[k][4] & 0xffu)) | ((255u - (m[k][5] & 0xffu)) << 8) | ((255u - (m[k][6] & 0xffu)) << 16) | ((255u - (m[k][7] & 0xffu)) << 24);
+            idx[((long)k * npix + p) * c8 + c] = pk;
+        }
+    }
+}
+// (The backward walk was built on the same tile too - argmax bytes and the pooled gradient rows in LDS, the exact any-byte-equal test in
+// front of the per-channel one, a row of codes fetched ahead of its tests: 279-327 us per launch against 237 us for spp_bwd_kernel, whose
+// 1 444 small workgroups hide the walk's dependent chains better than one 512-thread workgroup per CU does.  Not kept.)
+static bool spp_tile_ok(int H, int W) {
+    const char* e = getenv("HC_SPP_TILE");           // read per call: the test flips it inside one process
+    const int on = e == nullptr ? 1 : atoi(e);
+    return on && (long)(H + 12) * (W + 12) * SPP_G * 32 <= 96 * 1024;
 }
 
 // ---------------------------------------------------------------- SlimConv2d gate + fold (nn/modules/conv.py:352-364)
@@ -417,6 +511,17 @@ int hc_upsample2x_bwd(const void* g, int32_t g_ld, int32_t g_c0, void* dx, int32
 int hc_spp_fwd(const void* x, void* out, void* idx, int32_t N, int32_t H, int32_t W, int32_t C, hc_stream_t stream) {
     if (x == nullptr || out == nullptr || idx == nullptr || C <= 0 || (C & 7)) return HC_ERR_ARG;
     if ((long)N * H * W == 0) return HC_OK;
+    if (spp_tile_ok(H, W) && N <= 65535) {
+        const int smem = (H + 12) * (W + 12) * SPP_G * 32;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spp_fwd_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL(spp_fwd_tile_kernel, dim3((C / 8 + SPP_G - 1) / SPP_G, N), dim3(256), smem, (hipStream_t)stream, (const u32x4*)x,
+                           (u32x4*)out, (u32x2*)idx, N, H, W, C / 8);
+        return hc_launch_status();
+    }
     hipLaunchKernelGGL(spp_fwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
                        (const u32x4*)x, (u32x4*)out, (u32x2*)idx, N, H, W, C / 8);
     return hc_launch_status();

@@ -60,6 +60,34 @@ def test_nhwc_cat_chunk_upsample_spp_vs_torch():
         assert rel_l2(xg.grad.float().cpu(), xr.grad) < 4e-3
 
 
+def test_spp_lds_tiled_kernels_are_bit_identical_to_the_window_walk(monkeypatch):
+    """hc_spp_fwd (csrc/nhwc_ops.hip): the LDS-tiled integer-key kernel (one image x two channel groups per workgroup, smallest-key halo)
+    against the global-memory window walk (HC_SPP_TILE=0): values (== : the keyed kernel stores +0 where the walk may store -0), argmax
+    bytes (ties!) and the gradients computed from them, incl. a partial channel-group slice (40 channels = 5 groups) and non-square maps."""
+    from holocron_amd import _lib
+    from holocron_amd._lib import check, ptr, stream
+    from holocron_amd.ops.conv import empty_cl, to_cl_bf16
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    for (N, Cc, H, W) in [(3, 40, 19, 19), (2, 64, 13, 16), (1, 8, 5, 23), (16, 512, 19, 19)]:
+        x = _bf16(torch.randn((N, Cc, H, W), generator=g))
+        x[0, :, : H // 2] = x[0, :, : H // 2].round()
+        xg = to_cl_bf16(x.cuda())
+        gr = to_cl_bf16(_bf16(torch.randn((N, 4 * Cc, H, W), generator=g)).cuda())
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("HC_SPP_TILE", mode)
+            out = empty_cl(N, 4 * Cc, H, W, xg.device)
+            idx = torch.zeros((3, N, H, W, Cc), dtype=torch.uint8, device=xg.device)
+            dx = empty_cl(N, Cc, H, W, xg.device)
+            check(lib.hc_spp_fwd(ptr(xg), ptr(out), ptr(idx), N, H, W, Cc, stream()), "hc_spp_fwd")
+            check(lib.hc_spp_bwd(ptr(gr), ptr(idx), ptr(dx), N, H, W, Cc, stream()), "hc_spp_bwd")
+            torch.cuda.synchronize()
+            res[mode] = (out.clone(), idx.clone(), dx.clone())
+        for a, b, what in zip(res["0"], res["1"], ("out", "idx", "dx")):
+            assert torch.equal(a, b), (what, N, Cc, H, W)
+
+
 def test_conv_bias_matches_torch():
     import holocron_amd as h
     from holocron_amd.nn.convbn_op import conv_bias
