@@ -72,6 +72,9 @@ timeout 300 python scripts/bench_bigtile.py 2>&1 | grep -v amdgpu > $O/r06_final
 timeout 300 python scripts/layer_table.py --model yolov4 2>/dev/null > $O/r06_final_yolov4_layer_table.txt
 HC_WGRAD_DEFER=0 timeout 300 python scripts/layer_table.py --model yolov4 2>/dev/null > $O/r06_yolov4_layer_table_ungrouped_wgrad.txt
 ( for e in "HC_WGRAD_DEFER=1" "HC_WGRAD_DEFER=0" "HC_WGRAD_DEFER=1" "HC_WGRAD_DEFER=0"; do env $e timeout 300 python scripts/bench_yolov4.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$e', round(d['value'],1), 'img/s', round(d['ms_per_step'],3), 'ms/step')"; done
+  OLDD="HC_CONV_DEEP=0 HC_CONV_SHORT_FIRST=0 HC_CONV_SHORT_ALL=1 HC_CONV_C32=0 HC_CONV_CLSFAST=0 HC_CSP_SPLIT=0 HC_SPP_TILE=0"
+  for e in "HC_X=1" "$OLDD" "HC_X=1" "$OLDD"; do env $e timeout 300 python scripts/bench_yolov4.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('train [$e]', round(d['value'],1), 'img/s', round(d['ms_per_step'],3), 'ms/step')"; done
+  for e in "HC_X=1" "$OLDD" "HC_X=1" "$OLDD"; do env $e timeout 300 python scripts/bench_yolov4.py --eval --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('eval [$e]', round(d['value'],1), 'img/s', round(d['ms_per_step'],3), 'ms/pass')"; done
   for e in "HC_INFER_FUSED=1" "HC_INFER_FUSED=0" "HC_INFER_FUSED=1" "HC_INFER_FUSED=0"; do env $e timeout 300 python scripts/bench_yolov4.py --eval --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('eval $e', round(d['value'],1), 'img/s', round(d['ms_per_step'],3), 'ms/pass')"; done ) > $O/r06_yolov4_ab.txt
 bash scripts/trace.sh $O/r06_final_yolov4_eval "rocprofv3 --kernel-trace --stats -- python scripts/bench_yolov4.py --eval --steps 5 --warmup 2 --no-cpu-baseline  (MI355X; 8 eval passes of 16 images)" python $R/scripts/bench_yolov4.py --eval --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 trace yolov4 "rocprofv3 --kernel-trace --stats -- python scripts/bench_yolov4.py --batch 16 --steps 3 --warmup 1 --no-graph --no-cpu-baseline  (MI355X)" python $R/scripts/bench_yolov4.py --batch 16 --steps 3 --warmup 1 --no-graph --no-cpu-baseline
