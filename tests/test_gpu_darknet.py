@@ -148,3 +148,38 @@ def test_inference_unit_is_one_launch_and_matches_fp32_eval(act, cin, cout, k, s
     three = cb.conv_bn_act(x.cuda().requires_grad_(True), conv, bn, a, residual=None if r is None else r.cuda())
     assert rel_l2(three.float().cpu(), ref) < 6e-3
     assert rel_l2(got.float().cpu(), three.float().cpu()) < 6e-3
+
+
+def test_cspstage_split_in_the_concat_buffer_equals_the_three_copy_path(monkeypatch):
+    """CSPStage (models/classification/darknetv4.py; reference darknetv4.py:112-115): base layer written into the transition's concat
+    buffer + `split_keep_cl` (one activation copy forward, one backward - the split's gradient is the concat's gradient buffer) against
+    chunk + cat with three / two copies (HC_CSP_SPLIT=0): output, input gradient and every parameter gradient bit for bit in
+    deterministic mode (same kernels, same order; only the copies differ)."""
+    import copy
+
+    import holocron_amd as h
+    from holocron_amd.models.classification.darknetv4 import CSPStage
+    from holocron_amd.ops import conv as cv
+    h.set_deterministic(True)
+    try:
+        torch.manual_seed(3)
+        ref = CSPStage(32, 64, num_blocks=2, act_layer=torch.nn.Mish(), norm_layer=torch.nn.BatchNorm2d).cuda().train()
+        x0 = torch.randn(2, 32, 24, 20, device="cuda")
+        r = None
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("HC_CSP_SPLIT", mode)
+            m = copy.deepcopy(ref)
+            x = x0.clone().requires_grad_(True)
+            y = m(x)
+            if r is None:
+                r = torch.randn(y.shape, device="cuda")
+            (y.float() * r).sum().backward()
+            cv.flush_deferred_wgrads()
+            torch.cuda.synchronize()
+            res[mode] = [y.detach().float().clone(), x.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+        assert len(res["0"]) == len(res["1"])
+        for k, (a, b) in enumerate(zip(res["0"], res["1"])):
+            assert torch.equal(a, b), k
+    finally:
+        h.set_deterministic(False)
