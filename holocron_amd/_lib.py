@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libholocron_hip.so")
+LIB_PATH = os.environ.get("HC_LIB_PATH") or os.path.join(_HERE, "lib", "libholocron_hip.so")      # HC_LIB_PATH: another build of the library (same-box A/Bs of kernel changes)
 
 HC_MAX_TAPS = 12
 HC_MT_CHUNK = 8192
