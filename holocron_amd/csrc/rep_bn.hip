@@ -474,10 +474,11 @@ __device__ __forceinline__ float act_bwd(float v, int act, float slope) {   // d
         case 1: return v > 0.f ? 1.f : 0.f;
         case 2: { const float t = v + 2.f; float d = 0.5f * fminf(fmaxf(t, 0.f), 2.f); if (t >= 0.f && t <= 2.f) d += 0.5f * v; return d; }
         case 3: return v > 0.f ? 1.f : slope;
-        case 4: {   // d/dx [x t], t = n / (n + 2): t' = 4 e (e + 1) / (n + 2)^2
-            const float e = __expf(fminf(v, 20.f)), n = e * (e + 2.f);
-            const float r = __builtin_amdgcn_rcpf(n + 2.f);
-            return n * r + 4.f * v * e * (e + 1.f) * r * r;
+        case 4: {   // d/dx [x t], t = n / (n + 2) = 1 - 2 r, r = 1 / (n + 2), n = e (e + 2) = u + e, u = e (e + 1): t' = 4 u r^2, so
+            // mish' = 1 + r (4 x u r - 2): eleven instructions instead of fifteen - these passes are VALU-bound on YOLOv4
+            const float e = __expf(fminf(v, 20.f)), u = __builtin_fmaf(e, e, e);
+            const float r = __builtin_amdgcn_rcpf((u + e) + 2.f);
+            return __builtin_fmaf(r, __builtin_fmaf(v * u, 4.f * r, -2.f), 1.f);
         }
         case 5: { const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-v)); return sg * (1.f + v * (1.f - sg)); }
         case 6: return (v > 0.f && v < 6.f) ? 1.f : 0.f;
