@@ -793,10 +793,18 @@ extern "C" int hc_conv_gather(const hc_conv_desc* dp, hc_stream_t stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // narrow 1 x 1 convolutions: the weight-stationary streaming kernel (conv_pointwise.hip).  HC_CONV_PW=0 off; 1: launches WITHOUT
     // statistics whose output is at least twice as wide as the input (the data gradients of the projections: store-heavy, 1.4-2.7 TB/s
-    // in the gather form); 3: those with statistics too (the expansions forward); 2: everything the kernel supports
+    // in the gather form); 3: those with statistics too (the expansions forward); 2: everything the kernel supports; 4: = 1 without the
+    // narrow-source rule below (A/B)
     static const int pw = [] { const char* e = getenv("HC_CONV_PW"); return e == nullptr ? 1 : atoi(e); }();
+    // ... and of the launches WITH statistics (the expansions forward) those whose source has 16 or 48 channels on a large map: the gather
+    // form stages them in k16 steps (32-byte rows: 14 B/clk/CU of fill).  Per shape (profiles/r06_dispatch_by_shape.txt): 16@112 -> 192
+    // 687 -> 389 us, 48@56 -> 192 210 -> 125, 48@56 -> 256 156 -> 133, 48@28 -> 512 95 -> 76; every other expansion loses in this kernel
+    // (32@56 -> 192 97 -> 115 from the short-loop form, 80..128@14 -> 448..768 +50-100 %), which is why HC_CONV_PW=3 measured neutral
+    auto narrow_stats = [&]() {
+        return d.stats != nullptr && d.nclass == 1 && d.srcC % 32 != 0 && d.srcC <= 64 && (long)d.N * d.cls[0].OHg * d.cls[0].OWg >= 150000;
+    };
     if (pw > 0 && hc_conv_pointwise_supported(dp) &&
-        (pw == 2 || (d.Cout >= 2 * d.srcC && (pw == 3 || d.stats == nullptr))))
+        (pw == 2 || (d.Cout >= 2 * d.srcC && (pw == 3 || d.stats == nullptr || (pw == 1 && narrow_stats())))))
         return hc_conv_pointwise(dp, stream);
     if (d.ch_mult != nullptr) {   // fp8 inference path
         if ((d.srcC % 64) != 0 || (d.Cout % 4) != 0 || d.stats != nullptr || d.resid != nullptr || d.pix_scale != nullptr) return HC_ERR_ARG;
