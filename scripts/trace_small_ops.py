@@ -1,5 +1,5 @@
 """Where do the small torch kernels of a training step come from?  One eager step (repvgg_a0 by default, `yolov4` as first argument for
-the YOLOv4 608^2 batch-16 step) under torch.profiler with Python stacks: every op that launches a fill / copy / torch elementwise
+the YOLOv4 608^2 batch-16 step, `yolov4_eval` for one eval pass) under torch.profiler with Python stacks: every op that launches a fill / copy / torch elementwise
 kernel, grouped by its innermost holocron_amd / bench frame."""
 import collections
 import os
@@ -24,6 +24,10 @@ if which == "yolov4":
 
     def loss_of():
         return sum(v.sum() for v in model(x, tg).values())
+elif which == "yolov4_eval":
+    model = h.models.detection.yolov4(pretrained_backbone=False, num_classes=80).to(dev).eval()
+    g_ = torch.Generator().manual_seed(0)
+    x = torch.rand((16, 3, 608, 608), generator=g_).to(dev)
 else:
     model = h.models.repvgg_a0(num_classes=10).to(dev).train()
     x = torch.rand((256, 3, 224, 224), device=dev)
@@ -31,10 +35,14 @@ else:
 
     def loss_of():
         return h.nn.functional.cross_entropy(model(x), t, label_smoothing=0.1)
-opt = h.optim.AdaBelief(model.parameters(), lr=1e-3, betas=(0.95, 0.99), eps=1e-6, weight_decay=0.0)
+opt = None if which == "yolov4_eval" else h.optim.AdaBelief(model.parameters(), lr=1e-3, betas=(0.95, 0.99), eps=1e-6, weight_decay=0.0)
 
 
 def step():
+    if which == "yolov4_eval":
+        with torch.no_grad():
+            model(x)
+        return
     opt.zero_grad(set_to_none=True)
     loss = loss_of()
     loss.backward()
