@@ -57,6 +57,7 @@ _CAT_GRADS = {}        # data_ptr of a concat gradient's first slice -> the whol
 class _CatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, holder, *parts):
+        _CAT_GRADS.clear()            # gradient buffers of an earlier backward pass that nobody claimed
         buf = holder[0]
         N, Ct, H, W = buf.shape
         c0 = 0
