@@ -51,6 +51,7 @@ def _copy(src, dst, Cc):
     check(_lib.load().hc_nhwc_copy(ptr(src), _ld(src), 0, ptr(dst), _ld(dst), 0, N * H * W, Cc, stream()), "hc_nhwc_copy")
 
 
+SPLIT_STATS = {"reused": 0, "copied": 0}      # _SplitKeepFn.backward: concat gradient buffer reused / two-copy fallback (tests)
 _CAT_GRADS = {}        # data_ptr of a concat gradient's first slice -> the whole gradient buffer (see _CatFn.backward)
 
 
@@ -155,7 +156,9 @@ class _SplitKeepFn(torch.autograd.Function):
             if _ld(gb) is None:
                 gb = to_cl_bf16(gb)
             check(_lib.load().hc_nhwc_copy(ptr(gb), _ld(gb), 0, ptr(g), 2 * h, h, N * H * W, h, stream()), "hc_nhwc_copy")
+            SPLIT_STATS["reused"] += 1
             return g
+        SPLIT_STATS["copied"] += 1
         return _Chunk2Fn.backward(ctx, ga, gb)
 
 

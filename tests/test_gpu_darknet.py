@@ -160,6 +160,7 @@ def test_cspstage_split_in_the_concat_buffer_equals_the_three_copy_path(monkeypa
     import holocron_amd as h
     from holocron_amd.models.classification.darknetv4 import CSPStage
     from holocron_amd.ops import conv as cv
+    from holocron_amd.ops import nhwc
     h.set_deterministic(True)
     try:
         torch.manual_seed(3)
@@ -178,6 +179,9 @@ def test_cspstage_split_in_the_concat_buffer_equals_the_three_copy_path(monkeypa
             cv.flush_deferred_wgrads()
             torch.cuda.synchronize()
             res[mode] = [y.detach().float().clone(), x.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+            if mode == "0":
+                reused0 = nhwc.SPLIT_STATS["reused"]
+        assert nhwc.SPLIT_STATS["reused"] == reused0 + 1          # the one-copy backward really ran in the second arm
         assert len(res["0"]) == len(res["1"])
         for k, (a, b) in enumerate(zip(res["0"], res["1"])):
             assert torch.equal(a, b), k
