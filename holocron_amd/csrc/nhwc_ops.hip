@@ -260,6 +260,52 @@ __global__ __launch_bounds__(256) void spp_fwd_tile_kernel(const u32x4* __restri
 // (The backward walk was built on the same tile too - argmax bytes and the pooled gradient rows in LDS, the exact any-byte-equal test in
 // front of the per-channel one, a row of codes fetched ahead of its tests: 279-327 us per launch against 237 us for spp_bwd_kernel, whose
 // 1 444 small workgroups hide the walk's dependent chains better than one 512-thread workgroup per CU does.  Not kept.)
+// backward as a SCATTER (not in deterministic mode): a workgroup owns one image x SPP_G channel groups and an fp32 tile of their dx in LDS;
+// every output position q adds its three pooled gradients to the pixels its argmax bytes name (24 `ds_add_f32` per (q, channel group)
+// instead of a 275-position search per pixel), then the tile plus the pass-through part of g is written out.  The order of the fp32
+// additions into one pixel is not fixed (sums of at most 275 terms, rounded to bf16 afterwards); hc_set_deterministic(1) keeps the walk.
+__global__ __launch_bounds__(256) void spp_bwd_scatter_kernel(const u32x4* __restrict__ g, const u32x2* __restrict__ idx, u32x4* __restrict__ dx,
+                                                              int N, int H, int W, int c8) {
+    extern __shared__ __attribute__((aligned(16))) char spp_smem[];
+    float* acc = reinterpret_cast<float*>(spp_smem);           // [H * W][SPP_G][8]
+    const int n = blockIdx.y, cg0 = blockIdx.x * SPP_G;
+    const int ng = (c8 - cg0) < SPP_G ? (c8 - cg0) : SPP_G;
+    const int tid = threadIdx.x, HW = H * W;
+    const long npix = (long)N * HW;
+    for (int i = tid; i < HW * SPP_G * 8; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < HW * SPP_G * 3; i += 256) {
+        const int k = i % 3, j = i / 3, gi = j % SPP_G, qq = j / SPP_G;
+        if (gi >= ng) continue;
+        const int qx = qq % W, qy = qq / W;
+        const long q = (long)n * HW + qq;
+        const u32x2 pk = idx[((long)k * npix + q) * c8 + cg0 + gi];
+        float f[8];
+        unpack8(g[q * 4 * c8 + (k + 1) * c8 + cg0 + gi], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int code = (int)((pk[e >> 2] >> (8 * (e & 3))) & 0xffu);
+            const int py = qy + code / 13 - 6, px = qx + code % 13 - 6;      // always inside the map (the forward never picks padding)
+            atomicAdd(acc + ((py * W + px) * SPP_G + gi) * 8 + e, f[e]);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < HW * SPP_G; i += 256) {
+        const int gi = i % SPP_G, pp = i / SPP_G;
+        if (gi >= ng) continue;
+        const long p = (long)n * HW + pp;
+        float a[8];
+        unpack8(g[p * 4 * c8 + cg0 + gi], a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += acc[(pp * SPP_G + gi) * 8 + e];
+        dx[p * c8 + cg0 + gi] = pack8(a);
+    }
+}
+static bool spp_scatter_ok(int H, int W) {
+    const char* e = getenv("HC_SPP_TILE");
+    const int on = e == nullptr ? 1 : atoi(e);
+    return on && !hc_get_deterministic() && (long)H * W * SPP_G * 32 <= 96 * 1024;
+}
 static bool spp_tile_ok(int H, int W) {
     const char* e = getenv("HC_SPP_TILE");           // read per call: the test flips it inside one process
     const int on = e == nullptr ? 1 : atoi(e);
@@ -529,6 +575,17 @@ int hc_spp_fwd(const void* x, void* out, void* idx, int32_t N, int32_t H, int32_
 int hc_spp_bwd(const void* g, const void* idx, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, hc_stream_t stream) {
     if (g == nullptr || dx == nullptr || idx == nullptr || C <= 0 || (C & 7)) return HC_ERR_ARG;
     if ((long)N * H * W == 0) return HC_OK;
+    if (spp_scatter_ok(H, W) && N <= 65535) {
+        const int smem = H * W * SPP_G * 32;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(spp_bwd_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL(spp_bwd_scatter_kernel, dim3((C / 8 + SPP_G - 1) / SPP_G, N), dim3(256), smem, (hipStream_t)stream, (const u32x4*)g,
+                           (const u32x2*)idx, (u32x4*)dx, N, H, W, C / 8);
+        return hc_launch_status();
+    }
     hipLaunchKernelGGL(spp_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)stream,
                        (const u32x4*)g, (const u32x2*)idx, (u32x4*)dx, N, H, W, C / 8);
     return hc_launch_status();

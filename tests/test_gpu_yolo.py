@@ -62,8 +62,9 @@ def test_nhwc_cat_chunk_upsample_spp_vs_torch():
 
 def test_spp_lds_tiled_kernels_are_bit_identical_to_the_window_walk(monkeypatch):
     """hc_spp_fwd (csrc/nhwc_ops.hip): the LDS-tiled integer-key kernel (one image x two channel groups per workgroup, smallest-key halo)
-    against the global-memory window walk (HC_SPP_TILE=0): values (== : the keyed kernel stores +0 where the walk may store -0), argmax
-    bytes (ties!) and the gradients computed from them, incl. a partial channel-group slice (40 channels = 5 groups) and non-square maps."""
+    against the global-memory window walk (HC_SPP_TILE=0): values (== : the keyed kernel stores +0 where the walk may store -0) and argmax
+    bytes (ties!) bit for bit; hc_spp_bwd's LDS scatter against the walk's gather: the same sums up to fp32 addition order (and the walk
+    itself in deterministic mode); incl. a partial channel-group slice (40 channels = 5 groups) and non-square maps."""
     from holocron_amd import _lib
     from holocron_amd._lib import check, ptr, stream
     from holocron_amd.ops.conv import empty_cl, to_cl_bf16
@@ -84,8 +85,21 @@ def test_spp_lds_tiled_kernels_are_bit_identical_to_the_window_walk(monkeypatch)
             check(lib.hc_spp_bwd(ptr(gr), ptr(idx), ptr(dx), N, H, W, Cc, stream()), "hc_spp_bwd")
             torch.cuda.synchronize()
             res[mode] = (out.clone(), idx.clone(), dx.clone())
-        for a, b, what in zip(res["0"], res["1"], ("out", "idx", "dx")):
+        for a, b, what in zip(res["0"][:2], res["1"][:2], ("out", "idx")):
             assert torch.equal(a, b), (what, N, Cc, H, W)
+        # the backward of mode 1 is the LDS scatter: same terms, fp32 additions in arrival order, rounded to bf16 once
+        a, b = res["0"][2].float(), res["1"][2].float()
+        assert torch.allclose(a, b, rtol=8e-3, atol=1e-3 * float(a.abs().max())), ("dx", N, Cc, H, W, float((a - b).abs().max()))
+        assert float((a != b).float().mean()) < 0.05, ("dx: more than rounding-order differences", N, Cc, H, W)
+        import holocron_amd as h
+        h.set_deterministic(True)                      # deterministic mode keeps the fixed-order walk: bit-equal to mode 0
+        try:
+            dxd = empty_cl(N, Cc, H, W, xg.device)
+            check(lib.hc_spp_bwd(ptr(gr), ptr(res["1"][1]), ptr(dxd), N, H, W, Cc, stream()), "hc_spp_bwd")
+            torch.cuda.synchronize()
+            assert torch.equal(dxd, res["0"][2]), ("deterministic dx", N, Cc, H, W)
+        finally:
+            h.set_deterministic(False)
 
 
 def test_conv_bias_matches_torch():
