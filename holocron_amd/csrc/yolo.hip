@@ -218,11 +218,25 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(Logits x, Grads dx, int 
             acc[2] += loss_min;
             const int lab = (int)gt_label[kmax];
             float bce = 0.f;
-            for (int c = 0; c < nc; ++c) {
-                const float v = x.get(n, pix, c0 + 5 + c);
-                const float tgt = c == lab ? 1.f : 0.f;
-                bce += fmaxf(v, 0.f) - v * tgt + log1pf(expf(-fabsf(v)));
-                if (BWD) dx.put(n, pix, c0 + 5 + c, gc[3] * (sigmoidf_(v) - tgt) / (float)nc);
+            // the class logits sixteen at a time, all loads first: the few assigned predictors of a launch (one lane of a wave here and
+            // there) each walked nc DEPENDENT global loads - 80 round trips, which WAS the kernel's duration (66 / 85 us per launch for
+            // 0.3 M predictors).  Same additions in the same order.
+            for (int cb = 0; cb < nc; cb += 16) {
+                float vv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) vv[u] = x.get(n, pix, c0 + 5 + (cb + u < nc ? cb + u : nc - 1));
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int c = cb + u;
+                    if (c >= nc) break;
+                    const float v = vv[u];
+                    const float tgt = c == lab ? 1.f : 0.f;
+                    // softplus(-|v|) with the hardware exp / log: the library log1pf(expf()) pair is ~250 instructions, and 80 of them in
+                    // the one active lane of a wave WAS the forward launch (70-85 us; the backward, which does not evaluate it, 43 us)
+                    const float tq = __expf(-fabsf(v));
+                    bce += fmaxf(v, 0.f) - v * tgt + (tq < 1e-4f ? tq : __logf(1.f + tq));
+                    if (BWD) dx.put(n, pix, c0 + 5 + c, gc[3] * (sigmoidf_(v) - tgt) / (float)nc);
+                }
             }
             acc[3] += bce / (float)nc;
             if (BWD) {
@@ -242,10 +256,9 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(Logits x, Grads dx, int 
                 dx.put(n, pix, c0 + 2, (rw >= 0.f && rw <= 2.f) ? gbw * rw : 0.f);
                 dx.put(n, pix, c0 + 3, (rh >= 0.f && rh <= 2.f) ? gbh * rh : 0.f);
             }
-        } else if (BWD) {
-            for (int c = 0; c < 4; ++c) dx.put(n, pix, c0 + c, 0.f);
-            for (int c = 0; c < nc; ++c) dx.put(n, pix, c0 + 5 + c, 0.f);
         }
+        // (predictors without an assigned box: their box and class gradients are zero - dlogits ARRIVES zeroed, hc_yolo_loss_bwd's
+        // contract; writing 4 + nc scattered 2-byte zeros per predictor here was the kernel: 143 us per launch on the 76 x 76 map)
         if (BWD) dx.put(n, pix, c0 + 4, go);
     }
     if (!BWD) {

@@ -632,7 +632,8 @@ int hc_dropblock_mask_batched(const hc_drop_item* items, int32_t nitems, int64_t
  *   without ground truth, min_k (1 - IoU_k + penalty_k) (ciou_loss == diou_loss in the reference), mean_c BCE; the host
  *   applies lambda / N.  gt_off int32 [N+1] = per-image ranges into gt_boxes / gt_labels.
  * loss_bwd: dlogits (same dtype / strides as logits) = sum_i gcoef[i] * d sums[i] / d logits, including the gradient
- *   that reaches the boxes through the IoU objectness target (the reference does not detach it). */
+ *   that reaches the boxes through the IoU objectness target (the reference does not detach it).  dlogits must ARRIVE ZEROED: the
+ *   kernel writes the objectness gradient of every predictor and the box / class gradients of the assigned ones only. */
 int hc_yolo_decode(const void* logits, int32_t dtype, int64_t sn, int64_t sc, int64_t sp, int32_t N, int32_t H, int32_t W,
                    int32_t A, int32_t num_classes, const float* anchors, float scale_xy, float* boxes, float* obj,
                    float* score, int64_t* label, int32_t clamp01, hc_stream_t stream);
