@@ -29,9 +29,10 @@ elif which == "yolov4_eval":
     g_ = torch.Generator().manual_seed(0)
     x = torch.rand((16, 3, 608, 608), generator=g_).to(dev)
 else:
-    model = h.models.repvgg_a0(num_classes=10).to(dev).train()
+    nc_ = 1000 if which.startswith("rexnet") else 10
+    model = getattr(h.models, which)(num_classes=nc_).to(dev).train()
     x = torch.rand((256, 3, 224, 224), device=dev)
-    t = torch.randint(0, 10, (256,), device=dev)
+    t = torch.randint(0, nc_, (256,), device=dev)
 
     def loss_of():
         return h.nn.functional.cross_entropy(model(x), t, label_smoothing=0.1)
