@@ -198,6 +198,8 @@ SIGNATURES = {
     "hc_yolo1_loss_fwd": (c_int32, [c_void_p] * 3 + [c_int32] * 8 + [c_void_p] * 4 + [c_int32] + [c_void_p] * 4),
     "hc_yolo1_loss_bwd": (c_int32, [c_void_p] * 3 + [c_int32] * 8 + [c_void_p] * 4 + [c_int32] + [c_void_p] * 7),
     "hc_yolo1_decode": (c_int32, [c_void_p] * 3 + [c_int32] * 7 + [c_void_p] * 4),
+    "hc_yolo_format_fwd": (c_int32, [c_void_p] * 2 + [c_int32] * 7 + [c_void_p] * 5),
+    "hc_yolo_format_bwd": (c_int32, [c_void_p] * 3 + [c_int32] * 7 + [c_void_p] * 7),
     "hc_lamb_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "hc_tadam_step": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "hc_adan_step": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),

@@ -441,6 +441,99 @@ inline int grid_for(long total, int threads = 256, int cap = 4096) {
     return (int)b;
 }
 
+// _format_outputs of YOLOv1 (yolo.py:314-334) and YOLOv2 (yolov2.py:175-200): raw head output -> boxes / objectness / class
+// distribution, one thread per predictor (n, i, j, a).  The two layouts differ only in where a predictor's logits sit, so the host
+// hands over element strides: box / objectness logit k of predictor (n, i, j, a) at n*sn + i*si + j*sj + a*sa + k*sk, class logit c
+// at cls0 + n*sn + i*si + j*sj + a*ca + c*cc.  YOLOv1 (v2 == 0): four sigmoids, the class softmax is shared by the anchors of a
+// cell (As = 1, ca = 0: anchor 0's thread owns it).  YOLOv2: sigmoid + cell offset over the grid size for the centre, anchor * exp
+// for the size.
+struct FmtLayout { long sn, si, sj, sa, sk, cls0, ca, cc; };
+
+__global__ void yolo_format_fwd_kernel(const float* __restrict__ x, FmtLayout L, long total, int H, int W, int A, int As, int nc, int v2,
+                                       const float* __restrict__ anchors, float* __restrict__ boxes, float* __restrict__ obj,
+                                       float* __restrict__ scores) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int a = (int)(t % A);
+        const long cell = t / A;
+        const int j = (int)(cell % W), i = (int)((cell / W) % H);
+        const long n = cell / ((long)W * H);
+        const long pos = n * L.sn + i * L.si + j * L.sj;
+        const float* xb = x + pos + a * L.sa;
+        const float s0 = sigmoidf_(xb[0]), s1 = sigmoidf_(xb[L.sk]);
+        float b0, b1, b2, b3;
+        if (v2) {
+            b0 = (s0 + (float)j) / (float)W;
+            b1 = (s1 + (float)i) / (float)H;
+            b2 = anchors[2 * a] * expf(xb[2 * L.sk]);
+            b3 = anchors[2 * a + 1] * expf(xb[3 * L.sk]);
+        } else {
+            b0 = s0; b1 = s1;
+            b2 = sigmoidf_(xb[2 * L.sk]);
+            b3 = sigmoidf_(xb[3 * L.sk]);
+        }
+        boxes[4 * t] = b0; boxes[4 * t + 1] = b1; boxes[4 * t + 2] = b2; boxes[4 * t + 3] = b3;
+        obj[t] = sigmoidf_(xb[4 * L.sk]);
+        if (a < As) {
+            const float* xc = x + L.cls0 + pos + a * L.ca;
+            float* ps = scores + (cell * As + a) * nc;
+            float mx = xc[0];
+            for (int c = 1; c < nc; ++c) mx = fmaxf(mx, xc[c * L.cc]);
+            float sum = 0.f;
+            for (int c = 0; c < nc; ++c) {
+                const float e = expf(xc[c * L.cc] - mx);
+                ps[c] = e;
+                sum += e;
+            }
+            for (int c = 0; c < nc; ++c) ps[c] = ps[c] / sum;
+        }
+    }
+}
+
+// gradient of the above: every logit belongs to exactly one predictor thread, so dx (layout Ld, same shape as x) is written once
+// everywhere and needs no zero fill; a missing cotangent (nullptr) counts as zero.  p is the forward's class distribution.
+__global__ void yolo_format_bwd_kernel(const float* __restrict__ x, FmtLayout L, FmtLayout Ld, long total, int H, int W, int A, int As,
+                                       int nc, int v2, const float* __restrict__ anchors, const float* __restrict__ p,
+                                       const float* __restrict__ gb, const float* __restrict__ go, const float* __restrict__ gs,
+                                       float* __restrict__ dx) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int a = (int)(t % A);
+        const long cell = t / A;
+        const int j = (int)(cell % W), i = (int)((cell / W) % H);
+        const long n = cell / ((long)W * H);
+        const float* xb = x + n * L.sn + i * L.si + j * L.sj + a * L.sa;
+        const long dpos = n * Ld.sn + i * Ld.si + j * Ld.sj;
+        float* db = dx + dpos + a * Ld.sa;
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gb != nullptr) { g[0] = gb[4 * t]; g[1] = gb[4 * t + 1]; g[2] = gb[4 * t + 2]; g[3] = gb[4 * t + 3]; }
+        const float s0 = sigmoidf_(xb[0]), s1 = sigmoidf_(xb[L.sk]);
+        if (v2) {
+            db[0] = g[0] / (float)W * (s0 * (1.f - s0));
+            db[Ld.sk] = g[1] / (float)H * (s1 * (1.f - s1));
+            db[2 * Ld.sk] = g[2] * (anchors[2 * a] * expf(xb[2 * L.sk]));
+            db[3 * Ld.sk] = g[3] * (anchors[2 * a + 1] * expf(xb[3 * L.sk]));
+        } else {
+            const float s2 = sigmoidf_(xb[2 * L.sk]), s3 = sigmoidf_(xb[3 * L.sk]);
+            db[0] = g[0] * (s0 * (1.f - s0));
+            db[Ld.sk] = g[1] * (s1 * (1.f - s1));
+            db[2 * Ld.sk] = g[2] * (s2 * (1.f - s2));
+            db[3 * Ld.sk] = g[3] * (s3 * (1.f - s3));
+        }
+        const float s4 = sigmoidf_(xb[4 * L.sk]);
+        db[4 * Ld.sk] = (go != nullptr ? go[t] : 0.f) * (s4 * (1.f - s4));
+        if (a < As) {
+            float* dc = dx + Ld.cls0 + dpos + a * Ld.ca;
+            const long so = (cell * As + a) * nc;
+            if (gs == nullptr) {
+                for (int c = 0; c < nc; ++c) dc[c * Ld.cc] = 0.f;
+            } else {
+                float dot = 0.f;
+                for (int c = 0; c < nc; ++c) dot += gs[so + c] * p[so + c];
+                for (int c = 0; c < nc; ++c) dc[c * Ld.cc] = p[so + c] * (gs[so + c] - dot);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -568,6 +661,32 @@ int hc_yolo1_decode(const float* b_coords, const float* b_o, const float* b_scor
     if (total == 0) return HC_OK;
     hipLaunchKernelGGL(yolo1_decode_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, b_coords, b_o, b_scores, total, H, W, A,
                        nc, cell_rel, clamp01, boxes, score, (long*)label);
+    return hc_launch_status();
+}
+
+static inline FmtLayout fmt_layout(const int64_t* s) { return FmtLayout{s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]}; }
+
+int hc_yolo_format_fwd(const float* x, const int64_t* layout, int32_t N, int32_t H, int32_t W, int32_t A, int32_t As, int32_t nc,
+                       int32_t v2, const float* anchors, float* boxes, float* obj, float* scores, hc_stream_t stream) {
+    if (x == nullptr || layout == nullptr || boxes == nullptr || obj == nullptr || scores == nullptr) return HC_ERR_ARG;
+    if (N < 0 || H <= 0 || W <= 0 || A <= 0 || nc <= 0 || (As != 1 && As != A) || (v2 != 0 && anchors == nullptr)) return HC_ERR_ARG;
+    const long total = (long)N * H * W * A;
+    if (total == 0) return HC_OK;
+    hipLaunchKernelGGL(yolo_format_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, fmt_layout(layout), total, H, W,
+                       A, As, nc, v2, anchors, boxes, obj, scores);
+    return hc_launch_status();
+}
+
+int hc_yolo_format_bwd(const float* x, const int64_t* layout, const int64_t* dx_layout, int32_t N, int32_t H, int32_t W, int32_t A,
+                       int32_t As, int32_t nc, int32_t v2, const float* anchors, const float* scores, const float* g_boxes,
+                       const float* g_obj, const float* g_scores, float* dx, hc_stream_t stream) {
+    if (x == nullptr || layout == nullptr || dx_layout == nullptr || dx == nullptr) return HC_ERR_ARG;
+    if (N < 0 || H <= 0 || W <= 0 || A <= 0 || nc <= 0 || (As != 1 && As != A) || (v2 != 0 && anchors == nullptr)) return HC_ERR_ARG;
+    if (g_scores != nullptr && scores == nullptr) return HC_ERR_ARG;
+    const long total = (long)N * H * W * A;
+    if (total == 0) return HC_OK;
+    hipLaunchKernelGGL(yolo_format_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, fmt_layout(layout),
+                       fmt_layout(dx_layout), total, H, W, A, As, nc, v2, anchors, scores, g_boxes, g_obj, g_scores, dx);
     return hc_launch_status();
 }
 

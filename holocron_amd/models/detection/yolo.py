@@ -10,7 +10,6 @@ from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 from torch import Tensor
 
 from ... import _lib
@@ -41,6 +40,42 @@ def _pack_targets(target: List[Dict[str, Tensor]], device):
 
 def _f32c(t: Tensor) -> Tensor:
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+
+
+class _FormatFn(torch.autograd.Function):
+    """``_format_outputs`` of YOLOv1 (yolo.py:314-334) / YOLOv2 (yolov2.py:175-200) as one launch each way
+    (``hc_yolo_format_fwd`` / ``_bwd``): raw head output -> boxes [N, H, W, A, 4], objectness [N, H, W, A], class distribution
+    [N, H, W, As, C].  ``layout`` holds the element strides of the logits (include/holocron_hip.h), ``dx_layout_of`` derives the
+    same for the gradient buffer, which is ``empty_like(x)``: every logit is written exactly once."""
+
+    @staticmethod
+    def forward(ctx, x, dims, layout_of, anchors):
+        import ctypes as C
+        N, H, W, A, As, nc = dims
+        v2 = anchors is not None
+        dev = x.device
+        boxes = torch.empty((N, H, W, A, 4), dtype=torch.float32, device=dev)
+        obj = torch.empty((N, H, W, A), dtype=torch.float32, device=dev)
+        scores = torch.empty((N, H, W, As, nc), dtype=torch.float32, device=dev)
+        lay = (C.c_int64 * 8)(*layout_of(x))
+        check(_lib.load().hc_yolo_format_fwd(ptr(x), lay, N, H, W, A, As, nc, int(v2), ptr(anchors) if v2 else None, ptr(boxes), ptr(obj),
+                                             ptr(scores), stream()), "hc_yolo_format_fwd")
+        ctx.save_for_backward(x, scores, anchors)
+        ctx.meta = (dims, layout_of)
+        return boxes, obj, scores
+
+    @staticmethod
+    def backward(ctx, g_boxes, g_obj, g_scores):
+        import ctypes as C
+        x, scores, anchors = ctx.saved_tensors
+        (N, H, W, A, As, nc), layout_of = ctx.meta
+        dx = torch.empty_like(x)
+        gb, go, gs = (None if g is None else _f32c(g) for g in (g_boxes, g_obj, g_scores))
+        check(_lib.load().hc_yolo_format_bwd(ptr(x), (C.c_int64 * 8)(*layout_of(x)), (C.c_int64 * 8)(*layout_of(dx)), N, H, W, A, As, nc,
+                                             int(anchors is not None), ptr(anchors) if anchors is not None else None, ptr(scores),
+                                             ptr(gb) if gb is not None else None, ptr(go) if go is not None else None,
+                                             ptr(gs) if gs is not None else None, ptr(dx), stream()), "hc_yolo_format_bwd")
+        return dx, None, None, None
 
 
 class _Yolo1LossFn(torch.autograd.Function):
@@ -187,13 +222,18 @@ class YOLOv1(_YOLO):
 
     def _format_outputs(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
         """[N, 7*7*(A*5 + C)] -> boxes [N, 7, 7, A, 4], objectness [N, 7, 7, A], class distribution [N, 7, 7, 1, C]
-        (yolo.py:314-334).  A [N, 1470] tensor: sigmoid / softmax stay on torch (autograd plumbing)."""
+        (yolo.py:314-334): one launch (``_FormatFn``), one more for its gradient."""
+        _lib.require_gpu(x)
         b, _ = x.shape
         h, w = 7, 7
-        x = x.reshape(b, h, w, self.num_anchors * 5 + self.num_classes)
-        b_scores = F.softmax(x[..., -self.num_classes:].unsqueeze(3), dim=-1)
-        x = torch.sigmoid(x[..., :self.num_anchors * 5].reshape(b, h, w, self.num_anchors, 5))
-        return x[..., :4], x[..., 4], b_scores
+        A, nc = self.num_anchors, self.num_classes
+        D = A * 5 + nc
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+
+        def layout_of(t):      # [N, 7 * 7 * (A * 5 + C)] contiguous: a cell's A * 5 box logits, then its C class logits
+            return (h * w * D, w * D, D, 5, 1, A * 5, 0, 1)
+        return _FormatFn.apply(x, (b, h, w, A, 1, nc), layout_of, None)
 
     def _forward(self, x: Tensor) -> Tensor:
         from ...nn.convbn_op import prepack_model_convs

@@ -7,7 +7,6 @@ from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 from torch import Tensor
 
 from ... import _lib
@@ -19,7 +18,7 @@ from ...ops.nhwc import cat_cl
 from ..classification.darknet import _FusedSequential
 from ..classification.darknetv2 import DarknetBodyV2
 from ..utils import conv_sequence
-from .yolo import _YOLO
+from .yolo import _YOLO, _FormatFn
 
 __all__ = ["YOLOv2", "yolov2"]
 
@@ -73,19 +72,18 @@ class YOLOv2(_YOLO):
 
     def _format_outputs(self, x: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
         """[N, A*(5 + C), H, W] -> boxes [N, H, W, A, 4] (absolute xc, yc, w, h), objectness, class probabilities
-        (yolov2.py:175-200).  The head output is a few hundred KB: the sigmoid / exp / softmax stay on torch."""
+        (yolov2.py:175-200): one launch (``yolo._FormatFn``: sigmoid / exp / softmax of every predictor), one more for its gradient."""
+        _lib.require_gpu(x)
         b, _, h, w = x.shape
-        x = x.reshape(b, self.num_anchors, 5 + self.num_classes, h, w).permute(0, 3, 4, 1, 2)
-        b_scores = F.softmax(x[..., -self.num_classes:], dim=-1)
-        c_x = torch.arange(w, dtype=torch.float, device=x.device)
-        c_y = torch.arange(h, dtype=torch.float, device=x.device)
-        b_x = (torch.sigmoid(x[..., 0]) + c_x.reshape(1, 1, -1, 1)) / w
-        b_y = (torch.sigmoid(x[..., 1]) + c_y.reshape(1, -1, 1, 1)) / h
-        b_w = self.anchors[:, 0].reshape(1, 1, 1, -1) * torch.exp(x[..., 2])
-        b_h = self.anchors[:, 1].reshape(1, 1, 1, -1) * torch.exp(x[..., 3])
-        b_coords = torch.stack((b_x, b_y, b_w, b_h), dim=4)
-        b_o = torch.sigmoid(x[..., 4])
-        return b_coords, b_o, b_scores
+        A, nc = self.num_anchors, self.num_classes
+        if x.dtype != torch.float32:
+            x = x.float()
+
+        def layout_of(t):      # [N, A * (5 + C), H, W] with whatever strides the head left (channels-last after the padded conv)
+            sn, sc, sh, sw = t.stride()
+            return (sn, sh, sw, (5 + nc) * sc, sc, 5 * sc, (5 + nc) * sc, sc)
+        anchors = self.anchors.to(device=x.device, dtype=torch.float32).contiguous()
+        return _FormatFn.apply(x, (b, h, w, A, A, nc), layout_of, anchors)
 
     def _forward(self, x: Tensor) -> Tensor:
         _lib.require_gpu(x)

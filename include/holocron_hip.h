@@ -672,6 +672,22 @@ int hc_yolo1_decode(const float* b_coords, const float* b_o, const float* b_scor
                     int32_t nc, int32_t cell_rel, int32_t clamp01, float* boxes, float* score, int64_t* label,
                     hc_stream_t stream);
 
+/* ---- YOLOv1._format_outputs (holocron/models/detection/yolo.py:314-334) and YOLOv2._format_outputs
+ * (holocron/models/detection/yolov2.py:175-200): raw head output (fp32, any strides) -> boxes [N][H][W][A][4], objectness
+ * [N][H][W][A], class distribution [N][H][W][As][nc] (fp32, contiguous; As = 1: one softmax per cell, YOLOv1; As = A: YOLOv2).
+ * Replaces the reshape / sigmoid / exp / softmax / stack chain of those lines and its autograd.
+ * layout int64 [8], HOST memory, element strides of the logits: {sn, si, sj, sa, sk, cls0, ca, cc} - box / objectness logit k of
+ * predictor (n, i, j, a) sits at n*sn + i*si + j*sj + a*sa + k*sk, class logit c at cls0 + n*sn + i*si + j*sj + a*ca + c*cc.
+ * v2 == 0: boxes = sigmoid of the four logits (YOLOv1).  v2 != 0: ((sigmoid(tx) + j) / W, (sigmoid(ty) + i) / H,
+ * anchors[a][0] * exp(tw), anchors[a][1] * exp(th)) with anchors fp32 [A][2] on the device.
+ * format_bwd: cotangents g_boxes / g_obj / g_scores (contiguous, nullptr = zero) and the forward's `scores` -> dx in the layout
+ * dx_layout (every logit is written exactly once: no zero fill needed). ---- */
+int hc_yolo_format_fwd(const float* x, const int64_t* layout, int32_t N, int32_t H, int32_t W, int32_t A, int32_t As, int32_t nc,
+                       int32_t v2, const float* anchors, float* boxes, float* obj, float* scores, hc_stream_t stream);
+int hc_yolo_format_bwd(const float* x, const int64_t* layout, const int64_t* dx_layout, int32_t N, int32_t H, int32_t W, int32_t A,
+                       int32_t As, int32_t nc, int32_t v2, const float* anchors, const float* scores, const float* g_boxes,
+                       const float* g_obj, const float* g_scores, float* dx, hc_stream_t stream);
+
 /* ---- DarkNet-19 / 24 bodies and the YOLOv2 passthrough (darknet.py:83, darknetv2.py:94, nn/functional.py:116-136), NHWC bf16,
  * C % 8 == 0.
  * maxpool2: nn.MaxPool2d(2) (floor mode); idx uint16 [N][H/2][W/2][C/8]: 2 bits per channel, the first maximum in row-major

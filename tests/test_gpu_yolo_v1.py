@@ -63,6 +63,41 @@ def test_losses_and_gradients_match_reference(golden):
             assert torch.allclose(got.cpu(), ref, rtol=1e-4, atol=1e-6), (c["tag"], c["ignore"], name, float((got.cpu() - ref).abs().max()))
 
 
+def test_format_outputs_kernels_match_reference_fixture(golden):
+    """YOLOv1 / YOLOv2 ``_format_outputs`` (yolo.py:314-334, yolov2.py:175-200) as one launch: the reference's own outputs on
+    the fixture's raw head tensors (fp32: 1e-5 relative - device expf against libm), and the gradient against autograd through the
+    CPU restatement for random cotangents, for a contiguous and a channels-last YOLOv2 head output, and with a missing cotangent."""
+    import holocron_amd as h
+    from oracle import yolo_v1 as oy
+    f = golden("yolo_v1.pt")["fmt"]
+    m1 = h.models.detection.yolov1(num_classes=10).cuda()
+    m2 = h.models.detection.yolov2(num_classes=10).cuda()
+    m2.anchors.copy_(f["anchors"])
+    gen = torch.Generator().manual_seed(11)
+    cases = [("v1", m1, f["x1"], f["v1"], lambda t: oy.format_outputs_v1(t, 2, 10), False),
+             ("v2", m2, f["x2"], f["v2"], lambda t: oy.format_outputs_v2(t, f["anchors"], 10), False),
+             ("v2 channels-last", m2, f["x2"], f["v2"], lambda t: oy.format_outputs_v2(t, f["anchors"], 10), True)]
+    for tag, m, x, ref, ofn, cl in cases:
+        xg = x.cuda()
+        if cl:
+            xg = xg.contiguous(memory_format=torch.channels_last)
+        xg.requires_grad_(True)
+        got = m._format_outputs(xg)
+        assert [tuple(t.shape) for t in got] == [tuple(t.shape) for t in ref], tag
+        for a, b, name in zip(got, ref, ("boxes", "obj", "scores")):
+            assert torch.allclose(a.cpu(), b, rtol=1e-5, atol=1e-6), (tag, name, float((a.cpu() - b).abs().max()))
+        xc = x.clone().requires_grad_(True)
+        outs = ofn(xc)
+        cot = [torch.randn(t.shape, generator=gen) for t in outs]
+        want = torch.autograd.grad(sum((o * c).sum() for o, c in zip(ofn(xc), cot)), xc)[0]
+        (dx,) = torch.autograd.grad(sum((o * c.cuda()).sum() for o, c in zip(got, cot)), xg, retain_graph=True)
+        assert dx.shape == x.shape and rel_l2(dx.cpu(), want) < 1e-5, (tag, rel_l2(dx.cpu(), want))
+        # objectness cotangent only: the box and class logits get exact zeros, not stale memory
+        (dx,) = torch.autograd.grad((got[1] * cot[1].cuda()).sum(), xg)
+        want = torch.autograd.grad((ofn(xc)[1] * cot[1]).sum(), xc)[0]
+        assert rel_l2(dx.cpu(), want) < 1e-5 and bool(((want == 0) == (dx.cpu() == 0)).all()), tag
+
+
 def test_to_isoboxes_and_empty_targets(golden):
     from oracle import yolo_v1 as oy
     g = torch.Generator().manual_seed(3)
