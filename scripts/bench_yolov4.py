@@ -110,10 +110,19 @@ def main():
             fl, sec, nl, nb = fam[dom]
             t_m, t_h = fl / MF, nb / HB
             bound = "mfma" if t_m >= t_h else "hbm"
+            # HBM-side bytes per launch of the dominant family from the committed PMC passes of this command (scripts/pmc_families.sh)
+            traffic = traffic_src = None
+            pf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_pmc_yolov4_eval_traffic.json")
+            if os.path.exists(pf):
+                with open(pf) as fh:
+                    traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_src = "profiles/r06_pmc_yolov4_eval_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; committed, not live)"
             line["roofline"] = {"bound": bound, "kernel": dom,
                                 "achieved": (fl / sec / 1e12) if bound == "mfma" else (nb / sec / 1e9),
                                 "peak": MF / 1e12 if bound == "mfma" else HB / 1e9, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-                                "frac": max(t_m, t_h) / sec, "traffic": None, "launches_per_pass": nl, "avg_launch_ms": sec / nl * 1e3,
+                                "frac": max(t_m, t_h) / sec, "traffic": traffic, "traffic_source": traffic_src,
+                                "algorithmic_bytes_per_launch": nb / nl, "launches_per_pass": nl, "avg_launch_ms": sec / nl * 1e3,
                                 "covered_ms_per_pass": sum(v[1] for v in fam.values()) * 1e3,
                                 "families": {k: {"ms_per_pass": v[1] * 1e3, "launches": v[2], "tflops": v[0] / v[1] / 1e12 if v[1] else 0.0,
                                                  "gbps": v[3] / v[1] / 1e9 if v[1] else 0.0,

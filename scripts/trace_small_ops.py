@@ -75,6 +75,13 @@ for ev in prof.events():
         if root in fr and "site-packages" not in fr and "dist-packages" not in fr:
             where = fr.replace(root + "/", "")
             break
+    if where == "?":
+        # no Python stack (ops issued from inside the autograd engine): name the enclosing profiler ranges instead
+        chain, par = [], getattr(ev, "cpu_parent", None)
+        while par is not None and len(chain) < 4:
+            chain.append(par.name[:60])
+            par = getattr(par, "cpu_parent", None)
+        where = " < ".join(chain) if chain else "?"
     by[(ev.name, names, where)] += 1
 for (name, names, where), n in sorted(by.items(), key=lambda kv: -kv[1]):
     print(f"{n:4d}  {name:28s} {names:50s} {where}")
