@@ -1066,72 +1066,155 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const hc_pack_it
 }
 
 // im2col for tiny Cin (stem): x NCHW fp32 -> col [N][OH][OW][Kpad] bf16, k = (kh*KW+kw)*Cin+ci
-// CINC / KSC: compile-time channel count and (square) kernel size, 0 = run time: the index arithmetic is all div / mod
-template <int CINC, int KSC>
-__global__ void im2col_small_kernel(const float* __restrict__ x, bf16_t* __restrict__ col, int N, int Cin_, int H, int W, int OH,
-                                    int OW, int KH_, int KW_, int stride, int pad, int Kpad) {
+// CINC / KSC: compile-time channel count and (square) kernel size, 0 = run time.
+// Grid: y walks the output rows (n, oy), x the (ox, 8-wide k chunk) items of one row - the former flat index cost three 64-bit
+// div / mod pairs per item (a few hundred VALU instructions for eight 4-byte gathers: the YOLOv4 stem ran at 2 TB/s of its own bytes);
+// here a row costs one 32-bit division per thread and an item one more, offsets inside an image are 32-bit.
+template <int CINC, int KSC, typename Store>
+__device__ __forceinline__ void im2col_rows(const float* __restrict__ x, int N, int Cin_, int H, int W, int OH, int OW, int KH_, int KW_,
+                                            int stride, int pad, int Kpad, Store store) {
     const int Cin = CINC ? CINC : Cin_, KH = KSC ? KSC : KH_, KW = KSC ? KSC : KW_;
-    const int kchunks = Kpad / 8;
-    const long total = (long)N * OH * OW * kchunks;
+    const unsigned kchunks = (unsigned)Kpad / 8u, rowq = (unsigned)OW * kchunks;
     const int K = Cin * KH * KW;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
-        const int kc = (int)(q % kchunks);
-        const long p = q / kchunks;
-        const int ox = (int)(p % OW);
-        const long r = p / OW;
-        const int oy = (int)(r % OH);
-        const int n = (int)(r / OH);
-        float f[8];
+    const unsigned rows = (unsigned)N * (unsigned)OH;
+    for (unsigned row = blockIdx.y; row < rows; row += gridDim.y) {
+        const unsigned n = row / (unsigned)OH;
+        const int oy = (int)(row - n * (unsigned)OH);
+        const float* __restrict__ xn = x + (size_t)n * Cin * H * W;
+        for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < rowq; t += gridDim.x * blockDim.x) {
+            const unsigned oxu = t / kchunks;
+            const int kc = (int)(t - oxu * kchunks), ox = (int)oxu;
+            float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = kc * 8 + e;
-            float v = 0.f;
-            if (k < K) {
-                const int ci = k % Cin, t = k / Cin;
-                const int kh = t / KW, kw = t % KW;
-                const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[(((long)n * Cin + ci) * H + iy) * W + ix];
+            for (int e = 0; e < 8; ++e) {
+                const int k = kc * 8 + e;
+                float v = 0.f;
+                if (k < K) {
+                    const int ci = k % Cin, tp = k / Cin;
+                    const int kh = tp / KW, kw = tp % KW;
+                    const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
+                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xn[(ci * H + iy) * W + ix];
+                }
+                f[e] = v;
             }
-            f[e] = v;
+            store((size_t)row * rowq + t, f);
         }
-        reinterpret_cast<u32x4*>(col)[q] = pack8(f);
     }
 }
+
+template <int CINC, int KSC>
+__global__ __launch_bounds__(256) void im2col_small_kernel(const float* __restrict__ x, bf16_t* __restrict__ col, int N, int Cin, int H, int W,
+                                                           int OH, int OW, int KH, int KW, int stride, int pad, int Kpad) {
+    im2col_rows<CINC, KSC>(x, N, Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad,
+                           [col](size_t q, const float (&f)[8]) { reinterpret_cast<u32x4*>(col)[q] = pack8(f); });
+}
 // same gather, quantised straight to OCP e4m3 bytes (fp8 inference stem): col [N][OH][OW][Kpad] uint8 = fp8(x * inv_scale)
-__global__ void im2col_small_fp8_kernel(const float* __restrict__ x, unsigned char* __restrict__ col, int N, int Cin, int H, int W,
-                                        int OH, int OW, int KH, int KW, int stride, int pad, int Kpad, float inv_scale) {
-    const long total = (long)N * OH * OW * (Kpad / 8);
-    const int K = Cin * KH * KW;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
-        const int kc = (int)(q % (Kpad / 8));
-        const long p = q / (Kpad / 8);
-        const int ox = (int)(p % OW);
-        const long r = p / OW;
-        const int oy = (int)(r % OH);
-        const int n = (int)(r / OH);
-        float f[8];
+template <int CINC, int KSC>
+__global__ __launch_bounds__(256) void im2col_small_fp8_kernel(const float* __restrict__ x, unsigned char* __restrict__ col, int N, int Cin,
+                                                               int H, int W, int OH, int OW, int KH, int KW, int stride, int pad, int Kpad,
+                                                               float inv_scale) {
+    im2col_rows<CINC, KSC>(x, N, Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad, [col, inv_scale](size_t q, const float (&f)[8]) {
+        float g[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = kc * 8 + e;
-            float v = 0.f;
-            if (k < K) {
-                const int ci = k % Cin, t = k / Cin;
-                const int kh = t / KW, kw = t % KW;
-                const int iy = oy * stride + kh - pad, ix = ox * stride + kw - pad;
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = x[(((long)n * Cin + ci) * H + iy) * W + ix];
-            }
-            f[e] = fminf(fmaxf(v * inv_scale, -448.f), 448.f);
-        }
+        for (int e = 0; e < 8; ++e) g[e] = fminf(fmaxf(f[e] * inv_scale, -448.f), 448.f);
         int lo = 0, hi = 0;
-        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
-        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
-        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
-        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(g[0], g[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(g[2], g[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(g[4], g[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(g[6], g[7], hi, true);
         u32x2 pk;
         pk[0] = (unsigned)lo;
         pk[1] = (unsigned)hi;
         reinterpret_cast<u32x2*>(col)[q] = pk;
+    });
+}
+// The 3-channel 3 x 3 pad-1 stem (every model's first layer) with the input staged through LDS: a workgroup owns an output row, loads the
+// 3 channels x 3 input rows it needs with coalesced 16-byte loads (zero halo columns / rows written in place), and the eight 4-byte
+// gathers of an item become LDS reads - the global-memory side of the kernel is then two coalesced streams.  Same values, same
+// layout as im2col_rows (bit-identical column tensor).  LDS: 9 rows of W + 2 floats.
+template <typename Store>
+__device__ __forceinline__ void im2col3_lds_rows(const float* __restrict__ x, int N, int H, int W, int OH, int OW, int stride, int Kpad,
+                                                 float* __restrict__ tile, Store store) {
+    const unsigned kchunks = (unsigned)Kpad / 8u, rowq = (unsigned)OW * kchunks;
+    const unsigned rows = (unsigned)N * (unsigned)OH;
+    const int LW = W + 2;
+    for (unsigned row = blockIdx.x; row < rows; row += gridDim.x) {
+        const unsigned n = row / (unsigned)OH;
+        const int oy = (int)(row - n * (unsigned)OH);
+        const float* __restrict__ xn = x + (size_t)n * 3 * H * W;
+        __syncthreads();                         // the previous row's readers are done with the tile
+        if ((W & 3) == 0) {
+            const int w4 = W >> 2;
+            for (int i = threadIdx.x; i < 9 * w4; i += blockDim.x) {
+                const int r = i / w4, c4 = i - r * w4;          // r = ci * 3 + kh
+                const int ci = r / 3, kh = r - ci * 3;
+                const int iy = oy * stride + kh - 1;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)iy < (unsigned)H) v = *reinterpret_cast<const f32x4*>(xn + (ci * H + iy) * W + c4 * 4);
+                float* d = tile + r * LW + 1 + c4 * 4;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            }
+        } else {
+            for (int i = threadIdx.x; i < 9 * W; i += blockDim.x) {
+                const int r = i / W, c = i - r * W;
+                const int ci = r / 3, kh = r - ci * 3;
+                const int iy = oy * stride + kh - 1;
+                tile[r * LW + 1 + c] = (unsigned)iy < (unsigned)H ? xn[(ci * H + iy) * W + c] : 0.f;
+            }
+        }
+        if (threadIdx.x < 18) tile[(threadIdx.x >> 1) * LW + ((threadIdx.x & 1) ? W + 1 : 0)] = 0.f;     // halo columns
+        __syncthreads();
+        for (unsigned t = threadIdx.x; t < rowq; t += blockDim.x) {
+            const unsigned oxu = t / kchunks;
+            const int kc = (int)(t - oxu * kchunks);
+            const float* base = tile + (int)oxu * stride;        // column ix = ox * stride + kw - 1 sits at index ix + 1
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = kc * 8 + e;
+                const int ci = k % 3, tp = k / 3;
+                const int kh = tp / 3, kw = tp - kh * 3;
+                f[e] = k < 27 ? base[(ci * 3 + kh) * LW + kw] : 0.f;
+            }
+            store((size_t)row * rowq + t, f);
+        }
     }
+}
+
+__global__ __launch_bounds__(256) void im2col3_lds_kernel(const float* __restrict__ x, bf16_t* __restrict__ col, int N, int H, int W, int OH,
+                                                          int OW, int stride, int Kpad) {
+    extern __shared__ float im2col_tile[];
+    im2col3_lds_rows(x, N, H, W, OH, OW, stride, Kpad, im2col_tile,
+                     [col](size_t q, const float (&f)[8]) { reinterpret_cast<u32x4*>(col)[q] = pack8(f); });
+}
+__global__ __launch_bounds__(256) void im2col3_lds_fp8_kernel(const float* __restrict__ x, unsigned char* __restrict__ col, int N, int H, int W,
+                                                              int OH, int OW, int stride, int Kpad, float inv_scale) {
+    extern __shared__ float im2col_tile[];
+    im2col3_lds_rows(x, N, H, W, OH, OW, stride, Kpad, im2col_tile, [col, inv_scale](size_t q, const float (&f)[8]) {
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = fminf(fmaxf(f[e] * inv_scale, -448.f), 448.f);
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(g[0], g[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(g[2], g[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(g[4], g[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(g[6], g[7], hi, true);
+        u32x2 pk;
+        pk[0] = (unsigned)lo;
+        pk[1] = (unsigned)hi;
+        reinterpret_cast<u32x2*>(col)[q] = pk;
+    });
+}
+// the LDS form applies to the 3-channel 3 x 3 pad-1 stem whose nine staged rows fit 64 KB; HC_IM2COL_LDS=0 keeps the gather form (A/B)
+static inline bool im2col3_lds_ok(int Cin, int KH, int KW, int pad, int W, int OW, int stride) {
+    static const int on = [] { const char* e = getenv("HC_IM2COL_LDS"); return e == nullptr ? 1 : atoi(e); }();
+    return on && Cin == 3 && KH == 3 && KW == 3 && pad == 1 && stride >= 1 && (size_t)9 * (W + 2) * sizeof(float) <= 64 * 1024
+           && (long)(OW - 1) * stride + 1 <= W;
+}
+// grid of the row walk: x covers one output row's items, y the rows (grid-stride beyond 65 535)
+static inline dim3 im2col_grid(int N, int OH, int OW, int Kpad) {
+    const long rowq = (long)OW * (Kpad / 8), rows = (long)N * OH;
+    return dim3((unsigned)((rowq + 255) / 256), (unsigned)(rows > 65535 ? 65535 : (rows < 1 ? 1 : rows)));
 }
 // dwcol fp32 [Cout][Kpad] (k = (kh*KW+kw)*Cin+ci) -> dw OIHW
 __global__ void unpack_im2col_grad_kernel(const float* __restrict__ dwcol, float* __restrict__ dw, int Cout, int Cin, int KH, int KW,
@@ -1436,21 +1519,42 @@ int hc_pack_conv_weights_multi(const hc_pack_item* items, int32_t nitems, int64_
 int hc_im2col_small(const float* x, void* col, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t KH,
                     int32_t KW, int32_t stride, int32_t pad, int32_t Kpad, hc_stream_t stream) {
     if (x == nullptr || col == nullptr || (Kpad % 8) != 0 || Cin * KH * KW > Kpad) return HC_ERR_ARG;
-    const long total = (long)N * OH * OW * (Kpad / 8);
+    if ((long)Cin * H * W > 2147483647L) return HC_ERR_ARG;          // offsets inside an image are 32-bit
+    if (N <= 0 || OH <= 0 || OW <= 0) return HC_OK;
+    const dim3 grid = im2col_grid(N, OH, OW, Kpad);
+    if (im2col3_lds_ok(Cin, KH, KW, pad, W, OW, stride)) {
+        const long rows = (long)N * OH;
+        hipLaunchKernelGGL(im2col3_lds_kernel, dim3((unsigned)(rows > 65535 ? 65535 : rows)), dim3(256), (size_t)9 * (W + 2) * sizeof(float),
+                           (hipStream_t)stream, x, (bf16_t*)col, N, H, W, OH, OW, stride, Kpad);
+        return hc_launch_status();
+    }
     if (Cin == 3 && KH == 3 && KW == 3)
-        hipLaunchKernelGGL((im2col_small_kernel<3, 3>), dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)col,
-                           N, Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad);
+        hipLaunchKernelGGL((im2col_small_kernel<3, 3>), grid, dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)col, N, Cin, H, W, OH, OW, KH, KW,
+                           stride, pad, Kpad);
     else
-        hipLaunchKernelGGL((im2col_small_kernel<0, 0>), dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)col,
-                           N, Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad);
+        hipLaunchKernelGGL((im2col_small_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)col, N, Cin, H, W, OH, OW, KH, KW,
+                           stride, pad, Kpad);
     return hc_launch_status();
 }
 int hc_im2col_small_fp8(const float* x, void* col, int32_t N, int32_t Cin, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t KH,
                         int32_t KW, int32_t stride, int32_t pad, int32_t Kpad, float inv_scale, hc_stream_t stream) {
     if (x == nullptr || col == nullptr || (Kpad % 8) != 0 || Cin * KH * KW > Kpad) return HC_ERR_ARG;
-    const long total = (long)N * OH * OW * (Kpad / 8);
-    hipLaunchKernelGGL(im2col_small_fp8_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x,
-                       (unsigned char*)col, N, Cin, H, W, OH, OW, KH, KW, stride, pad, Kpad, inv_scale);
+    if ((long)Cin * H * W > 2147483647L) return HC_ERR_ARG;
+    if (N <= 0 || OH <= 0 || OW <= 0) return HC_OK;
+    const dim3 grid = im2col_grid(N, OH, OW, Kpad);
+    if (im2col3_lds_ok(Cin, KH, KW, pad, W, OW, stride)) {
+        const long rows = (long)N * OH;
+        hipLaunchKernelGGL(im2col3_lds_fp8_kernel, dim3((unsigned)(rows > 65535 ? 65535 : rows)), dim3(256),
+                           (size_t)9 * (W + 2) * sizeof(float), (hipStream_t)stream, x, (unsigned char*)col, N, H, W, OH, OW, stride, Kpad,
+                           inv_scale);
+        return hc_launch_status();
+    }
+    if (Cin == 3 && KH == 3 && KW == 3)
+        hipLaunchKernelGGL((im2col_small_fp8_kernel<3, 3>), grid, dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)col, N, Cin, H, W, OH,
+                           OW, KH, KW, stride, pad, Kpad, inv_scale);
+    else
+        hipLaunchKernelGGL((im2col_small_fp8_kernel<0, 0>), grid, dim3(256), 0, (hipStream_t)stream, x, (unsigned char*)col, N, Cin, H, W, OH,
+                           OW, KH, KW, stride, pad, Kpad, inv_scale);
     return hc_launch_status();
 }
 int hc_unpack_im2col_grad(const float* dwcol, float* dw, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t Kpad,

@@ -249,3 +249,23 @@ def test_grouped_wgrad_matches_single_launches(N, Cin, Cout, H, k, jobs):
     outs2 = [torch.full((Cout, Cin, k, k), 0.5, dtype=torch.float32, device="cuda") for _ in range(jobs)]
     cv._WCONV.launch(key, [(a, b, None, o.data_ptr(), 0) for a, b, o in zip(xg, dg, outs2)], accumulate=True)
     assert all(torch.equal(a, b) for a, b in zip(outs, outs2))
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 30, 30, 3, 1, 1, 32), (2, 3, 31, 29, 3, 2, 1, 32), (3, 3, 64, 48, 3, 2, 1, 32), (1, 3, 17, 608, 3, 1, 1, 32),
+                                   (2, 3, 32, 32, 3, 1, 0, 32), (2, 3, 28, 28, 7, 2, 3, 152), (2, 4, 20, 24, 3, 1, 1, 40)])
+def test_stem_im2col_matches_unfold(shape):
+    """hc_im2col_small (the stems' column tensor: models/utils.py:73 with Cin = 3) against F.unfold, bit for bit: the LDS-staged form
+    of the 3-channel 3 x 3 pad-1 stem (widths that are and are not multiples of four, odd heights, strides 1 / 2) and the gather
+    form of everything else (no padding, 7 x 7, four channels).  k = (kh * KW + kw) * Cin + ci, zero beyond Cin * KH * KW."""
+    import torch.nn.functional as F
+    from holocron_amd.ops import conv as cv
+    N, Cin, H, W, k, stride, pad, Kpad = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn((N, Cin, H, W), generator=g)
+    col = cv.im2col_small(x.cuda(), k, k, stride, pad, Kpad)                       # logical [N, Kpad, OH, OW], NHWC bf16
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    assert tuple(col.shape) == (N, Kpad, OH, OW)
+    u = F.unfold(x, k, padding=pad, stride=stride).view(N, Cin, k * k, OH, OW)     # [N, ci, tap, OH, OW]
+    want = torch.zeros((N, Kpad, OH, OW))
+    want[:, :Cin * k * k] = u.permute(0, 2, 1, 3, 4).reshape(N, k * k * Cin, OH, OW)
+    assert torch.equal(col.float().cpu(), want.bfloat16().float()), shape
