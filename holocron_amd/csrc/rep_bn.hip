@@ -1132,19 +1132,33 @@ __global__ __launch_bounds__(256) void im2col_small_fp8_kernel(const float* __re
 // 3 channels x 3 input rows it needs with coalesced 16-byte loads (zero halo columns / rows written in place), and the eight 4-byte
 // gathers of an item become LDS reads - the global-memory side of the kernel is then two coalesced streams.  Same values, same
 // layout as im2col_rows (bit-identical column tensor).  LDS: 9 rows of W + 2 floats.
+// The assembly of an item is VALU-bound if the (ci, kh, kw) of each of its eight k are derived arithmetically (~200 instructions per
+// item, four clocks each per wave: 3-5 CU clocks per item measured, whatever the grid): a table of LDS byte offsets per k, built once
+// per workgroup, leaves one add and two LDS reads per element; the padding k >= 27 point into a tenth, all-zero tile row, so there
+// is no select either.  (A persistent grid with the next row's loads prefetched into registers measured the same as one row per
+// workgroup - the latency chain was never the limit - and is not kept.)
+// LDS: 10 rows of W + 2 floats, then Kpad ints.
 template <typename Store>
 __device__ __forceinline__ void im2col3_lds_rows(const float* __restrict__ x, int N, int H, int W, int OH, int OW, int stride, int Kpad,
                                                  float* __restrict__ tile, Store store) {
     const unsigned kchunks = (unsigned)Kpad / 8u, rowq = (unsigned)OW * kchunks;
     const unsigned rows = (unsigned)N * (unsigned)OH;
-    const int LW = W + 2;
+    const int LW = W + 2, w4 = W >> 2;
+    int* __restrict__ offs = reinterpret_cast<int*>(tile + 10 * LW);
+    for (int k = threadIdx.x; k < Kpad; k += blockDim.x) {
+        const int ci = k % 3, tp = k / 3;
+        const int kh = tp / 3, kw = tp - kh * 3;
+        offs[k] = (k < 27 ? (ci * 3 + kh) * LW + kw : 9 * LW) * 4;
+    }
+    for (int i = threadIdx.x; i < LW; i += blockDim.x) tile[9 * LW + i] = 0.f;
+    const bool p2 = (kchunks & (kchunks - 1u)) == 0u;
+    const int sh = __ffs((int)kchunks) - 1;
     for (unsigned row = blockIdx.x; row < rows; row += gridDim.x) {
         const unsigned n = row / (unsigned)OH;
         const int oy = (int)(row - n * (unsigned)OH);
         const float* __restrict__ xn = x + (size_t)n * 3 * H * W;
         __syncthreads();                         // the previous row's readers are done with the tile
         if ((W & 3) == 0) {
-            const int w4 = W >> 2;
             for (int i = threadIdx.x; i < 9 * w4; i += blockDim.x) {
                 const int r = i / w4, c4 = i - r * w4;          // r = ci * 3 + kh
                 const int ci = r / 3, kh = r - ci * 3;
@@ -1164,18 +1178,15 @@ __device__ __forceinline__ void im2col3_lds_rows(const float* __restrict__ x, in
         }
         if (threadIdx.x < 18) tile[(threadIdx.x >> 1) * LW + ((threadIdx.x & 1) ? W + 1 : 0)] = 0.f;     // halo columns
         __syncthreads();
+        const char* tb = reinterpret_cast<const char*>(tile);
         for (unsigned t = threadIdx.x; t < rowq; t += blockDim.x) {
-            const unsigned oxu = t / kchunks;
+            const unsigned oxu = p2 ? (t >> sh) : (t / kchunks);
             const int kc = (int)(t - oxu * kchunks);
-            const float* base = tile + (int)oxu * stride;        // column ix = ox * stride + kw - 1 sits at index ix + 1
+            const int bbyte = (int)oxu * stride * 4;             // column ix = ox * stride + kw - 1 sits at index ix + 1
+            const int* ok = offs + kc * 8;
             float f[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = kc * 8 + e;
-                const int ci = k % 3, tp = k / 3;
-                const int kh = tp / 3, kw = tp - kh * 3;
-                f[e] = k < 27 ? base[(ci * 3 + kh) * LW + kw] : 0.f;
-            }
+            for (int e = 0; e < 8; ++e) f[e] = *reinterpret_cast<const float*>(tb + bbyte + ok[e]);
             store((size_t)row * rowq + t, f);
         }
     }
@@ -1205,10 +1216,11 @@ __global__ __launch_bounds__(256) void im2col3_lds_fp8_kernel(const float* __res
         reinterpret_cast<u32x2*>(col)[q] = pk;
     });
 }
-// the LDS form applies to the 3-channel 3 x 3 pad-1 stem whose nine staged rows fit 64 KB; HC_IM2COL_LDS=0 keeps the gather form (A/B)
-static inline bool im2col3_lds_ok(int Cin, int KH, int KW, int pad, int W, int OW, int stride) {
+static inline size_t im2col3_lds_bytes(int W, int Kpad) { return ((size_t)10 * (W + 2) + Kpad) * sizeof(float); }
+// the LDS form applies to the 3-channel 3 x 3 pad-1 stem whose staged rows fit 64 KB; HC_IM2COL_LDS=0 keeps the gather form (A/B)
+static inline bool im2col3_lds_ok(int Cin, int KH, int KW, int pad, int W, int OW, int stride, int Kpad) {
     static const int on = [] { const char* e = getenv("HC_IM2COL_LDS"); return e == nullptr ? 1 : atoi(e); }();
-    return on && Cin == 3 && KH == 3 && KW == 3 && pad == 1 && stride >= 1 && (size_t)9 * (W + 2) * sizeof(float) <= 64 * 1024
+    return on && Cin == 3 && KH == 3 && KW == 3 && pad == 1 && stride >= 1 && Kpad <= 256 && im2col3_lds_bytes(W, Kpad) <= 64 * 1024
            && (long)(OW - 1) * stride + 1 <= W;
 }
 // grid of the row walk: x covers one output row's items, y the rows (grid-stride beyond 65 535)
@@ -1522,10 +1534,10 @@ int hc_im2col_small(const float* x, void* col, int32_t N, int32_t Cin, int32_t H
     if ((long)Cin * H * W > 2147483647L) return HC_ERR_ARG;          // offsets inside an image are 32-bit
     if (N <= 0 || OH <= 0 || OW <= 0) return HC_OK;
     const dim3 grid = im2col_grid(N, OH, OW, Kpad);
-    if (im2col3_lds_ok(Cin, KH, KW, pad, W, OW, stride)) {
+    if (im2col3_lds_ok(Cin, KH, KW, pad, W, OW, stride, Kpad)) {
         const long rows = (long)N * OH;
-        hipLaunchKernelGGL(im2col3_lds_kernel, dim3((unsigned)(rows > 65535 ? 65535 : rows)), dim3(256), (size_t)9 * (W + 2) * sizeof(float),
-                           (hipStream_t)stream, x, (bf16_t*)col, N, H, W, OH, OW, stride, Kpad);
+        hipLaunchKernelGGL(im2col3_lds_kernel, dim3((unsigned)(rows > 65535 ? 65535 : rows)), dim3(256), im2col3_lds_bytes(W, Kpad), (hipStream_t)stream, x,
+                           (bf16_t*)col, N, H, W, OH, OW, stride, Kpad);
         return hc_launch_status();
     }
     if (Cin == 3 && KH == 3 && KW == 3)
@@ -1542,11 +1554,10 @@ int hc_im2col_small_fp8(const float* x, void* col, int32_t N, int32_t Cin, int32
     if ((long)Cin * H * W > 2147483647L) return HC_ERR_ARG;
     if (N <= 0 || OH <= 0 || OW <= 0) return HC_OK;
     const dim3 grid = im2col_grid(N, OH, OW, Kpad);
-    if (im2col3_lds_ok(Cin, KH, KW, pad, W, OW, stride)) {
+    if (im2col3_lds_ok(Cin, KH, KW, pad, W, OW, stride, Kpad)) {
         const long rows = (long)N * OH;
-        hipLaunchKernelGGL(im2col3_lds_fp8_kernel, dim3((unsigned)(rows > 65535 ? 65535 : rows)), dim3(256),
-                           (size_t)9 * (W + 2) * sizeof(float), (hipStream_t)stream, x, (unsigned char*)col, N, H, W, OH, OW, stride, Kpad,
-                           inv_scale);
+        hipLaunchKernelGGL(im2col3_lds_fp8_kernel, dim3((unsigned)(rows > 65535 ? 65535 : rows)), dim3(256), im2col3_lds_bytes(W, Kpad), (hipStream_t)stream, x,
+                           (unsigned char*)col, N, H, W, OH, OW, stride, Kpad, inv_scale);
         return hc_launch_status();
     }
     if (Cin == 3 && KH == 3 && KW == 3)
