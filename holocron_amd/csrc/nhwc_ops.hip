@@ -27,13 +27,16 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
 }
 
 // dst[p][dc0 + c] = src[p][sc0 + c], c < C ; everything in units of 8 channels
+// IDX = unsigned when every index of the launch fits 32 bits (the launcher checks): the 64-bit division per 16-byte element was a
+// hundred VALU instructions for one load and one store
+template <typename IDX>
 __global__ void nhwc_copy_kernel(const u32x4* __restrict__ src, int sld8, int sc8, u32x4* __restrict__ dst, int dld8, int dc8,
                                  long npix, int c8) {
-    const long total = npix * c8;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long p = i / c8;
-        const int c = (int)(i - p * c8);
-        dst[p * dld8 + dc8 + c] = src[p * sld8 + sc8 + c];
+    const IDX total = (IDX)npix * (IDX)c8;
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
+        const IDX p = i / (IDX)c8;
+        const IDX c = i - p * (IDX)c8;
+        dst[p * (IDX)dld8 + (IDX)dc8 + c] = src[p * (IDX)sld8 + (IDX)sc8 + c];
     }
 }
 
@@ -528,8 +531,14 @@ int hc_nhwc_copy(const void* src, int32_t src_ld, int32_t src_c0, void* dst, int
     if ((src_ld | src_c0 | dst_ld | dst_c0 | C) & 7) return HC_ERR_ARG;
     if (C <= 0 || src_c0 + C > src_ld || dst_c0 + C > dst_ld) return HC_ERR_ARG;
     if (npix == 0) return HC_OK;
-    hipLaunchKernelGGL(nhwc_copy_kernel, dim3(grid_for(npix * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src,
-                       src_ld / 8, src_c0 / 8, (u32x4*)dst, dst_ld / 8, dst_c0 / 8, (long)npix, C / 8);
+    // 32-bit indices when the element count (plus one grid stride) and both buffers' extents fit
+    const long ext = (long)npix * ((src_ld > dst_ld ? src_ld : dst_ld) / 8) + 16384L * 256;
+    if (ext < 4294967295L)
+        hipLaunchKernelGGL(nhwc_copy_kernel<unsigned>, dim3(grid_for(npix * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src,
+                           src_ld / 8, src_c0 / 8, (u32x4*)dst, dst_ld / 8, dst_c0 / 8, (long)npix, C / 8);
+    else
+        hipLaunchKernelGGL(nhwc_copy_kernel<long>, dim3(grid_for(npix * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src,
+                           src_ld / 8, src_c0 / 8, (u32x4*)dst, dst_ld / 8, dst_c0 / 8, (long)npix, C / 8);
     return hc_launch_status();
 }
 
