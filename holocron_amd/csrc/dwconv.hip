@@ -872,13 +872,16 @@ __global__ void max_bwd_kernel(const u32x4* __restrict__ a, const u32x4* __restr
 
 // ---------------------------------------------------------------- squeeze-excite gate (rexnet.py:63-66) + ReLU6
 // out = relu6(z * sigmoid(l[n][c])) ; z NHWC bf16 [N][HW][C], l bf16 [N][C] (gate logits).  act: 0 none, 6 relu6.
+// IDX = unsigned when the element count plus one grid stride fits 32 bits (the launchers check): two 64-bit div / mod per 16-byte
+// item were ~200 of the ~300 VALU instructions of these passes
+template <typename IDX>
 __global__ __launch_bounds__(DW_THREADS) void se_scale_fwd_kernel(const u32x4* __restrict__ z, const u32x4* __restrict__ l,
                                                                   u32x4* __restrict__ out, long N, long HW, int C, int act) {
     const int cg = C / 8;
-    const long total = N * HW * cg;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cg);
-        const long n = i / (HW * cg);
+    const IDX total = (IDX)(N * HW * cg), per_img = (IDX)(HW * cg);
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
+        const IDX n = i / per_img;
+        const int c = (int)((i - n * per_img) % (IDX)cg);
         float fz[8], fl[8], o[8];
         unpack8(z[i], fz);
         unpack8(l[n * cg + c], fl);
@@ -931,15 +934,16 @@ __global__ void se_gate_grad_kernel(const float* __restrict__ dgate, const bf16_
     dl[i] = f32_to_bf16(dgate[i] * s * (1.f - s));
 }
 // dz = g * mask * s + dpool[n][c] / HW   (dpool: gradient of the global average pool input, fp32 [N][C])
+template <typename IDX>
 __global__ __launch_bounds__(DW_THREADS) void se_scale_bwd_apply_kernel(const u32x4* __restrict__ g, const u32x4* __restrict__ z,
                                                                         const u32x4* __restrict__ l, const float* __restrict__ dpool,
                                                                         u32x4* __restrict__ dz, long N, long HW, int C, int act) {
     const int cg = C / 8;
-    const long total = N * HW * cg;
+    const IDX total = (IDX)(N * HW * cg), per_img = (IDX)(HW * cg);
     const float inv = 1.f / (float)HW;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cg);
-        const long n = i / (HW * cg);
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
+        const IDX n = i / per_img;
+        const int c = (int)((i - n * per_img) % (IDX)cg);
         float fg[8], fz[8], fl[8], o[8];
         unpack8(g[i], fg);
         unpack8(z[i], fz);
@@ -1253,8 +1257,12 @@ int hc_se_scale_fwd(const void* z, const void* gate_logits, void* out, int64_t N
     if (total == 0) return HC_OK;
     long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(se_scale_fwd_kernel, dim3((int)blocks), dim3(DW_THREADS), 0, (hipStream_t)stream, (const u32x4*)z,
-                       (const u32x4*)gate_logits, (u32x4*)out, (long)N, (long)HW, C, act);
+    if (total + 8192L * DW_THREADS < 4294967295L)
+        hipLaunchKernelGGL(se_scale_fwd_kernel<unsigned>, dim3((int)blocks), dim3(DW_THREADS), 0, (hipStream_t)stream, (const u32x4*)z,
+                           (const u32x4*)gate_logits, (u32x4*)out, (long)N, (long)HW, C, act);
+    else
+        hipLaunchKernelGGL(se_scale_fwd_kernel<long>, dim3((int)blocks), dim3(DW_THREADS), 0, (hipStream_t)stream, (const u32x4*)z,
+                           (const u32x4*)gate_logits, (u32x4*)out, (long)N, (long)HW, C, act);
     return hc_launch_status();
 }
 int hc_se_scale_bwd_gate(const void* g, const void* z, const void* gate_logits, float* dgate, void* dlogits, int64_t N, int64_t HW,
@@ -1285,8 +1293,12 @@ int hc_se_scale_bwd_apply(const void* g, const void* z, const void* gate_logits,
     if (total == 0) return HC_OK;
     long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(se_scale_bwd_apply_kernel, dim3((int)blocks), dim3(DW_THREADS), 0, (hipStream_t)stream, (const u32x4*)g,
-                       (const u32x4*)z, (const u32x4*)gate_logits, dpool, (u32x4*)dz, (long)N, (long)HW, C, act);
+    if (total + 8192L * DW_THREADS < 4294967295L)
+        hipLaunchKernelGGL(se_scale_bwd_apply_kernel<unsigned>, dim3((int)blocks), dim3(DW_THREADS), 0, (hipStream_t)stream, (const u32x4*)g,
+                           (const u32x4*)z, (const u32x4*)gate_logits, dpool, (u32x4*)dz, (long)N, (long)HW, C, act);
+    else
+        hipLaunchKernelGGL(se_scale_bwd_apply_kernel<long>, dim3((int)blocks), dim3(DW_THREADS), 0, (hipStream_t)stream, (const u32x4*)g,
+                           (const u32x4*)z, (const u32x4*)gate_logits, dpool, (u32x4*)dz, (long)N, (long)HW, C, act);
     return hc_launch_status();
 }
 
