@@ -146,7 +146,11 @@ def test_dropblock_batched_masks_equal_per_call_masks():
     from holocron_amd import _lib
     from holocron_amd._lib import check, ptr, stream
     lib = _lib.load()
-    shapes = [(2, 9, 11, 3, 0.05), (3, 19, 19, 7, 0.004), (1, 5, 4, 5, 0.2), (2, 16, 16, 7, 1e-9)]
+    # single-tile maps, maps of several 32 x 32 tiles (ragged edges, tiles straddling images) and more layers than one launch of the
+    # flat tile list takes (256): the tile -> (layer, image, ty, tx) decode of the persistent grid
+    shapes = [(2, 9, 11, 3, 0.05), (3, 19, 19, 7, 0.004), (1, 5, 4, 5, 0.2), (2, 16, 16, 7, 1e-9), (2, 76, 76, 7, 0.004),
+              (1, 100, 37, 5, 0.01), (3, 33, 64, 3, 0.02), (2, 152, 152, 13, 0.0005)]
+    shapes += [(1 + i % 3, 7 + i % 11, 5 + i % 40, 3 + 2 * (i % 3), 0.01 + 0.001 * (i % 7)) for i in range(290)]
     total = sum(n * h * w for n, h, w, _, _ in shapes)
     noise = torch.rand((total,), device="cuda")
     arr = (_lib.DropItem * len(shapes))()
